@@ -1,0 +1,316 @@
+/*
+ * oracle/tho_poa.c -- TEST INFRASTRUCTURE (see tho.h).
+ *
+ * PARITY UNPINNED.  The reference calls abpoa_msa() (src/abpoa_cons.c:86-87) from libabpoa, a
+ * git submodule that is empty in /root/reference (.gitmodules:1-4; commit id unknown, no copy
+ * anywhere in this image).  This file therefore restates the *published* abPOA algorithm
+ * (Gao et al., Bioinformatics 2021) with the parameters TideHunter sets
+ * (src/abpoa_cons.c:12-28: match 2, mismatch 4, convex gaps O1=4,E1=2,O2=24,E2=1,
+ * cons_agrm = 1 "RC"), not abPOA's source.  It is the de-facto oracle for the HIP POA kernel;
+ * nothing here may be cited as "equal to the reference" beyond trivially identical units.
+ *
+ * Algorithm, as restated:
+ *   graph    : nodes 0 = source, 1 = sink, >=2 bases in creation order; weighted edges kept in
+ *              insertion order; nodes that carry different bases of one MSA column form an
+ *              "aligned ring".
+ *   order    : Kahn/BFS topological sort from the source, FIFO; a node is released only when
+ *              every member of its aligned ring is ready, and the ring is released together
+ *              (so a column's nodes are adjacent).  max_remain[v] = longest node count from v
+ *              to the sink (sink = -1).
+ *   DP       : global alignment of the query (columns 0..qlen) against the ordered nodes,
+ *              convex gap = two affine pieces, 32-bit scores, score(a,b) = 0 if either is N(4),
+ *              +match if equal, -mismatch otherwise.
+ *              adaptive band (abPOA: b = 10, f = 0.01): w = 10 + qlen/100,
+ *                beg = max(0, min(max_pos_left[v],  qlen - max_remain[v]) - w), not below the
+ *                      smallest beg of v's predecessors,
+ *                end = min(qlen, max(max_pos_right[v], qlen - max_remain[v]) + w),
+ *              where max_pos_left/right[v] = 1 + leftmost/rightmost column of the row maximum
+ *              of any predecessor row.  Cells outside a band read as NEG.
+ *   ties     : H prefers M, then E1, E2 (node skipped), then F1, F2 (query base inserted);
+ *              among predecessors the first in edge order; a gap is continued only when
+ *              that is strictly better than re-opening it (same convention as ksw2).
+ *   merge    : walk the alignment; a matched base re-uses the node (or a ring member with that
+ *              base), a mismatched base becomes a new ring member, an inserted base a new node.
+ *   consensus: per column (ring) in topological order, the most frequent symbol among the
+ *              column's bases (count = reads through the node) and the gap
+ *              (n_seq - sum of counts); symbols are scanned A,C,G,T,N,gap and a later one must be
+ *              strictly more frequent to win (so a base beats an equally frequent gap and the
+ *              smaller code wins among bases).  cov = count of the chosen base.
+ *              (Sanity anchor, not a pin: on test_data/full_length.fa this rule gives a 201-base
+ *              consensus against the 203 bases README.md:232 shows for an older partition of
+ *              the same read; requiring a strict majority over the gap gives 198.)
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include "tho.h"
+
+#define NEG (-0x20000000)
+#define WB 10
+
+typedef struct {
+    uint8_t base; int n_read;
+    int in_head, in_tail, out_head, out_tail, in_n;
+    int ring;                 /* next node of the aligned ring (self if alone) */
+} node_t;
+typedef struct { int from, to, w, next_in, next_out; } edge_t;
+
+typedef struct {
+    node_t *node; int n_node, m_node;
+    edge_t *edge; int n_edge, m_edge;
+    int *order, *index;       /* order[idx] = node id, index[node id] = idx */
+    int *remain;              /* by node id */
+} graph_t;
+
+static int new_node(graph_t *g, uint8_t base)
+{
+    if (g->n_node == g->m_node) { g->m_node = g->m_node ? g->m_node * 2 : 256; g->node = (node_t *)realloc(g->node, sizeof(node_t) * g->m_node); }
+    node_t *v = &g->node[g->n_node];
+    v->base = base; v->n_read = 0; v->in_head = v->in_tail = v->out_head = v->out_tail = -1; v->in_n = 0;
+    v->ring = g->n_node;
+    return g->n_node++;
+}
+
+static void add_edge(graph_t *g, int from, int to)
+{
+    for (int e = g->node[from].out_head; e >= 0; e = g->edge[e].next_out)
+        if (g->edge[e].to == to) { ++g->edge[e].w; return; }
+    if (g->n_edge == g->m_edge) { g->m_edge = g->m_edge ? g->m_edge * 2 : 256; g->edge = (edge_t *)realloc(g->edge, sizeof(edge_t) * g->m_edge); }
+    int id = g->n_edge++;
+    edge_t *e = &g->edge[id];
+    e->from = from; e->to = to; e->w = 1; e->next_in = e->next_out = -1;
+    node_t *a = &g->node[from], *b = &g->node[to];
+    if (a->out_tail < 0) a->out_head = id; else g->edge[a->out_tail].next_out = id;
+    a->out_tail = id;
+    if (b->in_tail < 0) b->in_head = id; else g->edge[b->in_tail].next_in = id;
+    b->in_tail = id; ++b->in_n;
+}
+
+static void topo_sort(graph_t *g)
+{
+    int n = g->n_node;
+    g->order = (int *)realloc(g->order, sizeof(int) * n);
+    g->index = (int *)realloc(g->index, sizeof(int) * n);
+    g->remain = (int *)realloc(g->remain, sizeof(int) * n);
+    int *rem = (int *)malloc(sizeof(int) * n), *queue = (int *)malloc(sizeof(int) * n);
+    for (int i = 0; i < n; ++i) rem[i] = g->node[i].in_n;
+    int qh = 0, qt = 0, on = 0;
+    queue[qt++] = 0;
+    while (qh < qt) {
+        int u = queue[qh++];
+        g->index[u] = on; g->order[on++] = u;
+        for (int e = g->node[u].out_head; e >= 0; e = g->edge[e].next_out) {
+            int v = g->edge[e].to;
+            if (--rem[v] > 0) continue;
+            int ok = 1;
+            for (int m = g->node[v].ring; m != v; m = g->node[m].ring) if (rem[m] > 0) { ok = 0; break; }
+            if (!ok) continue;
+            queue[qt++] = v;
+            for (int m = g->node[v].ring; m != v; m = g->node[m].ring) queue[qt++] = m;
+        }
+    }
+    if (on != n) { fprintf(stderr, "[tho_poa] topological sort left %d of %d nodes\n", n - on, n); exit(1); }
+    for (int i = n - 1; i >= 0; --i) {
+        int u = g->order[i], r = -1;
+        if (u != 1)
+            for (int e = g->node[u].out_head; e >= 0; e = g->edge[e].next_out) {
+                int x = g->remain[g->edge[e].to] + 1;
+                if (x > r) r = x;
+            }
+        g->remain[u] = r;
+    }
+    free(rem); free(queue);
+}
+
+/* alignment ops, forward order */
+typedef struct { int op, node, qpos; } aop_t;   /* op: 0 match/mismatch, 1 insertion (query only), 2 deletion (node only) */
+
+#define D_SRC(d)  ((d) & 7)
+#define D_PM(d)   (((d) >> 3) & 0xff)
+#define D_PE1(d)  (((d) >> 11) & 0xff)
+#define D_PE2(d)  (((d) >> 19) & 0xff)
+#define D_XE1 (1u << 27)
+#define D_XE2 (1u << 28)
+#define D_XF1 (1u << 29)
+#define D_XF2 (1u << 30)
+
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+
+static int align_to_graph(graph_t *g, const uint8_t *q, int qlen, const tho_para_t *p, aop_t **ops_out)
+{
+    const int M = p->match, X = p->mismatch, O1 = p->gap_open1, E1 = p->gap_ext1, O2 = p->gap_open2, E2 = p->gap_ext2;
+    int n = g->n_node, w = WB + qlen / 100;
+    int *beg = (int *)malloc(sizeof(int) * n * 4), *end = beg + n, *mpl = end + n, *mpr = mpl + n;
+    size_t *roff = (size_t *)malloc(sizeof(size_t) * n), ncell = 0, mcell = (size_t)n * (2 * w + 64);
+    /* band-only storage: row i holds columns beg[i]..end[i] at roff[i] */
+    int *H = (int *)malloc(sizeof(int) * mcell), *N1 = (int *)malloc(sizeof(int) * mcell), *N2 = (int *)malloc(sizeof(int) * mcell);
+    uint32_t *D = (uint32_t *)malloc(sizeof(uint32_t) * mcell);
+    for (int i = 0; i < n; ++i) { mpl[i] = 0x7fffffff; mpr[i] = 0; }
+#define AT(A, i, j) ((A)[roff[i] + (size_t)((j) - beg[i])])
+#define RD(A, i, j) (((j) < beg[i] || (j) > end[i]) ? NEG : AT(A, i, j))
+    for (int i = 0; i + 1 < n; ++i) {            /* every row except the sink's */
+        int v = g->order[i];
+        int b, e;
+        if (i == 0) { b = 0; }
+        else {
+            b = imax(0, imin(mpl[v], qlen - g->remain[v]) - w);
+            int mb = 0x7fffffff;
+            for (int ed = g->node[v].in_head; ed >= 0; ed = g->edge[ed].next_in) mb = imin(mb, beg[g->index[g->edge[ed].from]]);
+            if (b < mb) b = mb;
+        }
+        e = imin(qlen, imax(mpr[v], qlen - g->remain[v]) + w);
+        if (b > e) { fprintf(stderr, "[tho_poa] empty band at row %d\n", i); exit(1); }
+        beg[i] = b; end[i] = e; roff[i] = ncell; ncell += (size_t)(e - b + 1);
+        if (ncell > mcell) {
+            while (ncell > mcell) mcell *= 2;
+            H = (int *)realloc(H, sizeof(int) * mcell); N1 = (int *)realloc(N1, sizeof(int) * mcell);
+            N2 = (int *)realloc(N2, sizeof(int) * mcell); D = (uint32_t *)realloc(D, sizeof(uint32_t) * mcell);
+        }
+        int f1 = NEG, f2 = NEG, rmax = NEG - 0x10000000, left = b, right = b;
+        for (int j = b; j <= e; ++j) {
+            int h, src = 0, pm = 0, pe1 = 0, pe2 = 0, e1v = NEG, e2v = NEG;
+            if (i == 0) {
+                h = j == 0 ? 0 : -imin(O1 + j * E1, O2 + j * E2);
+                /* the row maximum of the source row is column 0 by construction */
+            } else {
+                int m = NEG; int ord = 0;
+                for (int ed = g->node[v].in_head; ed >= 0; ed = g->edge[ed].next_in, ++ord) {
+                    int pi = g->index[g->edge[ed].from];
+                    if (j >= 1) {
+                        uint8_t qb = q[j - 1], nb = g->node[v].base;
+                        int s = (qb == 4 || nb == 4) ? 0 : (qb == nb ? M : -X);
+                        int c = RD(H, pi, j - 1) + s;
+                        if (ord == 0 || c > m) { m = c; pm = ord; }
+                    }
+                    int c1 = RD(N1, pi, j), c2 = RD(N2, pi, j);
+                    if (ord == 0 || c1 > e1v) { e1v = c1; pe1 = ord; }
+                    if (ord == 0 || c2 > e2v) { e2v = c2; pe2 = ord; }
+                }
+                if (ord > 256) { fprintf(stderr, "[tho_poa] in-degree %d > 256\n", ord); exit(1); }
+                h = m; src = 0;
+                if (e1v > h) { h = e1v; src = 1; }
+                if (e2v > h) { h = e2v; src = 2; }
+                if (f1 > h) { h = f1; src = 3; }
+                if (f2 > h) { h = f2; src = 4; }
+            }
+            uint32_t d = (uint32_t)src | (uint32_t)pm << 3 | (uint32_t)pe1 << 11 | (uint32_t)pe2 << 19;
+            if (i == 0) { e1v = NEG; e2v = NEG; if (j > 0) { f1 = -(O1 + j * E1); f2 = -(O2 + j * E2); } }
+            if (e1v > h - O1) d |= D_XE1;
+            if (e2v > h - O2) d |= D_XE2;
+            if (f1 > h - O1) d |= D_XF1;
+            if (f2 > h - O2) d |= D_XF2;
+            AT(H, i, j) = h; AT(D, i, j) = d;
+            AT(N1, i, j) = imax(h - O1, e1v) - E1;
+            AT(N2, i, j) = imax(h - O2, e2v) - E2;
+            f1 = imax(h - O1, f1) - E1;
+            f2 = imax(h - O2, f2) - E2;
+            if (h > rmax) { rmax = h; left = right = j; } else if (h == rmax) right = j;
+        }
+        for (int ed = g->node[v].out_head; ed >= 0; ed = g->edge[ed].next_out) {
+            int u = g->edge[ed].to;
+            if (right + 1 > mpr[u]) mpr[u] = right + 1;
+            if (left + 1 < mpl[u]) mpl[u] = left + 1;
+        }
+    }
+    /* global end: best predecessor row of the sink at column qlen (first in edge order) */
+    int bi = -1, bs = 0, ord = 0;
+    for (int ed = g->node[1].in_head; ed >= 0; ed = g->edge[ed].next_in, ++ord) {
+        int pi = g->index[g->edge[ed].from], c = RD(H, pi, qlen);
+        if (ord == 0 || c > bs) { bs = c; bi = pi; }
+    }
+    if (bs <= NEG / 2) { fprintf(stderr, "[tho_poa] band lost the global path (score %d)\n", bs); exit(1); }
+    /* traceback */
+    aop_t *ops = (aop_t *)malloc(sizeof(aop_t) * (size_t)(n + qlen + 2));
+    int no = 0, i = bi, j = qlen, st = 0;
+    while (i > 0) {
+        uint32_t d = AT(D, i, j);
+        int v = g->order[i];
+        if (st == 0) st = D_SRC(d);
+        if (st == 0 || st == 1 || st == 2) {
+            int want = st == 0 ? D_PM(d) : st == 1 ? D_PE1(d) : D_PE2(d), ed = g->node[v].in_head;
+            for (int x = 0; x < want; ++x) ed = g->edge[ed].next_in;
+            int pi = g->index[g->edge[ed].from];
+            if (st == 0) { aop_t o = { 0, v, j - 1 }; ops[no++] = o; i = pi; --j; }
+            else {
+                aop_t o = { 2, v, -1 }; ops[no++] = o; i = pi;
+                uint32_t pd = AT(D, i, j);
+                if (i == 0 || !(pd & (st == 1 ? D_XE1 : D_XE2))) st = 0;
+            }
+        } else {
+            aop_t o = { 1, -1, j - 1 }; ops[no++] = o; --j;
+            uint32_t pd = AT(D, i, j);
+            if (!(pd & (st == 3 ? D_XF1 : D_XF2))) st = 0;
+        }
+    }
+    while (j > 0) { aop_t o = { 1, -1, j - 1 }; ops[no++] = o; --j; }
+    for (int a = 0, b2 = no - 1; a < b2; ++a, --b2) { aop_t t = ops[a]; ops[a] = ops[b2]; ops[b2] = t; }
+#undef AT
+#undef RD
+    free(beg); free(roff); free(H); free(N1); free(N2); free(D);
+    *ops_out = ops;
+    return no;
+}
+
+static void add_alignment(graph_t *g, const uint8_t *q, int qlen, const aop_t *ops, int n_ops)
+{
+    int last = 0;
+    if (ops == NULL) {                       /* first sequence: a plain chain */
+        for (int j = 0; j < qlen; ++j) { int v = new_node(g, q[j]); ++g->node[v].n_read; add_edge(g, last, v); last = v; }
+    } else {
+        for (int a = 0; a < n_ops; ++a) {
+            if (ops[a].op == 2) continue;
+            uint8_t b = q[ops[a].qpos];
+            int v = -1;
+            if (ops[a].op == 0) {
+                int u = ops[a].node;
+                if (g->node[u].base == b) v = u;
+                else {
+                    for (int m = g->node[u].ring; m != u; m = g->node[m].ring) if (g->node[m].base == b) { v = m; break; }
+                    if (v < 0) {             /* new member, linked right after u */
+                        v = new_node(g, b);
+                        g->node[v].ring = g->node[u].ring; g->node[u].ring = v;
+                    }
+                }
+            } else v = new_node(g, b);
+            ++g->node[v].n_read;
+            add_edge(g, last, v);
+            last = v;
+        }
+    }
+    add_edge(g, last, 1);
+}
+
+int tho_poa_consensus(int n_seqs, const uint8_t *const *seqs, const int *lens, const tho_para_t *p, uint8_t *cons, int *cov)
+{
+    graph_t g; memset(&g, 0, sizeof(g));
+    new_node(&g, 4); new_node(&g, 4);        /* source, sink */
+    uint8_t *buf = NULL; int mbuf = 0;
+    for (int s = 0; s < n_seqs; ++s) {
+        if (lens[s] > mbuf) { mbuf = lens[s]; buf = (uint8_t *)realloc(buf, mbuf); }
+        for (int j = 0; j < lens[s]; ++j) buf[j] = seqs[s][j] > 4 ? 4 : seqs[s][j];
+        if (s == 0) add_alignment(&g, buf, lens[s], NULL, 0);
+        else {
+            topo_sort(&g);
+            aop_t *ops; int n_ops = align_to_graph(&g, buf, lens[s], p, &ops);
+            add_alignment(&g, buf, lens[s], ops, n_ops);
+            free(ops);
+        }
+    }
+    topo_sort(&g);
+    int cl = 0;
+    for (int i = 1; i + 1 < g.n_node;) {
+        int v = g.order[i], cnt[5] = { 0, 0, 0, 0, 0 }, tot = 0, k = i;
+        /* the ring's members are adjacent in the order */
+        int members = 1;
+        for (int m = g.node[v].ring; m != v; m = g.node[m].ring) ++members;
+        for (k = i; k < i + members; ++k) { int u = g.order[k]; cnt[g.node[u].base] += g.node[u].n_read; tot += g.node[u].n_read; }
+        int gap = n_seqs - tot, best = 0, bb = -1;
+        for (int b = 0; b < 5; ++b) if (cnt[b] > best) { best = cnt[b]; bb = b; }
+        if (gap > best) bb = -1;
+        if (bb >= 0) { cons[cl] = (uint8_t)bb; if (cov) cov[cl] = best; ++cl; }
+        i += members;
+    }
+    free(buf); free(g.node); free(g.edge); free(g.order); free(g.index); free(g.remain);
+    return cl;
+}
