@@ -1,0 +1,110 @@
+/*
+ * include/tidehunter_amd.h -- C-ABI of the MI355X-native TideHunter hot path.
+ *
+ * Plain C, plain pointers and sizes, no torch/HIP types.  Each entry point names the reference
+ * interface it stands in for (paths relative to the TideHunter v1.5.5 tree).  The library is a
+ * drop-in for the per-read hot path only: k-mer self-hits, chaining, partition, POA consensus and
+ * the consensus statistics, i.e. what tidehunter_core() (src/tidehunter.c:23-60) does for every
+ * read of a chunk inside mini_tandem() (src/main.c:402-425).  There is NO CPU fallback: every
+ * compute entry point fails (NULL / negative return, message on stderr and in th_last_error())
+ * when no AMD GPU / HIP runtime is present.
+ *
+ * Error convention: the reference terminates the process on any error (err_fatal,
+ * src/utils.c:91-117).  A library cannot do that to its host, so functions return -1 (or NULL) after
+ * printing "[tidehunter_amd] <message>" to stderr; partial output is never produced.  The bundled
+ * command line (TideHunter-amd) turns that into exit status 1, like the reference.
+ */
+#ifndef TIDEHUNTER_AMD_H
+#define TIDEHUNTER_AMD_H
+#include <stdint.h>
+#include <stdio.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TH_FASTA_FMT 1      /* src/tidehunter.h:36-39 */
+#define TH_TAB_FMT 2
+#define TH_FASTQ_FMT 3
+#define TH_TAB_QUAL_FMT 4
+
+/* mini_tandem_para, src/tidehunter.h:47-61 (same field names and meaning; cons_out/detail_fp, which
+ * are FILE* owned by main(), are left to the caller) */
+typedef struct {
+    int64_t k, w; int hpc;
+    int min_copy, min_cov; double max_div, div_exp, min_frac;
+    int64_t min_p, max_p;
+    int64_t max_range;
+    int match, mismatch, gap_open1, gap_open2, gap_ext1, gap_ext2;
+    float ada_match_rat;
+    char *five_fn, *five_seq, *five_rc_seq; int five_len;
+    char *three_fn, *three_seq, *three_rc_seq; int three_len;
+    int out_fmt, min_len, only_unit, only_longest, only_full_length, single_copy;
+    int n_thread;
+} th_para_t;
+
+/* tandem_seq_t, src/tidehunter.h:63-72.  cons_seq/cons_qual replace the kseq seq_t: the consensus
+ * strings of one read are concatenated and split by cons_len[], exactly as in the reference
+ * (src/main.c:253-263). */
+typedef struct {
+    char *cons_seq; size_t cons_seq_l, cons_seq_m;
+    char *cons_qual; size_t cons_qual_l, cons_qual_m;
+    int cons_n, cons_m;
+    int *cons_start, *cons_end, *cons_len; double *copy_num, *ave_match;
+    int8_t *full_length;
+    int **sub_pos; int *pos_n, *pos_m;
+    int *cons_score;
+} th_tandem_seq_t;
+
+typedef struct th_handle th_handle_t;
+
+/* mini_tandem_init_para() / mini_tandem_free_para(), src/main.c:329-373 */
+th_para_t *th_init_para(void);
+void th_free_para(th_para_t *p);
+/* adapter loading as in mini_tandem(), src/main.c:389-394 (needs five_fn and three_fn set) */
+int th_load_adapters(th_para_t *p);
+
+/* alloc_tandem_seq() / tandem_seq_free(), src/main.c:293-324 */
+th_tandem_seq_t *th_alloc_tandem_seq(int n);
+void th_free_tandem_seq(th_tandem_seq_t *t, int n);
+
+/* aux_init() / aux_free(), src/main.c:184-206: one handle = one GPU (device ordinal) + its stream,
+ * buffers and the read-only parameter snapshot.  Not re-entrant per handle; use one per thread/GPU. */
+th_handle_t *th_init(const th_para_t *p, int device);
+void th_destroy(th_handle_t *h);
+
+/* The batch seam, src/main.c:402-425: fills out[0..n) so that th_output() prints what
+ * mini_tandem_output() would.  Equivalent to calling tidehunter_core() (src/tidehunter.h:85) on every
+ * read.  out[] must come from th_alloc_tandem_seq(); slots are reset first. */
+int th_process_batch(th_handle_t *h, const char *const *seqs, const int *lens, int n, th_tandem_seq_t *out);
+
+/* The same in three steps, so that a caller (bench.py) can keep a batch resident in HBM and time
+ * the device path alone:  upload (H2D) -> run (all kernels + small D2H) -> collect (host-side
+ * double arithmetic, adapter search, filters; src/gen_cons.c:208-301, src/abpoa_cons.c:92-108). */
+int th_batch_upload(th_handle_t *h, const char *const *seqs, const int *lens, int n);
+int th_batch_run(th_handle_t *h);
+int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out);
+/* device milliseconds of the last th_batch_run(): all kernels, and the dominant kernel (th_k_align) */
+int th_batch_timing(th_handle_t *h, double *ms_all, double *ms_dominant);
+
+/* mini_tandem_output(), src/main.c:214-271 (resets the slots after printing, as the reference does) */
+void th_output(FILE *fp, int n, const char *const *names, const char *const *seqs, const int *lens,
+               th_tandem_seq_t *tseq, const th_para_t *p);
+
+/* mini_tandem(), src/main.c:375-436: whole-file driver (FASTA/FASTQ, optionally gzipped) */
+int th_run_file(const char *read_fn, th_para_t *p, FILE *out, int device, int batch_reads);
+
+/* deterministic synthetic tandem-repeat reads; returns read length, writes at most cap bases */
+int th_synth_read(uint64_t seed, uint64_t read_index, int period, int copies, double err, char *dst, int cap);
+
+const char *th_last_error(void);
+const char *th_version(void);
+
+/* test hook (tests/ only): see tidehunter_amd/csrc/th_internal.h th_gpu_debug() */
+long long th_debug_stage(th_handle_t *h, int what, void *dst, long long cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

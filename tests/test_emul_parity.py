@@ -1,0 +1,89 @@
+"""Kernel-logic parity on the CPU: the SAME kernel sources (tidehunter_amd/csrc/*.hip) compiled under the
+test-only lock-step emulation (tests/cpu_emul/) against the oracle.  Small inputs only: the
+emulation runs every HIP thread as a fiber.  The product library is never involved here; the GPU
+parity proper is tests/test_gpu_parity.py (-m gpu)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import th_util as U
+import tidehunter_amd as TH
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return U.emul_lib_path()
+
+
+def _reads(lib, spec, seed=11):
+    return [TH.synth_read(lib, seed, i, per, cop, err) for i, (per, cop, err) in enumerate(spec)]
+
+
+def test_emul_test_50x4_golden(emu):
+    th = TH.TideHunter(lib_path=emu)
+    seq = U.read_fastx(os.path.join(U.DATA, "test_50x4.fa"))[0][1]
+    (recs,) = th.process([seq])
+    assert len(recs) == 1
+    r = recs[0]     # README.md:222
+    assert r["seq"] == b"CGATCGATCGGCATGCATGCATGCTAGTCGATGCATCGGGATCAGCTAGT"
+    assert (r["start"] + 1, r["end"] + 1, r["cons_len"], r["full_length"]) == (51, 250, 50, 0)
+    assert "%.1f %.1f" % (r["copy_num"], r["ave_match"]) == "4.0 100.0"
+    assert [p + 2 for p in r["sub_pos"][:-1]] + [r["sub_pos"][-1] + 1] == [59, 109, 159, 208]
+    th.close()
+
+
+def test_emul_stages_and_records_small_synthetic(emu):
+    th = TH.TideHunter(lib_path=emu)
+    seqs = _reads(th.lib, [(60, 8, 0.10), (120, 5, 0.08), (35, 12, 0.12), (200, 3, 0.10), (90, 6, 0.0)])
+    seqs += [b"ACGT" * 3, b"A" * 200, b"ACGTNNNNACGT" * 20, b""]          # ragged / degenerate inputs
+    para = O.default_para()
+    got = th.process(seqs)
+    U.stage_compare(th, seqs, para)
+    assert U.assert_records_equal(seqs, got, para, "emul") >= 5
+    th.close()
+
+
+def test_emul_unit_mode_and_filters(emu):
+    spec = [(60, 8, 0.10), (120, 5, 0.08)]
+    for kw in (dict(only_unit=1), dict(min_len=70), dict(only_longest=1), dict(min_copy=4), dict(out_fmt=3), dict(min_cov=3, out_fmt=4)):
+        th = TH.TideHunter(lib_path=emu, **kw)
+        seqs = _reads(th.lib, spec)
+        para = O.default_para(**kw)
+        U.assert_records_equal(seqs, th.process(seqs), para, str(kw))
+        th.close()
+
+
+def test_emul_bridging_alignment_sparse_anchors(emu):
+    """large k makes anchors sparse, so the partition walk has to bridge gaps with the DP engine"""
+    th = TH.TideHunter(lib_path=emu, k=12)
+    seqs = _reads(th.lib, [(150, 5, 0.12), (150, 5, 0.15)], seed=5)
+    para = O.default_para(k=12)
+    got = th.process(seqs)
+    U.stage_compare(th, seqs, para)
+    U.assert_records_equal(seqs, got, para, "k12")
+    th.close()
+
+
+def test_emul_adapters_full_length(emu):
+    ad = (os.path.join(U.DATA, "5prime.fa"), os.path.join(U.DATA, "3prime.fa"))
+    five = U.read_fastx(ad[0])[0][1]; three = U.read_fastx(ad[1])[0][1]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    rng = np.random.default_rng(3)
+    ins = bytes(b"ACGT"[i] for i in rng.integers(0, 4, 70))
+    unit = five + ins + three.translate(comp)[::-1]
+    read = unit * 4
+    th = TH.TideHunter(lib_path=emu, adapters=ad)
+    para = O.default_para()
+    O.load().tho_para_load_adapters(para, ad[0].encode(), ad[1].encode())
+    got = th.process([read])
+    assert got[0] and got[0][0]["full_length"] == 1 and got[0][0]["seq"] == ins
+    U.assert_records_equal([read], got, para, "adapters")
+    th.close()
+
+
+def test_refuses_unimplemented_modes(emu):
+    for kw in (dict(w=5), dict(hpc=1)):
+        with pytest.raises(RuntimeError):
+            TH.TideHunter(lib_path=emu, **kw)

@@ -1,0 +1,121 @@
+"""GPU parity proper: the HIP path (tidehunter_amd/libtidehunter_amd.so, through the C-ABI) against the
+CPU oracle on the same inputs.  Bit-exact: consensus strings, every integer field, and the doubles
+(which both sides compute with the same expressions from the same integers).  For everything POA
+touches the claim is "GPU == oracle/tho_poa.c", not "== reference" (abPOA is absent)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import th_util as U
+import tidehunter_amd as TH
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def th():
+    t = TH.TideHunter(device=0)
+    yield t
+    t.close()
+
+
+def _synth(lib, n, period, copies, err, seed):
+    return [TH.synth_read(lib, seed, i, period, copies, err) for i in range(n)]
+
+
+def test_gpu_readme_line_222(th):
+    seq = U.read_fastx(os.path.join(U.DATA, "test_50x4.fa"))[0][1]
+    (recs,) = th.process([seq])
+    r = recs[0]
+    assert r["seq"] == b"CGATCGATCGGCATGCATGCATGCTAGTCGATGCATCGGGATCAGCTAGT"
+    assert (r["start"] + 1, r["end"] + 1, r["cons_len"], r["full_length"]) == (51, 250, 50, 0)
+    assert "%.1f %.1f" % (r["copy_num"], r["ave_match"]) == "4.0 100.0"
+    assert [p + 2 for p in r["sub_pos"][:-1]] + [r["sub_pos"][-1] + 1] == [59, 109, 159, 208]
+
+
+def test_gpu_reference_test_data(th):
+    para = O.default_para()
+    seqs = [U.read_fastx(os.path.join(U.DATA, f))[0][1] for f in ("test_50x4.fa", "test_1000x10.fa", "full_length.fa")]
+    got = th.process(seqs)
+    U.stage_compare(th, seqs, para)
+    assert U.assert_records_equal(seqs, got, para, "test_data") >= 3
+
+
+def test_gpu_test_fq_real_reads(th):
+    para = O.default_para()
+    seqs = [s for _, s in U.read_fastx(os.path.join(U.DATA, "test.fq"))]
+    assert len(seqs) == 100
+    got = th.process(seqs)
+    U.stage_compare(th, seqs, para)
+    assert U.assert_records_equal(seqs, got, para, "test.fq") == 57     # 57 groups
+
+
+@pytest.mark.parametrize("period,copies,err,n,seed", [
+    (200, 20, 0.10, 40, 2),      # config 2 shape: short period, chain-dominated
+    (1000, 10, 0.10, 24, 1),     # config 3 shape (headline)
+    (5000, 4, 0.15, 4, 3),       # config 4 shape: long period, wide POA band, 5000^2 alignments
+    (50, 30, 0.05, 16, 9),
+])
+def test_gpu_synthetic_configs(th, period, copies, err, n, seed):
+    para = O.default_para()
+    seqs = _synth(th.lib, n, period, copies, err, seed)
+    got = th.process(seqs)
+    U.stage_compare(th, seqs, para)
+    assert U.assert_records_equal(seqs, got, para, "p%d" % period) >= n // 2
+
+
+def test_gpu_ragged_and_degenerate_inputs(th):
+    para = O.default_para()
+    rng = np.random.default_rng(0)
+    seqs = [b"", b"ACG", b"ACGTACGT", b"A" * 5000, b"AC" * 3000, b"ACGTNNNNACGT" * 50,
+            bytes(b"ACGT"[i] for i in rng.integers(0, 4, 3000)),          # no repeat at all
+            b"acgtnacgt-acgt" * 40]
+    seqs += _synth(th.lib, 3, 300, 6, 0.1, 4)
+    got = th.process(seqs)
+    U.stage_compare(th, seqs, para)
+    U.assert_records_equal(seqs, got, para, "ragged")
+
+
+def test_gpu_options(th):
+    seqs = _synth(th.lib, 6, 150, 8, 0.1, 21)
+    for kw in (dict(only_unit=1), dict(min_len=160), dict(only_longest=1), dict(min_copy=5), dict(out_fmt=3),
+               dict(min_cov=4, out_fmt=4), dict(k=12), dict(max_div=0.05), dict(min_p=200), dict(max_p=100)):
+        t = TH.TideHunter(device=0, **kw)
+        U.assert_records_equal(seqs, t.process(seqs), O.default_para(**kw), str(kw))
+        t.close()
+
+
+def test_gpu_adapters_full_length(th):
+    ad = (os.path.join(U.DATA, "5prime.fa"), os.path.join(U.DATA, "3prime.fa"))
+    para = O.default_para()
+    O.load().tho_para_load_adapters(para, ad[0].encode(), ad[1].encode())
+    seq = U.read_fastx(os.path.join(U.DATA, "full_length.fa"))[0][1]
+    t = TH.TideHunter(device=0, adapters=ad)
+    got = t.process([seq])
+    assert got[0][0]["full_length"] == 1 and got[0][0]["start"] + 1 == 31 and got[0][0]["end"] + 1 == 5215
+    U.assert_records_equal([seq], got, para, "full_length")
+    t.close()
+
+
+def test_gpu_batch_order_and_idempotence(th):
+    """results do not depend on what else is in the batch or on running it twice"""
+    seqs = _synth(th.lib, 12, 250, 6, 0.1, 33)
+    a = th.process(seqs)
+    b = th.process(seqs[::-1])[::-1]
+    c = th.process(seqs)
+    assert a == b == c
+
+
+def test_gpu_headline_shape_properties(th):
+    """size-independent properties at the headline read shape: every read yields one consensus of
+    roughly one period, spanning nearly the whole read, with ~10 copies"""
+    seqs = _synth(th.lib, 64, 1000, 10, 0.10, 1)
+    got = th.process(seqs)
+    one = [r for r in got if len(r) >= 1]
+    assert len(one) >= 60
+    for recs in one:
+        r = max(recs, key=lambda x: x["end"] - x["start"])
+        assert 900 <= r["cons_len"] <= 1100 and r["end"] - r["start"] > 8000 and 8.5 <= r["copy_num"] <= 11.5
+        assert r["ave_match"] > 80.0

@@ -1,0 +1,89 @@
+"""Shared helpers for the parity tests (CPU emulation and GPU)."""
+import os
+import subprocess
+
+import numpy as np
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DATA = os.path.join(ROOT, "tests", "golden", "data")
+EMUL_SO = os.path.join(ROOT, "tests", "cpu_emul", "libth_emul.so")
+
+
+def emul_lib_path():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpu_emul")], check=True, stdout=subprocess.DEVNULL)
+    return EMUL_SO
+
+
+def read_fastx(path):
+    """tiny FASTA/FASTQ reader for test inputs -> list of (name, seq bytes)"""
+    out, name, seq, fq = [], None, [], False
+    lines = open(path, "rb").read().split(b"\n")
+    i = 0
+    while i < len(lines):
+        l = lines[i].rstrip(b"\r")
+        if l.startswith(b">"):
+            if name is not None:
+                out.append((name, b"".join(seq)))
+            name, seq = l[1:].split()[0], []
+        elif l.startswith(b"@") and i + 3 < len(lines) and lines[i + 2].startswith(b"+"):
+            if name is not None:
+                out.append((name, b"".join(seq)))
+            out.append((l[1:].split()[0], lines[i + 1].rstrip(b"\r")))
+            name, seq = None, []
+            i += 3
+        elif l:
+            seq.append(l)
+        i += 1
+    if name is not None:
+        out.append((name, b"".join(seq)))
+    return out
+
+
+def assert_records_equal(seqs, got, para, label=""):
+    """got: TideHunter.process() output; compared field by field with the oracle's tho_core()."""
+    n = 0
+    for idx, (s, recs) in enumerate(zip(seqs, got)):
+        exp = O.core(s, para)
+        assert len(exp) == len(recs), "%s read %d: %d records, oracle %d" % (label, idx, len(recs), len(exp))
+        for a, b in zip(exp, recs):
+            assert a["sub_pos"] == b["sub_pos"], (label, idx)
+            if para.only_unit:
+                continue
+            assert a["seq"] == b["seq"], (label, idx, a["seq"], b["seq"])
+            assert (a["start"], a["end"], a["cons_len"], a["full_length"]) == (b["start"], b["end"], b["cons_len"], b["full_length"]), (label, idx)
+            # doubles come from the same integer evidence and the same expressions: bit-identical
+            assert a["copy_num"] == b["copy_num"] and a["ave_match"] == b["ave_match"], (label, idx)
+            if a["qual"] is not None or b["qual"] is not None:
+                assert a["qual"] == b["qual"], (label, idx)
+            n += 1
+    return n
+
+
+def stage_compare(th, seqs, para):
+    """hits / chain DP / chains / par_pos of the resident batch against the oracle's stage dumps."""
+    T = sum(len(s) for s in seqs)
+    roff = th.debug_stage(8, 4 * (len(seqs) + 1), np.uint32)
+    hn = th.debug_stage(1, 4 * len(seqs), np.int32)
+    he, hp = th.debug_stage(2, 4 * T, np.int32), th.debug_stage(3, 4 * T, np.int32)
+    sc, fr = th.debug_stage(4, 4 * T, np.int32), th.debug_stage(5, 4 * T, np.int32)
+    rec = th.debug_stage(6, 32 * (8 * len(seqs) + 4096), np.int32).reshape(-1, 8)
+    cells = th.debug_stage(7, 4 * T, np.int32)
+    parc = th.debug_stage(9, 8 * T + 1024, np.int32)
+    bseq = th.debug_stage(0, T, np.uint8)
+    for r, s in enumerate(seqs):
+        st = O.stages(s, para)
+        o, n = int(roff[r]), int(hn[r])
+        assert np.array_equal(bseq[o:o + len(s)], st["bseq"]), r
+        hits = (he[o:o + n].astype(np.uint64) << np.uint64(32)) | hp[o:o + n].astype(np.uint64)
+        assert np.array_equal(hits, st["hits"]), "hits differ, read %d" % r
+        if n >= 2:
+            assert np.array_equal(sc[o:o + n], st["score"]), "chain scores differ, read %d" % r
+            assert np.array_equal(fr[o:o + n], st["frm"]), "chain predecessors differ, read %d" % r
+        mine = [x for x in rec if x[0] == r]
+        assert len(mine) == len(st["chains"]), "chain count differs, read %d" % r
+        for m, c in zip(mine, st["chains"]):
+            assert list(cells[m[1]:m[1] + m[2]]) == c["cells"], r
+            assert (m[3], m[4]) == (c["est_start"], c["est_period"]), r
+            assert list(parc[m[5]:m[5] + m[6]]) == c["par_pos"], "par_pos differs, read %d" % r

@@ -1,0 +1,177 @@
+"""tidehunter_amd -- Python binding (ctypes) of the MI355X-native TideHunter hot path.
+
+The compute lives in tidehunter_amd/libtidehunter_amd.so (hand-written HIP for gfx950 behind the
+C-ABI of include/tidehunter_amd.h).  This module is plumbing: it loads the library, mirrors the
+parameter/result structs and exposes the batch seam.  There is no CPU fallback: if the HIP library
+is missing or no GPU is present, calls raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtidehunter_amd.so")
+
+
+class Para(C.Structure):
+    """th_para_t == mini_tandem_para (src/tidehunter.h:47-61)"""
+    _fields_ = [("k", C.c_int64), ("w", C.c_int64), ("hpc", C.c_int), ("min_copy", C.c_int), ("min_cov", C.c_int),
+                ("max_div", C.c_double), ("div_exp", C.c_double), ("min_frac", C.c_double),
+                ("min_p", C.c_int64), ("max_p", C.c_int64), ("max_range", C.c_int64),
+                ("match", C.c_int), ("mismatch", C.c_int), ("gap_open1", C.c_int), ("gap_open2", C.c_int),
+                ("gap_ext1", C.c_int), ("gap_ext2", C.c_int), ("ada_match_rat", C.c_float),
+                ("five_fn", C.c_void_p), ("five_seq", C.c_void_p), ("five_rc_seq", C.c_void_p), ("five_len", C.c_int),
+                ("three_fn", C.c_void_p), ("three_seq", C.c_void_p), ("three_rc_seq", C.c_void_p), ("three_len", C.c_int),
+                ("out_fmt", C.c_int), ("min_len", C.c_int), ("only_unit", C.c_int), ("only_longest", C.c_int),
+                ("only_full_length", C.c_int), ("single_copy", C.c_int), ("n_thread", C.c_int)]
+
+
+class TandemSeq(C.Structure):
+    """th_tandem_seq_t == tandem_seq_t (src/tidehunter.h:63-72)"""
+    _fields_ = [("cons_seq", C.POINTER(C.c_char)), ("cons_seq_l", C.c_size_t), ("cons_seq_m", C.c_size_t),
+                ("cons_qual", C.POINTER(C.c_char)), ("cons_qual_l", C.c_size_t), ("cons_qual_m", C.c_size_t),
+                ("cons_n", C.c_int), ("cons_m", C.c_int),
+                ("cons_start", C.POINTER(C.c_int)), ("cons_end", C.POINTER(C.c_int)), ("cons_len", C.POINTER(C.c_int)),
+                ("copy_num", C.POINTER(C.c_double)), ("ave_match", C.POINTER(C.c_double)),
+                ("full_length", C.POINTER(C.c_int8)),
+                ("sub_pos", C.POINTER(C.POINTER(C.c_int))), ("pos_n", C.POINTER(C.c_int)), ("pos_m", C.POINTER(C.c_int)),
+                ("cons_score", C.POINTER(C.c_int))]
+
+
+def load_library(path=None):
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError("tidehunter_amd: %s is missing -- build it with __graft_entry__.build() "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    lib.th_init_para.restype = C.POINTER(Para)
+    lib.th_free_para.argtypes = [C.POINTER(Para)]
+    lib.th_load_adapters.argtypes = [C.POINTER(Para)]
+    lib.th_alloc_tandem_seq.argtypes = [C.c_int]
+    lib.th_alloc_tandem_seq.restype = C.POINTER(TandemSeq)
+    lib.th_free_tandem_seq.argtypes = [C.POINTER(TandemSeq), C.c_int]
+    lib.th_init.argtypes = [C.POINTER(Para), C.c_int]
+    lib.th_init.restype = C.c_void_p
+    lib.th_destroy.argtypes = [C.c_void_p]
+    pp, ip = C.POINTER(C.c_char_p), C.POINTER(C.c_int)
+    lib.th_process_batch.argtypes = [C.c_void_p, pp, ip, C.c_int, C.POINTER(TandemSeq)]
+    lib.th_batch_upload.argtypes = [C.c_void_p, pp, ip, C.c_int]
+    lib.th_batch_run.argtypes = [C.c_void_p]
+    lib.th_batch_collect.argtypes = [C.c_void_p, C.POINTER(TandemSeq)]
+    lib.th_batch_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.th_run_file.argtypes = [C.c_char_p, C.POINTER(Para), C.c_void_p, C.c_int, C.c_int]
+    lib.th_synth_read.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_char_p, C.c_int]
+    lib.th_last_error.restype = C.c_char_p
+    lib.th_version.restype = C.c_char_p
+    lib.th_debug_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]
+    lib.th_debug_stage.restype = C.c_longlong
+    return lib
+
+
+class TideHunter:
+    """One handle = one GPU.  Mirrors the reference's per-chunk call surface (src/main.c:402-425)."""
+
+    def __init__(self, device=0, lib_path=None, adapters=None, **para):
+        self.lib = load_library(lib_path)
+        self._c = C.CDLL(None)
+        self._c.strdup.restype = C.c_void_p
+        self._c.strdup.argtypes = [C.c_char_p]
+        self.para = self.lib.th_init_para()
+        for k, v in para.items():
+            setattr(self.para.contents, k, v)
+        if adapters is not None:
+            self.para.contents.five_fn = self._c.strdup(os.fsencode(adapters[0]))
+            self.para.contents.three_fn = self._c.strdup(os.fsencode(adapters[1]))
+            if self.lib.th_load_adapters(self.para) != 0:
+                raise RuntimeError(self.lib.th_last_error().decode())
+        self.h = self.lib.th_init(self.para, device)
+        if not self.h:
+            raise RuntimeError("tidehunter_amd: " + self.lib.th_last_error().decode())
+        self._n = 0
+        self._ts = None
+        self._ts_n = 0
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.th_destroy(self.h)
+            self.h = None
+        if self._ts is not None:
+            self.lib.th_free_tandem_seq(self._ts, self._ts_n)
+            self._ts = None
+        if getattr(self, "para", None):
+            self.lib.th_free_para(self.para)
+            self.para = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("tidehunter_amd: " + self.lib.th_last_error().decode())
+
+    def upload(self, seqs):
+        n = len(seqs)
+        arr = (C.c_char_p * n)(*seqs)
+        lens = (C.c_int * n)(*[len(s) for s in seqs])
+        self._keep = (arr, lens, seqs)
+        self._n = n
+        if self._ts is None or self._ts_n < n:
+            if self._ts is not None:
+                self.lib.th_free_tandem_seq(self._ts, self._ts_n)
+            self._ts = self.lib.th_alloc_tandem_seq(max(n, 1))
+            self._ts_n = max(n, 1)
+        self._check(self.lib.th_batch_upload(self.h, arr, lens, n))
+
+    def run(self):
+        self._check(self.lib.th_batch_run(self.h))
+
+    def collect(self):
+        self._check(self.lib.th_batch_collect(self.h, self._ts))
+        return [self._records(i) for i in range(self._n)]
+
+    def timing(self):
+        a, d = C.c_double(), C.c_double()
+        self.lib.th_batch_timing(self.h, C.byref(a), C.byref(d))
+        return a.value, d.value
+
+    def process(self, seqs):
+        """tidehunter_core() on every read of the batch; returns a list (per read) of record dicts."""
+        self.upload(seqs)
+        self.run()
+        return self.collect()
+
+    def _records(self, i):
+        t = self._ts[i]
+        out, cs = [], 0
+        only_unit = self.para.contents.only_unit
+        for c in range(t.cons_n):
+            sub = [t.sub_pos[c][j] for j in range(t.pos_n[c])]
+            if only_unit:
+                out.append(dict(sub_pos=sub))
+                continue
+            L = t.cons_len[c]
+            seq = C.string_at(C.addressof(t.cons_seq.contents) + cs, L)
+            qual = C.string_at(C.addressof(t.cons_qual.contents) + cs, L) if t.cons_qual and t.cons_qual_l >= cs + L else None
+            out.append(dict(seq=seq, qual=qual, cons_len=L, start=t.cons_start[c], end=t.cons_end[c], copy_num=t.copy_num[c],
+                            ave_match=t.ave_match[c], full_length=int(t.full_length[c]), sub_pos=sub))
+            cs += L
+        return out
+
+    def debug_stage(self, what, nbytes, dtype):
+        import numpy as np
+        buf = np.zeros(max(1, nbytes // np.dtype(dtype).itemsize + 8), dtype=dtype)
+        got = self.lib.th_debug_stage(self.h, what, buf.ctypes.data_as(C.c_void_p), buf.nbytes)
+        if got < 0:
+            raise RuntimeError("debug_stage(%d) failed" % what)
+        return buf[: got // np.dtype(dtype).itemsize]
+
+
+def synth_read(lib, seed, index, period, copies, err):
+    cap = int(period * copies * (1 + err) + 64) + period
+    buf = C.create_string_buffer(cap)
+    n = lib.th_synth_read(seed, index, period, copies, err, buf, cap)
+    assert n <= cap
+    return buf.raw[:n]

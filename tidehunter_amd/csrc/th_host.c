@@ -1,0 +1,575 @@
+/*
+ * th_host.c -- C host layer of the MI355X TideHunter hot path: parameters, the batch seam, the
+ * floating-point record arithmetic the reference keeps on the host, adapter search, output
+ * formatting and the whole-file driver.  All device work is behind th_internal.h.
+ *
+ * Mirrors (same names, argument meaning, error behaviour where a library can):
+ *   mini_tandem_init_para / mini_tandem                      src/main.c:329-364, :375-436
+ *   seqs_msa (host part) / write_tandem_cons_seq / _unit      src/gen_cons.c:10-83, :173-301
+ *   abpoa_gen_cons (host part: min-cov filter, Phred)         src/abpoa_cons.c:49-108
+ *   single_copy_full_len_seq / collect_ed_res                 src/gen_cons.c:89-171
+ *   edlib_align_HW                                            src/edlib_align.c:73-85
+ *   mini_tandem_output                                        src/main.c:214-271
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <limits.h>
+#include <ctype.h>
+#include <zlib.h>
+#include "tidehunter_amd.h"
+#include "th_internal.h"
+
+static char g_err[512];
+const char *th_last_error(void) { return g_err[0] ? g_err : th_gpu_error(); }
+const char *th_version(void) { return "1.5.5-mi355x.r1"; }
+static int host_fail(const char *m) { snprintf(g_err, sizeof(g_err), "%s", m); fprintf(stderr, "[tidehunter_amd] %s\n", m); return -1; }
+
+struct th_handle {
+    th_para_t para;              /* snapshot (adapter strings are borrowed from the caller's th_para_t) */
+    th_gpu_t *gpu;
+    int n; const char *const *seqs; const int *lens;   /* the resident batch (borrowed until collect) */
+};
+
+/* ---------------------------------------------------------------- parameters */
+th_para_t *th_init_para(void)
+{
+    th_para_t *p = (th_para_t *)calloc(1, sizeof(th_para_t));
+    p->n_thread = 4; p->ada_match_rat = 0.8f;
+    p->k = 8; p->w = 1; p->hpc = 0; p->min_copy = 2; p->max_div = 0.25; p->div_exp = exp(2 * 8 * 0.25);
+    p->min_p = 30; p->max_p = 10000; p->min_cov = 0; p->min_frac = 0.0;
+    p->match = 2; p->mismatch = 4; p->gap_open1 = 4; p->gap_open2 = 24; p->gap_ext1 = 2; p->gap_ext2 = 1;
+    p->min_len = 30; p->out_fmt = TH_FASTA_FMT; p->max_range = -1;
+    return p;
+}
+void th_free_para(th_para_t *p)
+{
+    if (!p) return;
+    free(p->five_fn); free(p->five_seq); free(p->five_rc_seq); free(p->three_fn); free(p->three_seq); free(p->three_rc_seq);
+    free(p);
+}
+
+/* ---------------------------------------------------------------- FASTA/FASTQ(.gz) reader (kseq grammar, src/kseq.h:176-215) */
+typedef struct { gzFile fp; unsigned char *buf; int beg, end, eof, last; } th_reader_t;
+typedef struct { char *s; size_t l, m; } th_str_t;
+static void str_putc(th_str_t *s, int c)
+{
+    if (s->l + 2 > s->m) { s->m = s->m ? s->m * 2 : 256; s->s = (char *)realloc(s->s, s->m); }
+    s->s[s->l++] = (char)c; s->s[s->l] = 0;
+}
+static int rd_getc(th_reader_t *r)
+{
+    if (r->beg >= r->end) {
+        if (r->eof) return -1;
+        r->beg = 0; r->end = gzread(r->fp, r->buf, 1 << 18);
+        if (r->end <= 0) { r->eof = 1; r->end = 0; return -1; }
+    }
+    return r->buf[r->beg++];
+}
+static th_reader_t *rd_open(const char *fn)
+{
+    gzFile fp = strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(0, "r");
+    if (!fp) return NULL;
+    th_reader_t *r = (th_reader_t *)calloc(1, sizeof(*r));
+    r->fp = fp; r->buf = (unsigned char *)malloc(1 << 18);
+    return r;
+}
+static void rd_close(th_reader_t *r) { if (r) { gzclose(r->fp); free(r->buf); free(r); } }
+/* 1 = record read (name/seq malloc'd), 0 = end of file */
+static int rd_next(th_reader_t *r, char **name, char **seq, int *len)
+{
+    int c;
+    if (r->last == 0) {
+        while ((c = rd_getc(r)) != -1 && c != '>' && c != '@') {}
+        if (c == -1) return 0;
+        r->last = c;
+    }
+    th_str_t nm = { 0, 0, 0 }, sq = { 0, 0, 0 };
+    str_putc(&nm, 0); nm.l = 0; str_putc(&sq, 0); sq.l = 0;
+    while ((c = rd_getc(r)) != -1 && !isspace(c)) str_putc(&nm, c);
+    if (c != '\n' && c != -1) while ((c = rd_getc(r)) != -1 && c != '\n') {}
+    while ((c = rd_getc(r)) != -1 && c != '>' && c != '+' && c != '@') {
+        if (c == '\n') continue;
+        str_putc(&sq, c);
+        int d;
+        while ((d = rd_getc(r)) != -1 && d != '\n') str_putc(&sq, d);
+        if (sq.l > 1 && sq.s[sq.l - 1] == '\r') sq.s[--sq.l] = 0;
+    }
+    r->last = (c == '>' || c == '@') ? c : 0;
+    if (c == '+') {
+        while ((c = rd_getc(r)) != -1 && c != '\n') {}
+        size_t ql = 0;
+        while (ql < sq.l && (c = rd_getc(r)) != -1) if (c != '\n') ++ql;
+        r->last = 0;
+    }
+    *name = nm.s; *seq = sq.s; *len = (int)sq.l;
+    return 1;
+}
+
+static char *rc_seq(const char *s, int len)   /* get_rc_seq, src/seq.c:88-95 */
+{
+    char *rc = (char *)malloc((size_t)len + 1);
+    for (int i = 0; i < len; ++i) {
+        char c = s[i], o = 'N';
+        switch (c) {
+        case 'A': case 'a': case 0: o = 'T'; break;
+        case 'C': case 'c': case 1: o = 'G'; break;
+        case 'G': case 'g': case 2: o = 'C'; break;
+        case 'T': case 't': case 3: o = 'A'; break;
+        default: o = 'N';
+        }
+        rc[len - 1 - i] = o;
+    }
+    rc[len] = 0;
+    return rc;
+}
+
+static int load_first_seq(const char *fn, char **seq)
+{
+    th_reader_t *r = rd_open(fn);
+    if (!r) { char m[300]; snprintf(m, sizeof(m), "fail to open file '%s'", fn); host_fail(m); return -1; }
+    char *nm = NULL, *sq = NULL; int len = 0;
+    if (rd_next(r, &nm, &sq, &len) && len > 0) { *seq = sq; free(nm); }
+    else { fprintf(stderr, "[get_seq_from_fx] No sequence found.\n"); free(nm); free(sq); len = 0; }
+    rd_close(r);
+    return len;
+}
+
+int th_load_adapters(th_para_t *p)
+{
+    if (!p->five_fn || !p->three_fn) return 0;
+    if ((p->five_len = load_first_seq(p->five_fn, &p->five_seq)) < 0) return -1;
+    p->five_rc_seq = rc_seq(p->five_seq ? p->five_seq : "", p->five_len);
+    if ((p->three_len = load_first_seq(p->three_fn, &p->three_seq)) < 0) return -1;
+    p->three_rc_seq = rc_seq(p->three_seq ? p->three_seq : "", p->three_len);
+    return 0;
+}
+
+/* ---------------------------------------------------------------- tandem_seq_t */
+th_tandem_seq_t *th_alloc_tandem_seq(int n)
+{
+    th_tandem_seq_t *t = (th_tandem_seq_t *)calloc((size_t)n, sizeof(th_tandem_seq_t));
+    for (int i = 0; i < n; ++i) {
+        t[i].cons_m = 1;
+        t[i].cons_start = (int *)malloc(sizeof(int)); t[i].cons_end = (int *)malloc(sizeof(int)); t[i].cons_len = (int *)malloc(sizeof(int));
+        t[i].copy_num = (double *)malloc(sizeof(double)); t[i].ave_match = (double *)malloc(sizeof(double));
+        t[i].full_length = (int8_t *)malloc(1); t[i].cons_score = (int *)malloc(sizeof(int));
+        t[i].pos_n = (int *)calloc(1, sizeof(int)); t[i].pos_m = (int *)calloc(1, sizeof(int)); t[i].sub_pos = (int **)calloc(1, sizeof(int *));
+    }
+    return t;
+}
+void th_free_tandem_seq(th_tandem_seq_t *t, int n)
+{
+    if (!t) return;
+    for (int i = 0; i < n; ++i) {
+        free(t[i].cons_seq); free(t[i].cons_qual); free(t[i].cons_start); free(t[i].cons_end); free(t[i].cons_len);
+        free(t[i].copy_num); free(t[i].ave_match); free(t[i].full_length); free(t[i].cons_score); free(t[i].pos_n); free(t[i].pos_m);
+        for (int j = 0; j < t[i].cons_m; ++j) free(t[i].sub_pos[j]);
+        free(t[i].sub_pos);
+    }
+    free(t);
+}
+static void tseq_grow(th_tandem_seq_t *t)
+{
+    if (t->cons_n < t->cons_m) return;
+    int old = t->cons_m; t->cons_m <<= 1;
+    t->cons_start = (int *)realloc(t->cons_start, t->cons_m * sizeof(int)); t->cons_end = (int *)realloc(t->cons_end, t->cons_m * sizeof(int));
+    t->copy_num = (double *)realloc(t->copy_num, t->cons_m * sizeof(double)); t->ave_match = (double *)realloc(t->ave_match, t->cons_m * sizeof(double));
+    t->full_length = (int8_t *)realloc(t->full_length, t->cons_m); t->cons_len = (int *)realloc(t->cons_len, t->cons_m * sizeof(int));
+    t->cons_score = (int *)realloc(t->cons_score, t->cons_m * sizeof(int)); t->sub_pos = (int **)realloc(t->sub_pos, t->cons_m * sizeof(int *));
+    t->pos_n = (int *)realloc(t->pos_n, t->cons_m * sizeof(int)); t->pos_m = (int *)realloc(t->pos_m, t->cons_m * sizeof(int));
+    for (int i = old; i < t->cons_m; ++i) { t->pos_m[i] = 0; t->pos_n[i] = 0; t->sub_pos[i] = NULL; }
+}
+static void tseq_set_pos(th_tandem_seq_t *t, const int *pos, int pos_n)
+{
+    int c = t->cons_n;
+    t->pos_n[c] = pos_n;
+    if (pos_n > t->pos_m[c]) { t->pos_m[c] = pos_n; t->sub_pos[c] = (int *)realloc(t->sub_pos[c], pos_n * sizeof(int)); }
+    for (int i = 0; i < pos_n; ++i) t->sub_pos[c][i] = pos[i];
+}
+/* write_tandem_cons_seq, src/gen_cons.c:10-62.  (Unlike the reference, the quality buffer is rewound
+ * together with the sequence buffer: see DESIGN.md "reference bugs not mirrored".) */
+static void write_cons(th_tandem_seq_t *t, const char *seq, const uint8_t *qual, int cons_len, int start, int end, double copy_num,
+                       double ave_match, const th_para_t *p, int full_length, const int *pos, int pos_n)
+{
+    if (cons_len < p->min_len || cons_len > p->max_p) return;
+    if (p->only_longest && t->cons_n == 1) {
+        if (end - start > t->cons_end[0] - t->cons_start[0]) { t->cons_n = 0; t->cons_seq_l = 0; t->cons_qual_l = 0; }
+        else return;
+    }
+    if (t->cons_seq_l + cons_len >= t->cons_seq_m) { t->cons_seq_m = t->cons_seq_l + cons_len + 1; t->cons_seq = (char *)realloc(t->cons_seq, t->cons_seq_m); }
+    memcpy(t->cons_seq + t->cons_seq_l, seq, cons_len); t->cons_seq_l += cons_len;
+    if (qual) {
+        if (t->cons_qual_l + cons_len >= t->cons_qual_m) { t->cons_qual_m = t->cons_qual_l + cons_len + 1; t->cons_qual = (char *)realloc(t->cons_qual, t->cons_qual_m); }
+        memcpy(t->cons_qual + t->cons_qual_l, qual, cons_len); t->cons_qual_l += cons_len;
+    }
+    tseq_grow(t);
+    int c = t->cons_n;
+    t->cons_start[c] = start; t->cons_end[c] = end; t->copy_num[c] = copy_num; t->full_length[c] = (int8_t)full_length;
+    t->cons_len[c] = cons_len; t->ave_match[c] = ave_match;
+    tseq_set_pos(t, pos, pos_n);
+    ++t->cons_n;
+}
+static void write_unit(th_tandem_seq_t *t, const int *pos, int pos_n) { tseq_grow(t); tseq_set_pos(t, pos, pos_n); ++t->cons_n; }   /* src/gen_cons.c:64-83 */
+
+/* ---------------------------------------------------------------- edlib HW/LOC: Myers' block bit-vector, own implementation */
+static int eq_char(char a, char b)   /* byte equality + a/A c/C g/G t/T n/N (src/edlib_align.c:21-27) */
+{
+    if (a == b) return 1;
+    if ((a ^ b) != 0x20) return 0;
+    char x = a | 0x20;
+    return x == 'a' || x == 'c' || x == 'g' || x == 't' || x == 'n';
+}
+/* One pass of Myers' algorithm over `t` (read with stride ts), query bits precomputed per text byte.
+ * hw: 1 = infix (free leading text), 0 = prefix (SHW).  Calls back per column with the score. */
+typedef struct { int nb, m; uint64_t *peq; /* [256][nb] */ } myers_t;
+static myers_t *myers_build(const char *q, int qs, int m)
+{
+    myers_t *my = (myers_t *)calloc(1, sizeof(*my));
+    my->m = m; my->nb = (m + 63) / 64;
+    my->peq = (uint64_t *)calloc((size_t)256 * my->nb, sizeof(uint64_t));
+    for (int c = 0; c < 256; ++c)
+        for (int i = 0; i < m; ++i)
+            if (eq_char(q[(long)i * qs], (char)c)) my->peq[(size_t)c * my->nb + i / 64] |= 1ull << (i & 63);
+    return my;
+}
+static void myers_free(myers_t *my) { free(my->peq); free(my); }
+/* returns scores per column in sc[0..n) */
+static void myers_run(const myers_t *my, const char *t, int ts, int n, int hw, int *sc)
+{
+    int nb = my->nb, m = my->m, lastbit = (m - 1) & 63, score = m;
+    uint64_t *Pv = (uint64_t *)malloc(sizeof(uint64_t) * nb * 2), *Mv = Pv + nb;
+    for (int b = 0; b < nb; ++b) { Pv[b] = ~0ull; Mv[b] = 0; }
+    for (int c = 0; c < n; ++c) {
+        const uint64_t *peq = my->peq + (size_t)(unsigned char)t[(long)c * ts] * nb;
+        int hin = hw ? 0 : 1;
+        for (int b = 0; b < nb; ++b) {
+            uint64_t Eq = peq[b], pv = Pv[b], mv = Mv[b];
+            uint64_t Xv = Eq | mv;
+            if (hin < 0) Eq |= 1;
+            uint64_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+            uint64_t Ph = mv | ~(Xh | pv), Mh = pv & Xh;
+            int hout;
+            if (b == nb - 1) { hout = (int)((Ph >> lastbit) & 1) - (int)((Mh >> lastbit) & 1); score += hout; }
+            else hout = (int)(Ph >> 63) - (int)(Mh >> 63);
+            Ph <<= 1; Mh <<= 1;
+            if (hin < 0) Mh |= 1; else if (hin > 0) Ph |= 1;
+            Pv[b] = Mh | ~(Xv | Ph); Mv[b] = Ph & Xv;
+            hin = hout;
+        }
+        sc[c] = score;
+    }
+    free(Pv);
+}
+/* edlib_align_HW: distance, first best end, and edlib's start for it; -1 if the distance exceeds k */
+static int edlib_hw(const char *q, int qlen, const char *t, int tlen, int *start, int *end, int k)
+{
+    if (qlen <= 0 || tlen <= 0) return -1;
+    int *sc = (int *)malloc(sizeof(int) * (size_t)tlen);
+    myers_t *my = myers_build(q, 1, qlen);
+    myers_run(my, t, 1, tlen, 1, sc);
+    myers_free(my);
+    int best = sc[0], be = 0;
+    for (int c = 1; c < tlen; ++c) if (sc[c] < best) { best = sc[c]; be = c; }
+    if (k >= 0 && best > (k < qlen ? k : qlen)) { free(sc); return -1; }
+    if (best >= qlen && (64 - qlen % 64) % 64 > 0) { *start = 0; *end = -1; free(sc); return qlen; }   /* edlib's "position -1" */
+    /* start: reversed query against the reversed target prefix, prefix mode, last best column */
+    my = myers_build(q + qlen - 1, -1, qlen);
+    myers_run(my, t + be, -1, be + 1, 0, sc);
+    myers_free(my);
+    int last_p = -1;
+    for (int c = 0; c <= be; ++c) if (sc[c] == best) last_p = c;
+    free(sc);
+    *end = be; *start = be - last_p;
+    return best;
+}
+
+/* ---------------------------------------------------------------- batch seam */
+th_handle_t *th_init(const th_para_t *p, int device)
+{
+    g_err[0] = 0;
+    if (p->w > 1) { host_fail("-w > 1 (minimizer seeding, src/tandem_hit.c:97-157) is not implemented by the HIP path yet"); return NULL; }
+    if (p->hpc) { host_fail("-H (homopolymer-compressed k-mers, src/tandem_hit.c:46) is not implemented by the HIP path yet"); return NULL; }
+    if (p->k < 2 || p->k > 16) { host_fail("k-mer length must be in [2,16]"); return NULL; }
+    th_gpu_para_t gp; memset(&gp, 0, sizeof(gp));
+    gp.k = (int)p->k; gp.min_p = (uint32_t)p->min_p; gp.max_p = (uint32_t)p->max_p; gp.one_minus_div = 1 - p->max_div; gp.min_copy = p->min_copy;
+    gp.match = p->match; gp.mismatch = p->mismatch; gp.go1 = p->gap_open1; gp.ge1 = p->gap_ext1; gp.go2 = p->gap_open2; gp.ge2 = p->gap_ext2;
+    gp.only_unit = p->only_unit;
+    th_gpu_t *g = th_gpu_create(&gp, device);
+    if (!g) return NULL;
+    th_handle_t *h = (th_handle_t *)calloc(1, sizeof(*h));
+    h->para = *p; h->gpu = g;
+    return h;
+}
+void th_destroy(th_handle_t *h) { if (!h) return; th_gpu_destroy(h->gpu); free(h); }
+
+int th_batch_upload(th_handle_t *h, const char *const *seqs, const int *lens, int n)
+{
+    h->n = n; h->seqs = seqs; h->lens = lens;
+    return th_gpu_upload(h->gpu, seqs, lens, n);
+}
+int th_batch_run(th_handle_t *h) { return th_gpu_run(h->gpu); }
+int th_batch_timing(th_handle_t *h, double *ms_all, double *ms_dom)
+{
+    th_gpu_out_t o; th_gpu_get(h->gpu, &o);
+    if (ms_all) *ms_all = o.ms_kernels; if (ms_dom) *ms_dom = o.ms_dominant;
+    return 0;
+}
+long long th_debug_stage(th_handle_t *h, int what, void *dst, long long cap) { return th_gpu_debug(h->gpu, what, dst, cap); }
+
+typedef struct { int ed, start, end; } ed_res_t;
+static int collect_ed(const th_para_t *p, const char *q, int qlen, const char *seq, int seq_len, ed_res_t *r)   /* src/gen_cons.c:89-110 */
+{
+    int n = 0, ed, s = 0, e = 0, k = (int)(qlen * (1 - p->ada_match_rat));
+    ed = edlib_hw(q, qlen, seq, seq_len, &s, &e, k);
+    if (ed != -1) {
+        r[0].ed = ed; r[0].start = s; r[0].end = e; n = 1;
+        if (r[0].start >= qlen) { ed = edlib_hw(q, qlen, seq, r[0].start, &s, &e, k); if (ed != -1) { r[n].ed = ed; r[n].start = s; r[n].end = e; ++n; } }
+        if (r[0].end <= seq_len - qlen) {
+            ed = edlib_hw(q, qlen, seq + r[0].end, seq_len - r[0].end, &s, &e, k);
+            if (ed != -1) { r[n].ed = ed; r[n].start = r[0].end + s; r[n].end = r[0].end + e; ++n; }
+        }
+    }
+    return n;
+}
+static int full_len_pick(const th_para_t *p, int ln, const ed_res_t *l, int rn, const ed_res_t *r, int *ts, int *te)   /* :112-126 */
+{
+    int tot = INT_MAX;
+    for (int i = 0; i < ln; ++i) for (int j = 0; j < rn; ++j)
+        if (r[j].start - l[i].end - 1 >= p->min_len && tot > l[i].ed + r[j].ed) { tot = l[i].ed + r[j].ed; *ts = l[i].end + 1; *te = r[j].start - 1; }
+    return tot;
+}
+static void single_copy(int seq_len, const char *seq, th_tandem_seq_t *t, const th_para_t *p)   /* :128-171 */
+{
+    int cons_len = 0, full_length = 0, ts = -1, te = -1, tot, pos[2] = { 0, 0 };
+    ed_res_t r5[3], r3[3];
+    int n5 = collect_ed(p, p->five_seq, p->five_len, seq, seq_len, r5), n3 = collect_ed(p, p->three_rc_seq, p->three_len, seq, seq_len, r3);
+    tot = full_len_pick(p, n5, r5, n3, r3, &ts, &te);
+    if (tot != INT_MAX) { pos[0] = ts; pos[1] = te; cons_len = te - ts + 1; full_length = 1; }
+    if (tot > 0) {
+        n5 = collect_ed(p, p->five_rc_seq, p->five_len, seq, seq_len, r5); n3 = collect_ed(p, p->three_seq, p->three_len, seq, seq_len, r3);
+        if (full_len_pick(p, n3, r3, n5, r5, &ts, &te) < tot) { pos[0] = ts; pos[1] = te; cons_len = te - ts + 1; full_length = 2; }
+    }
+    if (full_length > 0) {
+        if (p->only_unit) write_unit(t, pos, 2);
+        else {
+            uint8_t *q = NULL;
+            if (p->out_fmt == TH_FASTQ_FMT || p->out_fmt == TH_TAB_QUAL_FMT) { q = (uint8_t *)malloc((size_t)cons_len + 1); memset(q, 33, cons_len); }
+            write_cons(t, seq + pos[0], q, cons_len, pos[0], pos[1], 1.0, 100.0, p, full_length, pos, 2);
+            free(q);
+        }
+    }
+}
+
+static int code_of(unsigned char c)
+{
+    switch (c) { case 0: case 'A': case 'a': return 0; case 1: case 'C': case 'c': return 1; case 2: case 'G': case 'g': return 2;
+                 case 3: case 'T': case 't': return 3; case '-': return 5; default: return 4; }
+}
+
+/* host half of seqs_msa()/abpoa_gen_cons() for one run, from the integer evidence the device produced */
+static void finish_job(const th_handle_t *h, const th_gpu_out_t *o, const th_job_t *j, th_tandem_seq_t *t)
+{
+    const th_para_t *p = &h->para;
+    const int *pos = o->par + j->pos_off; const int pos_n = j->pos_n;
+    const char *seq = h->seqs[j->read]; const int seq_len = h->lens[j->read];
+    if (p->only_unit) { write_unit(t, pos, pos_n); return; }
+    int cons_len = j->cons_len, n_seqs = j->n_seqs;
+    if (cons_len <= 0) return;
+    const uint8_t *cb = o->cons + j->cons_off; const int *cov = o->cov + j->cons_off;
+    const int want_q = p->out_fmt == TH_FASTQ_FMT || p->out_fmt == TH_TAB_QUAL_FMT;
+    int min_cov = 0;
+    if (p->min_frac > 0.0) min_cov = (int)(n_seqs * p->min_frac); else if (p->min_cov > 0) min_cov = p->min_cov;
+    uint8_t *qual = want_q ? (uint8_t *)malloc((size_t)cons_len * 2 + 2) : NULL;
+    if (n_seqs <= 2) {                                             /* src/abpoa_cons.c:60-83 */
+        if (min_cov > 0) {
+            /* the first two units that pass the filter at :43 */
+            int u[2], nu = 0;
+            for (int i = 0; i < pos_n - 1 && nu < 2; ++i) {
+                int s = pos[i], e = pos[i + 1];
+                if (s < 0 || e < 0 || s >= seq_len - 1 || e + 1 > seq_len) continue;
+                u[nu++] = i;
+            }
+            int mc = 2, l0 = pos[u[0] + 1] - pos[u[0]], l1 = pos[u[1] + 1] - pos[u[1]];
+            if (l0 != l1) mc = 1;
+            else for (int i = 0; i < l0; ++i) if (code_of((unsigned char)seq[pos[u[0]] + 1 + i]) != code_of((unsigned char)seq[pos[u[1]] + 1 + i])) { mc = 1; break; }
+            if (mc < min_cov) { free(qual); return; }
+        }
+        if (qual) memset(qual, 33, cons_len);
+    } else {                                                       /* :88-108 */
+        if (min_cov > 0) for (int i = 0; i < cons_len; ++i) if (cov[i] < min_cov) { free(qual); return; }
+        if (qual) for (int i = 0; i < cons_len; ++i) {
+            double x = 13.8 * (1.25 * cov[i] / n_seqs - 0.25);
+            double pe = 1 - 1.0 / (1.0 + pow(2.718281828459045, -1 * x));
+            qual[i] = (uint8_t)(33 + (int)(-10 * log10(pe) + 0.499));
+        }
+    }
+    double ave = 0;                                                /* src/gen_cons.c:208-214 */
+    for (int k = 0; k < pos_n - 1; ++k) { int len = pos[k + 1] - pos[k]; ave += (o->iden[j->aln_off + k] * 100 / (len + 0.0)); }
+    char *cons_seq = (char *)malloc((size_t)cons_len * 2 + 2);
+    for (int s = 0; s < cons_len; ++s) cons_seq[s] = cb[s] <= 4 ? "ACGTN"[cb[s]] : 'N';
+    cons_seq[cons_len] = 0;
+    double copy_num = n_seqs;                                      /* :217-223 */
+    int cons_start = pos[0] - j->max_t_l;
+    copy_num += (j->max_q_l + 1.0) / cons_len;
+    int cons_end = pos[pos_n - 1] + j->max_t_r + 1;
+    copy_num += (j->max_q_r + 1.0) / cons_len;
+    int full_length = 0, out_len = cons_len;
+    if (p->five_seq != NULL && p->three_seq != NULL && cons_len > p->five_len + p->three_len) {   /* :226-291 */
+        char *cons2 = (char *)malloc(((size_t)cons_len << 1) + 1); uint8_t *qual2 = NULL;
+        memcpy(cons2, cons_seq, cons_len); memcpy(cons2 + cons_len, cons_seq, cons_len); cons2[cons_len << 1] = 0;
+        if (qual) { qual2 = (uint8_t *)malloc((size_t)cons_len << 1); memcpy(qual2, qual, cons_len); memcpy(qual2 + cons_len, qual, cons_len); }
+        int tar_start = -1, tar_end = -1, tot_ed = INT_MAX, e5, e3, s5 = -1, n5 = -1, s3 = -1, n3 = -1;
+        int k5 = (int)(p->five_len * (1 - p->ada_match_rat)), k3 = (int)(p->three_len * (1 - p->ada_match_rat));
+        e5 = edlib_hw(p->five_seq, p->five_len, cons2, cons_len << 1, &s5, &n5, k5);
+        if (e5 == -1) goto REV;
+        e3 = edlib_hw(p->three_rc_seq, p->three_len, cons2, cons_len << 1, &s3, &n3, k3);
+        if (e3 == -1) goto REV;
+        if (s3 <= n5) {
+            if (n3 + cons_len < cons_len << 1 && s3 + cons_len > n5) { tar_start = n5 + 1; tar_end = s3 + cons_len - 1; full_length = 1; tot_ed = e5 + e3; }
+        } else { tar_start = n5 + 1; tar_end = s3 - 1; tot_ed = e5 + e3; full_length = 1; }
+        if (tot_ed == 0) goto WRITE;
+REV:
+        e5 = edlib_hw(p->five_rc_seq, p->five_len, cons2, cons_len << 1, &s5, &n5, k5);
+        if (e5 == -1) goto WRITE;
+        e3 = edlib_hw(p->three_seq, p->three_len, cons2, cons_len << 1, &s3, &n3, k3);
+        if (e3 == -1) goto WRITE;
+        if (e5 + e3 < tot_ed) {
+            if (s5 <= n3) {
+                if (n5 + cons_len < cons_len << 1 && s5 + cons_len > n3) { tar_start = n3 + 1; tar_end = s5 + cons_len - 1; full_length = 2; }
+            } else { tar_start = n3 + 1; tar_end = s5 - 1; full_length = 2; }
+        }
+WRITE:
+        if (tar_start > 0 && tar_end > tar_start) {
+            out_len = tar_end - tar_start + 1;
+            memcpy(cons_seq, cons2 + tar_start, out_len); cons_seq[out_len] = 0;
+            if (qual) for (int k = tar_start; k <= tar_end; ++k) qual[k - tar_start] = qual2[k];
+        }
+        free(cons2); free(qual2);
+    }
+    if (!p->only_full_length || full_length > 0)
+        write_cons(t, cons_seq, qual, out_len, cons_start, cons_end, copy_num, ave / (pos_n - 1), p, full_length, pos, pos_n);
+    free(cons_seq); free(qual);
+}
+
+int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out)
+{
+    th_gpu_out_t o; th_gpu_get(h->gpu, &o);
+    const th_para_t *p = &h->para;
+    for (int i = 0; i < h->n; ++i) { out[i].cons_n = 0; out[i].cons_seq_l = 0; out[i].cons_qual_l = 0; }
+    int ji = 0;
+    for (int r = 0; r < h->n; ++r) {
+        while (ji < o.n_jobs && o.jobs[ji].read == r) { finish_job(h, &o, &o.jobs[ji], &out[r]); ++ji; }
+        if (h->lens[r] >= p->k && p->single_copy == 1 && p->only_full_length && p->five_seq != NULL && p->three_seq != NULL)
+            single_copy(h->lens[r], h->seqs[r], &out[r], p);   /* src/tidehunter.c:24,49-51 */
+    }
+    return 0;
+}
+
+int th_process_batch(th_handle_t *h, const char *const *seqs, const int *lens, int n, th_tandem_seq_t *out)
+{
+    if (th_batch_upload(h, seqs, lens, n)) return -1;
+    if (th_batch_run(h)) return -1;
+    return th_batch_collect(h, out);
+}
+
+/* ---------------------------------------------------------------- output, src/main.c:214-271 */
+static void put_subpos(FILE *fp, const int *sp, int pos_n, char term)
+{
+    int i;
+    fprintf(fp, "%d", sp[0] + 2);
+    for (i = 1; i < pos_n - 1; ++i) fprintf(fp, ",%d", sp[i] + 2);
+    fprintf(fp, ",%d%c", sp[i] + 1, term);
+}
+void th_output(FILE *fp, int n, const char *const *names, const char *const *seqs, const int *lens, th_tandem_seq_t *tseq, const th_para_t *p)
+{
+    for (int si = 0; si < n; ++si) {
+        th_tandem_seq_t *t = tseq + si;
+        size_t cs = 0;
+        for (int ci = 0; ci < t->cons_n; ++ci) {
+            if (p->only_unit) {
+                for (int i = 0; i < t->pos_n[ci] - 1; ++i) {
+                    if (p->out_fmt == TH_FASTA_FMT) {
+                        fprintf(fp, ">%s_rep%d_sub%d\n", names[si], ci, i);
+                        fwrite(seqs[si] + t->sub_pos[ci][i] + 1, 1, (size_t)(t->sub_pos[ci][i + 1] - t->sub_pos[ci][i]), fp);
+                        fputc('\n', fp);
+                    } else if (p->out_fmt == TH_TAB_FMT) {
+                        fprintf(fp, "%s\trep%d\tsub%d\t", names[si], ci, i);
+                        int len = t->sub_pos[ci][i + 1] - t->sub_pos[ci][i] - 1;           /* '<' at src/main.c:224: one base fewer */
+                        if (len > 0) fwrite(seqs[si] + t->sub_pos[ci][i] + 1, 1, (size_t)len, fp);
+                        fputc('\n', fp);
+                    }
+                }
+                continue;
+            }
+            if (p->out_fmt == TH_FASTA_FMT || p->out_fmt == TH_FASTQ_FMT) {
+                fprintf(fp, "%c%s_rep%d_%.1f %d_%d_%d_%d_%.1f_%d_", p->out_fmt == TH_FASTA_FMT ? '>' : '@', names[si], ci, t->copy_num[ci], lens[si],
+                        t->cons_start[ci] + 1, t->cons_end[ci] + 1, t->cons_len[ci], t->ave_match[ci], t->full_length[ci]);
+                put_subpos(fp, t->sub_pos[ci], t->pos_n[ci], '\n');
+            } else {
+                fprintf(fp, "%s\trep%d\t%.1f\t%d\t%d\t%d\t%d\t%.1f\t%d\t", names[si], ci, t->copy_num[ci], lens[si],
+                        t->cons_start[ci] + 1, t->cons_end[ci] + 1, t->cons_len[ci], t->ave_match[ci], t->full_length[ci]);
+                put_subpos(fp, t->sub_pos[ci], t->pos_n[ci], '\t');
+            }
+            fwrite(t->cons_seq + cs, 1, (size_t)t->cons_len[ci], fp);
+            if (p->out_fmt == TH_FASTQ_FMT) fputs("\n+\n", fp); else if (p->out_fmt == TH_TAB_QUAL_FMT) fputc('\t', fp);
+            if (p->out_fmt == TH_FASTQ_FMT || p->out_fmt == TH_TAB_QUAL_FMT) fwrite(t->cons_qual + cs, 1, (size_t)t->cons_len[ci], fp);
+            fputc('\n', fp);
+            cs += (size_t)t->cons_len[ci];
+        }
+        t->cons_n = 0; t->cons_seq_l = 0; t->cons_qual_l = 0;
+    }
+}
+
+/* ---------------------------------------------------------------- whole-file driver, src/main.c:375-436 */
+int th_run_file(const char *read_fn, th_para_t *p, FILE *out, int device, int batch_reads)
+{
+    if (batch_reads <= 0) batch_reads = 16384;
+    if (p->five_fn && p->three_fn && !p->five_seq) if (th_load_adapters(p)) return -1;
+    th_reader_t *r = rd_open(read_fn);
+    if (!r) { char m[300]; snprintf(m, sizeof(m), "fail to open file '%s'", read_fn); return host_fail(m); }
+    th_handle_t *h = th_init(p, device);
+    if (!h) { rd_close(r); return -1; }
+    char **names = (char **)calloc(batch_reads, sizeof(char *)), **seqs = (char **)calloc(batch_reads, sizeof(char *));
+    int *lens = (int *)calloc(batch_reads, sizeof(int));
+    th_tandem_seq_t *ts = th_alloc_tandem_seq(batch_reads);
+    int total = 0, rc = 0;
+    const long long max_bases = 512LL << 20;
+    for (;;) {
+        int n = 0; long long bases = 0;
+        while (n < batch_reads && bases < max_bases && rd_next(r, &names[n], &seqs[n], &lens[n])) { bases += lens[n]; ++n; }
+        if (n == 0) break;
+        rc = th_process_batch(h, (const char *const *)seqs, lens, n, ts);
+        if (rc == 0 && out) th_output(out, n, (const char *const *)names, (const char *const *)seqs, lens, ts, p);
+        for (int i = 0; i < n; ++i) { free(names[i]); free(seqs[i]); }
+        if (rc) break;
+        total += n;
+    }
+    th_free_tandem_seq(ts, batch_reads); free(names); free(seqs); free(lens);
+    th_destroy(h); rd_close(r);
+    return rc ? -1 : total;
+}
+
+/* ---------------------------------------------------------------- synthetic reads */
+static uint64_t sm64(uint64_t *s) { uint64_t z = (*s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+static double sm_u(uint64_t *s) { return (double)(sm64(s) >> 11) / 9007199254740992.0; }
+int th_synth_read(uint64_t seed, uint64_t read_index, int period, int copies, double err, char *dst, int cap)
+{
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + read_index * 0xD1342543DE82EF95ull + 0x632BE59BD9B4E019ull;
+    char *unit = (char *)malloc((size_t)period);
+    for (int i = 0; i < period; ++i) unit[i] = "ACGT"[sm64(&s) >> 62];
+    int n = 0;
+    for (int c = 0; c < copies; ++c)
+        for (int i = 0; i < period; ++i) {
+            char b = unit[i];
+            if (sm_u(&s) < err) {
+                int kind = (int)(sm_u(&s) * 3);
+                if (kind == 0) { int bi = (int)(strchr("ACGT", b) - "ACGT"); b = "ACGT"[(bi + 1 + (int)(sm_u(&s) * 3)) & 3]; if (n < cap) dst[n] = b; ++n; }
+                else if (kind == 1) { if (n < cap) dst[n] = b; ++n; char x = "ACGT"[(int)(sm_u(&s) * 4) & 3]; if (n < cap) dst[n] = x; ++n; }
+                /* kind 2: deletion */
+            } else { if (n < cap) dst[n] = b; ++n; }
+        }
+    free(unit);
+    return n;
+}

@@ -1,0 +1,56 @@
+/* th_internal.h -- interface between the C host layer (th_host.c) and the device pipeline
+ * (th_pipeline.hip).  Not part of the public C-ABI (include/tidehunter_amd.h). */
+#ifndef TH_INTERNAL_H
+#define TH_INTERNAL_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int k; uint32_t min_p, max_p; double one_minus_div; int min_copy;
+    int match, mismatch, go1, ge1, go2, ge2;
+    int only_unit;          /* -u: stop after partition (no POA, no alignment) */
+} th_gpu_para_t;
+
+/* one consensus job as the host sees it after the device run */
+typedef struct {
+    int read;               /* read index in the batch */
+    int pos_off, pos_n;     /* boundaries of the run inside par[] */
+    int n_seqs;             /* units handed to POA (src/abpoa_cons.c:36-48) */
+    int cons_off, cons_len; /* consensus codes / coverage inside cons[] / cov[] (cons_len 0 = none) */
+    int aln_off;            /* iden[aln_off + u] = identical columns of unit u vs consensus */
+    int max_q_l, max_t_l, max_q_r, max_t_r;   /* ksw2 extension results (src/gen_cons.c:218-223) */
+    int status;             /* POA kernel status, 0 = ok */
+} th_job_t;
+
+typedef struct {
+    int n_jobs; const th_job_t *jobs;
+    const int *par;         /* compact par_pos values */
+    const uint8_t *cons; const int *cov; const int *iden;
+    double ms_kernels;      /* device time of the last run (HIP events), all kernels */
+    double ms_dominant;     /* device time of the dominant kernel (th_k_align) in the last run */
+} th_gpu_out_t;
+
+typedef struct th_gpu th_gpu_t;
+
+th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device);
+void th_gpu_destroy(th_gpu_t *g);
+/* copies the reads into pinned memory and on to HBM; the batch stays resident until the next upload */
+int th_gpu_upload(th_gpu_t *g, const char *const *seqs, const int *lens, int n);
+/* runs the whole device path on the resident batch and brings the small result records back */
+int th_gpu_run(th_gpu_t *g);
+int th_gpu_get(th_gpu_t *g, th_gpu_out_t *out);
+const char *th_gpu_error(void);
+
+/* test hook: copies an intermediate stage of the resident batch to the host.
+ * what: 0 bseq(u8) 1 hit_n(i32/read) 2 hit_end 3 hit_per 4 score 5 from (i32, read-major at roff)
+ *       6 chain records (8 x i32 each, grouped by read in emission order) 7 cells (i32)
+ *       8 roff (u32, n+1)   returns bytes written or -1 */
+long long th_gpu_debug(th_gpu_t *g, int what, void *dst, long long cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,64 @@
+// th_k_align.hip -- stage 4 follow-up: every unit against the consensus (aveMatch) and the consensus
+// extended into both flanks (start / end / fractional copy number), gfx950.
+//
+// Replaces the ksw2 calls of seqs_msa(), src/gen_cons.c:209-223:
+//   ksw2_global(unit, cons) per unit, ksw2_left_ext(cons, read[0..first]), ksw2_right_ext(cons, read[last+1..]).
+// One alignment per wavefront (th_ksw.h), waves loop over the item list.
+#include "th_dev.h"
+#include "th_ksw.h"
+
+#define TH_ALN_BLOCK 64
+
+struct ThAlnItem { int task, which; };   // which >= 0: unit index in the run; -1 left extension; -2 right extension
+
+// Gathers the scattered per-chain par_pos regions into one compact array (host gives offsets).
+__global__ void th_k_gather_par(const ThChainRec *__restrict__ rec, int n_rec, const int *__restrict__ par, const int *__restrict__ par_n,
+                                const int *__restrict__ dst_off, int *__restrict__ dst)
+{
+    const int c = blockIdx.x;
+    if (c >= n_rec) return;
+    const int *src = par + 2LL * rec[c].cell_off + 16LL * c;
+    const int n = par_n[c], o = dst_off[c];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[o + i] = src[i];
+}
+
+__global__ void __launch_bounds__(TH_ALN_BLOCK)
+th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__restrict__ tasks, const int *__restrict__ pos,
+           const uint32_t *__restrict__ roff, const uint8_t *__restrict__ bseq,
+           const uint8_t *__restrict__ cons, const int *__restrict__ cons_len,
+           int *__restrict__ bnd, long long bnd_stride, int *__restrict__ iden, int *__restrict__ ext, int *__restrict__ err)
+{
+    const int lane = TH_LANE();
+    const int wave = blockIdx.x, nwave = gridDim.x;
+    int *mybnd = bnd + (long long)wave * bnd_stride;
+    for (int it = wave; it < n_items; it += nwave) {
+        const ThAlnItem I = items[it];
+        const ThTask T = tasks[I.task];
+        const int cl = cons_len[I.task];
+        const uint8_t *rb = bseq + roff[T.read];
+        const int L = (int)(roff[T.read + 1] - roff[T.read]);
+        const uint8_t *cs = cons + T.cons_off;
+        const int *ps = pos + T.pos_off;
+        if (I.which >= 0) {
+            int v = 0;
+            if (cl > 0) {
+                const int start = ps[I.which], len = ps[I.which + 1] - start;
+                if ((long long)((cl + 63) & ~63) * 4 > bnd_stride) { if (lane == 0) atomicOr(err, 4); }
+                else if (len > 0) v = th_ksw_global_wave<false>(rb + start + 1, len, cs, cl, 0, mybnd, nullptr);
+            }
+            if (lane == 0) iden[T.aln_off + I.which] = v;
+        } else {
+            int mq = -1, mt = -1;
+            if (cl > 0) {
+                int tlen; const uint8_t *tp, *qp; int st;
+                if (I.which == -1) { tlen = ps[0] + 1; tp = rb + ps[0]; qp = cs + cl - 1; st = -1; }          // src/gen_cons.c:218
+                else { const int lastp = ps[T.pos_n - 1]; tlen = L - lastp - 1; tp = rb + lastp + 1; qp = cs; st = 1; }   // :221
+                if (tlen > 0) {
+                    if ((long long)((tlen + 63) & ~63) * 2 > bnd_stride) { if (lane == 0) atomicOr(err, 4); }
+                    else th_ksw_ext_wave(qp, st, cl, tp, st, tlen, mybnd, &mq, &mt);
+                }
+            }
+            if (lane == 0) { const int o = 4 * I.task + (I.which == -1 ? 0 : 2); ext[o] = mq; ext[o + 1] = mt; }
+        }
+    }
+}

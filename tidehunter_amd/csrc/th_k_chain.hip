@@ -1,0 +1,206 @@
+// th_k_chain.hip -- stage 2: chaining DP over self-hits and score-ranked chain extraction (gfx950).
+//
+// Replaces tandem_chain() and helpers, src/tandem_chain.c:290-404 (get_con_score :151-166,
+// init_dp :113-126, sort_dp_score :32-43, backtrack_dp :86-111, is_in_chain :170-185,
+// is_overlap_chain :54-83, sort_chain :188-207, copy_chain :209-223, set_start_period :251-255).
+// With -w 1 every DP row holds exactly one cell (one hit per end position), so a "cell" is a
+// hit index.
+#include "th_dev.h"
+
+#define TH_CHAIN_BLOCK 256      // th_k_chain_dp: 4 waves = 4 reads per workgroup
+#define TH_TOPN 1000            // src/tandem_chain.c:361
+#define TH_XSORT_LDS 8192       // candidates sorted in LDS up to this many hits, else in HBM scratch
+#define TH_XBLOCK 256
+
+enum { TH_NO_CON = 0, TH_REG_CON = 1, TH_SAME_CON = 2, TH_OVL_CON = 3 };
+
+// ---------------------------------------------------------------------------------------------
+// Chain DP, one read per wavefront.  `cur` advances sequentially (its predecessors' scores must be
+// final); the scan over predecessors cur-1, cur-2, ... runs 64 at a time.  The reference's
+// order-dependent early exits (src/tandem_chain.c:331-350) are reproduced exactly: an exclusive
+// prefix-max of the candidate scores, seeded with the running best, tells every lane whether it
+// would have improved the best in sequential order; ballots of the four stop rules give the
+// first lane (in scan order) that ends the scan, and lanes beyond it are discarded.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TH_CHAIN_BLOCK)
+th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
+              const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ hit_n,
+              int *__restrict__ score, int *__restrict__ from)
+{
+    const int lane = TH_LANE();
+    const int r = blockIdx.x * (TH_CHAIN_BLOCK / TH_WAVE) + (threadIdx.x >> 6);
+    const bool live = r < n_reads;
+    const uint32_t off = live ? roff[r] : 0;
+    const int n = live ? hit_n[r] : 0, k = P.k;
+    const int *E = hit_end + off, *Pd = hit_per + off;
+    int *S = score + off, *F = from + off;
+    // init_dp (src/tandem_chain.c:113-126): score = k + min(k, period), no predecessor
+    for (int i = lane; i < n; i += TH_WAVE) { S[i] = k + min(k, Pd[i]); F[i] = -1; }
+    TH_WAVE_FENCE();
+    for (int cur = 1; cur < n; ++cur) {
+        const int ce = E[cur], cp = Pd[cur], cs = ce - cp;
+        const int init = k + min(k, cp);
+        int best = init, bi = -1, iter = 0;
+        const int max_h = cp;
+        for (int base = cur - 1; base >= 0; base -= TH_WAVE) {
+            const int idx = base - lane;
+            const bool valid = idx >= 0;
+            const int pe = valid ? E[idx] : 0, pp = valid ? Pd[idx] : 1, psc = valid ? S[idx] : 0;
+            const int ps = pe - pp;
+            const bool dstop = !valid || pe < cs;                  // :331  predecessor ends before cur starts
+            int type = TH_NO_CON, con = 0;
+            if (!dstop && !(cs <= ps || (double)cp >= pp * 1.8 || (double)pp >= cp * 1.8)) {   // :154
+                const int dis1 = abs(ce - pe), dis2 = abs(cs - ps);
+                const int matched = min(dis1, k) + min(dis2, k);
+                const int dp = abs(cp - pp);
+                const int gap = dp * dp / 2 + (31 - __clz(dis1 + dis2)) / 2;                   // :128-142
+                con = matched - gap;
+                type = dp == 0 ? (matched < 2 * k ? TH_OVL_CON : TH_SAME_CON) : TH_REG_CON;
+            }
+            const int s = type != TH_NO_CON ? psc + con : -0x40000000;
+            const int rb = th_wave_excl_max(s, best);              // best as seen just before this lane
+            const bool imp = type != TH_NO_CON && s > rb;
+            const unsigned long long impm = __ballot(imp);
+            const unsigned long long A = __ballot(imp && (type == TH_SAME_CON || type == TH_OVL_CON));   // :342
+            const unsigned long long B = __ballot(!imp && type == TH_OVL_CON);                          // :344-346
+            const unsigned long long D = __ballot(dstop);
+            const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1);
+            const unsigned long long below = impm & upto;
+            const int iter_after = below ? lane - th_msb64(below) : iter + lane + 1;
+            const unsigned long long C = __ballot(!imp && !dstop && iter_after >= max_h);                // :349
+            const unsigned long long stopm = A | B | C | D;
+            const int f = th_ctz64(stopm);
+            const unsigned long long lim = f >= 63 ? ~0ull : ((2ull << f) - 1);
+            const unsigned long long taken = impm & lim;
+            if (taken) { const int last = th_msb64(taken); best = __shfl(s, last); bi = base - last; }
+            if (f < 64) break;
+            iter = impm ? 63 - th_msb64(impm) : iter + TH_WAVE;
+        }
+        if (lane == 0 && best > init) { S[cur] = best; F[cur] = bi; }                                   // :352-354
+        TH_WAVE_FENCE();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Chain extraction, one workgroup per read: candidates (score<<32 | hit index) are bitonic-sorted
+// descending -- equal scores keep the larger hit index first, which is the order glibc's stable
+// qsort leaves -- then thread 0 walks them exactly as the reference does.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TH_XBLOCK)
+th_k_chain_extract(const uint32_t *__restrict__ roff, ThDevPara P,
+                   const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ hit_n,
+                   const int *__restrict__ score, const int *__restrict__ from,
+                   uint8_t *__restrict__ tracked, int *__restrict__ cells,
+                   unsigned long long *__restrict__ gsort, const long long *__restrict__ gsort_off,
+                   ThChainRec *__restrict__ rec, int rec_cap, int *__restrict__ rec_count,
+                   int *__restrict__ read_ch_base, int *__restrict__ read_ch_n, int *__restrict__ err)
+{
+    __shared__ unsigned long long lds[TH_XSORT_LDS];
+    __shared__ int ch_off[TH_TOPN], ch_len[TH_TOPN], ch_score[TH_TOPN], ch_fs[TH_TOPN], ch_ls[TH_TOPN], ch_le[TH_TOPN];
+    __shared__ short ch_idx[TH_TOPN];
+    const int tid = threadIdx.x, r = blockIdx.x;
+    const uint32_t off = roff[r];
+    const int n = hit_n[r];
+    if (n < 2) { if (tid == 0) { read_ch_base[r] = 0; read_ch_n[r] = 0; } return; }     // src/tandem_chain.c:291
+    const int *E = hit_end + off, *Pd = hit_per + off, *S = score + off, *F = from + off;
+    uint8_t *T = tracked + off; int *CL = cells + off;
+    int N = 1; while (N < n) N <<= 1;
+    unsigned long long *buf = N <= TH_XSORT_LDS ? lds : gsort + gsort_off[r];
+    for (int i = tid; i < N; i += TH_XBLOCK) buf[i] = i < n ? ((unsigned long long)(uint32_t)S[i] << 32 | (uint32_t)i) : 0ull;
+    for (int i = tid; i < n; i += TH_XBLOCK) T[i] = 0;
+    __syncthreads();
+    for (int size = 2; size <= N; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (N >> 1); t += TH_XBLOCK) {
+                int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                bool desc = (lo & size) == 0;
+                unsigned long long a = buf[lo], c = buf[hi];
+                if ((a < c) == desc) { buf[lo] = c; buf[hi] = a; }
+            }
+            __syncthreads();
+        }
+    if (tid != 0) return;
+
+    int ch_n = 0, top = 0;
+    for (int i = 0; i < TH_TOPN; ++i) ch_idx[i] = (short)i;
+    for (int ci = 0; ci < n && ch_n < TH_TOPN; ++ci) {
+        const int cand = (int)(uint32_t)buf[ci];
+        const int cell_end = E[cand], cell_start = cell_end - Pd[cand];
+        // is_in_chain, src/tandem_chain.c:170-185 (accepted chains scanned in chain_idx order)
+        bool in = false;
+        for (int q = 0; q < ch_n; ++q) {
+            const int c = ch_idx[q];
+            if (ch_len[c] <= 0) continue;
+            const int cst = ch_fs[c], cen = ch_le[c];
+            if (cen < cell_start) break;
+            if (cst > cell_end) continue;
+            if (cell_end - cst >= (cen - cst) / 2) { in = true; break; }
+        }
+        if (in) continue;
+        // backtrack_dp, src/tandem_chain.c:86-111, into slot ch_n
+        int ok = 0;
+        if (!T[cand]) {
+            int sc = S[cand], cur = cand, len = 0;
+            for (;;) {
+                T[cur] = 1; CL[top + len++] = cur;
+                const int pre = F[cur];
+                if (pre == -1) break;
+                if (T[pre]) { sc -= S[pre]; break; }
+                cur = pre;
+            }
+            for (int a = 0, b = len - 1; a < b; ++a, --b) { int x = CL[top + a]; CL[top + a] = CL[top + b]; CL[top + b] = x; }
+            const int nw = ch_n;
+            ch_off[nw] = top; ch_len[nw] = len; ch_score[nw] = sc;
+            const int c0 = CL[top], c1 = CL[top + len - 1];
+            ch_fs[nw] = E[c0] - Pd[c0]; ch_ls[nw] = E[c1] - Pd[c1]; ch_le[nw] = E[c1];
+            if (len > 1) {
+                // is_overlap_chain, src/tandem_chain.c:68-83 (and is_overlap_chain1 :54-65)
+                int loses = 0;
+                const int start = ch_ls[nw];
+                for (int i = ch_n - 1; i >= 0; --i) {
+                    if (ch_len[i] <= 0) continue;
+                    if (ch_le[i] <= start) break;
+                    const int s1 = ch_fs[i], e1 = ch_ls[i], s2 = ch_fs[nw], e2 = ch_ls[nw];
+                    const int mn = min(e1 - s1, e2 - s2), ov = min(e1, e2) - max(s1, s2);
+                    if (ov / (mn + 0.0) >= 0.5) {
+                        if (ch_score[i] > ch_score[nw]) loses = 1; else ch_len[i] = 0;
+                        break;
+                    }
+                }
+                ok = !loses;
+            }
+        }
+        if (ok) { top += ch_len[ch_n]; ++ch_n; }
+        // sort_chain, src/tandem_chain.c:188-207 (selection pass keeps the reference's stale `i`)
+        for (int a = 0; a + 1 < ch_n; ++a) {
+            const int i = ch_idx[a];
+            if (ch_len[i] <= 0) continue;
+            int e1 = ch_le[i];
+            for (int b = a + 1; b < ch_n; ++b) {
+                const int j = ch_idx[b];
+                if (ch_len[j] <= 0) continue;
+                const int e2 = ch_le[j];
+                if (e1 < e2) { ch_idx[a] = (short)j; ch_idx[b] = (short)i; e1 = e2; }
+            }
+        }
+    }
+    // copy_chain in reverse rank order (ascending end), chains with >= 3 cells; seed = first cell (:251-255)
+    int cnt = 0;
+    for (int q = ch_n - 1; q >= 0; --q) if (ch_len[ch_idx[q]] >= 3) ++cnt;
+    int base = cnt ? atomicAdd(rec_count, cnt) : 0;
+    if (base + cnt > rec_cap) { atomicOr(err, 1); cnt = 0; }
+    read_ch_base[r] = base; read_ch_n[r] = cnt;
+    if (cnt) {
+        int o = base;
+        for (int q = ch_n - 1; q >= 0; --q) {
+            const int c = ch_idx[q];
+            if (ch_len[c] < 3) continue;
+            const int c0 = CL[ch_off[c]];
+            ThChainRec x;
+            x.read = r; x.cell_off = (int)off + ch_off[c]; x.len = ch_len[c];
+            x.est_start = ch_fs[c]; x.est_period = E[c0] - ch_fs[c];
+            x.first_end = E[c0]; x.last_start = ch_ls[c]; x.pad = 0;
+            rec[o++] = x;
+        }
+    }
+}

@@ -1,0 +1,73 @@
+// th_k_partition.hip -- stage 3: split the read into repeat units along one chain (gfx950).
+//
+// Replaces get_partition_pos_with_narrow_global_alignment(), src/partition.c:171-276.
+// One chain per wavefront.  The seed unit is always the chain's first cell (est_ch_i == 0,
+// src/tandem_chain.c:251-255), so the reference's left walk (:186-224, guarded by ch_i > 0) never
+// runs and only the right walk (:236-273) is implemented.  Anchor search is a 64-wide scan (cell
+// starts grow strictly along a chain); bridging alignments run on the wave DP engine with the
+// forward back-projection functional instead of a CIGAR.
+#include "th_dev.h"
+#include "th_ksw.h"
+
+#define TH_PART_BLOCK 64
+
+// par: chain c writes at par + par_off[c], capacity par_cap[c]; bnd: per-wave scratch, bnd_stride ints each
+__global__ void __launch_bounds__(TH_PART_BLOCK)
+th_k_partition(const ThChainRec *__restrict__ rec, int n_rec, const uint32_t *__restrict__ roff, const uint8_t *__restrict__ bseq,
+               const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ cells, ThDevPara P,
+               int *__restrict__ par, int *__restrict__ par_n, int *__restrict__ bnd, long long bnd_stride, int *__restrict__ err)
+{
+    const int lane = TH_LANE();
+    const int wave = blockIdx.x, nwave = gridDim.x;
+    int *mybnd = bnd + (long long)wave * bnd_stride;
+    const int k = P.k;
+    for (int c = wave; c < n_rec; c += nwave) {
+        const ThChainRec R = rec[c];
+        const uint32_t off = roff[R.read];
+        const uint8_t *b = bseq + off;
+        const int *E = hit_end + off, *Pd = hit_per + off, *CL = cells + R.cell_off;
+        int *out = par + 2LL * R.cell_off + 16LL * c;
+        const int cap = 2 * R.len + 16;
+        int n = 0, bad = 0;
+        int ch_i = 0, s = R.est_start, e = R.est_start + R.est_period;
+        if (lane == 0) { out[0] = s; out[1] = e; }
+        n = 2;
+        while (ch_i < R.len - 1 && e <= R.last_start && !bad) {
+            // first cell beyond ch_i whose start is >= e (exists: last_start >= e)
+            int istar = -1;
+            for (int base = ch_i + 1; base < R.len && istar < 0; base += TH_WAVE) {
+                const int x = base + lane;
+                int st = -1;
+                if (x < R.len) { const int h = CL[x]; st = E[h] - Pd[h]; }
+                const unsigned long long m = __ballot(x < R.len && st >= e);
+                if (m) istar = base + th_ctz64(m);
+            }
+            if (istar < 0) break;   // cannot happen (see above)
+            const int h2 = CL[istar];
+            const int e2 = E[h2], s2 = e2 - Pd[h2];
+            int s1 = s, e1 = e;
+            if (istar - 1 > ch_i) { const int h1 = CL[istar - 1]; e1 = E[h1]; s1 = e1 - Pd[h1]; }
+            if (n + 3 > cap) { bad = 1; break; }
+            if (s2 == e) {                                   // abutting anchor, :244-247
+                if (lane == 0) out[n] = e2;
+                ++n; ch_i = istar; s = s2; e = e2;
+            } else {                                         // bridge, :248-268
+                const int ql = s2 - s1 + k, tl = e2 - e1 + k;
+                if ((long long)((tl + 63) & ~63) * 6 > bnd_stride) { bad = 1; break; }
+                int bt = 0;
+                const int iden = th_ksw_global_wave<true>(b + s1 - k + 1, ql, b + e1 - k + 1, tl, s2 - e, mybnd, &bt);
+                if ((double)iden >= (double)min(ql, tl) * P.one_minus_div) {
+                    s = e; e = e2 - bt;
+                    if (e == s) break;                       // no progress: ch_i = ch.len, :254-256
+                    if (lane == 0) out[n] = e;
+                    ++n; ch_i = istar - 1;
+                } else {
+                    if (lane == 0) { out[n] = -1; out[n + 1] = s2; out[n + 2] = e2; }
+                    n += 3; ch_i = istar; s = s2; e = e2;
+                }
+            }
+        }
+        if (bad && lane == 0) atomicOr(err, 2);
+        if (lane == 0) par_n[c] = bad ? 0 : n;
+    }
+}

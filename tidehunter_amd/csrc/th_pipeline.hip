@@ -1,0 +1,388 @@
+// th_pipeline.hip -- host-side orchestration of the device path for one batch of reads.
+//
+// This is what stands behind the fan-out of mini_tandem() (src/main.c:402-425): instead of
+// n_thread pthreads each calling tidehunter_core() per read, the whole batch goes through
+//   encode -> self-hits -> chain DP -> chain extraction -> partition -> [host: split runs]
+//   -> POA consensus -> unit/consensus alignments -> small result records back to the host.
+// All kernels of one batch run on one HIP stream; the host only synchronises where a later launch
+// needs a count produced by an earlier one.
+#include <vector>
+#include <string>
+#include <algorithm>
+#include "th_internal.h"
+#include "th_dev.h"
+#include "th_k_seed.hip"
+#include "th_k_chain.hip"
+#include "th_k_partition.hip"
+#include "th_k_poa.hip"
+#include "th_k_align.hip"
+
+static std::string g_th_err;
+extern "C" const char *th_gpu_error(void) { return g_th_err.c_str(); }
+static int th_fail(const std::string &m) { g_th_err = m; fprintf(stderr, "[tidehunter_amd] %s\n", m.c_str()); return -1; }
+
+template <class T> struct DBuf {
+    T *p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) th_rt_free(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 8 + 64;
+        if (th_rt_malloc((void **)&p, want * sizeof(T))) return -1;
+        cap = want; return 0;
+    }
+    void release() { if (p) th_rt_free(p); p = nullptr; cap = 0; }
+};
+
+#ifndef TH_CPU_EMUL
+struct Ev { hipEvent_t a, b; };
+#endif
+
+struct th_gpu {
+    th_gpu_para_t para; ThDevPara dp; int device; th_stream_t stream;
+    int n = 0; long long T = 0; int max_len = 0;
+    uint8_t *h_seq = nullptr; size_t h_seq_cap = 0;
+    std::vector<uint32_t> h_roff; std::vector<long long> h_gsort_off; long long gsort_total = 0;
+    DBuf<uint8_t> d_seq, d_bseq, d_tracked, d_cons;
+    DBuf<uint32_t> d_roff, d_tmp;
+    DBuf<int> d_hit_end, d_hit_per, d_hit_n, d_score, d_from, d_cells, d_cnt, d_read_ch_base, d_read_ch_n;
+    DBuf<unsigned long long> d_gsort; DBuf<long long> d_gsort_off;
+    DBuf<ThChainRec> d_rec;
+    DBuf<int> d_par, d_par_n, d_par_dst, d_parc, d_bnd, d_scratch, d_cov, d_cons_len, d_status, d_iden, d_ext;
+    DBuf<ThTask> d_tasks; DBuf<ThUnit> d_units; DBuf<ThAlnItem> d_items;
+    int n_rec = 0;
+    std::vector<ThChainRec> h_rec; std::vector<int> h_par_n, h_par_dst, h_parc, h_read_ch_base, h_read_ch_n;
+    std::vector<ThTask> h_tasks; std::vector<ThUnit> h_units; std::vector<ThAlnItem> h_items;
+    std::vector<int> h_cons_len, h_status, h_iden, h_ext, h_cov; std::vector<uint8_t> h_cons;
+    std::vector<th_job_t> jobs;
+    double ms_kernels = 0, ms_dominant = 0;
+    int waves_part = 4096, waves_poa = 2048, waves_aln = 8192;
+};
+
+static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
+
+extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
+{
+    th_gpu *g = new th_gpu();
+    g->para = *p;
+    g->dp.k = p->k; g->dp.min_p = p->min_p; g->dp.max_p = p->max_p; g->dp.one_minus_div = p->one_minus_div; g->dp.min_copy = p->min_copy;
+    g->dp.match = p->match; g->dp.mismatch = p->mismatch; g->dp.go1 = p->go1; g->dp.ge1 = p->ge1; g->dp.go2 = p->go2; g->dp.ge2 = p->ge2;
+    g->device = device;
+#ifdef TH_CPU_EMUL
+    g->stream = 0;
+    g->waves_part = 2; g->waves_poa = 2; g->waves_aln = 3;
+#else
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { th_fail("no HIP device: the TideHunter HIP path needs an AMD GPU (no CPU fallback)"); delete g; return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { th_fail("hipSetDevice failed"); delete g; return nullptr; }
+    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) { th_fail("hipStreamCreate failed"); delete g; return nullptr; }
+#endif
+    g->waves_part = env_int("TH_WAVES_PART", g->waves_part);
+    g->waves_poa = env_int("TH_WAVES_POA", g->waves_poa);
+    g->waves_aln = env_int("TH_WAVES_ALN", g->waves_aln);
+    return g;
+}
+
+extern "C" void th_gpu_destroy(th_gpu_t *g)
+{
+    if (!g) return;
+    g->d_seq.release(); g->d_bseq.release(); g->d_tracked.release(); g->d_cons.release(); g->d_roff.release(); g->d_tmp.release();
+    g->d_hit_end.release(); g->d_hit_per.release(); g->d_hit_n.release(); g->d_score.release(); g->d_from.release(); g->d_cells.release();
+    g->d_cnt.release(); g->d_read_ch_base.release(); g->d_read_ch_n.release(); g->d_gsort.release(); g->d_gsort_off.release(); g->d_rec.release();
+    g->d_par.release(); g->d_par_n.release(); g->d_par_dst.release(); g->d_parc.release(); g->d_bnd.release(); g->d_scratch.release();
+    g->d_cov.release(); g->d_cons_len.release(); g->d_status.release(); g->d_iden.release(); g->d_ext.release();
+    g->d_tasks.release(); g->d_units.release(); g->d_items.release();
+    if (g->h_seq) th_rt_host_free(g->h_seq);
+#ifndef TH_CPU_EMUL
+    hipStreamDestroy(g->stream);
+#endif
+    delete g;
+}
+
+#define TRY(x) do { if ((x) != 0) return th_fail(std::string("device runtime call failed: ") + #x); } while (0)
+
+extern "C" int th_gpu_upload(th_gpu_t *g, const char *const *seqs, const int *lens, int n)
+{
+    g->n = n; g->h_roff.assign((size_t)n + 1, 0);
+    long long T = 0; int mx = 0;
+    for (int i = 0; i < n; ++i) { g->h_roff[i] = (uint32_t)T; T += lens[i]; mx = std::max(mx, lens[i]); }
+    if (T >= (1LL << 31)) return th_fail("batch holds 2^31 bases or more; split it");
+    g->h_roff[n] = (uint32_t)T; g->T = T; g->max_len = mx;
+    size_t padT = (size_t)((T + 15) & ~15LL);
+    if (padT + 16 > g->h_seq_cap) {
+        if (g->h_seq) th_rt_host_free(g->h_seq);
+        g->h_seq = nullptr; g->h_seq_cap = padT + padT / 8 + 4096;
+        TRY(th_rt_host_alloc((void **)&g->h_seq, g->h_seq_cap));
+    }
+    for (int i = 0; i < n; ++i) memcpy(g->h_seq + g->h_roff[i], seqs[i], (size_t)lens[i]);
+    memset(g->h_seq + T, 'N', padT - (size_t)T);
+    // reads whose sort does not fit the LDS buffers get a segment of HBM scratch
+    g->h_gsort_off.assign((size_t)n, -1); long long gs = 0;
+    for (int i = 0; i < n; ++i) {
+        int ne = lens[i] - g->dp.k + 1; if (ne < 1) continue;
+        long long N = 1; while (N < ne) N <<= 1;
+        if (N > TH_XSORT_LDS) { g->h_gsort_off[i] = gs; gs += N; }
+    }
+    g->gsort_total = gs;
+    TRY(g->d_seq.ensure(padT)); TRY(g->d_bseq.ensure(padT)); TRY(g->d_roff.ensure((size_t)n + 1));
+    TRY(g->d_gsort_off.ensure((size_t)n)); TRY(g->d_gsort.ensure((size_t)gs));
+    TRY(th_rt_h2d(g->d_seq.p, g->h_seq, padT, g->stream));
+    TRY(th_rt_h2d(g->d_roff.p, g->h_roff.data(), ((size_t)n + 1) * 4, g->stream));
+    TRY(th_rt_h2d(g->d_gsort_off.p, g->h_gsort_off.data(), (size_t)n * 8, g->stream));
+    TRY(th_rt_sync(g->stream));
+    return 0;
+}
+
+// ---- host: split each chain's par_pos at -1 separators into consensus jobs (src/gen_cons.c:192-205) ----
+static void build_jobs(th_gpu *g)
+{
+    g->h_tasks.clear(); g->h_units.clear(); g->h_items.clear(); g->jobs.clear();
+    const int min_copy = g->dp.min_copy;
+    long long cons_top = 0; int aln_top = 0;
+    // chains grouped by read, in emission order: records of read r are rec[base .. base+cnt)
+    for (int r = 0; r < g->n; ++r) {
+        const int L = (int)(g->h_roff[r + 1] - g->h_roff[r]);
+        for (int c = g->h_read_ch_base[r]; c < g->h_read_ch_base[r] + g->h_read_ch_n[r]; ++c) {
+            const int par_n = g->h_par_n[c]; const int *pp = g->h_parc.data() + g->h_par_dst[c];
+            if (par_n < min_copy + 1) continue;                        // src/tidehunter.c:42
+            int i = 0;
+            while (i < par_n - min_copy) {
+                if (pp[i] < 0) { ++i; continue; }
+                int j; for (j = i + 1; j < par_n; ++j) if (pp[j] < 0) break;
+                if (j - i > min_copy) {
+                    ThTask t; memset(&t, 0, sizeof(t));
+                    t.read = r; t.pos_off = g->h_par_dst[c] + i; t.pos_n = j - i; t.unit_off = (int)g->h_units.size();
+                    for (int u = i; u < j - 1; ++u) {                  // src/abpoa_cons.c:41-48
+                        const int start = pp[u], end = pp[u + 1];
+                        if (start < 0 || end < 0 || start >= L - 1 || end + 1 > L) continue;
+                        ThUnit x = { start + 1, end - start }; g->h_units.push_back(x);
+                        ++t.n_units; t.sum_len += x.len; t.max_len = std::max(t.max_len, x.len);
+                    }
+                    t.cons_cap = t.n_units <= 2 ? (t.n_units ? g->h_units[t.unit_off].len : 0) : std::min(t.sum_len, 3 * t.max_len + 64);
+                    t.cons_off = (int)cons_top; cons_top += (t.cons_cap + 15) & ~15;
+                    t.aln_off = aln_top; aln_top += t.pos_n - 1;
+                    g->h_tasks.push_back(t);
+                }
+                i = j + 1;
+            }
+        }
+    }
+}
+
+static long long poa_need_ints(const ThTask &t, double cell_factor)
+{
+    if (t.n_units <= 2) return 0;
+    const long long cap = t.sum_len + 2, ocap = t.sum_len + t.n_units + 8;
+    long long graph = 27 * cap + 4 * ocap + 2 * (cap + t.max_len + 2) + 256;
+    const long long w = TH_POA_WB + t.max_len / 100;
+    long long rows = std::min<long long>(cap, (long long)(2.2 * t.max_len) + 64);
+    long long cells = (long long)(rows * (2 * w + 1 + 48) * cell_factor);
+    return (graph + 4 * cells + 63) & ~63LL;
+}
+
+#ifndef TH_CPU_EMUL
+#define EV_BEGIN(e) do { hipEventCreate(&(e).a); hipEventCreate(&(e).b); hipEventRecord((e).a, g->stream); } while (0)
+#define EV_END(e) hipEventRecord((e).b, g->stream)
+static double ev_ms(Ev &e) { float ms = 0; hipEventSynchronize(e.b); hipEventElapsedTime(&ms, e.a, e.b); hipEventDestroy(e.a); hipEventDestroy(e.b); return ms; }
+#endif
+
+extern "C" int th_gpu_run(th_gpu_t *g)
+{
+    const int n = g->n; const long long T = g->T; const size_t padT = (size_t)((T + 15) & ~15LL);
+    g->jobs.clear(); g->ms_kernels = g->ms_dominant = 0; g->n_rec = 0;
+    g->h_tasks.clear(); g->h_parc.clear();
+    if (n == 0) return 0;
+#ifndef TH_CPU_EMUL
+    Ev ev_all, ev_dom; bool dom_timed = false;
+    EV_BEGIN(ev_all);
+#endif
+    const int rec_cap = n * 8 + 4096;
+    TRY(g->d_tmp.ensure(padT)); TRY(g->d_hit_end.ensure(padT)); TRY(g->d_hit_per.ensure(padT)); TRY(g->d_hit_n.ensure(n));
+    TRY(g->d_score.ensure(padT)); TRY(g->d_from.ensure(padT)); TRY(g->d_cells.ensure(padT)); TRY(g->d_tracked.ensure(padT));
+    TRY(g->d_cnt.ensure(8)); TRY(g->d_read_ch_base.ensure(n)); TRY(g->d_read_ch_n.ensure(n)); TRY(g->d_rec.ensure(rec_cap));
+    TRY(th_rt_memset(g->d_cnt.p, 0, 8 * sizeof(int), g->stream));
+
+    const int enc_blocks = (int)std::min<long long>(2048, (T / 16 + 255) / 256 + 1);
+    TH_LAUNCH(th_k_encode, enc_blocks, 256, g->stream, (const uint8_t *)g->d_seq.p, g->d_bseq.p, (long long)T);
+    TH_LAUNCH(th_k_hits, n, TH_SEED_BLOCK, g->stream, (const uint8_t *)g->d_bseq.p, (const uint32_t *)g->d_roff.p, g->dp,
+              g->d_hit_end.p, g->d_hit_per.p, g->d_hit_n.p, g->d_tmp.p, g->d_gsort.p, (const long long *)g->d_gsort_off.p);
+    TH_LAUNCH(th_k_chain_dp, (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
+              (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p);
+    TH_LAUNCH(th_k_chain_extract, n, TH_XBLOCK, g->stream, (const uint32_t *)g->d_roff.p, g->dp,
+              (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p,
+              (const int *)g->d_score.p, (const int *)g->d_from.p, g->d_tracked.p, g->d_cells.p,
+              g->d_gsort.p, (const long long *)g->d_gsort_off.p, g->d_rec.p, rec_cap, g->d_cnt.p,
+              g->d_read_ch_base.p, g->d_read_ch_n.p, g->d_cnt.p + 1);
+    int cnt[8];
+    TRY(th_rt_d2h(cnt, g->d_cnt.p, sizeof(cnt), g->stream));
+    TRY(th_rt_sync(g->stream));
+    if (cnt[1]) return th_fail("chain record arena overflow");
+    const int n_rec = cnt[0]; g->n_rec = n_rec;
+    g->h_read_ch_base.resize(n); g->h_read_ch_n.resize(n);
+    TRY(th_rt_d2h(g->h_read_ch_base.data(), g->d_read_ch_base.p, (size_t)n * 4, g->stream));
+    TRY(th_rt_d2h(g->h_read_ch_n.data(), g->d_read_ch_n.p, (size_t)n * 4, g->stream));
+    g->h_rec.resize(n_rec); g->h_par_n.assign(n_rec, 0); g->h_par_dst.assign(n_rec, 0);
+    if (n_rec) {
+        // ---- partition ----
+        const long long bnd_part = ((long long)g->max_len + 128) * 6;
+        const int wp = std::min(n_rec, g->waves_part);
+        TRY(g->d_par.ensure(2 * padT + 16 * (size_t)rec_cap)); TRY(g->d_par_n.ensure(n_rec)); TRY(g->d_par_dst.ensure(n_rec));
+        TRY(g->d_bnd.ensure((size_t)(bnd_part * wp)));
+        TH_LAUNCH(th_k_partition, wp, TH_PART_BLOCK, g->stream, (const ThChainRec *)g->d_rec.p, n_rec, (const uint32_t *)g->d_roff.p,
+                  (const uint8_t *)g->d_bseq.p, (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_cells.p, g->dp,
+                  g->d_par.p, g->d_par_n.p, g->d_bnd.p, bnd_part, g->d_cnt.p + 1);
+        TRY(th_rt_d2h(g->h_rec.data(), g->d_rec.p, (size_t)n_rec * sizeof(ThChainRec), g->stream));
+        TRY(th_rt_d2h(g->h_par_n.data(), g->d_par_n.p, (size_t)n_rec * 4, g->stream));
+        TRY(th_rt_d2h(cnt, g->d_cnt.p, sizeof(cnt), g->stream));
+        TRY(th_rt_sync(g->stream));
+        if (cnt[1]) return th_fail("partition scratch overflow (par_pos region or boundary buffer)");
+        long long tot = 0;
+        for (int c = 0; c < n_rec; ++c) { g->h_par_dst[c] = (int)tot; tot += g->h_par_n[c]; }
+        g->h_parc.resize((size_t)tot);
+        TRY(g->d_parc.ensure((size_t)tot + 1));
+        TRY(th_rt_h2d(g->d_par_dst.p, g->h_par_dst.data(), (size_t)n_rec * 4, g->stream));
+        TH_LAUNCH(th_k_gather_par, n_rec, 64, g->stream, (const ThChainRec *)g->d_rec.p, n_rec, (const int *)g->d_par.p, (const int *)g->d_par_n.p,
+                  (const int *)g->d_par_dst.p, g->d_parc.p);
+        TRY(th_rt_d2h(g->h_parc.data(), g->d_parc.p, (size_t)tot * 4, g->stream));
+        TRY(th_rt_sync(g->stream));
+    } else TRY(th_rt_sync(g->stream));
+
+    build_jobs(g);
+    const int nt = (int)g->h_tasks.size();
+    g->jobs.resize(nt);
+    for (int t = 0; t < nt; ++t) {
+        const ThTask &k = g->h_tasks[t]; th_job_t &j = g->jobs[t];
+        j.read = k.read; j.pos_off = k.pos_off; j.pos_n = k.pos_n; j.n_seqs = k.n_units; j.cons_off = k.cons_off; j.cons_len = 0;
+        j.aln_off = k.aln_off; j.max_q_l = j.max_t_l = j.max_q_r = j.max_t_r = -1; j.status = 0;
+    }
+    if (nt && !g->para.only_unit) {
+        for (int t = 0; t < nt; ++t) if (g->h_tasks[t].n_units <= 1) return th_fail("Not enough sequences to perform msa.");  // src/abpoa_cons.c:61
+        const long long cons_total = g->h_tasks.back().cons_off + ((g->h_tasks.back().cons_cap + 15) & ~15) + 16;
+        const int aln_total = g->h_tasks.back().aln_off + g->h_tasks.back().pos_n - 1;
+        TRY(g->d_tasks.ensure(nt)); TRY(g->d_units.ensure(g->h_units.size() + 1)); TRY(g->d_cons.ensure((size_t)cons_total)); TRY(g->d_cov.ensure((size_t)cons_total));
+        TRY(g->d_cons_len.ensure(nt)); TRY(g->d_status.ensure(nt)); TRY(g->d_iden.ensure((size_t)aln_total + 1)); TRY(g->d_ext.ensure((size_t)nt * 4));
+        TRY(th_rt_h2d(g->d_tasks.p, g->h_tasks.data(), (size_t)nt * sizeof(ThTask), g->stream));
+        TRY(th_rt_h2d(g->d_units.p, g->h_units.data(), g->h_units.size() * sizeof(ThUnit), g->stream));
+        // ---- POA: persistent waves with private scratch; tasks that outgrow it are retried with more ----
+        g->h_cons_len.assign(nt, 0); g->h_status.assign(nt, 0);
+        std::vector<int> todo(nt); for (int t = 0; t < nt; ++t) todo[t] = t;
+        std::vector<ThTask> sub; double factor = 1.5;
+        for (int attempt = 0; attempt < 5 && !todo.empty(); ++attempt, factor *= 4) {
+            long long need = 1024;
+            for (int t : todo) need = std::max(need, poa_need_ints(g->h_tasks[t], factor));
+            const int wv = (int)std::min<long long>(std::min<long long>((long long)todo.size(), g->waves_poa), std::max<long long>(1, (24LL << 30) / (need * 4)));
+            TRY(g->d_scratch.ensure((size_t)(need * wv)));
+            const ThTask *dt = g->d_tasks.p; int *dcl = g->d_cons_len.p, *dst = g->d_status.p;
+            DBuf<ThTask> d_sub; DBuf<int> d_scl, d_sst;
+            if (attempt > 0) {
+                sub.clear(); for (int t : todo) sub.push_back(g->h_tasks[t]);
+                TRY(d_sub.ensure(sub.size())); TRY(d_scl.ensure(sub.size())); TRY(d_sst.ensure(sub.size()));
+                TRY(th_rt_h2d(d_sub.p, sub.data(), sub.size() * sizeof(ThTask), g->stream));
+                dt = d_sub.p; dcl = d_scl.p; dst = d_sst.p;
+            }
+            TH_LAUNCH(th_k_poa, wv, TH_POA_BLOCK, g->stream, dt, (int)todo.size(), (const ThUnit *)g->d_units.p, (const uint32_t *)g->d_roff.p,
+                      (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, dcl, dst);
+            std::vector<int> cl(todo.size()), st(todo.size());
+            TRY(th_rt_d2h(cl.data(), dcl, todo.size() * 4, g->stream));
+            TRY(th_rt_d2h(st.data(), dst, todo.size() * 4, g->stream));
+            TRY(th_rt_sync(g->stream));
+            std::vector<int> again;
+            for (size_t x = 0; x < todo.size(); ++x) {
+                const int t = todo[x];
+                g->h_cons_len[t] = cl[x]; g->h_status[t] = st[x];
+                if (st[x] == 1 || st[x] == 2) again.push_back(t);
+                else if (st[x] != 0) { d_sub.release(); d_scl.release(); d_sst.release(); return th_fail("POA kernel failed with status " + std::to_string(st[x])); }
+            }
+            if (attempt > 0) {   // results of a retried subset live in the subset arrays: patch the main ones
+                TRY(th_rt_h2d(g->d_cons_len.p, g->h_cons_len.data(), (size_t)nt * 4, g->stream));
+                TRY(th_rt_sync(g->stream));
+            }
+            d_sub.release(); d_scl.release(); d_sst.release();
+            todo.swap(again);
+        }
+        if (!todo.empty()) return th_fail("POA scratch still too small after 5 attempts");
+        // ---- unit-vs-consensus alignments and flank extensions ----
+        int max_cl = 0;
+        for (int t = 0; t < nt; ++t) {
+            max_cl = std::max(max_cl, g->h_cons_len[t]);
+            for (int u = 0; u < g->h_tasks[t].pos_n - 1; ++u) { ThAlnItem it = { t, u }; g->h_items.push_back(it); }
+            ThAlnItem l = { t, -1 }, r = { t, -2 }; g->h_items.push_back(l); g->h_items.push_back(r);
+        }
+        const int ni = (int)g->h_items.size();
+        const long long bnd_aln = std::max<long long>(((long long)max_cl + 128) * 4, ((long long)g->max_len + 128) * 2);
+        const int wa = std::min(ni, g->waves_aln);
+        TRY(g->d_items.ensure(ni)); TRY(g->d_bnd.ensure((size_t)(bnd_aln * wa)));
+        TRY(th_rt_h2d(g->d_items.p, g->h_items.data(), (size_t)ni * sizeof(ThAlnItem), g->stream));
+#ifndef TH_CPU_EMUL
+        EV_BEGIN(ev_dom); dom_timed = true;
+#endif
+        TH_LAUNCH(th_k_align, wa, TH_ALN_BLOCK, g->stream, (const ThAlnItem *)g->d_items.p, ni, (const ThTask *)g->d_tasks.p, (const int *)g->d_parc.p,
+                  (const uint32_t *)g->d_roff.p, (const uint8_t *)g->d_bseq.p, (const uint8_t *)g->d_cons.p, (const int *)g->d_cons_len.p,
+                  g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, g->d_cnt.p + 1);
+#ifndef TH_CPU_EMUL
+        EV_END(ev_dom);
+#endif
+        g->h_iden.resize(aln_total); g->h_ext.resize((size_t)nt * 4); g->h_cons.resize((size_t)cons_total); g->h_cov.resize((size_t)cons_total);
+        TRY(th_rt_d2h(g->h_iden.data(), g->d_iden.p, (size_t)aln_total * 4, g->stream));
+        TRY(th_rt_d2h(g->h_ext.data(), g->d_ext.p, (size_t)nt * 16, g->stream));
+        TRY(th_rt_d2h(g->h_cons.data(), g->d_cons.p, (size_t)cons_total, g->stream));
+        TRY(th_rt_d2h(g->h_cov.data(), g->d_cov.p, (size_t)cons_total * 4, g->stream));
+        TRY(th_rt_d2h(cnt, g->d_cnt.p, sizeof(cnt), g->stream));
+        TRY(th_rt_sync(g->stream));
+        if (cnt[1]) return th_fail("alignment boundary buffer overflow");
+        for (int t = 0; t < nt; ++t) {
+            th_job_t &j = g->jobs[t];
+            if (getenv("TH_DEBUG")) fprintf(stderr, "[th] job %d read %d pos_n %d n_units %d cons_len %d status %d\n", t, g->h_tasks[t].read, g->h_tasks[t].pos_n, g->h_tasks[t].n_units, g->h_cons_len[t], g->h_status[t]);
+            j.cons_len = g->h_cons_len[t]; j.status = g->h_status[t];
+            j.max_q_l = g->h_ext[4 * t]; j.max_t_l = g->h_ext[4 * t + 1]; j.max_q_r = g->h_ext[4 * t + 2]; j.max_t_r = g->h_ext[4 * t + 3];
+        }
+    }
+#ifndef TH_CPU_EMUL
+    EV_END(ev_all);
+    g->ms_kernels = ev_ms(ev_all);
+    if (dom_timed) g->ms_dominant = ev_ms(ev_dom);
+#endif
+    return 0;
+}
+
+extern "C" int th_gpu_get(th_gpu_t *g, th_gpu_out_t *out)
+{
+    out->n_jobs = (int)g->jobs.size(); out->jobs = g->jobs.data(); out->par = g->h_parc.data();
+    out->cons = g->h_cons.data(); out->cov = g->h_cov.data(); out->iden = g->h_iden.data();
+    out->ms_kernels = g->ms_kernels; out->ms_dominant = g->ms_dominant;
+    return 0;
+}
+
+extern "C" long long th_gpu_debug(th_gpu_t *g, int what, void *dst, long long cap)
+{
+    const void *src = nullptr; long long bytes = 0;
+    std::vector<int> tmp;
+    switch (what) {
+    case 0: src = g->d_bseq.p; bytes = g->T; break;
+    case 1: src = g->d_hit_n.p; bytes = 4LL * g->n; break;
+    case 2: src = g->d_hit_end.p; bytes = 4LL * g->T; break;
+    case 3: src = g->d_hit_per.p; bytes = 4LL * g->T; break;
+    case 4: src = g->d_score.p; bytes = 4LL * g->T; break;
+    case 5: src = g->d_from.p; bytes = 4LL * g->T; break;
+    case 6: {   // chain records regrouped by read (emission order inside a read is already ascending end)
+        for (int r = 0; r < g->n; ++r)
+            for (int c = g->h_read_ch_base[r]; c < g->h_read_ch_base[r] + g->h_read_ch_n[r]; ++c) {
+                const ThChainRec &x = g->h_rec[c];
+                int v[8] = { x.read, x.cell_off, x.len, x.est_start, x.est_period, g->h_par_dst[c], g->h_par_n[c], 0 };
+                tmp.insert(tmp.end(), v, v + 8);
+            }
+        bytes = 4LL * (long long)tmp.size();
+        if (bytes > cap) return -1;
+        memcpy(dst, tmp.data(), (size_t)bytes);
+        return bytes;
+    }
+    case 7: src = g->d_cells.p; bytes = 4LL * g->T; break;
+    case 8: if (4LL * (g->n + 1) > cap) return -1; memcpy(dst, g->h_roff.data(), 4 * ((size_t)g->n + 1)); return 4LL * (g->n + 1);
+    case 9: bytes = 4LL * (long long)g->h_parc.size(); if (bytes > cap) return -1; memcpy(dst, g->h_parc.data(), (size_t)bytes); return bytes;
+    default: return -1;
+    }
+    if (bytes > cap) return -1;
+    if (th_rt_d2h(dst, src, (size_t)bytes, g->stream)) return -1;
+    if (th_rt_sync(g->stream)) return -1;
+    return bytes;
+}

@@ -1,0 +1,41 @@
+// th_rt.h -- the thin runtime layer the pipeline talks to.
+//
+// Product build (hipcc, gfx950): HIP runtime calls, kernels launched on a HIP stream.
+// Test-only build (-DTH_CPU_EMUL, tests/cpu_emul/): the same kernel sources run under the lock-step
+// fiber emulation in tests/cpu_emul/hip_emul.h so kernel logic can be unit-tested and sanitised
+// without a GPU.  The emulation is never compiled into libtidehunter_amd.so.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#ifdef TH_CPU_EMUL
+#include "hip_emul.h"
+typedef int th_stream_t;
+#define TH_CHECK(x) (x)
+static inline int th_rt_malloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : -1; }
+static inline int th_rt_free(void *p) { free(p); return 0; }
+static inline int th_rt_h2d(void *d, const void *h, size_t n, th_stream_t) { memcpy(d, h, n); return 0; }
+static inline int th_rt_d2h(void *h, const void *d, size_t n, th_stream_t) { memcpy(h, d, n); return 0; }
+static inline int th_rt_memset(void *d, int v, size_t n, th_stream_t) { memset(d, v, n); return 0; }
+static inline int th_rt_sync(th_stream_t) { return 0; }
+static inline int th_rt_host_alloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : -1; }
+static inline int th_rt_host_free(void *p) { free(p); return 0; }
+#define TH_LAUNCH(kernel, grid, block, stream, ...) hipemul::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
+#define TH_LANE() ((int)(threadIdx.x & 63))
+#else
+#include <hip/hip_runtime.h>
+typedef hipStream_t th_stream_t;
+#define TH_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[tidehunter_amd] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
+static inline int th_rt_malloc(void **p, size_t n) { TH_CHECK(hipMalloc(p, n ? n : 1)); return 0; }
+static inline int th_rt_free(void *p) { if (p) TH_CHECK(hipFree(p)); return 0; }
+static inline int th_rt_h2d(void *d, const void *h, size_t n, th_stream_t s) { if (n) TH_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)); return 0; }
+static inline int th_rt_d2h(void *h, const void *d, size_t n, th_stream_t s) { if (n) TH_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s)); return 0; }
+static inline int th_rt_memset(void *d, int v, size_t n, th_stream_t s) { if (n) TH_CHECK(hipMemsetAsync(d, v, n, s)); return 0; }
+static inline int th_rt_sync(th_stream_t s) { TH_CHECK(hipStreamSynchronize(s)); return 0; }
+static inline int th_rt_host_alloc(void **p, size_t n) { TH_CHECK(hipHostMalloc(p, n ? n : 1, hipHostMallocDefault)); return 0; }
+static inline int th_rt_host_free(void *p) { if (p) TH_CHECK(hipHostFree(p)); return 0; }
+#define TH_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+#define TH_LANE() ((int)(threadIdx.x & 63))
+#endif
