@@ -85,8 +85,9 @@ int th_process_batch(th_handle_t *h, const char *const *seqs, const int *lens, i
 int th_batch_upload(th_handle_t *h, const char *const *seqs, const int *lens, int n);
 int th_batch_run(th_handle_t *h);
 int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out);
-/* device milliseconds of the last th_batch_run(): all kernels, and the dominant kernel (th_k_align) */
-int th_batch_timing(th_handle_t *h, double *ms_all, double *ms_dominant);
+/* device milliseconds of the last th_batch_run() per kernel, measured with HIP events on the library's own
+ * stream: [0] encode+hits [1] chain_dp [2] chain_extract [3] partition [4] poa [5] align; returns 6 */
+int th_batch_timing(th_handle_t *h, double *ms_kernel, int n);
 
 /* mini_tandem_output(), src/main.c:214-271 (resets the slots after printing, as the reference does) */
 void th_output(FILE *fp, int n, const char *const *names, const char *const *seqs, const int *lens,

@@ -57,7 +57,7 @@ def load_library(path=None):
     lib.th_batch_upload.argtypes = [C.c_void_p, pp, ip, C.c_int]
     lib.th_batch_run.argtypes = [C.c_void_p]
     lib.th_batch_collect.argtypes = [C.c_void_p, C.POINTER(TandemSeq)]
-    lib.th_batch_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.th_batch_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     lib.th_run_file.argtypes = [C.c_char_p, C.POINTER(Para), C.c_void_p, C.c_int, C.c_int]
     lib.th_synth_read.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_char_p, C.c_int]
     lib.th_last_error.restype = C.c_char_p
@@ -132,10 +132,13 @@ class TideHunter:
         self._check(self.lib.th_batch_collect(self.h, self._ts))
         return [self._records(i) for i in range(self._n)]
 
+    KERNELS = ("th_k_encode+th_k_hits", "th_k_chain_dp", "th_k_chain_extract", "th_k_partition", "th_k_poa", "th_k_align")
+
     def timing(self):
-        a, d = C.c_double(), C.c_double()
-        self.lib.th_batch_timing(self.h, C.byref(a), C.byref(d))
-        return a.value, d.value
+        """device ms of the last run() per kernel (HIP events on the library's stream)"""
+        a = (C.c_double * 8)()
+        n = self.lib.th_batch_timing(self.h, a, 8)
+        return {self.KERNELS[i]: a[i] for i in range(n)}
 
     def process(self, seqs):
         """tidehunter_core() on every read of the batch; returns a list (per read) of record dicts."""

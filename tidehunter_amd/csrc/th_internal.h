@@ -30,7 +30,8 @@ typedef struct {
     const int *par;         /* compact par_pos values */
     const uint8_t *cons; const int *cov; const int *iden;
     double ms_kernels;      /* device time of the last run (HIP events), all kernels */
-    double ms_dominant;     /* device time of the dominant kernel (th_k_align) in the last run */
+    double ms_dominant;     /* device time of the slowest kernel of the last run */
+    double ms_kernel[8];    /* per kernel: 0 encode+hits, 1 chain_dp, 2 chain_extract, 3 partition, 4 poa, 5 align */
 } th_gpu_out_t;
 
 typedef struct th_gpu th_gpu_t;

@@ -55,7 +55,7 @@ struct th_gpu {
     std::vector<ThTask> h_tasks; std::vector<ThUnit> h_units; std::vector<ThAlnItem> h_items;
     std::vector<int> h_cons_len, h_status, h_iden, h_ext, h_cov; std::vector<uint8_t> h_cons;
     std::vector<th_job_t> jobs;
-    double ms_kernels = 0, ms_dominant = 0;
+    double ms_kernels = 0, ms_dominant = 0, ms_k[8] = { 0 };
     int waves_part = 4096, waves_poa = 2048, waves_aln = 8192;
 };
 
@@ -180,10 +180,26 @@ static long long poa_need_ints(const ThTask &t, double cell_factor)
     return (graph + 4 * cells + 63) & ~63LL;
 }
 
+// per-kernel device time: HIP events recorded on the pipeline's own stream around each launch
+enum { TK_SEED = 0, TK_CHAIN_DP, TK_CHAIN_X, TK_PART, TK_POA, TK_ALIGN, TK_N };
 #ifndef TH_CPU_EMUL
-#define EV_BEGIN(e) do { hipEventCreate(&(e).a); hipEventCreate(&(e).b); hipEventRecord((e).a, g->stream); } while (0)
-#define EV_END(e) hipEventRecord((e).b, g->stream)
-static double ev_ms(Ev &e) { float ms = 0; hipEventSynchronize(e.b); hipEventElapsedTime(&ms, e.a, e.b); hipEventDestroy(e.a); hipEventDestroy(e.b); return ms; }
+struct KTimer {
+    std::vector<Ev> ev[TK_N]; th_stream_t s;
+    void begin(int k) { Ev e; hipEventCreate(&e.a); hipEventCreate(&e.b); hipEventRecord(e.a, s); ev[k].push_back(e); }
+    void end(int k) { hipEventRecord(ev[k].back().b, s); }
+    void collect(double *ms) {
+        for (int k = 0; k < TK_N; ++k) {
+            ms[k] = 0;
+            for (Ev &e : ev[k]) { float t = 0; hipEventSynchronize(e.b); hipEventElapsedTime(&t, e.a, e.b); ms[k] += t; hipEventDestroy(e.a); hipEventDestroy(e.b); }
+            ev[k].clear();
+        }
+    }
+};
+#define KT_BEGIN(k) kt.begin(k)
+#define KT_END(k) kt.end(k)
+#else
+#define KT_BEGIN(k) ((void)0)
+#define KT_END(k) ((void)0)
 #endif
 
 extern "C" int th_gpu_run(th_gpu_t *g)
@@ -192,9 +208,9 @@ extern "C" int th_gpu_run(th_gpu_t *g)
     g->jobs.clear(); g->ms_kernels = g->ms_dominant = 0; g->n_rec = 0;
     g->h_tasks.clear(); g->h_parc.clear();
     if (n == 0) return 0;
+    for (int k = 0; k < TK_N; ++k) g->ms_k[k] = 0;
 #ifndef TH_CPU_EMUL
-    Ev ev_all, ev_dom; bool dom_timed = false;
-    EV_BEGIN(ev_all);
+    KTimer kt; kt.s = g->stream;
 #endif
     const int rec_cap = n * 8 + 4096;
     TRY(g->d_tmp.ensure(padT)); TRY(g->d_hit_end.ensure(padT)); TRY(g->d_hit_per.ensure(padT)); TRY(g->d_hit_n.ensure(n));
@@ -203,16 +219,20 @@ extern "C" int th_gpu_run(th_gpu_t *g)
     TRY(th_rt_memset(g->d_cnt.p, 0, 8 * sizeof(int), g->stream));
 
     const int enc_blocks = (int)std::min<long long>(2048, (T / 16 + 255) / 256 + 1);
+    KT_BEGIN(TK_SEED);
     TH_LAUNCH(th_k_encode, enc_blocks, 256, g->stream, (const uint8_t *)g->d_seq.p, g->d_bseq.p, (long long)T);
     TH_LAUNCH(th_k_hits, n, TH_SEED_BLOCK, g->stream, (const uint8_t *)g->d_bseq.p, (const uint32_t *)g->d_roff.p, g->dp,
               g->d_hit_end.p, g->d_hit_per.p, g->d_hit_n.p, g->d_tmp.p, g->d_gsort.p, (const long long *)g->d_gsort_off.p);
+    KT_END(TK_SEED); KT_BEGIN(TK_CHAIN_DP);
     TH_LAUNCH(th_k_chain_dp, (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
               (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p);
+    KT_END(TK_CHAIN_DP); KT_BEGIN(TK_CHAIN_X);
     TH_LAUNCH(th_k_chain_extract, n, TH_XBLOCK, g->stream, (const uint32_t *)g->d_roff.p, g->dp,
               (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p,
               (const int *)g->d_score.p, (const int *)g->d_from.p, g->d_tracked.p, g->d_cells.p,
               g->d_gsort.p, (const long long *)g->d_gsort_off.p, g->d_rec.p, rec_cap, g->d_cnt.p,
               g->d_read_ch_base.p, g->d_read_ch_n.p, g->d_cnt.p + 1);
+    KT_END(TK_CHAIN_X);
     int cnt[8];
     TRY(th_rt_d2h(cnt, g->d_cnt.p, sizeof(cnt), g->stream));
     TRY(th_rt_sync(g->stream));
@@ -228,9 +248,11 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         const int wp = std::min(n_rec, g->waves_part);
         TRY(g->d_par.ensure(2 * padT + 16 * (size_t)rec_cap)); TRY(g->d_par_n.ensure(n_rec)); TRY(g->d_par_dst.ensure(n_rec));
         TRY(g->d_bnd.ensure((size_t)(bnd_part * wp)));
+        KT_BEGIN(TK_PART);
         TH_LAUNCH(th_k_partition, wp, TH_PART_BLOCK, g->stream, (const ThChainRec *)g->d_rec.p, n_rec, (const uint32_t *)g->d_roff.p,
                   (const uint8_t *)g->d_bseq.p, (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_cells.p, g->dp,
                   g->d_par.p, g->d_par_n.p, g->d_bnd.p, bnd_part, g->d_cnt.p + 1);
+        KT_END(TK_PART);
         TRY(th_rt_d2h(g->h_rec.data(), g->d_rec.p, (size_t)n_rec * sizeof(ThChainRec), g->stream));
         TRY(th_rt_d2h(g->h_par_n.data(), g->d_par_n.p, (size_t)n_rec * 4, g->stream));
         TRY(th_rt_d2h(cnt, g->d_cnt.p, sizeof(cnt), g->stream));
@@ -280,8 +302,10 @@ extern "C" int th_gpu_run(th_gpu_t *g)
                 TRY(th_rt_h2d(d_sub.p, sub.data(), sub.size() * sizeof(ThTask), g->stream));
                 dt = d_sub.p; dcl = d_scl.p; dst = d_sst.p;
             }
+            KT_BEGIN(TK_POA);
             TH_LAUNCH(th_k_poa, wv, TH_POA_BLOCK, g->stream, dt, (int)todo.size(), (const ThUnit *)g->d_units.p, (const uint32_t *)g->d_roff.p,
                       (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, dcl, dst);
+            KT_END(TK_POA);
             std::vector<int> cl(todo.size()), st(todo.size());
             TRY(th_rt_d2h(cl.data(), dcl, todo.size() * 4, g->stream));
             TRY(th_rt_d2h(st.data(), dst, todo.size() * 4, g->stream));
@@ -313,15 +337,11 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         const int wa = std::min(ni, g->waves_aln);
         TRY(g->d_items.ensure(ni)); TRY(g->d_bnd.ensure((size_t)(bnd_aln * wa)));
         TRY(th_rt_h2d(g->d_items.p, g->h_items.data(), (size_t)ni * sizeof(ThAlnItem), g->stream));
-#ifndef TH_CPU_EMUL
-        EV_BEGIN(ev_dom); dom_timed = true;
-#endif
+        KT_BEGIN(TK_ALIGN);
         TH_LAUNCH(th_k_align, wa, TH_ALN_BLOCK, g->stream, (const ThAlnItem *)g->d_items.p, ni, (const ThTask *)g->d_tasks.p, (const int *)g->d_parc.p,
                   (const uint32_t *)g->d_roff.p, (const uint8_t *)g->d_bseq.p, (const uint8_t *)g->d_cons.p, (const int *)g->d_cons_len.p,
                   g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, g->d_cnt.p + 1);
-#ifndef TH_CPU_EMUL
-        EV_END(ev_dom);
-#endif
+        KT_END(TK_ALIGN);
         g->h_iden.resize(aln_total); g->h_ext.resize((size_t)nt * 4); g->h_cons.resize((size_t)cons_total); g->h_cov.resize((size_t)cons_total);
         TRY(th_rt_d2h(g->h_iden.data(), g->d_iden.p, (size_t)aln_total * 4, g->stream));
         TRY(th_rt_d2h(g->h_ext.data(), g->d_ext.p, (size_t)nt * 16, g->stream));
@@ -338,10 +358,10 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         }
     }
 #ifndef TH_CPU_EMUL
-    EV_END(ev_all);
-    g->ms_kernels = ev_ms(ev_all);
-    if (dom_timed) g->ms_dominant = ev_ms(ev_dom);
+    kt.collect(g->ms_k);
 #endif
+    g->ms_kernels = 0; g->ms_dominant = 0;
+    for (int k = 0; k < TK_N; ++k) { g->ms_kernels += g->ms_k[k]; g->ms_dominant = std::max(g->ms_dominant, g->ms_k[k]); }
     return 0;
 }
 
@@ -350,6 +370,7 @@ extern "C" int th_gpu_get(th_gpu_t *g, th_gpu_out_t *out)
     out->n_jobs = (int)g->jobs.size(); out->jobs = g->jobs.data(); out->par = g->h_parc.data();
     out->cons = g->h_cons.data(); out->cov = g->h_cov.data(); out->iden = g->h_iden.data();
     out->ms_kernels = g->ms_kernels; out->ms_dominant = g->ms_dominant;
+    for (int k = 0; k < TK_N; ++k) out->ms_kernel[k] = g->ms_k[k];
     return 0;
 }
 
