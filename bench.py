@@ -130,7 +130,7 @@ def main():
                            "kernel_ms_per_step": {k: v / a.steps for k, v in kms.items()},
                            "algorithmic_bytes_per_launch": per_launch_bytes}
         if world == 1 and a.cpu_sample != 0:
-            n_cpu = a.cpu_sample if a.cpu_sample > 0 else min(16384, max(64, 118 * (os.cpu_count() or 8)))
+            n_cpu = a.cpu_sample if a.cpu_sample > 0 else min(4096, max(64, 16 * (os.cpu_count() or 8)))
             out["cpu_baseline"] = cpu_baseline(lib, TH, n_cpu)
         print(json.dumps(out))
     th.close()

@@ -56,7 +56,7 @@ struct th_gpu {
     std::vector<int> h_cons_len, h_status, h_iden, h_ext, h_cov; std::vector<uint8_t> h_cons;
     std::vector<th_job_t> jobs;
     double ms_kernels = 0, ms_dominant = 0, ms_k[8] = { 0 };
-    int waves_part = 4096, waves_poa = 2048, waves_aln = 8192;
+    int waves_part = 4096, waves_poa = 5120, waves_aln = 8192;   // persistent grids: 256 CUs x 4 SIMDs x resident waves
 };
 
 static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
@@ -292,7 +292,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         for (int attempt = 0; attempt < 5 && !todo.empty(); ++attempt, factor *= 4) {
             long long need = 1024;
             for (int t : todo) need = std::max(need, poa_need_ints(g->h_tasks[t], factor));
-            const int wv = (int)std::min<long long>(std::min<long long>((long long)todo.size(), g->waves_poa), std::max<long long>(1, (24LL << 30) / (need * 4)));
+            const int wv = (int)std::min<long long>(std::min<long long>((long long)todo.size(), g->waves_poa), std::max<long long>(1, (64LL << 30) / (need * 4)));
             TRY(g->d_scratch.ensure((size_t)(need * wv)));
             const ThTask *dt = g->d_tasks.p; int *dcl = g->d_cons_len.p, *dst = g->d_status.p;
             DBuf<ThTask> d_sub; DBuf<int> d_scl, d_sst;
