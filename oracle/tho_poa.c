@@ -13,10 +13,17 @@
  *   graph    : nodes 0 = source, 1 = sink, >=2 bases in creation order; weighted edges kept in
  *              insertion order; nodes that carry different bases of one MSA column form an
  *              "aligned ring".
- *   order    : Kahn/BFS topological sort from the source, FIFO; a node is released only when
- *              every member of its aligned ring is ready, and the ring is released together
- *              (so a column's nodes are adjacent).  max_remain[v] = longest node count from v
- *              to the sink (sink = -1).
+ *   order    : a topological order kept incrementally ("insertion order"): the first unit is a
+ *              chain source, bases, sink; when an alignment is merged, a new ring member is
+ *              placed right after the last member of its ring, and a run of inserted bases
+ *              right before the ring of the next aligned node of the path (before the sink
+ *              if there is none).  Rings stay adjacent, every edge points forward (the
+ *              path visits rows in increasing order).  The DP values of a row depend only on
+ *              its predecessors' rows, so they do not depend on which topological order is
+ *              used; only the left-to-right order of parallel insertion branches in the
+ *              consensus does.  (abPOA re-sorts with a BFS after every sequence; this order
+ *              is kept instead because it can be updated with prefix sums on the GPU.)
+ *              max_remain[v] = longest node count from v to the sink (sink = -1).
  *   DP       : global alignment of the query (columns 0..qlen) against the ordered nodes,
  *              convex gap = two affine pieces, 32-bit scores, score(a,b) = 0 if either is N(4),
  *              +match if equal, -mismatch otherwise.
@@ -86,30 +93,11 @@ static void add_edge(graph_t *g, int from, int to)
     b->in_tail = id; ++b->in_n;
 }
 
-static void topo_sort(graph_t *g)
+/* max_remain for every node: longest node count from v to the sink (sink = -1), reverse pass over the order */
+static void set_remain(graph_t *g)
 {
     int n = g->n_node;
-    g->order = (int *)realloc(g->order, sizeof(int) * n);
-    g->index = (int *)realloc(g->index, sizeof(int) * n);
     g->remain = (int *)realloc(g->remain, sizeof(int) * n);
-    int *rem = (int *)malloc(sizeof(int) * n), *queue = (int *)malloc(sizeof(int) * n);
-    for (int i = 0; i < n; ++i) rem[i] = g->node[i].in_n;
-    int qh = 0, qt = 0, on = 0;
-    queue[qt++] = 0;
-    while (qh < qt) {
-        int u = queue[qh++];
-        g->index[u] = on; g->order[on++] = u;
-        for (int e = g->node[u].out_head; e >= 0; e = g->edge[e].next_out) {
-            int v = g->edge[e].to;
-            if (--rem[v] > 0) continue;
-            int ok = 1;
-            for (int m = g->node[v].ring; m != v; m = g->node[m].ring) if (rem[m] > 0) { ok = 0; break; }
-            if (!ok) continue;
-            queue[qt++] = v;
-            for (int m = g->node[v].ring; m != v; m = g->node[m].ring) queue[qt++] = m;
-        }
-    }
-    if (on != n) { fprintf(stderr, "[tho_poa] topological sort left %d of %d nodes\n", n - on, n); exit(1); }
     for (int i = n - 1; i >= 0; --i) {
         int u = g->order[i], r = -1;
         if (u != 1)
@@ -119,7 +107,6 @@ static void topo_sort(graph_t *g)
             }
         g->remain[u] = r;
     }
-    free(rem); free(queue);
 }
 
 /* alignment ops, forward order */
@@ -258,30 +245,58 @@ static int align_to_graph(graph_t *g, const uint8_t *q, int qlen, const tho_para
 static void add_alignment(graph_t *g, const uint8_t *q, int qlen, const aop_t *ops, int n_ops)
 {
     int last = 0;
-    if (ops == NULL) {                       /* first sequence: a plain chain */
+    if (ops == NULL) {                       /* first sequence: a plain chain; order = source, bases, sink */
         for (int j = 0; j < qlen; ++j) { int v = new_node(g, q[j]); ++g->node[v].n_read; add_edge(g, last, v); last = v; }
-    } else {
-        for (int a = 0; a < n_ops; ++a) {
-            if (ops[a].op == 2) continue;
-            uint8_t b = q[ops[a].qpos];
-            int v = -1;
-            if (ops[a].op == 0) {
-                int u = ops[a].node;
-                if (g->node[u].base == b) v = u;
-                else {
-                    for (int m = g->node[u].ring; m != u; m = g->node[m].ring) if (g->node[m].base == b) { v = m; break; }
-                    if (v < 0) {             /* new member, linked right after u */
-                        v = new_node(g, b);
-                        g->node[v].ring = g->node[u].ring; g->node[u].ring = v;
-                    }
+        add_edge(g, last, 1);
+        int n = g->n_node;
+        g->order = (int *)realloc(g->order, sizeof(int) * n); g->index = (int *)realloc(g->index, sizeof(int) * n);
+        g->order[0] = 0; for (int j = 0; j < qlen; ++j) g->order[1 + j] = 2 + j; g->order[n - 1] = 1;
+        for (int i = 0; i < n; ++i) g->index[g->order[i]] = i;
+        return;
+    }
+    int n_old = g->n_node;
+    /* per old order position: new nodes to emit before it (a run of insertions) / one new ring member after it */
+    int *ins_head = (int *)malloc(sizeof(int) * n_old * 3), *ins_cnt = ins_head + n_old, *after = ins_cnt + n_old;
+    for (int i = 0; i < n_old; ++i) { ins_head[i] = -1; ins_cnt[i] = 0; after[i] = -1; }
+    int *pend = (int *)malloc(sizeof(int) * (size_t)(qlen + 1)), n_pend = 0;   /* inserted nodes waiting for their anchor */
+    for (int a = 0; a < n_ops; ++a) {
+        if (ops[a].op == 2) continue;
+        uint8_t b = q[ops[a].qpos];
+        int v = -1;
+        if (ops[a].op == 0) {
+            int u = ops[a].node;
+            /* first / last order position of u's ring (ring members are adjacent) */
+            int lo = g->index[u], hi = g->index[u];
+            for (int m = g->node[u].ring; m != u; m = g->node[m].ring) { if (g->index[m] < lo) lo = g->index[m]; if (g->index[m] > hi) hi = g->index[m]; }
+            if (g->node[u].base == b) v = u;
+            else {
+                for (int m = g->node[u].ring; m != u; m = g->node[m].ring) if (g->node[m].base == b) { v = m; break; }
+                if (v < 0) {             /* new member, linked right after u, ordered after the ring's last member */
+                    v = new_node(g, b);
+                    g->node[v].ring = g->node[u].ring; g->node[u].ring = v;
+                    after[hi] = v;
                 }
-            } else v = new_node(g, b);
-            ++g->node[v].n_read;
-            add_edge(g, last, v);
-            last = v;
-        }
+            }
+            if (n_pend) { ins_head[lo] = pend[0]; ins_cnt[lo] = n_pend; n_pend = 0; }   /* insertions go right before this ring */
+        } else { v = new_node(g, b); pend[n_pend++] = v; }
+        ++g->node[v].n_read;
+        add_edge(g, last, v);
+        last = v;
     }
     add_edge(g, last, 1);
+    int sink_pos = g->index[1];
+    if (n_pend) { ins_head[sink_pos] = pend[0]; ins_cnt[sink_pos] = n_pend; }
+    /* inserted nodes of one run have consecutive ids (created in path order) */
+    int n = g->n_node, *no = (int *)malloc(sizeof(int) * n), k = 0;
+    for (int i = 0; i < n_old; ++i) {
+        for (int x = 0; x < ins_cnt[i]; ++x) no[k++] = ins_head[i] + x;
+        no[k++] = g->order[i];
+        if (after[i] >= 0) no[k++] = after[i];
+    }
+    free(g->order); g->order = no;
+    g->index = (int *)realloc(g->index, sizeof(int) * n);
+    for (int i = 0; i < n; ++i) g->index[g->order[i]] = i;
+    free(ins_head); free(pend);
 }
 
 int tho_poa_consensus(int n_seqs, const uint8_t *const *seqs, const int *lens, const tho_para_t *p, uint8_t *cons, int *cov)
@@ -294,13 +309,12 @@ int tho_poa_consensus(int n_seqs, const uint8_t *const *seqs, const int *lens, c
         for (int j = 0; j < lens[s]; ++j) buf[j] = seqs[s][j] > 4 ? 4 : seqs[s][j];
         if (s == 0) add_alignment(&g, buf, lens[s], NULL, 0);
         else {
-            topo_sort(&g);
+            set_remain(&g);
             aop_t *ops; int n_ops = align_to_graph(&g, buf, lens[s], p, &ops);
             add_alignment(&g, buf, lens[s], ops, n_ops);
             free(ops);
         }
     }
-    topo_sort(&g);
     int cl = 0;
     for (int i = 1; i + 1 < g.n_node;) {
         int v = g.order[i], cnt[5] = { 0, 0, 0, 0, 0 }, tot = 0, k = i;

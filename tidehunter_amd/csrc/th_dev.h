@@ -38,48 +38,83 @@ struct ThUnit { int start, len; };   // start = index of the unit's first base i
 // needs a real rendezvous here.
 #ifdef TH_CPU_EMUL
 #define TH_WAVE_FENCE() do { (void)hipemul::wave_exchange(0); } while (0)
-#else
+#elif defined(TH_SAFE_FENCE)
 #define TH_WAVE_FENCE() __threadfence_block()
+#else
+// Every team in these kernels is ONE wavefront, so the hand-offs are lane-to-lane inside a wave: the
+// wave's vector-memory instructions reach its CU's L1 in issue order, which already orders a lane's
+// store before another lane's later load.  A wavefront-scope fence keeps the compiler from reordering
+// and, unlike __threadfence_block(), does not stall on s_waitcnt vmcnt(0) (the store round trip to L2,
+// ~1-2 us) -- that wait per POA row was the dominant cost of the first version.
+#define TH_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 #endif
 
-// ---- wave helpers (every lane of the wave must call these) ----
+// ---- wave helpers (every lane of the wave must call these; control flow around them is wave-uniform) ----
+// On gfx950 the lane shifts, scans and reductions are DPP moves on the VALU (row_shr / row_bcast /
+// wave_shr: a few cycles each) instead of ds_bpermute through the LDS crossbar (~100 cycles of
+// latency per hop, which made every dependent scan step a stall).  The CPU emulation (tests only)
+// implements the same semantics with its rendezvous shuffles.
+#ifdef TH_CPU_EMUL
+#define TH_READLANE(v, l) __shfl((v), (l))
+__device__ __forceinline__ int th_shr1(int v, int fill) { int o = __shfl_up(v, 1); return TH_LANE() == 0 ? fill : o; }
+__device__ __forceinline__ int th_shl1(int v, int fill) { int o = __shfl_down(v, 1); return TH_LANE() == 63 ? fill : o; }
 __device__ __forceinline__ int th_wave_incl_max(int v)
 {
     const int lane = TH_LANE();
-#pragma unroll
     for (int d = 1; d < TH_WAVE; d <<= 1) { int o = __shfl_up(v, d); if (lane >= d) v = max(v, o); }
     return v;
-}
-__device__ __forceinline__ int th_wave_excl_max(int v, int seed)
-{
-    int inc = th_wave_incl_max(v);
-    int e = __shfl_up(inc, 1);
-    return TH_LANE() == 0 ? seed : max(e, seed);
 }
 __device__ __forceinline__ int th_wave_incl_sum(int v)
 {
     const int lane = TH_LANE();
-#pragma unroll
     for (int d = 1; d < TH_WAVE; d <<= 1) { int o = __shfl_up(v, d); if (lane >= d) v += o; }
     return v;
 }
-__device__ __forceinline__ int th_wave_max(int v)
+#else
+#define TH_READLANE(v, l) __builtin_amdgcn_readlane((v), (l))
+#define TH_DPP(old, src, ctrl, rmask, bmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), (bmask), false)
+__device__ __forceinline__ int th_shr1(int v, int fill) { return TH_DPP(fill, v, 0x138, 0xf, 0xf); }   // wave_shr:1
+__device__ __forceinline__ int th_shl1(int v, int fill) { return TH_DPP(fill, v, 0x130, 0xf, 0xf); }   // wave_shl:1
+__device__ __forceinline__ int th_wave_incl_max(int v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
-    return v;
+    const int id = -0x7fffffff - 1;
+    int x = v;
+    x = max(x, TH_DPP(id, v, 0x111, 0xf, 0xf));     // row_shr:1
+    x = max(x, TH_DPP(id, v, 0x112, 0xf, 0xf));     // row_shr:2
+    x = max(x, TH_DPP(id, v, 0x113, 0xf, 0xf));     // row_shr:3
+    x = max(x, TH_DPP(id, x, 0x114, 0xf, 0xe));     // row_shr:4, banks 1-3
+    x = max(x, TH_DPP(id, x, 0x118, 0xf, 0xc));     // row_shr:8, banks 2-3
+    x = max(x, TH_DPP(id, x, 0x142, 0xa, 0xf));     // row_bcast:15 into rows 1,3
+    x = max(x, TH_DPP(id, x, 0x143, 0xc, 0xf));     // row_bcast:31 into rows 2,3
+    return x;
 }
-__device__ __forceinline__ int th_wave_min(int v)
+__device__ __forceinline__ int th_wave_incl_sum(int v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
-    return v;
+    int x = v;
+    x += TH_DPP(0, v, 0x111, 0xf, 0xf);
+    x += TH_DPP(0, v, 0x112, 0xf, 0xf);
+    x += TH_DPP(0, v, 0x113, 0xf, 0xf);
+    x += TH_DPP(0, x, 0x114, 0xf, 0xe);
+    x += TH_DPP(0, x, 0x118, 0xf, 0xc);
+    x += TH_DPP(0, x, 0x142, 0xa, 0xf);
+    x += TH_DPP(0, x, 0x143, 0xc, 0xf);
+    return x;
 }
-__device__ __forceinline__ int th_wave_sum(int v)
+#endif
+__device__ __forceinline__ int th_wave_excl_max(int v, int seed) { return max(th_shr1(th_wave_incl_max(v), seed), seed); }
+__device__ __forceinline__ int th_wave_max(int v) { return TH_READLANE(th_wave_incl_max(v), 63); }
+__device__ __forceinline__ int th_wave_min(int v) { return -TH_READLANE(th_wave_incl_max(-v), 63); }
+__device__ __forceinline__ int th_wave_sum(int v) { return TH_READLANE(th_wave_incl_sum(v), 63); }
+// lane l <- lane l+off for a wave-uniform offset (fill where the source lane does not exist)
+__device__ __forceinline__ int th_lane_shift(int v, int off, int fill)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
+    if (off == 0) return v;
+    if (off == -1) return th_shr1(v, fill);
+    if (off == 1) return th_shl1(v, fill);
+    if (off == 2) return th_shl1(th_shl1(v, fill), fill);
+    const int src = TH_LANE() + off;
+    const int o = __shfl(v, src & 63);
+    return (src >= 0 && src < TH_WAVE) ? o : fill;
 }
 __device__ __forceinline__ int th_ctz64(unsigned long long m) { return m ? __ffsll((long long)m) - 1 : 64; }
 __device__ __forceinline__ int th_msb64(unsigned long long m) { return 63 - __clzll((long long)m); }   // m != 0

@@ -11,6 +11,7 @@
 #define TH_TOPN 1000            // src/tandem_chain.c:361
 #define TH_XSORT_LDS 8192       // candidates sorted in LDS up to this many hits, else in HBM scratch
 #define TH_XBLOCK 256
+#define TH_XFAST_MAX 8192       // reads with at most this many hits take the one-wave-per-read extraction kernel
 
 enum { TH_NO_CON = 0, TH_REG_CON = 1, TH_SAME_CON = 2, TH_OVL_CON = 3 };
 
@@ -72,7 +73,7 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             const int f = th_ctz64(stopm);
             const unsigned long long lim = f >= 63 ? ~0ull : ((2ull << f) - 1);
             const unsigned long long taken = impm & lim;
-            if (taken) { const int last = th_msb64(taken); best = __shfl(s, last); bi = base - last; }
+            if (taken) { const int last = th_msb64(taken); best = TH_READLANE(s, last); bi = base - last; }
             if (f < 64) break;
             iter = impm ? 63 - th_msb64(impm) : iter + TH_WAVE;
         }
@@ -101,7 +102,7 @@ th_k_chain_extract(const uint32_t *__restrict__ roff, ThDevPara P,
     const int tid = threadIdx.x, r = blockIdx.x;
     const uint32_t off = roff[r];
     const int n = hit_n[r];
-    if (n < 2) { if (tid == 0) { read_ch_base[r] = 0; read_ch_n[r] = 0; } return; }     // src/tandem_chain.c:291
+    if (n <= TH_XFAST_MAX) return;            // handled by th_k_chain_extract_wave
     const int *E = hit_end + off, *Pd = hit_per + off, *S = score + off, *F = from + off;
     uint8_t *T = tracked + off; int *CL = cells + off;
     int N = 1; while (N < n) N <<= 1;
@@ -202,5 +203,162 @@ th_k_chain_extract(const uint32_t *__restrict__ roff, ThDevPara P,
             x.first_end = E[c0]; x.last_start = ch_ls[c]; x.pad = 0;
             rec[o++] = x;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Chain extraction, one read per wavefront (reads with <= TH_XFAST_MAX hits; the kernel above is the
+// fallback for longer ones).  Same decisions as the reference, organised for the wave:
+//   * candidates sorted by (score desc, hit index desc) as 32-bit keys in LDS;
+//   * the scan over candidates is 64-wide: a lane is skipped if its cell is covered by an accepted
+//     chain (is_in_chain, :170-185) or already tracked (backtrack_dp returns at once, :87, and the
+//     sort_chain that follows is a no-op on an unchanged list), the first surviving lane is attempted;
+//   * backtracking follows from[] through an LDS copy, tracked flags are an LDS bitmap.
+// ---------------------------------------------------------------------------------------------
+#define TH_XW_BLOCK 64
+__global__ void __launch_bounds__(TH_XW_BLOCK)
+th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
+                        const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ hit_n,
+                        const int *__restrict__ score, const int *__restrict__ from, int *__restrict__ cells,
+                        ThChainRec *__restrict__ rec, int rec_cap, int *__restrict__ rec_count,
+                        int *__restrict__ read_ch_base, int *__restrict__ read_ch_n, int *__restrict__ err)
+{
+    __shared__ uint32_t s_key[TH_XFAST_MAX];
+    __shared__ int s_from[TH_XFAST_MAX];
+    __shared__ uint32_t s_trk[TH_XFAST_MAX / 32];
+    __shared__ int ch_off[TH_TOPN], ch_len[TH_TOPN], ch_score[TH_TOPN], ch_fs[TH_TOPN], ch_ls[TH_TOPN], ch_le[TH_TOPN];
+    __shared__ short ch_idx[TH_TOPN];
+    const int lane = TH_LANE();
+    for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        const uint32_t off = roff[r];
+        const int n = hit_n[r];
+        if (n > TH_XFAST_MAX) continue;
+        if (n < 2) { if (lane == 0) { read_ch_base[r] = 0; read_ch_n[r] = 0; } continue; }     // src/tandem_chain.c:291
+        const int *E = hit_end + off, *Pd = hit_per + off, *S = score + off, *F = from + off;
+        int *CL = cells + off;
+        int N = 1; while (N < n) N <<= 1;
+        for (int i = lane; i < N; i += TH_WAVE) s_key[i] = i < n ? ((uint32_t)S[i] << 13 | (uint32_t)i) : 0u;
+        for (int i = lane; i < n; i += TH_WAVE) s_from[i] = F[i];
+        for (int i = lane; i < (n + 31) / 32; i += TH_WAVE) s_trk[i] = 0;
+        for (int i = lane; i < TH_TOPN; i += TH_WAVE) ch_idx[i] = (short)i;
+        TH_WAVE_FENCE();
+        for (int size = 2; size <= N; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = lane; t < (N >> 1); t += TH_WAVE) {
+                    const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                    const bool desc = (lo & size) == 0;
+                    const uint32_t a = s_key[lo], c = s_key[hi];
+                    if ((a < c) == desc) { s_key[lo] = c; s_key[hi] = a; }
+                }
+                TH_WAVE_FENCE();
+            }
+        int ch_n = 0, top = 0, ci = 0;
+        while (ci < n && ch_n < TH_TOPN) {
+#ifdef TH_CPU_EMUL
+            if (lane == 0 && getenv("TH_DEBUG_X")) fprintf(stderr, "[xw] r %d ci %d n %d ch_n %d top %d\n", r, ci, n, ch_n, top);
+#endif
+            // ---- 64 candidates at once: covered by an accepted chain, or already tracked? ----
+            const int x = ci + lane;
+            const bool valid = x < n;
+            const int cand = valid ? (int)(s_key[x] & 0x1fff) : 0;
+            const int cell_end = valid ? E[cand] : 0, cell_start = valid ? cell_end - Pd[cand] : 0;
+            bool skip = !valid || ((s_trk[cand >> 5] >> (cand & 31)) & 1);
+            bool open = !skip;                       // is_in_chain's scan is still running for this lane
+            for (int q = 0; q < ch_n; ++q) {
+                const int c = ch_idx[q];
+                if (ch_len[c] <= 0) continue;
+                const int cst = ch_fs[c], cen = ch_le[c];
+                if (open) {
+                    if (cen < cell_start) open = false;
+                    else if (cst > cell_end) {}
+                    else if (cell_end - cst >= (cen - cst) / 2) { skip = true; open = false; }
+                }
+                if (!__any(open)) break;
+            }
+            const unsigned long long m = __ballot(valid && !skip);
+            if (!m) { ci += TH_WAVE; continue; }
+            const int f = th_ctz64(m);
+            const int c0 = TH_READLANE(cand, f);
+            ci += f + 1;
+            // ---- attempt: backtrack_dp into slot ch_n (wave-uniform scalar walk; cells written by lane 0) ----
+            int sc = S[c0], cur = c0, len = 0;
+            for (;;) {
+                if (lane == 0) { s_trk[cur >> 5] |= 1u << (cur & 31); CL[top + len] = cur; }
+                ++len;
+                TH_WAVE_FENCE();
+                const int pre = s_from[cur];
+                if (pre == -1) break;
+                if ((s_trk[pre >> 5] >> (pre & 31)) & 1) { sc -= S[pre]; break; }
+                cur = pre;
+                TH_WAVE_FENCE();     // every lane has tested `pre` before lane 0 marks it in the next trip
+            }
+            const int nw = ch_n;
+            const int cfirst = cur, clast = c0;      // the walk ran from the chain's last cell to its first
+            int ok = 0;
+            if (len > 1) {
+                const int fs = E[cfirst] - Pd[cfirst], ls = E[clast] - Pd[clast], le = E[clast];
+                int loses = 0, kill = -1;
+                for (int i = ch_n - 1; i >= 0; --i) {            // is_overlap_chain, :68-83
+                    if (ch_len[i] <= 0) continue;
+                    if (ch_le[i] <= ls) break;
+                    const int s1 = ch_fs[i], e1 = ch_ls[i];
+                    const int mn = min(e1 - s1, ls - fs), ov = min(e1, ls) - max(s1, fs);
+                    if (ov / (mn + 0.0) >= 0.5) {
+                        if (ch_score[i] > sc) loses = 1; else kill = i;
+                        break;
+                    }
+                }
+                TH_WAVE_FENCE();
+                if (lane == 0 && kill >= 0) ch_len[kill] = 0;    // the older chain loses
+                TH_WAVE_FENCE();
+                ok = !loses;
+                if (ok) {
+                    // reverse the cells in place (they were written last-to-first)
+                    for (int a = lane; a < len / 2; a += TH_WAVE) { const int b2 = len - 1 - a; const int t0 = CL[top + a], t1 = CL[top + b2]; CL[top + a] = t1; CL[top + b2] = t0; }
+                    if (lane == 0) { ch_off[nw] = top; ch_len[nw] = len; ch_score[nw] = sc; ch_fs[nw] = fs; ch_ls[nw] = ls; ch_le[nw] = le; }
+                    top += len; ++ch_n;
+                }
+            }
+            TH_WAVE_FENCE();
+            // sort_chain, src/tandem_chain.c:188-207 (selection pass with the reference's stale `i`), by lane 0
+            if (lane == 0) {
+                for (int a = 0; a + 1 < ch_n; ++a) {
+                    const int i = ch_idx[a];
+                    if (ch_len[i] <= 0) continue;
+                    int e1 = ch_le[i];
+                    for (int b = a + 1; b < ch_n; ++b) {
+                        const int j = ch_idx[b];
+                        if (ch_len[j] <= 0) continue;
+                        const int e2 = ch_le[j];
+                        if (e1 < e2) { ch_idx[a] = (short)j; ch_idx[b] = (short)i; e1 = e2; }
+                    }
+                }
+            }
+            TH_WAVE_FENCE();
+        }
+        // copy_chain in reverse rank order (ascending end), chains with >= 3 cells; seed = first cell (:251-255)
+        int cnt = 0;
+        for (int q = ch_n - 1; q >= 0; --q) if (ch_len[ch_idx[q]] >= 3) ++cnt;
+        int base = 0;
+        if (lane == 0 && cnt) base = atomicAdd(rec_count, cnt);
+        base = TH_READLANE(base, 0);
+        if (base + cnt > rec_cap) { if (lane == 0) atomicOr(err, 1); cnt = 0; }
+        if (lane == 0) {
+            read_ch_base[r] = base; read_ch_n[r] = cnt;
+            if (cnt) {
+                int o = base;
+                for (int q = ch_n - 1; q >= 0; --q) {
+                    const int c = ch_idx[q];
+                    if (ch_len[c] < 3) continue;
+                    const int cc0 = CL[ch_off[c]];
+                    ThChainRec xr;
+                    xr.read = r; xr.cell_off = (int)off + ch_off[c]; xr.len = ch_len[c];
+                    xr.est_start = ch_fs[c]; xr.est_period = E[cc0] - ch_fs[c];
+                    xr.first_end = E[cc0]; xr.last_start = ch_ls[c]; xr.pad = 0;
+                    rec[o++] = xr;
+                }
+            }
+        }
+        TH_WAVE_FENCE();
     }
 }

@@ -4,18 +4,28 @@
 // submodule -- see DESIGN.md "POA parity").  The algorithm is the one oracle/tho_poa.c states:
 // progressive alignment of units 1..n-1 onto a graph seeded by unit 0, adaptive band
 // (w = 10 + qlen/100 around the row maxima of the predecessor rows and the expected diagonal),
-// convex gap cost (two affine pieces), row-column consensus by most frequent symbol.
+// convex gap cost (two affine pieces), row-column consensus by most frequent symbol, graph kept
+// in "insertion order".
 //
-// One consensus task per wavefront, waves loop over the task list (persistent launch).
-//   * band cells of a graph row are one lane each (64 columns per trip); the in-row gap recurrences
-//     F1/F2 are an exclusive max-plus prefix scan across the wave;
-//   * each cell stores {H, E1-next, E2-next, direction word} as one 16-byte vector;
-//   * graph maintenance (topological order, traceback, merging the alignment) is sequential
-//     pointer work done by lane 0 on HBM-resident arrays of the wave's private scratch.
+// One consensus job per wavefront, waves loop over the job list (persistent launch).  Every
+// phase is wave-parallel except the traceback walk:
+//   remain     : longest path to the sink by 64-node chunks, in-chunk dependencies resolved by
+//                register relaxation (no memory round trips);
+//   row tables : per row (order index) base, degrees, predecessor / successor ROW indices, so the DP
+//                loop never chases node ids;
+//   DP         : band cells one lane each, F1/F2 as max-plus prefix scans; the previous row stays
+//                in registers (lane shuffles) when it is the only predecessor, so the common
+//                row has no dependent HBM load; cells {H,E1',E2',dir} go to HBM as 16-byte vectors;
+//   traceback  : sequential, but reads its direction words from 16-row x 4-diagonal tiles
+//                prefetched by the whole wave;
+//   merge      : one alignment column per lane (node choice, ring splice, new ids by prefix sum,
+//                edges: every node is `from` once and `to` once per path, so lanes never collide);
+//   order      : positions of new nodes by a prefix sum over the old order.
 #include "th_dev.h"
 
 #define TH_POA_BLOCK 64
 #define TH_POA_WB 10
+#define TH_POA_QCAP 4096        // query bases staged in LDS (jobs with longer units use the LQ=false instantiation)
 
 #define TH_D_SRC(d)  ((d) & 7)
 #define TH_D_PM(d)   (((d) >> 3) & 0xff)
@@ -26,18 +36,23 @@
 #define TH_D_XF1 (1u << 29)
 #define TH_D_XF2 (1u << 30)
 
-#define TH_POA_INL 4     // adjacency entries kept inline per node; more go to the overflow pool
+#define TH_POA_INL 4
+#define TH_BIG 0x3fffffff
 
 struct ThPoaG {
-    int cap, n_node;            // node capacity / nodes in use (0 = source, 1 = sink)
-    int *base, *nread, *ring, *inn, *outn, *in4, *out4, *in_oh, *in_ot, *out_oh, *out_ot;
-    int *ovf_val, *ovf_next; int ovf_n, ovf_cap;
-    int *order, *index, *remain, *rem, *mpl, *mpr, *beg, *end, *ops;
-    long long *roff;            // cell offset of each row
+    int cap, n_node;
+    // by node id
+    int *nbase, *nread, *ring, *inn, *outn, *in4, *out4, *in_oh, *in_ot, *out_oh, *out_ot, *pos;
+    int *ovf_val, *ovf_next, *ovf_cnt;
+    int *order, *order2;
+    // by row (order index)
+    int *r_meta, *r_p, *r_s, *r_rem, *r_beg, *r_end, *r_mpl, *r_mpr;
+    long long *r_off;
+    int *cntB, *headB, *aft;
+    int *ops, *pv, *glo, *pth;
     int4 *cell; long long cell_cap;
 };
 
-// ---- adjacency (insertion order preserved: inline slots first, then the overflow list) ----
 __device__ __forceinline__ int th_poa_in(const ThPoaG &g, int v, int ord)
 {
     if (ord < TH_POA_INL) return g.in4[v * TH_POA_INL + ord];
@@ -52,17 +67,11 @@ __device__ __forceinline__ int th_poa_out(const ThPoaG &g, int v, int ord)
     for (int x = TH_POA_INL; x < ord; ++x) e = g.ovf_next[e];
     return g.ovf_val[e];
 }
-__device__ int th_poa_new_node(ThPoaG &g, int b)
-{
-    const int v = g.n_node++;
-    g.base[v] = b; g.nread[v] = 0; g.ring[v] = v; g.inn[v] = 0; g.outn[v] = 0;
-    g.in_oh[v] = g.in_ot[v] = g.out_oh[v] = g.out_ot[v] = -1;
-    return v;
-}
+// one lane adds edge from->to if absent; `from` and `to` are each handled by exactly one lane per path
 __device__ void th_poa_add_edge(ThPoaG &g, int from, int to)
 {
     const int on = g.outn[from];
-    {   // already there?
+    {
         int e = g.out_oh[from];
         for (int x = 0; x < on; ++x) {
             int u;
@@ -73,7 +82,7 @@ __device__ void th_poa_add_edge(ThPoaG &g, int from, int to)
     }
     if (on < TH_POA_INL) g.out4[from * TH_POA_INL + on] = to;
     else {
-        const int id = g.ovf_n++; g.ovf_val[id] = to; g.ovf_next[id] = -1;
+        const int id = atomicAdd(g.ovf_cnt, 1); g.ovf_val[id] = to; g.ovf_next[id] = -1;
         if (g.out_ot[from] < 0) g.out_oh[from] = id; else g.ovf_next[g.out_ot[from]] = id;
         g.out_ot[from] = id;
     }
@@ -81,124 +90,234 @@ __device__ void th_poa_add_edge(ThPoaG &g, int from, int to)
     const int in = g.inn[to];
     if (in < TH_POA_INL) g.in4[to * TH_POA_INL + in] = from;
     else {
-        const int id = g.ovf_n++; g.ovf_val[id] = from; g.ovf_next[id] = -1;
+        const int id = atomicAdd(g.ovf_cnt, 1); g.ovf_val[id] = from; g.ovf_next[id] = -1;
         if (g.in_ot[to] < 0) g.in_oh[to] = id; else g.ovf_next[g.in_ot[to]] = id;
         g.in_ot[to] = id;
     }
     g.inn[to] = in + 1;
 }
-
-// Kahn/BFS order, FIFO, aligned rings released together; `order` doubles as the queue.
-__device__ int th_poa_topo(ThPoaG &g)
+__device__ __forceinline__ void th_poa_init_node(ThPoaG &g, int v, int b, int nread)
 {
-    const int n = g.n_node;
-    for (int i = 0; i < n; ++i) g.rem[i] = g.inn[i];
-    int qh = 0, qt = 0;
-    g.order[qt++] = 0;
-    while (qh < qt) {
-        const int u = g.order[qh];
-        g.index[u] = qh++;
-        const int on = g.outn[u];
-        int e = g.out_oh[u];
-        for (int x = 0; x < on; ++x) {
-            int v;
-            if (x < TH_POA_INL) v = g.out4[u * TH_POA_INL + x];
-            else { v = g.ovf_val[e]; e = g.ovf_next[e]; }
-            if (--g.rem[v] > 0) continue;
-            bool ok = true;
-            for (int m = g.ring[v]; m != v; m = g.ring[m]) if (g.rem[m] > 0) { ok = false; break; }
-            if (!ok) continue;
-            g.order[qt++] = v;
-            for (int m = g.ring[v]; m != v; m = g.ring[m]) g.order[qt++] = m;
-        }
-    }
-    if (qt != n) return -1;
-    for (int i = n - 1; i >= 0; --i) {
-        const int u = g.order[i];
-        int r = -1;
-        if (u != 1) {
-            const int on = g.outn[u];
-            int e = g.out_oh[u];
-            for (int x = 0; x < on; ++x) {
-                int v;
-                if (x < TH_POA_INL) v = g.out4[u * TH_POA_INL + x];
-                else { v = g.ovf_val[e]; e = g.ovf_next[e]; }
-                r = max(r, g.remain[v] + 1);
-            }
-        }
-        g.remain[u] = r;
-    }
-    return 0;
+    g.nbase[v] = b; g.nread[v] = nread; g.ring[v] = v; g.inn[v] = 0; g.outn[v] = 0;
+    g.in_oh[v] = g.in_ot[v] = g.out_oh[v] = g.out_ot[v] = -1;
 }
 
-// banded DP of query q[0..qlen) against the ordered graph; wave-cooperative.  Returns the row index
-// of the sink's best predecessor (>= 0) or a negative status.
-__device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, int qlen, const ThDevPara &P)
+// ---- first unit: chain source(0) -> bases(2..L+1) -> sink(1); order = source, bases, sink ----
+__device__ void th_poa_seed(ThPoaG &g, const uint8_t *__restrict__ q, int L)
+{
+    const int lane = TH_LANE();
+    for (int j = lane; j < L; j += TH_WAVE) {
+        const int v = 2 + j;
+        th_poa_init_node(g, v, min((int)q[j], 4), 1);
+        g.inn[v] = 1; g.in4[v * TH_POA_INL] = j == 0 ? 0 : v - 1;
+        g.outn[v] = 1; g.out4[v * TH_POA_INL] = j == L - 1 ? 1 : v + 1;
+        g.order[1 + j] = v; g.pos[v] = 1 + j;
+    }
+    if (lane == 0) {
+        th_poa_init_node(g, 0, 4, 0); th_poa_init_node(g, 1, 4, 0);
+        g.outn[0] = 1; g.out4[0] = 2; g.inn[1] = 1; g.in4[TH_POA_INL] = L + 1;
+        g.order[0] = 0; g.pos[0] = 0; g.order[L + 1] = 1; g.pos[1] = L + 1;
+        *g.ovf_cnt = 0;
+    }
+    g.n_node = L + 2;
+    TH_WAVE_FENCE();
+}
+
+// ---- remain (longest node count to the sink) + row tables, 64 rows per trip from the end ----
+__device__ int th_poa_rows(ThPoaG &g)
+{
+    const int lane = TH_LANE(), n = g.n_node;
+    int maxdeg = 0;
+    for (int c0 = (n - 1) & ~63; c0 >= 0; c0 -= TH_WAVE) {
+        const int idx = c0 + lane; const bool ok = idx < n;
+        const int u = ok ? g.order[idx] : 0;
+        const int on = ok ? g.outn[u] : 0, in = ok ? g.inn[u] : 0;
+        int s[TH_POA_INL], p[TH_POA_INL];
+#pragma unroll
+        for (int k = 0; k < TH_POA_INL; ++k) {
+            s[k] = (ok && k < on) ? g.pos[g.out4[u * TH_POA_INL + k]] : -1;
+            p[k] = (ok && k < in) ? g.pos[g.in4[u * TH_POA_INL + k]] : -1;
+        }
+        // successors outside the chunk are final; in-chunk ones are relaxed in registers
+        int base = (ok && u == 1) ? -1 : -TH_BIG;
+#pragma unroll
+        for (int k = 0; k < TH_POA_INL; ++k) if (s[k] >= c0 + TH_WAVE) base = max(base, g.r_rem[s[k]] + 1);
+        const bool big = ok && on > TH_POA_INL;
+        if (big) {          // overflow successors that are already final
+            int e = g.out_oh[u];
+            for (int x = TH_POA_INL; x < on; ++x) { const int sx = g.pos[g.ovf_val[e]]; e = g.ovf_next[e]; if (sx >= c0 + TH_WAVE) base = max(base, g.r_rem[sx] + 1); }
+        }
+        const bool hard = __any(big);
+        // in-chunk successors are almost always 1..3 rows ahead: then a relaxation round is three lane shifts
+        bool nearok = true; int has1 = 0, has2 = 0, has3 = 0;
+#pragma unroll
+        for (int k = 0; k < TH_POA_INL; ++k) if (s[k] >= c0 && s[k] < c0 + TH_WAVE) {
+            const int dl = s[k] - idx;
+            if (dl == 1) has1 = 1; else if (dl == 2) has2 = 1; else if (dl == 3) has3 = 1; else nearok = false;
+        }
+        const bool fastrel = !hard && !__any(!nearok);
+        int cur = base;
+        for (int it = 0; it < TH_WAVE + 1; ++it) {
+            int v = base;
+            if (fastrel) {
+                const int c1 = th_shl1(cur, -TH_BIG), c2 = th_shl1(c1, -TH_BIG), c3 = th_shl1(c2, -TH_BIG);
+                if (has1 && c1 > -TH_BIG) v = max(v, c1 + 1);
+                if (has2 && c2 > -TH_BIG) v = max(v, c2 + 1);
+                if (has3 && c3 > -TH_BIG) v = max(v, c3 + 1);
+            } else {
+#pragma unroll
+                for (int k = 0; k < TH_POA_INL; ++k) {
+                    const int o = __shfl(cur, (s[k] - c0) & 63);
+                    if (s[k] >= c0 && s[k] < c0 + TH_WAVE && o > -TH_BIG) v = max(v, o + 1);
+                }
+            }
+            if (hard) {     // rare: a node with > 4 successors, some inside the chunk -> exchange through memory
+                if (ok) g.r_rem[idx] = cur;
+                TH_WAVE_FENCE();
+                if (big) {
+                    int e = g.out_oh[u];
+                    for (int x = TH_POA_INL; x < on; ++x) {
+                        const int sx = g.pos[g.ovf_val[e]]; e = g.ovf_next[e];
+                        if (sx >= c0 && sx < c0 + TH_WAVE) { const int o = g.r_rem[sx]; if (o > -TH_BIG) v = max(v, o + 1); }
+                    }
+                }
+                TH_WAVE_FENCE();
+            }
+            const bool ch = ok && v != cur;
+            cur = v;
+            if (!__any(ch)) break;
+        }
+        if (ok) {
+            g.r_rem[idx] = cur;
+            g.r_meta[idx] = g.nbase[u] | min(in, 255) << 8 | min(on, 255) << 16;
+#pragma unroll
+            for (int k = 0; k < TH_POA_INL; ++k) g.r_p[idx * TH_POA_INL + k] = p[k];
+        }
+        maxdeg = max(maxdeg, in);
+        TH_WAVE_FENCE();
+    }
+    return th_wave_max(maxdeg);
+}
+
+#if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
+__device__ unsigned long long th_poa_prof[8];
+#define TH_PROF_CNT(k, v) ((void)0)
+#define TH_PROF_T0() unsigned long long pt_ = __builtin_amdgcn_s_memtime()
+#define TH_PROF(k) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (TH_LANE() == 0) atomicAdd(&th_poa_prof[k], n_ - pt_); pt_ = n_; } while (0)
+#else
+#define TH_PROF_CNT(k, v) ((void)0)
+#define TH_PROF_T0() ((void)0)
+#define TH_PROF(k) ((void)0)
+#endif
+
+// ---- banded DP; returns the row of the sink's best predecessor (>= 0) or a negative status ----
+// The three most recent rows stay in an LDS ring (H, E1', E2' per column) together with their band and
+// row-maximum columns in wave-uniform registers, so a row whose predecessors are among them -- nearly
+// all rows: the previous node and the members of the previous column -- issues no HBM load at all; its
+// own cells leave as fire-and-forget 16-byte stores (needed by the traceback and by far predecessors).
+#define TH_POA_RING 4
+#define TH_POA_RW 192
+#define TH_SEL4(s, a0, a1, a2, a3) ((s) == 0 ? (a0) : (s) == 1 ? (a1) : (s) == 2 ? (a2) : (a3))
+#define TH_SET4(s, a0, a1, a2, a3, v) do { if ((s) == 0) a0 = (v); else if ((s) == 1) a1 = (v); else if ((s) == 2) a2 = (v); else a3 = (v); } while (0)
+
+template <bool LQ>
+__device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t *s_q, int (*s_ring)[3][TH_POA_RW], int qlen, const ThDevPara &P)
 {
     const int lane = TH_LANE();
     const int M = P.match, X = P.mismatch, O1 = P.go1, E1 = P.ge1, O2 = P.go2, E2 = P.ge2;
     const int n = g.n_node, w = TH_POA_WB + qlen / 100;
-    for (int i = lane; i < n; i += TH_WAVE) { g.mpl[i] = 0x7fffffff; g.mpr[i] = 0; }
-    TH_WAVE_FENCE();
     long long ncell = 0;
+    int c_meta = 0, c_rem = 0, c_p0 = -1, c_p1 = -1, c_p2 = -1, c_p3 = -1, c_id = 0;   // row-table chunk cache
+    // ring slot state (wave-uniform): row held, band, row-maximum columns, cell offset, cached-in-LDS flag
+    int R_row0 = -1, R_row1 = -1, R_row2 = -1, R_row3 = -1, R_b0 = 0, R_b1 = 0, R_b2 = 0, R_b3 = 0, R_e0 = 0, R_e1 = 0, R_e2 = 0, R_e3 = 0;
+    int R_l0 = 0, R_l1 = 0, R_l2 = 0, R_l3 = 0, R_r0 = 0, R_r1 = 0, R_r2 = 0, R_r3 = 0, R_c0 = 0, R_c1 = 0, R_c2 = 0, R_c3 = 0;
+    long long R_o0 = 0, R_o1 = 0, R_o2 = 0, R_o3 = 0;
     for (int i = 0; i + 1 < n; ++i) {
-        const int v = g.order[i];
-        const int inn = g.inn[v], rm = g.remain[v];
-        int b = 0;
-        if (i > 0) {
-            b = max(0, min(g.mpl[v], qlen - rm) - w);
-            int mb = 0x7fffffff;
-            for (int o = 0; o < inn; ++o) mb = min(mb, g.beg[g.index[th_poa_in(g, v, o)]]);
-            b = max(b, mb);
+        if ((i & 63) == 0) {
+            const int r = i + lane;
+            if (r < n) {
+                c_meta = g.r_meta[r]; c_rem = g.r_rem[r]; c_id = g.order[r];
+                c_p0 = g.r_p[r * 4]; c_p1 = g.r_p[r * 4 + 1]; c_p2 = g.r_p[r * 4 + 2]; c_p3 = g.r_p[r * 4 + 3];
+            }
         }
-        const int e = min(qlen, max(g.mpr[v], qlen - rm) + w);
+        const int sl = i & 63;
+        const int meta = TH_READLANE(c_meta, sl), rm = TH_READLANE(c_rem, sl);
+        const int nb = meta & 0xff, inn = (meta >> 8) & 0xff;
+        const int p0 = TH_READLANE(c_p0, sl), p1 = TH_READLANE(c_p1, sl), p2 = TH_READLANE(c_p2, sl), p3 = TH_READLANE(c_p3, sl);
+        const int vid = TH_READLANE(c_id, sl);
+        // ---- band: pull the predecessors' band start and row-maximum columns ----
+        int b = 0, e;
+        {
+            int mpl = 0x7fffffff, mpr = 0, mb = 0x7fffffff;
+            for (int o = 0; o < inn; ++o) {
+                const int pi = o == 0 ? p0 : o == 1 ? p1 : o == 2 ? p2 : o == 3 ? p3 : g.pos[th_poa_in(g, vid, o)];
+                const int s = pi & 3;
+                int pb, pl, pr;
+                if (i - pi < TH_POA_RING && TH_SEL4(s, R_row0, R_row1, R_row2, R_row3) == pi) {
+                    pb = TH_SEL4(s, R_b0, R_b1, R_b2, R_b3); pl = TH_SEL4(s, R_l0, R_l1, R_l2, R_l3); pr = TH_SEL4(s, R_r0, R_r1, R_r2, R_r3);
+                } else { pb = g.r_beg[pi]; pl = g.r_mpl[pi]; pr = g.r_mpr[pi]; }
+                mpl = min(mpl, pl + 1); mpr = max(mpr, pr + 1); mb = min(mb, pb);
+            }
+            if (i > 0) { b = max(0, min(mpl, qlen - rm) - w); b = max(b, mb); }
+            e = min(qlen, max(mpr, qlen - rm) + w);
+        }
         if (b > e) return -2;
         if (ncell + (e - b + 1) > g.cell_cap) return -3;
-        if (lane == 0) { g.beg[i] = b; g.end[i] = e; g.roff[i] = ncell; }
         int4 *row = g.cell + ncell;
+        const long long my_off = ncell;
         ncell += e - b + 1;
-        const int nb = g.base[v];
+        const int myslot = i & 3;
+        const bool cache_me = e - b < TH_POA_RW;
         int rmax = TH_NEG - 0x10000000, left = b, right = b;
-        int carry1 = TH_NEG + b * E1, carry2 = TH_NEG + b * E2;      // F recurrences in the "+ j*E" domain
+        int carry1 = TH_NEG + b * E1, carry2 = TH_NEG + b * E2;
+        int slow_row = 0;
         for (int c0 = b; c0 <= e; c0 += TH_WAVE) {
             const int j = c0 + lane;
             const bool in = j <= e;
             int m = TH_NEG, e1v = TH_NEG, e2v = TH_NEG, pm = 0, pe1 = 0, pe2 = 0;
             if (i > 0) {
                 int sc = 0;
-                if (in && j >= 1) { const int qb = min((int)q[j - 1], 4); sc = (qb == 4 || nb == 4) ? 0 : (qb == nb ? M : -X); }
+                if (in && j >= 1) { const int qb = min(LQ ? (int)s_q[j - 1] : (int)q[j - 1], 4); sc = (qb == 4 || nb == 4) ? 0 : (qb == nb ? M : -X); }
                 for (int o = 0; o < inn; ++o) {
-                    const int pi = g.index[th_poa_in(g, v, o)];
-                    const int pb = g.beg[pi], pe = g.end[pi];
-                    const int4 *prow = g.cell + g.roff[pi];
-                    if (in) {
-                        if (j >= 1) {
-                            const int hp = (j - 1 >= pb && j - 1 <= pe) ? prow[j - 1 - pb].x : TH_NEG;
-                            const int c = hp + sc;
-                            if (o == 0 || c > m) { m = c; pm = o; }
+                    const int pi = o == 0 ? p0 : o == 1 ? p1 : o == 2 ? p2 : o == 3 ? p3 : g.pos[th_poa_in(g, vid, o)];
+                    const int s = pi & 3;
+                    int hp = TH_NEG, c1 = TH_NEG, c2 = TH_NEG;
+                    const bool recent = i - pi < TH_POA_RING && TH_SEL4(s, R_row0, R_row1, R_row2, R_row3) == pi;
+                    if (recent && TH_SEL4(s, R_c0, R_c1, R_c2, R_c3)) {           // LDS ring: no HBM round trip
+                        const int pb = TH_SEL4(s, R_b0, R_b1, R_b2, R_b3), pe = TH_SEL4(s, R_e0, R_e1, R_e2, R_e3);
+                        if (in) {
+                            if (j >= 1 && j - 1 >= pb && j - 1 <= pe) hp = s_ring[s][0][j - 1 - pb];
+                            if (j >= pb && j <= pe) { c1 = s_ring[s][1][j - pb]; c2 = s_ring[s][2][j - pb]; }
                         }
-                        int c1 = TH_NEG, c2 = TH_NEG;
-                        if (j >= pb && j <= pe) { const int4 pc = prow[j - pb]; c1 = pc.y; c2 = pc.z; }
+                    } else {
+                        slow_row = 1;
+                        int pb, pe; long long po;
+                        if (recent) { pb = TH_SEL4(s, R_b0, R_b1, R_b2, R_b3); pe = TH_SEL4(s, R_e0, R_e1, R_e2, R_e3); po = TH_SEL4(s, R_o0, R_o1, R_o2, R_o3); }
+                        else { pb = g.r_beg[pi]; pe = g.r_end[pi]; po = g.r_off[pi]; }
+                        const int4 *prow = g.cell + po;
+                        if (in) {
+                            if (j >= 1 && j - 1 >= pb && j - 1 <= pe) hp = prow[j - 1 - pb].x;
+                            if (j >= pb && j <= pe) { const int4 pc = prow[j - pb]; c1 = pc.y; c2 = pc.z; }
+                        }
+                    }
+                    if (in) {
+                        if (j >= 1) { const int c = hp + sc; if (o == 0 || c > m) { m = c; pm = o; } }
                         if (o == 0 || c1 > e1v) { e1v = c1; pe1 = o; }
                         if (o == 0 || c2 > e2v) { e2v = c2; pe2 = o; }
                     }
                 }
             } else if (in) {
-                m = j == 0 ? 0 : -min(O1 + j * E1, O2 + j * E2);       // source row: pure leading gap
+                m = j == 0 ? 0 : -min(O1 + j * E1, O2 + j * E2);
             }
-            // H without the in-row gap states
             int hnf = m, src = 0;
             if (e1v > hnf) { hnf = e1v; src = 1; }
             if (e2v > hnf) { hnf = e2v; src = 2; }
-            // F1(j) = max_{k<j}(H(k) - O1 - (j-k)E1): exclusive prefix max of H(k) - O1 + k*E1
             const int a1 = in ? hnf - O1 + j * E1 : TH_NEG * 2, a2 = in ? hnf - O2 + j * E2 : TH_NEG * 2;
             const int i1 = th_wave_incl_max(a1), i2 = th_wave_incl_max(a2);
-            int x1 = __shfl_up(i1, 1), x2 = __shfl_up(i2, 1);
-            if (lane == 0) { x1 = carry1; x2 = carry2; } else { x1 = max(x1, carry1); x2 = max(x2, carry2); }
-            carry1 = max(carry1, __shfl(i1, 63)); carry2 = max(carry2, __shfl(i2, 63));
+            const int x1 = max(th_shr1(i1, carry1), carry1), x2 = max(th_shr1(i2, carry2), carry2);
+            carry1 = max(carry1, TH_READLANE(i1, 63)); carry2 = max(carry2, TH_READLANE(i2, 63));
             int f1 = x1 - j * E1, f2 = x2 - j * E2;
             if (i == 0) { f1 = TH_NEG; f2 = TH_NEG; }
-            else if (j == b) { f1 = TH_NEG; f2 = TH_NEG; }
             int h = hnf;
             if (f1 > h) { h = f1; src = 3; }
             if (f2 > h) { h = f2; src = 4; }
@@ -211,115 +330,230 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, int qlen, con
                     if (f1 > h - O1) d |= TH_D_XF1;
                     if (f2 > h - O2) d |= TH_D_XF2;
                 }
-#ifdef TH_CPU_EMUL
-                if (getenv("TH_DEBUG3") && i == 5) fprintf(stderr, "[th_w] lane %d j %d b %d e %d ncell %lld h %d\n", lane, j, b, e, ncell, h);
-#endif
-                int4 cv; cv.x = h; cv.y = max(h - O1, e1v) - E1; cv.z = max(h - O2, e2v) - E2; cv.w = (int)d;
+                const int n1 = max(h - O1, e1v) - E1, n2 = max(h - O2, e2v) - E2;
+                int4 cv; cv.x = h; cv.y = n1; cv.z = n2; cv.w = (int)d;
                 row[j - b] = cv;
+                if (cache_me) { s_ring[myslot][0][j - b] = h; s_ring[myslot][1][j - b] = n1; s_ring[myslot][2][j - b] = n2; }
             }
-            // row maximum, leftmost / rightmost column
             const int hm = th_wave_max(in ? h : TH_NEG * 2);
             const unsigned long long mm = __ballot(in && h == hm);
             if (hm > rmax) { rmax = hm; left = c0 + th_ctz64(mm); right = c0 + th_msb64(mm); }
             else if (hm == rmax) right = c0 + th_msb64(mm);
         }
-#ifdef TH_CPU_EMUL
-        if (lane == 0 && getenv("TH_DEBUG2") && i < 9) { fprintf(stderr, "[th_H] i %d:", i); for (int j = b; j <= e; ++j) fprintf(stderr, " %d/%d/%d", row[j-b].x, row[j-b].y, row[j-b].z); fprintf(stderr, "\n"); }
-        if (lane == 0 && getenv("TH_DEBUG2")) fprintf(stderr, "[th_row] i %d v %d b %d e %d rmax %d l %d r %d\n", i, v, b, e, rmax, left, right);
-#endif
-        if (lane == 0) {
-            const int on = g.outn[v];
-            for (int o = 0; o < on; ++o) {
-                const int u = th_poa_out(g, v, o);
-                if (right + 1 > g.mpr[u]) g.mpr[u] = right + 1;
-                if (left + 1 < g.mpl[u]) g.mpl[u] = left + 1;
-            }
-        }
+        if (lane == 0) { g.r_beg[i] = b; g.r_end[i] = e; g.r_off[i] = my_off; g.r_mpl[i] = left; g.r_mpr[i] = right; }
+        TH_SET4(myslot, R_row0, R_row1, R_row2, R_row3, i); TH_SET4(myslot, R_b0, R_b1, R_b2, R_b3, b); TH_SET4(myslot, R_e0, R_e1, R_e2, R_e3, e);
+        TH_SET4(myslot, R_l0, R_l1, R_l2, R_l3, left); TH_SET4(myslot, R_r0, R_r1, R_r2, R_r3, right);
+        TH_SET4(myslot, R_c0, R_c1, R_c2, R_c3, cache_me ? 1 : 0); TH_SET4(myslot, R_o0, R_o1, R_o2, R_o3, my_off);
+        TH_PROF_CNT(4, 1); TH_PROF_CNT(5, slow_row); TH_PROF_CNT(6, (e - b) / 64 + 1); TH_PROF_CNT(7, inn);
         TH_WAVE_FENCE();
     }
-    // global end: best predecessor row of the sink at column qlen, first in edge order
+    // global end: best predecessor row of the sink (row n-1) at column qlen, first in edge order
     int bi = -1, bs = 0;
-    const int sinn = g.inn[1];
-    for (int o = 0; o < sinn; ++o) {
-        const int pi = g.index[th_poa_in(g, 1, o)];
-        const int c = (qlen >= g.beg[pi] && qlen <= g.end[pi]) ? g.cell[g.roff[pi] + (qlen - g.beg[pi])].x : TH_NEG;
-        if (o == 0 || c > bs) { bs = c; bi = pi; }
+    {
+        const int sinn = g.inn[1];
+        for (int o = 0; o < sinn; ++o) {
+            const int pi = g.pos[th_poa_in(g, 1, o)];
+            const int pb = g.r_beg[pi], pe = g.r_end[pi];
+            const int c = (qlen >= pb && qlen <= pe) ? g.cell[g.r_off[pi] + (qlen - pb)].x : TH_NEG;
+            if (o == 0 || c > bs) { bs = c; bi = pi; }
+        }
     }
-#ifdef TH_CPU_EMUL
-    if (lane == 0 && getenv("TH_DEBUG")) fprintf(stderr, "[th_poa] n_node %d qlen %d best %d at row %d\n", n, qlen, bs, bi);
-#endif
     if (bs <= TH_NEG / 2) return -4;
     return bi;
 }
 
-// traceback (lane 0): ops written backwards into g.ops as pairs (op | node<<2, qpos); returns count
+// ---- traceback: wave-uniform walk; direction words come from tiles of 16 rows x 4 diagonals ----
 __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
 {
-    int no = 0, i = bi, j = qlen, st = 0;
-    while (i > 0) {
-        const uint32_t d = (uint32_t)g.cell[g.roff[i] + (j - g.beg[i])].w;
-        const int v = g.order[i];
+    const int lane = TH_LANE();
+    int no = 0, ci = bi, cj = qlen, st = 0;
+    int ti = -1000000, tj = 0;              // tile anchor; lane l = 4*k + o holds cell (ti - k, tj - k + o - 1)
+    int t_d = 0, t_p0 = -1, t_p1 = -1, t_p2 = -1, t_p3 = -1, t_ok = 0;
+    while (ci > 0) {
+        int k = ti - ci, o = cj - (tj - k) + 1;
+        bool hit0 = k >= 0 && k <= 15 && o >= 0 && o <= 3;
+        const int ok0 = TH_READLANE(t_ok, hit0 ? (k * 4 + o) : 0);
+        if (!hit0 || !ok0) {
+            ti = ci; tj = cj;
+            const int row = ti - (lane >> 2), col = tj - (lane >> 2) + (lane & 3) - 1;
+            t_ok = 0; t_d = 0;
+            if (row >= 1) {
+                const int rb = g.r_beg[row], re = g.r_end[row];
+                t_p0 = g.r_p[row * 4]; t_p1 = g.r_p[row * 4 + 1]; t_p2 = g.r_p[row * 4 + 2]; t_p3 = g.r_p[row * 4 + 3];
+                if (col >= rb && col <= re) { t_d = g.cell[g.r_off[row] + (col - rb)].w; t_ok = 1; }
+            }
+            k = 0; o = 1;
+        }
+        const int tl = k * 4 + o;
+        const uint32_t d = (uint32_t)TH_READLANE(t_d, tl);
+        const int a0 = TH_READLANE(t_p0, tl), a1 = TH_READLANE(t_p1, tl), a2 = TH_READLANE(t_p2, tl), a3 = TH_READLANE(t_p3, tl);
         if (st == 0) st = TH_D_SRC(d);
+        int moved_gap = 0;
         if (st <= 2) {
             const int want = st == 0 ? TH_D_PM(d) : st == 1 ? TH_D_PE1(d) : TH_D_PE2(d);
-            const int pi = g.index[th_poa_in(g, v, want)];
-            if (st == 0) { g.ops[2 * no] = 0 | v << 2; g.ops[2 * no + 1] = j - 1; ++no; i = pi; --j; }
-            else {
-                g.ops[2 * no] = 2 | v << 2; g.ops[2 * no + 1] = -1; ++no; i = pi;
-                if (i == 0) st = 0;
+            int pi;
+            if (want < TH_POA_INL) pi = want == 0 ? a0 : want == 1 ? a1 : want == 2 ? a2 : a3;
+            else pi = g.pos[th_poa_in(g, g.order[ci], want)];
+            if (st == 0) { if (lane == 0) { g.ops[2 * no] = 0 | ci << 2; g.ops[2 * no + 1] = cj - 1; } ++no; ci = pi; --cj; }
+            else { if (lane == 0) { g.ops[2 * no] = 2 | ci << 2; g.ops[2 * no + 1] = -1; } ++no; ci = pi; moved_gap = 1; }
+        } else { if (lane == 0) { g.ops[2 * no] = 1; g.ops[2 * no + 1] = cj - 1; } ++no; --cj; moved_gap = 1; }
+        // a gap state continues only if the cell we arrived at says so (its word may sit in the tile)
+        {
+            const int k2 = ti - ci, o2 = cj - (tj - k2) + 1;
+            const bool hit = k2 >= 0 && k2 <= 15 && o2 >= 0 && o2 <= 3;
+            const int okv = TH_READLANE(t_ok, hit ? (k2 * 4 + o2) : 0), dv = TH_READLANE(t_d, hit ? (k2 * 4 + o2) : 0);
+            if (moved_gap) {
+                if (ci == 0) st = 0;
                 else {
-                    const uint32_t pd = (uint32_t)g.cell[g.roff[i] + (j - g.beg[i])].w;
-                    if (!(pd & (st == 1 ? TH_D_XE1 : TH_D_XE2))) st = 0;
+                    uint32_t pd;
+                    if (hit && okv) pd = (uint32_t)dv;
+                    else pd = (uint32_t)g.cell[g.r_off[ci] + (cj - g.r_beg[ci])].w;
+                    const uint32_t bit = st == 1 ? TH_D_XE1 : st == 2 ? TH_D_XE2 : st == 3 ? TH_D_XF1 : TH_D_XF2;
+                    if (!(pd & bit)) st = 0;
                 }
             }
-        } else {
-            g.ops[2 * no] = 1; g.ops[2 * no + 1] = j - 1; ++no; --j;
-            const uint32_t pd = (uint32_t)g.cell[g.roff[i] + (j - g.beg[i])].w;
-            if (!(pd & (st == 3 ? TH_D_XF1 : TH_D_XF2))) st = 0;
         }
     }
-    while (j > 0) { g.ops[2 * no] = 1; g.ops[2 * no + 1] = j - 1; ++no; --j; }
+    while (cj > 0) { if (lane == 0) { g.ops[2 * no] = 1; g.ops[2 * no + 1] = cj - 1; } ++no; --cj; }
+    TH_WAVE_FENCE();
     return no;
 }
 
-// merge (lane 0); ops == nullptr means "first sequence"
-__device__ void th_poa_add(ThPoaG &g, const uint8_t *__restrict__ q, int qlen, int n_ops)
+// ---- merge the alignment (ops were written backwards; rows refer to the CURRENT order) ----
+__device__ void th_poa_merge(ThPoaG &g, const uint8_t *__restrict__ q, int n_ops)
 {
-    int last = 0;
-    if (n_ops < 0) {
-        for (int j = 0; j < qlen; ++j) { const int v = th_poa_new_node(g, q[j] > 4 ? 4 : q[j]); g.nread[v] = 1; th_poa_add_edge(g, last, v); last = v; }
-    } else {
-        for (int a = n_ops - 1; a >= 0; --a) {          // ops were written backwards
-            const int op = g.ops[2 * a] & 3;
-            if (op == 2) continue;
-            int b = q[g.ops[2 * a + 1]]; if (b > 4) b = 4;
-            int v = -1;
-            if (op == 0) {
-                const int u = g.ops[2 * a] >> 2;
-                if (g.base[u] == b) v = u;
-                else {
-                    for (int m = g.ring[u]; m != u; m = g.ring[m]) if (g.base[m] == b) { v = m; break; }
-                    if (v < 0) { v = th_poa_new_node(g, b); g.ring[v] = g.ring[u]; g.ring[u] = v; }
-                }
-            } else v = th_poa_new_node(g, b);
-            ++g.nread[v];
-            th_poa_add_edge(g, last, v);
-            last = v;
+    const int lane = TH_LANE(), n_old = g.n_node;
+    for (int p = lane; p < n_old; p += TH_WAVE) { g.cntB[p] = 0; g.headB[p] = 0x7fffffff; g.aft[p] = -1; }
+    TH_WAVE_FENCE();
+    // pass 1 (forward): choose / create the node of every column, ring splice, read counts
+    int new_cnt = 0, path_cnt = 0;
+    for (int f0 = 0; f0 < n_ops; f0 += TH_WAVE) {
+        const int f = f0 + lane; const bool ok = f < n_ops;
+        const int a = n_ops - 1 - f;
+        const int w0 = ok ? g.ops[2 * a] : 2, op = w0 & 3;
+        const int qpos = ok ? g.ops[2 * a + 1] : 0;
+        int b = 4, v = -1, lo = -1, hi = -1, u = -1, kind = 0;      // kind: 1 new ring member, 2 new inserted node
+        if (ok && op != 2) b = min((int)q[qpos], 4);
+        if (ok && op == 0) {
+            u = g.order[w0 >> 2];
+            lo = hi = g.pos[u];
+            int found = g.nbase[u] == b ? u : -1;
+            for (int m = g.ring[u]; m != u; m = g.ring[m]) {
+                const int pm = g.pos[m]; lo = min(lo, pm); hi = max(hi, pm);
+                if (found < 0 && g.nbase[m] == b) found = m;
+            }
+            if (found >= 0) v = found; else kind = 1;
+        } else if (ok && op == 1) kind = 2;
+        const bool isnew = kind != 0;
+        const unsigned long long nm = __ballot(isnew);
+        if (isnew) {
+            v = n_old + new_cnt + __popcll(nm & ((1ull << lane) - 1));
+            th_poa_init_node(g, v, b, 0);
+            if (kind == 1) { g.ring[v] = g.ring[u]; g.ring[u] = v; g.aft[hi] = v; }
         }
+        new_cnt += __popcll(nm);
+        const bool isnode = ok && op != 2;
+        if (isnode) g.nread[v] += 1;
+        const unsigned long long pmk = __ballot(isnode);
+        if (isnode) g.pth[1 + path_cnt + __popcll(pmk & ((1ull << lane) - 1))] = v;
+        path_cnt += __popcll(pmk);
+        if (ok) { g.pv[f] = kind == 2 ? v : -1; g.glo[f] = op == 0 ? lo : -1; }
     }
-    th_poa_add_edge(g, last, 1);
+    if (lane == 0) { g.pth[0] = 0; g.pth[1 + path_cnt] = 1; }
+    g.n_node = n_old + new_cnt;
+    TH_WAVE_FENCE();
+    // pass 2: edges along the path (each node is `from` once and `to` once -> no two lanes touch one list)
+    for (int k0 = 0; k0 <= path_cnt; k0 += TH_WAVE) {
+        const int k = k0 + lane;
+        if (k <= path_cnt) th_poa_add_edge(g, g.pth[k], g.pth[k + 1]);
+    }
+    // pass 3 (backward over forward indices): inserted runs are anchored before the ring of the next aligned column
+    int carry_lo = g.pos[1];                   // nothing aligned after them: before the sink
+    for (int f0 = ((n_ops - 1) & ~63); f0 >= 0; f0 -= TH_WAVE) {
+        const int f = f0 + lane; const bool ok = f < n_ops;
+        const int lo = ok ? g.glo[f] : -1, vi = ok ? g.pv[f] : -1;
+        const unsigned long long mM = __ballot(lo >= 0);
+        const unsigned long long higher = lane == 63 ? 0ull : (mM & ~((2ull << lane) - 1));
+        const int srcl = higher ? th_ctz64(higher) : 0;
+        const int alo = __shfl(lo, srcl);
+        const int anchor = higher ? alo : carry_lo;
+        if (vi >= 0) { atomicAdd(&g.cntB[anchor], 1); atomicMin(&g.headB[anchor], vi); }
+        const int first_lo = TH_READLANE(lo, mM ? th_ctz64(mM) : 0);
+        if (mM) carry_lo = first_lo;
+    }
+    TH_WAVE_FENCE();
+    // pass 4: new positions = old position + inserted nodes at or before it + ring members added before it
+    int shift = 0;
+    for (int p0 = 0; p0 < n_old; p0 += TH_WAVE) {
+        const int p = p0 + lane; const bool ok = p < n_old;
+        const int cb = ok ? g.cntB[p] : 0, af = ok ? (g.aft[p] >= 0) : 0;
+        const int incB = th_wave_incl_sum(cb), incA = th_wave_incl_sum(af);
+        if (ok) {
+            const int np = p + shift + incB + (incA - af);
+            const int id = g.order[p];
+            g.order2[np] = id; g.pos[id] = np;
+            const int hb = g.headB[p];
+            for (int x = 0; x < cb; ++x) { g.order2[np - cb + x] = hb + x; g.pos[hb + x] = np - cb + x; }
+            if (af) { const int m = g.aft[p]; g.order2[np + 1] = m; g.pos[m] = np + 1; }
+        }
+        shift += TH_READLANE(incB, 63) + TH_READLANE(incA, 63);
+    }
+    int *t = g.order; g.order = g.order2; g.order2 = t;
+    TH_WAVE_FENCE();
 }
 
-// scratch layout helper: carve `cnt` ints
+// ---- row-column consensus: one column = one aligned ring (its members are adjacent in the order) ----
+__device__ int th_poa_consensus(ThPoaG &g, int n_seqs, uint8_t *__restrict__ cons, int *__restrict__ cov, int cons_cap)
+{
+    const int lane = TH_LANE(), n = g.n_node;
+    int cl = 0, over = 0;
+    for (int c0 = 0; c0 < n; c0 += TH_WAVE) {
+        const int idx = c0 + lane;
+        int bb = -1, best = 0;
+        if (idx >= 1 && idx < n) {
+            const int u = g.order[idx];
+            if (u != 1) {
+                int c_a = 0, c_c = 0, c_g = 0, c_t = 0, c_n = 0, tot = 0, lead = 1;
+                int m = u;
+                do {
+                    const int nr = g.nread[m], bs = g.nbase[m];
+                    if (g.pos[m] < idx) lead = 0;
+                    c_a += bs == 0 ? nr : 0; c_c += bs == 1 ? nr : 0; c_g += bs == 2 ? nr : 0; c_t += bs == 3 ? nr : 0; c_n += bs == 4 ? nr : 0;
+                    tot += nr; m = g.ring[m];
+                } while (m != u);
+                if (lead) {
+                    if (c_a > best) { best = c_a; bb = 0; }
+                    if (c_c > best) { best = c_c; bb = 1; }
+                    if (c_g > best) { best = c_g; bb = 2; }
+                    if (c_t > best) { best = c_t; bb = 3; }
+                    if (c_n > best) { best = c_n; bb = 4; }
+                    if (n_seqs - tot > best) bb = -1;
+                }
+            }
+        }
+        const unsigned long long em = __ballot(bb >= 0);
+        if (bb >= 0) {
+            const int o = cl + __popcll(em & ((1ull << lane) - 1));
+            if (o < cons_cap) { cons[o] = (uint8_t)bb; cov[o] = best; } else over = 1;
+        }
+        cl += __popcll(em);
+    }
+    return __any(over) ? -1 : cl;
+}
+
 __device__ __forceinline__ int *th_carve(int *&p, long long cnt) { int *r = p; p += (cnt + 3) & ~3LL; return r; }
 
-// status: 0 ok, 1 scratch too small for the graph, 2 band cells overflow, 3 topo failure, 4 band lost the path,
+// status: 0 ok, 1 scratch too small for the graph, 2 band cells overflow, 3 internal order error, 4 band lost the path,
 //         5 in-degree > 255, 6 consensus longer than cons_cap
+// LQ = true: the query of every alignment fits the LDS staging buffer (the common case); LQ = false reads it from HBM
+template <bool LQ>
 __global__ void __launch_bounds__(TH_POA_BLOCK)
 th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict__ units, const uint32_t *__restrict__ roff,
          const uint8_t *__restrict__ bseq, ThDevPara P, int *__restrict__ scratch, long long scratch_ints,
          uint8_t *__restrict__ cons, int *__restrict__ cov, int *__restrict__ cons_len, int *__restrict__ status)
 {
+    __shared__ uint8_t s_q[TH_POA_QCAP];
+    __shared__ int s_ring[TH_POA_RING][3][TH_POA_RW];
     const int lane = TH_LANE();
     const int wave = blockIdx.x, nwave = gridDim.x;
     int *my = scratch + (long long)wave * scratch_ints;
@@ -329,82 +563,50 @@ th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict
         const ThUnit *U = units + T.unit_off;
         if (T.n_units <= 2) {            // src/abpoa_cons.c:60-83: consensus := unit 0
             const int len = U[0].len;
-            int st = len > T.cons_cap ? 6 : 0;
+            const int st = len > T.cons_cap ? 6 : 0;
             if (!st) for (int x = lane; x < len; x += TH_WAVE) { cons[T.cons_off + x] = rb[U[0].start + x]; cov[T.cons_off + x] = 0; }
             if (lane == 0) { cons_len[t] = st ? 0 : len; status[t] = st; }
             continue;
         }
-        // ---- carve the wave's scratch for this task ----
         ThPoaG g;
-        const int cap = T.sum_len + 2, ocap = T.sum_len + T.n_units + 8;
+        const long long cap = T.sum_len + 2, ocap = 2LL * (T.sum_len + T.n_units + 8), opn = cap + T.max_len + 2;
         int *p = my;
-        g.cap = cap; g.n_node = 0; g.ovf_n = 0; g.ovf_cap = ocap;
-        g.base = th_carve(p, cap); g.nread = th_carve(p, cap); g.ring = th_carve(p, cap); g.inn = th_carve(p, cap); g.outn = th_carve(p, cap);
-        g.in4 = th_carve(p, (long long)cap * TH_POA_INL); g.out4 = th_carve(p, (long long)cap * TH_POA_INL);
-        g.in_oh = th_carve(p, cap); g.in_ot = th_carve(p, cap); g.out_oh = th_carve(p, cap); g.out_ot = th_carve(p, cap);
-        g.ovf_val = th_carve(p, 2LL * ocap); g.ovf_next = th_carve(p, 2LL * ocap);
-        g.order = th_carve(p, cap); g.index = th_carve(p, cap); g.remain = th_carve(p, cap); g.rem = th_carve(p, cap);
-        g.mpl = th_carve(p, cap); g.mpr = th_carve(p, cap); g.beg = th_carve(p, cap); g.end = th_carve(p, cap);
-        g.ops = th_carve(p, 2LL * (cap + T.max_len + 2));
-        g.roff = (long long *)th_carve(p, 2LL * cap);
+        g.cap = (int)cap; g.n_node = 0;
+        g.nbase = th_carve(p, cap); g.nread = th_carve(p, cap); g.ring = th_carve(p, cap); g.inn = th_carve(p, cap); g.outn = th_carve(p, cap);
+        g.in4 = th_carve(p, cap * TH_POA_INL); g.out4 = th_carve(p, cap * TH_POA_INL);
+        g.in_oh = th_carve(p, cap); g.in_ot = th_carve(p, cap); g.out_oh = th_carve(p, cap); g.out_ot = th_carve(p, cap); g.pos = th_carve(p, cap);
+        g.ovf_val = th_carve(p, ocap); g.ovf_next = th_carve(p, ocap); g.ovf_cnt = th_carve(p, 4);
+        g.order = th_carve(p, cap); g.order2 = th_carve(p, cap);
+        g.r_meta = th_carve(p, cap); g.r_p = th_carve(p, cap * 4); g.r_s = th_carve(p, cap * 4); g.r_rem = th_carve(p, cap);
+        g.r_beg = th_carve(p, cap); g.r_end = th_carve(p, cap); g.r_mpl = th_carve(p, cap); g.r_mpr = th_carve(p, cap);
+        g.r_off = (long long *)th_carve(p, 2 * cap);
+        g.cntB = th_carve(p, cap); g.headB = th_carve(p, cap); g.aft = th_carve(p, cap);
+        g.ops = th_carve(p, 2 * opn); g.pv = th_carve(p, opn); g.glo = th_carve(p, opn); g.pth = th_carve(p, opn + 2);
         g.cell = (int4 *)p;
         g.cell_cap = (scratch_ints - (p - my)) / 4;
         int st = 0;
         if (p - my > scratch_ints || g.cell_cap < 64) st = 1;
-        int n_node = 0, ovf_n = 0;
-        if (!st) {
-            if (lane == 0) {
-                th_poa_new_node(g, 4); th_poa_new_node(g, 4);
-                th_poa_add(g, rb + U[0].start, U[0].len, -1);
-            }
-            TH_WAVE_FENCE();
-            n_node = __shfl(g.n_node, 0); ovf_n = __shfl(g.ovf_n, 0);
-        }
+        if (!st) th_poa_seed(g, rb + U[0].start, U[0].len);
         for (int s = 1; s < T.n_units && !st; ++s) {
             const uint8_t *q = rb + U[s].start; const int qlen = U[s].len;
-            g.n_node = n_node; g.ovf_n = ovf_n;
-            int ts = 0;
-            if (lane == 0) ts = th_poa_topo(g);
+            if (LQ) for (int x = lane; x < qlen; x += TH_WAVE) s_q[x] = q[x];
             TH_WAVE_FENCE();
-            ts = __shfl(ts, 0);
-            if (ts < 0) { st = 3; break; }
-            int deg = 0;
-            for (int i = lane; i < n_node; i += TH_WAVE) deg = max(deg, g.inn[i]);
-            if (th_wave_max(deg) > 255) { st = 5; break; }
-            const int bi = th_poa_dp(g, q, qlen, P);
+            TH_PROF_T0();
+            const int deg = th_poa_rows(g);
+            TH_PROF(0);
+            if (deg > 255) { st = 5; break; }
+            const int bi = th_poa_dp<LQ>(g, q, s_q, s_ring, qlen, P);
+            TH_PROF(1);
             if (bi < 0) { st = bi == -3 ? 2 : 4; break; }
-            if (lane == 0) {
-                const int no = th_poa_traceback(g, bi, qlen);
-                th_poa_add(g, q, qlen, no);
-            }
-            TH_WAVE_FENCE();
-            n_node = __shfl(g.n_node, 0); ovf_n = __shfl(g.ovf_n, 0);
+            const int no = th_poa_traceback(g, bi, qlen);
+            TH_PROF(2);
+            th_poa_merge(g, q, no);
+            TH_PROF(3);
         }
         int cl = 0;
         if (!st) {
-            g.n_node = n_node; g.ovf_n = ovf_n;
-            if (lane == 0) {
-                if (th_poa_topo(g) < 0) st = 3;
-                else {
-                    // row-column consensus: a column = one aligned ring (its members are adjacent in the order)
-                    for (int i = 1; i + 1 < n_node;) {
-                        const int v = g.order[i];
-                        int members = 1;
-                        for (int m = g.ring[v]; m != v; m = g.ring[m]) ++members;
-                        int cnt[5] = { 0, 0, 0, 0, 0 }, tot = 0;
-                        for (int x = i; x < i + members; ++x) { const int u = g.order[x]; cnt[g.base[u]] += g.nread[u]; tot += g.nread[u]; }
-                        int best = 0, bb = -1;
-                        for (int b = 0; b < 5; ++b) if (cnt[b] > best) { best = cnt[b]; bb = b; }
-                        if (T.n_units - tot > best) bb = -1;
-                        if (bb >= 0) {
-                            if (cl >= T.cons_cap) { st = 6; break; }
-                            cons[T.cons_off + cl] = (uint8_t)bb; cov[T.cons_off + cl] = best; ++cl;
-                        }
-                        i += members;
-                    }
-                }
-            }
-            st = __shfl(st, 0); cl = __shfl(cl, 0);
+            cl = th_poa_consensus(g, T.n_units, cons + T.cons_off, cov + T.cons_off, T.cons_cap);
+            if (cl < 0) { st = 6; cl = 0; }
         }
         if (lane == 0) { cons_len[t] = st ? 0 : cl; status[t] = st; }
         TH_WAVE_FENCE();

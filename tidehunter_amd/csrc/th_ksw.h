@@ -27,12 +27,6 @@
 #define TH_KQ 2   // gap open
 #define TH_KE 1   // gap extend
 
-#ifdef TH_CPU_EMUL
-#define TH_READLANE(v, l) __shfl((v), (l))
-#else
-#define TH_READLANE(v, l) __builtin_amdgcn_readlane((v), (l))
-#endif
-
 __device__ __forceinline__ int th_ksw_sc(int a, int b) { return (a == 4 || b == 4) ? -TH_KE : (a == b ? 1 : -2); }
 
 // Global alignment.  q: query (columns), t: target (rows).  bnd: per-wave scratch of
@@ -82,10 +76,10 @@ __device__ int th_ksw_global_wave(const uint8_t *__restrict__ q, int qlen, const
                 }
             }
             // left inputs: from lane-1 (previous step) or, for lane 0, from the inbox / the matrix's left border
-            int lH = __shfl_up(oH, 1), lF = __shfl_up(oF, 1), lCH = __shfl_up(oCH, 1), lT2 = __shfl_up(oT2, 1);
+            int lH = th_shr1(oH, 0), lF = th_shr1(oF, 0), lCH = th_shr1(oCH, 0), lT2 = th_shr1(oT2, 0);
             int lR0 = 0, lR2 = 0;
-            if (WITH_R) { lR0 = __shfl_up(oR0, 1); lR2 = __shfl_up(oR2, 1); }
-            int ti = __shfl_up(tcur, 1);
+            if (WITH_R) { lR0 = th_shr1(oR0, 0); lR2 = th_shr1(oR2, 0); }
+            int ti = th_shr1(tcur, 4);
             {
                 const int sl = s & 63;
                 const int bH = TH_READLANE(ibH, sl), bF = TH_READLANE(ibF, sl), bCH = TH_READLANE(ibCH, sl), bT2 = TH_READLANE(ibT2, sl);
@@ -202,7 +196,7 @@ __device__ void th_ksw_ext_wave(const uint8_t *__restrict__ q, int qs, int qlen,
                 tnx = row < tlen ? t[(long long)row * ts] : 4;
                 if (!first && row < tlen) { nbH = bnd[row]; nbF = bnd[tpad + row]; }
             }
-            int lH = __shfl_up(oH, 1), lF = __shfl_up(oF, 1), ti = __shfl_up(tcur, 1);
+            int lH = th_shr1(oH, 0), lF = th_shr1(oF, 0), ti = th_shr1(tcur, 4);
             {
                 const int sl = s & 63;
                 const int bH = TH_READLANE(ibH, sl), bF = TH_READLANE(ibF, sl), bt = TH_READLANE(tch, sl);

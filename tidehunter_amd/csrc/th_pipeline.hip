@@ -56,7 +56,7 @@ struct th_gpu {
     std::vector<int> h_cons_len, h_status, h_iden, h_ext, h_cov; std::vector<uint8_t> h_cons;
     std::vector<th_job_t> jobs;
     double ms_kernels = 0, ms_dominant = 0, ms_k[8] = { 0 };
-    int waves_part = 4096, waves_poa = 5120, waves_aln = 8192;   // persistent grids: 256 CUs x 4 SIMDs x resident waves
+    int waves_part = 4096, waves_poa = 5120, waves_aln = 8192, waves_xw = 1024;   // persistent grids: 256 CUs x 4 SIMDs x resident waves
 };
 
 static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
@@ -70,7 +70,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
     g->device = device;
 #ifdef TH_CPU_EMUL
     g->stream = 0;
-    g->waves_part = 2; g->waves_poa = 2; g->waves_aln = 3;
+    g->waves_part = 2; g->waves_poa = 2; g->waves_aln = 3; g->waves_xw = 2;
 #else
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { th_fail("no HIP device: the TideHunter HIP path needs an AMD GPU (no CPU fallback)"); delete g; return nullptr; }
@@ -172,8 +172,9 @@ static void build_jobs(th_gpu *g)
 static long long poa_need_ints(const ThTask &t, double cell_factor)
 {
     if (t.n_units <= 2) return 0;
-    const long long cap = t.sum_len + 2, ocap = t.sum_len + t.n_units + 8;
-    long long graph = 27 * cap + 4 * ocap + 2 * (cap + t.max_len + 2) + 256;
+    // mirrors the carve in th_k_poa: 39 node/row arrays of `cap`, the overflow pool, the alignment-op arrays
+    const long long cap = t.sum_len + 2, ocap = 2LL * (t.sum_len + t.n_units + 8), opn = cap + t.max_len + 2;
+    long long graph = 39 * cap + 2 * ocap + 5 * opn + 512;
     const long long w = TH_POA_WB + t.max_len / 100;
     long long rows = std::min<long long>(cap, (long long)(2.2 * t.max_len) + 64);
     long long cells = (long long)(rows * (2 * w + 1 + 48) * cell_factor);
@@ -231,6 +232,10 @@ extern "C" int th_gpu_run(th_gpu_t *g)
               (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p,
               (const int *)g->d_score.p, (const int *)g->d_from.p, g->d_tracked.p, g->d_cells.p,
               g->d_gsort.p, (const long long *)g->d_gsort_off.p, g->d_rec.p, rec_cap, g->d_cnt.p,
+              g->d_read_ch_base.p, g->d_read_ch_n.p, g->d_cnt.p + 1);
+    TH_LAUNCH(th_k_chain_extract_wave, std::min(n, g->waves_xw), TH_XW_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
+              (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p,
+              (const int *)g->d_score.p, (const int *)g->d_from.p, g->d_cells.p, g->d_rec.p, rec_cap, g->d_cnt.p,
               g->d_read_ch_base.p, g->d_read_ch_n.p, g->d_cnt.p + 1);
     KT_END(TK_CHAIN_X);
     int cnt[8];
@@ -302,9 +307,15 @@ extern "C" int th_gpu_run(th_gpu_t *g)
                 TRY(th_rt_h2d(d_sub.p, sub.data(), sub.size() * sizeof(ThTask), g->stream));
                 dt = d_sub.p; dcl = d_scl.p; dst = d_sst.p;
             }
+            int max_unit = 0;
+            for (int t : todo) max_unit = std::max(max_unit, g->h_tasks[t].max_len);
             KT_BEGIN(TK_POA);
-            TH_LAUNCH(th_k_poa, wv, TH_POA_BLOCK, g->stream, dt, (int)todo.size(), (const ThUnit *)g->d_units.p, (const uint32_t *)g->d_roff.p,
-                      (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, dcl, dst);
+            if (max_unit <= TH_POA_QCAP)
+                TH_LAUNCH(th_k_poa<true>, wv, TH_POA_BLOCK, g->stream, dt, (int)todo.size(), (const ThUnit *)g->d_units.p, (const uint32_t *)g->d_roff.p,
+                          (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, dcl, dst);
+            else
+                TH_LAUNCH(th_k_poa<false>, wv, TH_POA_BLOCK, g->stream, dt, (int)todo.size(), (const ThUnit *)g->d_units.p, (const uint32_t *)g->d_roff.p,
+                          (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, dcl, dst);
             KT_END(TK_POA);
             std::vector<int> cl(todo.size()), st(todo.size());
             TRY(th_rt_d2h(cl.data(), dcl, todo.size() * 4, g->stream));
@@ -325,6 +336,11 @@ extern "C" int th_gpu_run(th_gpu_t *g)
             todo.swap(again);
         }
         if (!todo.empty()) return th_fail("POA scratch still too small after 5 attempts");
+#if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
+        { unsigned long long pr[8]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(th_poa_prof), sizeof(pr)); 
+          fprintf(stderr, "[poa_prof] rows %llu dp %llu traceback %llu merge %llu (cycles summed over waves); dp rows %llu slow %llu chunks %llu preds %llu\n", pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7]);
+          unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(th_poa_prof), z, sizeof(z)); }
+#endif
         // ---- unit-vs-consensus alignments and flank extensions ----
         int max_cl = 0;
         for (int t = 0; t < nt; ++t) {
