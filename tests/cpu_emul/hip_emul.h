@@ -32,6 +32,7 @@ struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c 
 struct uint3_e { unsigned x, y, z; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(8) int2 { int x, y; };
 
 namespace hipemul {
 constexpr int WAVE = 64;

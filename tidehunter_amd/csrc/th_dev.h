@@ -58,6 +58,10 @@ struct ThUnit { int start, len; };   // start = index of the unit's first base i
 #define TH_READLANE(v, l) __shfl((v), (l))
 __device__ __forceinline__ int th_shr1(int v, int fill) { int o = __shfl_up(v, 1); return TH_LANE() == 0 ? fill : o; }
 __device__ __forceinline__ int th_shl1(int v, int fill) { int o = __shfl_down(v, 1); return TH_LANE() == 63 ? fill : o; }
+// lane l <- lane l-1, lane 0 <- lane 0 of `inj` (a per-lane register: only its lane 0 matters)
+__device__ __forceinline__ int th_shr1_inject(int v, int inj) { int o = __shfl_up(v, 1); return TH_LANE() == 0 ? inj : o; }
+// rotate towards lane 0: lane l <- lane l+1, lane 63 <- lane 0
+__device__ __forceinline__ int th_rol1(int v) { return __shfl(v, (TH_LANE() + 1) & 63); }
 __device__ __forceinline__ int th_wave_incl_max(int v)
 {
     const int lane = TH_LANE();
@@ -75,6 +79,8 @@ __device__ __forceinline__ int th_wave_incl_sum(int v)
 #define TH_DPP(old, src, ctrl, rmask, bmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), (bmask), false)
 __device__ __forceinline__ int th_shr1(int v, int fill) { return TH_DPP(fill, v, 0x138, 0xf, 0xf); }   // wave_shr:1
 __device__ __forceinline__ int th_shl1(int v, int fill) { return TH_DPP(fill, v, 0x130, 0xf, 0xf); }   // wave_shl:1
+__device__ __forceinline__ int th_shr1_inject(int v, int inj) { return TH_DPP(inj, v, 0x138, 0xf, 0xf); }  // lane 0 keeps inj[0]
+__device__ __forceinline__ int th_rol1(int v) { return TH_DPP(v, v, 0x134, 0xf, 0xf); }                   // wave_rol:1
 __device__ __forceinline__ int th_wave_incl_max(int v)
 {
     const int id = -0x7fffffff - 1;

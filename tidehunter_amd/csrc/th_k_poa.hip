@@ -221,17 +221,19 @@ __device__ unsigned long long th_poa_prof[8];
 #define TH_SET4(s, a0, a1, a2, a3, v) do { if ((s) == 0) a0 = (v); else if ((s) == 1) a1 = (v); else if ((s) == 2) a2 = (v); else a3 = (v); } while (0)
 
 template <bool LQ>
-__device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t *s_q, int (*s_ring)[3][TH_POA_RW], int qlen, const ThDevPara &P)
+__device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t *s_q, int (*s_ring)[3][TH_POA_RW], int (*s_rmeta)[8], int qlen, const ThDevPara &P)
 {
     const int lane = TH_LANE();
     const int M = P.match, X = P.mismatch, O1 = P.go1, E1 = P.ge1, O2 = P.go2, E2 = P.ge2;
     const int n = g.n_node, w = TH_POA_WB + qlen / 100;
     long long ncell = 0;
     int c_meta = 0, c_rem = 0, c_p0 = -1, c_p1 = -1, c_p2 = -1, c_p3 = -1, c_id = 0;   // row-table chunk cache
-    // ring slot state (wave-uniform): row held, band, row-maximum columns, cell offset, cached-in-LDS flag
-    int R_row0 = -1, R_row1 = -1, R_row2 = -1, R_row3 = -1, R_b0 = 0, R_b1 = 0, R_b2 = 0, R_b3 = 0, R_e0 = 0, R_e1 = 0, R_e2 = 0, R_e3 = 0;
-    int R_l0 = 0, R_l1 = 0, R_l2 = 0, R_l3 = 0, R_r0 = 0, R_r1 = 0, R_r2 = 0, R_r3 = 0, R_c0 = 0, R_c1 = 0, R_c2 = 0, R_c3 = 0;
-    long long R_o0 = 0, R_o1 = 0, R_o2 = 0, R_o3 = 0;
+    // the previous row's band / row-maximum columns / LDS-cached flag stay in wave-uniform registers (the
+    // common row has exactly that predecessor); older ring slots keep theirs in s_rmeta[slot][]:
+    //   0 row, 1 beg, 2 end, 3 left, 4 right, 5 cached, 6..7 cell offset
+    int L_b = 0, L_e = -1, L_l = 0, L_r = 0, L_c = 0;
+    if (lane < TH_POA_RING) s_rmeta[lane][0] = -1;
+    TH_WAVE_FENCE();
     for (int i = 0; i + 1 < n; ++i) {
         if ((i & 63) == 0) {
             const int r = i + lane;
@@ -243,19 +245,24 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         const int sl = i & 63;
         const int meta = TH_READLANE(c_meta, sl), rm = TH_READLANE(c_rem, sl);
         const int nb = meta & 0xff, inn = (meta >> 8) & 0xff;
-        const int p0 = TH_READLANE(c_p0, sl), p1 = TH_READLANE(c_p1, sl), p2 = TH_READLANE(c_p2, sl), p3 = TH_READLANE(c_p3, sl);
-        const int vid = TH_READLANE(c_id, sl);
+        const int p0 = TH_READLANE(c_p0, sl);
+        const bool fast = inn == 1 && p0 == i - 1 && L_c;        // one predecessor, the previous row, cached in LDS
+        int p1 = -1, p2 = -1, p3 = -1, vid = 0;
         // ---- band: pull the predecessors' band start and row-maximum columns ----
         int b = 0, e;
-        {
+        if (fast) {
+            b = max(max(0, min(L_l + 1, qlen - rm) - w), L_b);
+            e = min(qlen, max(L_r + 1, qlen - rm) + w);
+        } else {
+            p1 = TH_READLANE(c_p1, sl); p2 = TH_READLANE(c_p2, sl); p3 = TH_READLANE(c_p3, sl); vid = TH_READLANE(c_id, sl);
             int mpl = 0x7fffffff, mpr = 0, mb = 0x7fffffff;
             for (int o = 0; o < inn; ++o) {
                 const int pi = o == 0 ? p0 : o == 1 ? p1 : o == 2 ? p2 : o == 3 ? p3 : g.pos[th_poa_in(g, vid, o)];
                 const int s = pi & 3;
                 int pb, pl, pr;
-                if (i - pi < TH_POA_RING && TH_SEL4(s, R_row0, R_row1, R_row2, R_row3) == pi) {
-                    pb = TH_SEL4(s, R_b0, R_b1, R_b2, R_b3); pl = TH_SEL4(s, R_l0, R_l1, R_l2, R_l3); pr = TH_SEL4(s, R_r0, R_r1, R_r2, R_r3);
-                } else { pb = g.r_beg[pi]; pl = g.r_mpl[pi]; pr = g.r_mpr[pi]; }
+                if (pi == i - 1) { pb = L_b; pl = L_l; pr = L_r; }
+                else if (i - pi < TH_POA_RING && s_rmeta[s][0] == pi) { pb = s_rmeta[s][1]; pl = s_rmeta[s][3]; pr = s_rmeta[s][4]; }
+                else { pb = g.r_beg[pi]; pl = g.r_mpl[pi]; pr = g.r_mpr[pi]; }
                 mpl = min(mpl, pl + 1); mpr = max(mpr, pr + 1); mb = min(mb, pb);
             }
             if (i > 0) { b = max(0, min(mpl, qlen - rm) - w); b = max(b, mb); }
@@ -266,33 +273,36 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         int4 *row = g.cell + ncell;
         const long long my_off = ncell;
         ncell += e - b + 1;
-        const int myslot = i & 3;
+        const int myslot = i & 3, lslot = (i - 1) & 3;
         const bool cache_me = e - b < TH_POA_RW;
         int rmax = TH_NEG - 0x10000000, left = b, right = b;
         int carry1 = TH_NEG + b * E1, carry2 = TH_NEG + b * E2;
-        int slow_row = 0;
         for (int c0 = b; c0 <= e; c0 += TH_WAVE) {
             const int j = c0 + lane;
             const bool in = j <= e;
             int m = TH_NEG, e1v = TH_NEG, e2v = TH_NEG, pm = 0, pe1 = 0, pe2 = 0;
-            if (i > 0) {
-                int sc = 0;
-                if (in && j >= 1) { const int qb = min(LQ ? (int)s_q[j - 1] : (int)q[j - 1], 4); sc = (qb == 4 || nb == 4) ? 0 : (qb == nb ? M : -X); }
+            int sc = 0;
+            if (in && j >= 1) { const int qb = min(LQ ? (int)s_q[j - 1] : (int)q[j - 1], 4); sc = (qb == 4 || nb == 4) ? 0 : (qb == nb ? M : -X); }
+            if (fast) {
+                if (in) {
+                    if (j >= 1) { m = ((j - 1 >= L_b && j - 1 <= L_e) ? s_ring[lslot][0][j - 1 - L_b] : TH_NEG) + sc; }
+                    if (j >= L_b && j <= L_e) { e1v = s_ring[lslot][1][j - L_b]; e2v = s_ring[lslot][2][j - L_b]; }
+                }
+            } else if (i > 0) {
                 for (int o = 0; o < inn; ++o) {
                     const int pi = o == 0 ? p0 : o == 1 ? p1 : o == 2 ? p2 : o == 3 ? p3 : g.pos[th_poa_in(g, vid, o)];
                     const int s = pi & 3;
                     int hp = TH_NEG, c1 = TH_NEG, c2 = TH_NEG;
-                    const bool recent = i - pi < TH_POA_RING && TH_SEL4(s, R_row0, R_row1, R_row2, R_row3) == pi;
-                    if (recent && TH_SEL4(s, R_c0, R_c1, R_c2, R_c3)) {           // LDS ring: no HBM round trip
-                        const int pb = TH_SEL4(s, R_b0, R_b1, R_b2, R_b3), pe = TH_SEL4(s, R_e0, R_e1, R_e2, R_e3);
+                    const bool recent = i - pi < TH_POA_RING && s_rmeta[s][0] == pi;
+                    if (recent && s_rmeta[s][5]) {           // LDS ring: no HBM round trip
+                        const int pb = s_rmeta[s][1], pe = s_rmeta[s][2];
                         if (in) {
                             if (j >= 1 && j - 1 >= pb && j - 1 <= pe) hp = s_ring[s][0][j - 1 - pb];
                             if (j >= pb && j <= pe) { c1 = s_ring[s][1][j - pb]; c2 = s_ring[s][2][j - pb]; }
                         }
                     } else {
-                        slow_row = 1;
                         int pb, pe; long long po;
-                        if (recent) { pb = TH_SEL4(s, R_b0, R_b1, R_b2, R_b3); pe = TH_SEL4(s, R_e0, R_e1, R_e2, R_e3); po = TH_SEL4(s, R_o0, R_o1, R_o2, R_o3); }
+                        if (recent) { pb = s_rmeta[s][1]; pe = s_rmeta[s][2]; po = ((long long)s_rmeta[s][7] << 32) | (uint32_t)s_rmeta[s][6]; }
                         else { pb = g.r_beg[pi]; pe = g.r_end[pi]; po = g.r_off[pi]; }
                         const int4 *prow = g.cell + po;
                         if (in) {
@@ -340,11 +350,12 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             if (hm > rmax) { rmax = hm; left = c0 + th_ctz64(mm); right = c0 + th_msb64(mm); }
             else if (hm == rmax) right = c0 + th_msb64(mm);
         }
-        if (lane == 0) { g.r_beg[i] = b; g.r_end[i] = e; g.r_off[i] = my_off; g.r_mpl[i] = left; g.r_mpr[i] = right; }
-        TH_SET4(myslot, R_row0, R_row1, R_row2, R_row3, i); TH_SET4(myslot, R_b0, R_b1, R_b2, R_b3, b); TH_SET4(myslot, R_e0, R_e1, R_e2, R_e3, e);
-        TH_SET4(myslot, R_l0, R_l1, R_l2, R_l3, left); TH_SET4(myslot, R_r0, R_r1, R_r2, R_r3, right);
-        TH_SET4(myslot, R_c0, R_c1, R_c2, R_c3, cache_me ? 1 : 0); TH_SET4(myslot, R_o0, R_o1, R_o2, R_o3, my_off);
-        TH_PROF_CNT(4, 1); TH_PROF_CNT(5, slow_row); TH_PROF_CNT(6, (e - b) / 64 + 1); TH_PROF_CNT(7, inn);
+        if (lane == 0) {
+            g.r_beg[i] = b; g.r_end[i] = e; g.r_off[i] = my_off; g.r_mpl[i] = left; g.r_mpr[i] = right;
+            s_rmeta[myslot][0] = i; s_rmeta[myslot][1] = b; s_rmeta[myslot][2] = e; s_rmeta[myslot][3] = left; s_rmeta[myslot][4] = right;
+            s_rmeta[myslot][5] = cache_me ? 1 : 0; s_rmeta[myslot][6] = (int)(uint32_t)my_off; s_rmeta[myslot][7] = (int)(my_off >> 32);
+        }
+        L_b = b; L_e = e; L_l = left; L_r = right; L_c = cache_me ? 1 : 0;
         TH_WAVE_FENCE();
     }
     // global end: best predecessor row of the sink (row n-1) at column qlen, first in edge order
@@ -554,6 +565,7 @@ th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict
 {
     __shared__ uint8_t s_q[TH_POA_QCAP];
     __shared__ int s_ring[TH_POA_RING][3][TH_POA_RW];
+    __shared__ int s_rmeta[TH_POA_RING][8];
     const int lane = TH_LANE();
     const int wave = blockIdx.x, nwave = gridDim.x;
     int *my = scratch + (long long)wave * scratch_ints;
@@ -595,7 +607,7 @@ th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict
             const int deg = th_poa_rows(g);
             TH_PROF(0);
             if (deg > 255) { st = 5; break; }
-            const int bi = th_poa_dp<LQ>(g, q, s_q, s_ring, qlen, P);
+            const int bi = th_poa_dp<LQ>(g, q, s_q, s_ring, s_rmeta, qlen, P);
             TH_PROF(1);
             if (bi < 0) { st = bi == -3 ? 2 : 4; break; }
             const int no = th_poa_traceback(g, bi, qlen);

@@ -9,9 +9,13 @@
 //
 // Layout: one alignment per wavefront.  Query columns are processed in strips of 64 (one column per
 // lane); inside a strip the wave sweeps anti-diagonals: at step s lane l updates cell
-// (row i = s - l, column j = j0 + l).  Values crossing to the right-hand neighbour move by one lane
-// per step; the strip's last column is parked in a per-wave boundary buffer (coalesced 64-row
-// chunks through an "outbox" register) and re-read by the next strip's lane 0 ("inbox").
+// (row i = s - l, column j = j0 + l).  Values crossing to the right-hand neighbour move one lane per
+// step with a DPP wave shift whose lane-0 input is the strip's left border: that border sits in an
+// "inbox" register holding 64 rows, rotated by one lane per step so the current row is always in
+// lane 0.  Lane 63 parks its column (the next strip's left border) with one 16-byte store per step;
+// the next strip prefetches it 64 rows at a time.  Lanes outside the matrix (before their first row,
+// after their last, or beyond the last column) simply compute on: nothing they produce is consumed
+// by a lane that is inside it, so the inner loop has no execution-mask juggling.
 //
 // No traceback matrix is stored (ksw2 allocates (qlen+tlen-1)*n_col*16 bytes, 2 MB at 1000^2): what
 // the callers need from the traceback are two path functionals, and both are propagated forward
@@ -30,72 +34,48 @@
 __device__ __forceinline__ int th_ksw_sc(int a, int b) { return (a == 4 || b == 4) ? -TH_KE : (a == b ? 1 : -2); }
 
 // Global alignment.  q: query (columns), t: target (rows).  bnd: per-wave scratch of
-// ((tlen+63)&~63) * (WITH_R ? 6 : 4) ints.  Returns iden_n; *tback = back-projection of q_left_ext.
-// Every lane of the wave must call; results are wave-uniform.
+// ((tlen+63)&~63) * (WITH_R ? 6 : 4) ints (16-byte aligned).  Returns iden_n; *tback = back-projection
+// of q_left_ext.  Every lane of the wave must call; results are wave-uniform.
 template <bool WITH_R>
 __device__ int th_ksw_global_wave(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen,
                                   int q_left_ext, int *__restrict__ bnd, int *tback)
 {
     const int lane = TH_LANE();
-    const int NV = WITH_R ? 6 : 4;
     const int tpad = (tlen + 63) & ~63;
-    const int jstar = qlen - q_left_ext;     // first column of the query suffix (WITH_R)
+    int4 *bnd4 = (int4 *)bnd;                 // {H, F', CH, T2} of the parked column, one per row
+    int2 *bndr = (int2 *)(bnd + 4 * tpad);    // {R0, R2} (WITH_R)
+    const int jstar = qlen - q_left_ext;      // first column of the query suffix (WITH_R)
+    const int nsteps = tlen + TH_WAVE - 1;
     int res_iden = 0, res_r = 0;
     for (int j0 = 0; j0 < qlen; j0 += TH_WAVE) {
         const int j = j0 + lane;
-        const bool colok = j < qlen;
-        const int qj = colok ? q[j] : 4;
+        const int qj = j < qlen ? q[j] : 4;
         const bool first = j0 == 0, last = j0 + TH_WAVE >= qlen;
-        // per-column state (own previous row)
-        int Hup = 0, Ein = 0, T1up = 0, R1up = 0, Hdiag = 0, CHdiag = 0, R0diag = 0;
-        // values produced by this lane at the previous step (consumed by lane+1)
-        int oH = 0, oF = 0, oCH = 0, oT2 = 0, oR0 = 0, oR2 = 0, tcur = 4;
-        // inbox / outbox chunks
-        int ibH = 0, ibF = 0, ibCH = 0, ibT2 = 0, ibR0 = 0, ibR2 = 0;
-        int nbH = 0, nbF = 0, nbCH = 0, nbT2 = 0, nbR0 = 0, nbR2 = 0;
-        int obH = 0, obF = 0, obCH = 0, obT2 = 0, obR0 = 0, obR2 = 0;
-        int tch = 4, tnx = 4;
-        // prefetch chunk 0
-        {
-            const int row = lane;
-            tnx = row < tlen ? t[row] : 4;
-            if (!first && row < tlen) {
-                nbH = bnd[0 * tpad + row]; nbF = bnd[1 * tpad + row]; nbCH = bnd[2 * tpad + row]; nbT2 = bnd[3 * tpad + row];
-                if (WITH_R) { nbR0 = bnd[4 * tpad + row]; nbR2 = bnd[5 * tpad + row]; }
-            }
-        }
-        const int nsteps = tlen + TH_WAVE - 1;
-        for (int s = 0; s < nsteps; ++s) {
-            if ((s & 63) == 0) {
-                ibH = nbH; ibF = nbF; ibCH = nbCH; ibT2 = nbT2; ibR0 = nbR0; ibR2 = nbR2; tch = tnx;
-                const int row = s + 64 + lane;
-                tnx = row < tlen ? t[row] : 4;
-                if (!first && row < tlen) {
-                    nbH = bnd[0 * tpad + row]; nbF = bnd[1 * tpad + row]; nbCH = bnd[2 * tpad + row]; nbT2 = bnd[3 * tpad + row];
-                    if (WITH_R) { nbR0 = bnd[4 * tpad + row]; nbR2 = bnd[5 * tpad + row]; }
-                }
-            }
-            // left inputs: from lane-1 (previous step) or, for lane 0, from the inbox / the matrix's left border
-            int lH = th_shr1(oH, 0), lF = th_shr1(oF, 0), lCH = th_shr1(oCH, 0), lT2 = th_shr1(oT2, 0);
-            int lR0 = 0, lR2 = 0;
-            if (WITH_R) { lR0 = th_shr1(oR0, 0); lR2 = th_shr1(oR2, 0); }
-            int ti = th_shr1(tcur, 4);
+        const bool owner = j == qlen - 1;
+        int Hup = 0, Ein = 0, T1up = 0, R1up = 0, Hdiag = 0, CHdiag = 0, R0diag = 0;     // column state
+        int oH = 0, oF = 0, oCH = 0, oT2 = 0, oR0 = 0, oR2 = 0, tcur = 4;                 // produced last step
+        // next chunk of the left border (prefetched) and of the target
+        int4 nb = { 0, 0, 0, 0 }; int2 nr = { 0, 0 }; int nt = 4;
+        if (lane < tlen) { nt = t[lane]; if (!first) { nb = bnd4[lane]; if (WITH_R) nr = bndr[lane]; } }
+        for (int s0 = 0; s0 < nsteps; s0 += TH_WAVE) {
+            int ibH, ibF, ibCH, ibT2, ibR0 = 0, ibR2 = 0, ibT = nt;
+            if (first) { ibH = -(TH_KQ + (s0 + lane + 1) * TH_KE); ibF = ibH - TH_KQ - TH_KE; ibCH = 0; ibT2 = 0; }
+            else { ibH = nb.x; ibF = nb.y; ibCH = nb.z; ibT2 = nb.w; ibR0 = nr.x; ibR2 = nr.y; }
             {
-                const int sl = s & 63;
-                const int bH = TH_READLANE(ibH, sl), bF = TH_READLANE(ibF, sl), bCH = TH_READLANE(ibCH, sl), bT2 = TH_READLANE(ibT2, sl);
-                const int bt = TH_READLANE(tch, sl);
-                int bR0 = 0, bR2 = 0;
-                if (WITH_R) { bR0 = TH_READLANE(ibR0, sl); bR2 = TH_READLANE(ibR2, sl); }
-                if (lane == 0) {
-                    ti = bt;
-                    if (first) { lH = -(TH_KQ + (s + 1) * TH_KE); lF = lH - TH_KQ - TH_KE; lCH = 0; lT2 = 0; lR0 = 0; lR2 = 0; }
-                    else { lH = bH; lF = bF; lCH = bCH; lT2 = bT2; lR0 = bR0; lR2 = bR2; }
-                }
+                const int row = s0 + TH_WAVE + lane;
+                nt = 4;
+                if (row < tlen) { nt = t[row]; if (!first) { nb = bnd4[row]; if (WITH_R) nr = bndr[row]; } }
             }
-            tcur = ti;
-            const int i = s - lane;
-            const bool act = colok && i >= 0 && i < tlen;
-            if (act) {
+            const int kend = min(TH_WAVE, nsteps - s0);
+            for (int k = 0; k < kend; ++k) {
+                const int i = s0 + k - lane;
+                // left inputs: lane-1's outputs of the previous step; lane 0 takes the border row (inbox lane 0)
+                const int lH = th_shr1_inject(oH, ibH), lF = th_shr1_inject(oF, ibF), lCH = th_shr1_inject(oCH, ibCH), lT2 = th_shr1_inject(oT2, ibT2);
+                const int ti = th_shr1_inject(tcur, ibT);
+                int lR0 = 0, lR2 = 0;
+                if (WITH_R) { lR0 = th_shr1_inject(oR0, ibR0); lR2 = th_shr1_inject(oR2, ibR2); ibR0 = th_rol1(ibR0); ibR2 = th_rol1(ibR2); }
+                ibH = th_rol1(ibH); ibF = th_rol1(ibF); ibCH = th_rol1(ibCH); ibT2 = th_rol1(ibT2); ibT = th_rol1(ibT);
+                tcur = ti;
                 if (i == 0) {   // top border of this column
                     Hup = -(TH_KQ + (j + 1) * TH_KE); Ein = Hup - TH_KQ - TH_KE; T1up = 0; R1up = tlen;
                     Hdiag = j == 0 ? 0 : -(TH_KQ + j * TH_KE); CHdiag = 0;
@@ -120,39 +100,23 @@ __device__ int th_ksw_global_wave(const uint8_t *__restrict__ q, int qlen, const
                         r2 = xf ? lR2 : r0;
                     }
                 }
-                // roll the column state
                 Hdiag = lH; CHdiag = lCH; R0diag = lR0;
                 Hup = h; T1up = t1; R1up = r1;
                 Ein = max(Ein, h - TH_KQ) - TH_KE;
                 oH = h; oF = max(lF, h - TH_KQ) - TH_KE; oCH = ch; oT2 = t2; oR0 = r0; oR2 = r2;
-                if (i == tlen - 1 && j == qlen - 1) { res_iden = ch; res_r = r0; }
-            }
-            // park the strip's last column for the next strip
-            if (!last) {
-                const int io = s - 63;                       // row lane 63 has just produced
-                const int vH = TH_READLANE(oH, 63), vF = TH_READLANE(oF, 63), vCH = TH_READLANE(oCH, 63), vT2 = TH_READLANE(oT2, 63);
-                int vR0 = 0, vR2 = 0;
-                if (WITH_R) { vR0 = TH_READLANE(oR0, 63); vR2 = TH_READLANE(oR2, 63); }
-                if (io >= 0 && io < tlen) {
-                    if (lane == (io & 63)) { obH = vH; obF = vF; obCH = vCH; obT2 = vT2; obR0 = vR0; obR2 = vR2; }
-                    if ((io & 63) == 63 || io == tlen - 1) {
-                        const int row = (io & ~63) + lane;
-                        if (row <= io) {
-                            bnd[0 * tpad + row] = obH; bnd[1 * tpad + row] = obF; bnd[2 * tpad + row] = obCH; bnd[3 * tpad + row] = obT2;
-                            if (WITH_R) { bnd[4 * tpad + row] = obR0; bnd[5 * tpad + row] = obR2; }
-                        }
-                    }
+                if (owner && i == tlen - 1) { res_iden = ch; res_r = r0; }
+                if (!last && lane == 63 && i >= 0 && i < tlen) {          // park the strip's last column
+                    int4 o; o.x = oH; o.y = oF; o.z = oCH; o.w = oT2; bnd4[i] = o;
+                    if (WITH_R) { int2 o2; o2.x = oR0; o2.y = oR2; bndr[i] = o2; }
                 }
             }
         }
         TH_WAVE_FENCE();
     }
-    // the result sits in the lane that owns column qlen-1
-    const int owner = (qlen - 1) & 63;
-    res_iden = __shfl(res_iden, owner);
-    if (WITH_R) res_r = __shfl(res_r, owner);
+    const int ol = (qlen - 1) & 63;
+    res_iden = TH_READLANE(res_iden, ol);
+    if (WITH_R) res_r = TH_READLANE(res_r, ol);
     if (tback) *tback = res_r;
-    (void)NV;
     return res_iden;
 }
 
@@ -174,66 +138,47 @@ __device__ void th_ksw_ext_wave(const uint8_t *__restrict__ q, int qs, int qlen,
                                 int *__restrict__ bnd, int *max_q, int *max_t)
 {
     const int lane = TH_LANE();
-    const int tpad = (tlen + 63) & ~63;
-    int bestH = 0, bestR = 0x7fffffff, bestRank = 0x7fffffff, bestT = -1;
+    int2 *bnd2 = (int2 *)bnd;                 // {H, F'} of the parked column
+    const int nsteps = tlen + TH_WAVE - 1;
+    int bestH = 0, bestR = 0x7fffffff, bestT = -1;
     for (int j0 = 0; j0 < qlen; j0 += TH_WAVE) {
         const int j = j0 + lane;
         const bool colok = j < qlen;
         const int qj = colok ? q[(long long)j * qs] : 4;
         const bool first = j0 == 0, last = j0 + TH_WAVE >= qlen;
-        int Hup = 0, Ein = 0, Hdiag = 0, oH = 0, oF = 0, tcur = 4;
-        int ibH = 0, ibF = 0, nbH = 0, nbF = 0, obH = 0, obF = 0, tch = 4, tnx = 4;
-        {
-            const int row = lane;
-            tnx = row < tlen ? t[(long long)row * ts] : 4;
-            if (!first && row < tlen) { nbH = bnd[row]; nbF = bnd[tpad + row]; }
-        }
-        const int nsteps = tlen + TH_WAVE - 1;
-        for (int s = 0; s < nsteps; ++s) {
-            if ((s & 63) == 0) {
-                ibH = nbH; ibF = nbF; tch = tnx;
-                const int row = s + 64 + lane;
-                tnx = row < tlen ? t[(long long)row * ts] : 4;
-                if (!first && row < tlen) { nbH = bnd[row]; nbF = bnd[tpad + row]; }
-            }
-            int lH = th_shr1(oH, 0), lF = th_shr1(oF, 0), ti = th_shr1(tcur, 4);
+        int Ein = 0, Hdiag = 0, oH = 0, oF = 0, tcur = 4;
+        int2 nb = { 0, 0 }; int nt = 4;
+        if (lane < tlen) { nt = t[(long long)lane * ts]; if (!first) nb = bnd2[lane]; }
+        for (int s0 = 0; s0 < nsteps; s0 += TH_WAVE) {
+            int ibH, ibF, ibT = nt;
+            if (first) { ibH = -(TH_KQ + (s0 + lane + 1) * TH_KE); ibF = ibH - TH_KQ - TH_KE; }
+            else { ibH = nb.x; ibF = nb.y; }
             {
-                const int sl = s & 63;
-                const int bH = TH_READLANE(ibH, sl), bF = TH_READLANE(ibF, sl), bt = TH_READLANE(tch, sl);
-                if (lane == 0) {
-                    ti = bt;
-                    if (first) { lH = -(TH_KQ + (s + 1) * TH_KE); lF = lH - TH_KQ - TH_KE; }
-                    else { lH = bH; lF = bF; }
-                }
+                const int row = s0 + TH_WAVE + lane;
+                nt = 4;
+                if (row < tlen) { nt = t[(long long)row * ts]; if (!first) nb = bnd2[row]; }
             }
-            tcur = ti;
-            const int i = s - lane;
-            const bool act = colok && i >= 0 && i < tlen;
-            if (act) {
-                if (i == 0) { Hup = -(TH_KQ + (j + 1) * TH_KE); Ein = Hup - TH_KQ - TH_KE; Hdiag = j == 0 ? 0 : -(TH_KQ + j * TH_KE); }
+            const int kend = min(TH_WAVE, nsteps - s0);
+            for (int k = 0; k < kend; ++k) {
+                const int i = s0 + k - lane;
+                const int lH = th_shr1_inject(oH, ibH), lF = th_shr1_inject(oF, ibF), ti = th_shr1_inject(tcur, ibT);
+                ibH = th_rol1(ibH); ibF = th_rol1(ibF); ibT = th_rol1(ibT);
+                tcur = ti;
+                if (i == 0) { const int hu = -(TH_KQ + (j + 1) * TH_KE); Ein = hu - TH_KQ - TH_KE; Hdiag = j == 0 ? 0 : -(TH_KQ + j * TH_KE); }
                 int h = Hdiag + th_ksw_sc(ti, qj);
                 h = max(h, Ein); h = max(h, lF);
-                Hdiag = lH; Hup = h;
+                Hdiag = lH;
                 Ein = max(Ein, h - TH_KQ) - TH_KE;
                 oH = h; oF = max(lF, h - TH_KQ) - TH_KE;
                 // within this lane r = i + j only grows, so a strict '>' keeps the earliest anti-diagonal
-                if (h > bestH) { bestH = h; bestR = i + j; bestT = i; bestRank = th_ext_rank(i + j, i, qlen, tlen); }
-            }
-            if (!last) {
-                const int io = s - 63;
-                const int vH = TH_READLANE(oH, 63), vF = TH_READLANE(oF, 63);
-                if (io >= 0 && io < tlen) {
-                    if (lane == (io & 63)) { obH = vH; obF = vF; }
-                    if ((io & 63) == 63 || io == tlen - 1) {
-                        const int row = (io & ~63) + lane;
-                        if (row <= io) { bnd[row] = obH; bnd[tpad + row] = obF; }
-                    }
-                }
+                if (colok && i >= 0 && i < tlen && h > bestH) { bestH = h; bestR = i + j; bestT = i; }
+                if (!last && lane == 63 && i >= 0 && i < tlen) { int2 o; o.x = oH; o.y = oF; bnd2[i] = o; }
             }
         }
         TH_WAVE_FENCE();
     }
     // wave arg-max by (H desc, anti-diagonal asc, SSE visiting rank asc)
+    int bestRank = bestT >= 0 ? th_ext_rank(bestR, bestT, qlen, tlen) : 0x7fffffff;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         const int oH2 = __shfl_xor(bestH, d), oR = __shfl_xor(bestR, d), oK = __shfl_xor(bestRank, d), oT = __shfl_xor(bestT, d);

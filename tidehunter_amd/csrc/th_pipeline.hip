@@ -249,7 +249,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
     g->h_rec.resize(n_rec); g->h_par_n.assign(n_rec, 0); g->h_par_dst.assign(n_rec, 0);
     if (n_rec) {
         // ---- partition ----
-        const long long bnd_part = ((long long)g->max_len + 128) * 6;
+        const long long bnd_part = (((long long)g->max_len + 128) * 6 + 3) & ~3LL;   // 16-byte aligned per-wave segments
         const int wp = std::min(n_rec, g->waves_part);
         TRY(g->d_par.ensure(2 * padT + 16 * (size_t)rec_cap)); TRY(g->d_par_n.ensure(n_rec)); TRY(g->d_par_dst.ensure(n_rec));
         TRY(g->d_bnd.ensure((size_t)(bnd_part * wp)));
@@ -349,7 +349,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
             ThAlnItem l = { t, -1 }, r = { t, -2 }; g->h_items.push_back(l); g->h_items.push_back(r);
         }
         const int ni = (int)g->h_items.size();
-        const long long bnd_aln = std::max<long long>(((long long)max_cl + 128) * 4, ((long long)g->max_len + 128) * 2);
+        const long long bnd_aln = (std::max<long long>(((long long)max_cl + 128) * 4, ((long long)g->max_len + 128) * 2) + 3) & ~3LL;
         const int wa = std::min(ni, g->waves_aln);
         TRY(g->d_items.ensure(ni)); TRY(g->d_bnd.ensure((size_t)(bnd_aln * wa)));
         TRY(th_rt_h2d(g->d_items.p, g->h_items.data(), (size_t)ni * sizeof(ThAlnItem), g->stream));
