@@ -87,3 +87,12 @@ def test_refuses_unimplemented_modes(emu):
     for kw in (dict(w=5), dict(hpc=1)):
         with pytest.raises(RuntimeError):
             TH.TideHunter(lib_path=emu, **kw)
+
+
+def test_emul_banded_alignment_long_units(emu):
+    """units long enough for th_k_align's certified banded pass (64 + 2W + |D| < 3/4 of the consensus length)"""
+    th = TH.TideHunter(lib_path=emu)
+    seqs = [TH.synth_read(th.lib, 5, 0, 500, 4, 0.10), TH.synth_read(th.lib, 5, 2, 520, 3, 0.16)]
+    para = O.default_para()
+    assert U.assert_records_equal(seqs, th.process(seqs), para, "band") >= 1
+    th.close()

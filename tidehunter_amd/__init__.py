@@ -128,9 +128,17 @@ class TideHunter:
     def run(self):
         self._check(self.lib.th_batch_run(self.h))
 
-    def collect(self):
+    def collect_native(self):
+        """th_batch_collect() only: fills the th_tandem_seq_t slots (host arithmetic in C); no Python objects"""
         self._check(self.lib.th_batch_collect(self.h, self._ts))
+
+    def records(self):
+        """Python view of the slots filled by collect_native()"""
         return [self._records(i) for i in range(self._n)]
+
+    def collect(self):
+        self.collect_native()
+        return self.records()
 
     KERNELS = ("th_k_encode+th_k_hits", "th_k_chain_dp", "th_k_chain_extract", "th_k_partition", "th_k_poa", "th_k_align")
 

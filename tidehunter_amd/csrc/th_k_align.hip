@@ -44,7 +44,13 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
             if (cl > 0) {
                 const int start = ps[I.which], len = ps[I.which + 1] - start;
                 if ((long long)((cl + 63) & ~63) * 4 > bnd_stride) { if (lane == 0) atomicOr(err, 4); }
-                else if (len > 0) v = th_ksw_global_wave<false>(rb + start + 1, len, cs, cl, 0, mybnd, nullptr);
+                else if (len > 0) {
+                    // banded pass with an exactness certificate first; the full matrix only when it cannot be certified
+                    const int W = cl / 8 + 32, D = cl - len;
+                    v = -1;
+                    if (64 + 2 * W + (D < 0 ? -D : D) < (cl * 3) / 4) v = th_ksw_global_band_wave(rb + start + 1, len, cs, cl, W, mybnd);
+                    if (v < 0) v = th_ksw_global_wave<false>(rb + start + 1, len, cs, cl, 0, mybnd, nullptr);
+                }
             }
             if (lane == 0) iden[T.aln_off + I.which] = v;
         } else {

@@ -120,6 +120,89 @@ __device__ int th_ksw_global_wave(const uint8_t *__restrict__ q, int qlen, const
     return res_iden;
 }
 
+// Banded global alignment with an exactness certificate (iden_n only, no back-projection).
+//
+// Cells with diagonal d = i - j outside [lo, hi] = [min(0,D) - W, max(0,D) + W] (D = tlen - qlen) are
+// treated as -infinity.  Any path that leaves the band must contain at least Gmin = 2W + 2 + |D| gap
+// bases in at least two gap runs (one to get out, one to come back to the end corner), so it scores at
+// most UB = (m + n - Gmin)/2 - 2*q - Gmin*e.  If the banded optimum S is strictly greater than UB,
+// every optimal path of the full matrix -- and every candidate that could tie with it at a cell of
+// the traceback -- lies inside the band, hence H, the tie-breaks and the '=' count along ksw_backtrack's
+// path are those of the full computation.  Returns -1 when the certificate fails (the caller then
+// runs the full matrix).  Strip geometry: columns j0..j0+63 need rows [j0+lo, j0+63+hi] only.
+__device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, int W, int *__restrict__ bnd)
+{
+    const int lane = TH_LANE();
+    const int D = tlen - qlen;
+    const int lo = min(0, D) - W, hi = max(0, D) + W;
+    int4 *bnd4 = (int4 *)bnd;
+    int res_iden = 0, res_h = TH_NEG;
+    for (int j0 = 0; j0 < qlen; j0 += TH_WAVE) {
+        const int j = j0 + lane;
+        const bool colok = j < qlen;
+        const int qj = colok ? q[j] : 4;
+        const bool first = j0 == 0, last = j0 + TH_WAVE >= qlen;
+        const bool owner = j == qlen - 1;
+        const int rs = max(0, j0 + lo), re = min(tlen - 1, j0 + 63 + hi);     // rows this strip touches
+        const int pre = min(tlen - 1, j0 - 1 + hi);                            // last in-band row of column j0-1
+        const int nsteps = re - rs + TH_WAVE;
+        int Hup = TH_NEG, Ein = TH_NEG, T1up = 0, Hdiag = TH_NEG, CHdiag = 0;
+        int oH = TH_NEG, oF = TH_NEG, oCH = 0, oT2 = 0, tcur = 4;
+        int4 nb = { TH_NEG, TH_NEG, 0, 0 }; int nt = 4;
+        {
+            const int row = rs + lane;
+            if (row < tlen) { nt = t[row]; if (!first && row <= pre) nb = bnd4[row]; }
+        }
+        for (int s0 = 0; s0 < nsteps; s0 += TH_WAVE) {
+            int ibH, ibF, ibCH, ibT2, ibT = nt;
+            if (first) {
+                const int row = rs + s0 + lane;
+                const bool inb = row + 1 <= hi;                     // border column -1 has d = row + 1
+                ibH = inb ? -(TH_KQ + (row + 1) * TH_KE) : TH_NEG; ibF = inb ? ibH - TH_KQ - TH_KE : TH_NEG; ibCH = 0; ibT2 = 0;
+            } else { ibH = nb.x; ibF = nb.y; ibCH = nb.z; ibT2 = nb.w; }
+            {
+                const int row = rs + s0 + TH_WAVE + lane;
+                nt = 4; nb.x = TH_NEG; nb.y = TH_NEG; nb.z = 0; nb.w = 0;
+                if (row < tlen) { nt = t[row]; if (!first && row <= pre) nb = bnd4[row]; }
+            }
+            const int kend = min(TH_WAVE, nsteps - s0);
+            for (int k = 0; k < kend; ++k) {
+                const int i = rs + s0 + k - lane;
+                const int lH = th_shr1_inject(oH, ibH), lF = th_shr1_inject(oF, ibF), lCH = th_shr1_inject(oCH, ibCH), lT2 = th_shr1_inject(oT2, ibT2);
+                const int ti = th_shr1_inject(tcur, ibT);
+                ibH = th_rol1(ibH); ibF = th_rol1(ibF); ibCH = th_rol1(ibCH); ibT2 = th_rol1(ibT2); ibT = th_rol1(ibT);
+                tcur = ti;
+                if (i == 0) {   // top border (row -1) where it lies inside the band
+                    Hup = (-1 - j >= lo) ? -(TH_KQ + (j + 1) * TH_KE) : TH_NEG; Ein = Hup > TH_NEG ? Hup - TH_KQ - TH_KE : TH_NEG; T1up = 0;
+                    Hdiag = j == 0 ? 0 : ((-j >= lo) ? -(TH_KQ + j * TH_KE) : TH_NEG); CHdiag = 0;
+                }
+                const int dd = i - j;
+                const bool inb = colok && i >= 0 && i < tlen && dd >= lo && dd <= hi;
+                const int diag = Hdiag + th_ksw_sc(ti, qj);
+                int d = Ein > diag ? 1 : 0;
+                int h = max(diag, Ein);
+                if (lF > h) { d = 2; h = lF; }
+                const bool xe = Ein > h - TH_KQ, xf = lF > h - TH_KQ;
+                const int ch = d == 0 ? CHdiag + (ti == qj) : d == 1 ? T1up : lT2;
+                const int t1 = xe ? T1up : ch, t2 = xf ? lT2 : ch;
+                Hdiag = lH; CHdiag = lCH;
+                Hup = h; T1up = t1;
+                Ein = inb ? max(Ein, h - TH_KQ) - TH_KE : TH_NEG;
+                oH = inb ? h : TH_NEG; oF = inb ? max(lF, h - TH_KQ) - TH_KE : TH_NEG; oCH = ch; oT2 = t2;
+                if (owner && i == tlen - 1) { res_iden = ch; res_h = h; }
+                if (!last && lane == 63 && i >= 0 && i < tlen) { int4 o; o.x = oH; o.y = oF; o.z = oCH; o.w = oT2; bnd4[i] = o; }
+            }
+        }
+        TH_WAVE_FENCE();
+    }
+    const int ol = (qlen - 1) & 63;
+    res_iden = TH_READLANE(res_iden, ol); res_h = TH_READLANE(res_h, ol);
+    const int gmin = 2 * W + 2 + (D < 0 ? -D : D);
+    // S > (m + n - Gmin)/2 - 2q - Gmin*e   <=>   2S > (m + n - Gmin) - 4q - 2*Gmin*e
+    if (2LL * res_h > (long long)(qlen + tlen - gmin) - 4 * TH_KQ - 2LL * gmin * TH_KE) return res_iden;
+    return -1;
+}
+
 // Extension, score only: returns (max_q, max_t) of the first strictly greater H over anti-diagonals
 // r = 0,1,..., candidates inside one anti-diagonal ranked as ksw2's SSE code visits them
 // (ksw2_extz2_sse.c:228-260): t = en0 first, then four interleaved lanes over [st0,en1), then the
