@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("TH_BENCH_BATCH", "4096")), help="reads per step per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("TH_BENCH_BATCH", "16384")), help="reads per step per GPU")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1: auto, 0: skip)")
     a = ap.parse_args()
 

@@ -119,3 +119,47 @@ def test_gpu_headline_shape_properties(th):
         r = max(recs, key=lambda x: x["end"] - x["start"])
         assert 900 <= r["cons_len"] <= 1100 and r["end"] - r["start"] > 8000 and 8.5 <= r["copy_num"] <= 11.5
         assert r["ave_match"] > 80.0
+
+
+def _cli(*args):
+    import subprocess
+    exe = os.path.join(U.ROOT, "tidehunter_amd", "TideHunter-amd")
+    return subprocess.run([exe, *args], check=True, capture_output=True, text=True).stdout
+
+
+def _oracle_cli(*args):
+    import subprocess
+    O.load()
+    return subprocess.run([os.path.join(O.ODIR, "tho_oracle"), *args], check=True, capture_output=True, text=True).stdout
+
+
+def test_gpu_cli_output_is_byte_identical():
+    """the command line (reader -> batch seam -> writer) against the oracle's fixtures and its CLI, byte for byte"""
+    fq = os.path.join(U.DATA, "test.fq")
+    golden = os.path.join(U.ROOT, "tests", "golden")
+    assert _cli("-f", "2", fq) == open(os.path.join(golden, "oracle_test_fq_tab.txt")).read()
+    assert _cli("-u", "-f", "2", fq) == open(os.path.join(golden, "oracle_test_fq_unit.txt")).read()
+    ad = ["-5", os.path.join(U.DATA, "5prime.fa"), "-3", os.path.join(U.DATA, "3prime.fa")]
+    fl = os.path.join(U.DATA, "full_length.fa")
+    assert _cli("-f", "3", *ad, fl) == open(os.path.join(golden, "oracle_full_length_fastq.txt")).read()
+    for extra in ([], ["-f", "4"], ["-l"], ["-c", "3", "-m", "100"], ["-F", *ad], ["-s", "-F", *ad], ["-p", "100", "-P", "2K"], ["-u"]):
+        assert _cli(*extra, fq) == _oracle_cli("-t", "8", *extra, fq), extra
+    # README.md:222
+    assert _cli("-f", "2", os.path.join(U.DATA, "test_50x4.fa")) == \
+        "test_50x4\trep0\t4.0\t300\t51\t250\t50\t100.0\t0\t59,109,159,208\tCGATCGATCGGCATGCATGCATGCTAGTCGATGCATCGGGATCAGCTAGT\n"
+
+
+def test_gpu_long_reads_take_the_hbm_sort_paths(th):
+    """reads with > 16384 k-mers / > 8192 hits: bitonic sorts in HBM scratch, block-wide extraction kernel"""
+    para = O.default_para()
+    seqs = [TH.synth_read(th.lib, 13, 0, 2000, 20, 0.08), TH.synth_read(th.lib, 13, 1, 150, 200, 0.05), TH.synth_read(th.lib, 13, 2, 700, 6, 0.1)]
+    assert len(seqs[0]) > 35000
+    got = th.process(seqs)
+    U.stage_compare(th, seqs, para)
+    U.assert_records_equal(seqs, got, para, "long")
+
+
+def test_gpu_multi_batch_file_run(tmp_path):
+    """th_run_file with a small batch size: several device batches, output order = input order"""
+    fq = os.path.join(U.DATA, "test.fq")
+    assert _cli("-b", "7", "-f", "2", fq) == open(os.path.join(U.ROOT, "tests", "golden", "oracle_test_fq_tab.txt")).read()
