@@ -37,6 +37,8 @@
 #define TH_D_XF2 (1u << 30)
 
 #define TH_POA_INL 4
+#define TH_POA_RING 4      // recent rows kept in LDS (a row can read the three before it)
+#define TH_POA_RW 192      // columns per cached row
 #define TH_BIG 0x3fffffff
 
 struct ThPoaG {
@@ -50,7 +52,7 @@ struct ThPoaG {
     long long *r_off;
     int *cntB, *headB, *aft;
     int *ops, *pv, *glo, *pth;
-    int4 *cell; long long cell_cap;
+    int4 *cell; int *dcell; long long cell_cap;     // full cells (rows some far row will read) / direction words (all rows)
 };
 
 __device__ __forceinline__ int th_poa_in(const ThPoaG &g, int v, int ord)
@@ -189,7 +191,10 @@ __device__ int th_poa_rows(ThPoaG &g)
         }
         if (ok) {
             g.r_rem[idx] = cur;
-            g.r_meta[idx] = g.nbase[u] | min(in, 255) << 8 | min(on, 255) << 16;
+            int needfull = on > TH_POA_INL;
+#pragma unroll
+            for (int k = 0; k < TH_POA_INL; ++k) if (s[k] >= 0 && (s[k] - idx >= TH_POA_RING || s[k] == n - 1)) needfull = 1;
+            g.r_meta[idx] = g.nbase[u] | min(in, 255) << 8 | min(on, 255) << 16 | needfull << 24;
 #pragma unroll
             for (int k = 0; k < TH_POA_INL; ++k) g.r_p[idx * TH_POA_INL + k] = p[k];
         }
@@ -215,8 +220,6 @@ __device__ unsigned long long th_poa_prof[8];
 // row-maximum columns in wave-uniform registers, so a row whose predecessors are among them -- nearly
 // all rows: the previous node and the members of the previous column -- issues no HBM load at all; its
 // own cells leave as fire-and-forget 16-byte stores (needed by the traceback and by far predecessors).
-#define TH_POA_RING 4
-#define TH_POA_RW 192
 #define TH_SEL4(s, a0, a1, a2, a3) ((s) == 0 ? (a0) : (s) == 1 ? (a1) : (s) == 2 ? (a2) : (a3))
 #define TH_SET4(s, a0, a1, a2, a3, v) do { if ((s) == 0) a0 = (v); else if ((s) == 1) a1 = (v); else if ((s) == 2) a2 = (v); else a3 = (v); } while (0)
 
@@ -245,6 +248,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         const int sl = i & 63;
         const int meta = TH_READLANE(c_meta, sl), rm = TH_READLANE(c_rem, sl);
         const int nb = meta & 0xff, inn = (meta >> 8) & 0xff;
+        const bool needfull = (meta >> 24) & 1;
         const int p0 = TH_READLANE(c_p0, sl);
         const bool fast = inn == 1 && p0 == i - 1 && L_c;        // one predecessor, the previous row, cached in LDS
         int p1 = -1, p2 = -1, p3 = -1, vid = 0;
@@ -270,11 +274,12 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         }
         if (b > e) return -2;
         if (ncell + (e - b + 1) > g.cell_cap) return -3;
-        int4 *row = g.cell + ncell;
+        int4 *row = g.cell + ncell; int *drow = g.dcell + ncell;
         const long long my_off = ncell;
         ncell += e - b + 1;
         const int myslot = i & 3, lslot = (i - 1) & 3;
         const bool cache_me = e - b < TH_POA_RW;
+        const bool store_full = needfull || !cache_me;     // otherwise only the direction word leaves the CU
         int rmax = TH_NEG - 0x10000000, left = b, right = b;
         int carry1 = TH_NEG + b * E1, carry2 = TH_NEG + b * E2;
         for (int c0 = b; c0 <= e; c0 += TH_WAVE) {
@@ -341,8 +346,8 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                     if (f2 > h - O2) d |= TH_D_XF2;
                 }
                 const int n1 = max(h - O1, e1v) - E1, n2 = max(h - O2, e2v) - E2;
-                int4 cv; cv.x = h; cv.y = n1; cv.z = n2; cv.w = (int)d;
-                row[j - b] = cv;
+                drow[j - b] = (int)d;
+                if (store_full) { int4 cv; cv.x = h; cv.y = n1; cv.z = n2; cv.w = (int)d; row[j - b] = cv; }
                 if (cache_me) { s_ring[myslot][0][j - b] = h; s_ring[myslot][1][j - b] = n1; s_ring[myslot][2][j - b] = n2; }
             }
             const int hm = th_wave_max(in ? h : TH_NEG * 2);
@@ -391,7 +396,7 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
             if (row >= 1) {
                 const int rb = g.r_beg[row], re = g.r_end[row];
                 t_p0 = g.r_p[row * 4]; t_p1 = g.r_p[row * 4 + 1]; t_p2 = g.r_p[row * 4 + 2]; t_p3 = g.r_p[row * 4 + 3];
-                if (col >= rb && col <= re) { t_d = g.cell[g.r_off[row] + (col - rb)].w; t_ok = 1; }
+                if (col >= rb && col <= re) { t_d = g.dcell[g.r_off[row] + (col - rb)]; t_ok = 1; }
             }
             k = 0; o = 1;
         }
@@ -418,7 +423,7 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
                 else {
                     uint32_t pd;
                     if (hit && okv) pd = (uint32_t)dv;
-                    else pd = (uint32_t)g.cell[g.r_off[ci] + (cj - g.r_beg[ci])].w;
+                    else pd = (uint32_t)g.dcell[g.r_off[ci] + (cj - g.r_beg[ci])];
                     const uint32_t bit = st == 1 ? TH_D_XE1 : st == 2 ? TH_D_XE2 : st == 3 ? TH_D_XF1 : TH_D_XF2;
                     if (!(pd & bit)) st = 0;
                 }
@@ -594,8 +599,8 @@ th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict
         g.r_off = (long long *)th_carve(p, 2 * cap);
         g.cntB = th_carve(p, cap); g.headB = th_carve(p, cap); g.aft = th_carve(p, cap);
         g.ops = th_carve(p, 2 * opn); g.pv = th_carve(p, opn); g.glo = th_carve(p, opn); g.pth = th_carve(p, opn + 2);
-        g.cell = (int4 *)p;
-        g.cell_cap = (scratch_ints - (p - my)) / 4;
+        g.cell_cap = (scratch_ints - (p - my)) / 5 & ~3LL;
+        g.cell = (int4 *)p; g.dcell = p + 4 * g.cell_cap;
         int st = 0;
         if (p - my > scratch_ints || g.cell_cap < 64) st = 1;
         if (!st) th_poa_seed(g, rb + U[0].start, U[0].len);

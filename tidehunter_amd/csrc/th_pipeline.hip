@@ -178,7 +178,7 @@ static long long poa_need_ints(const ThTask &t, double cell_factor)
     const long long w = TH_POA_WB + t.max_len / 100;
     long long rows = std::min<long long>(cap, (long long)(2.2 * t.max_len) + 64);
     long long cells = (long long)(rows * (2 * w + 1 + 48) * cell_factor);
-    return (graph + 4 * cells + 63) & ~63LL;
+    return (graph + 5 * cells + 63) & ~63LL;
 }
 
 // per-kernel device time: HIP events recorded on the pipeline's own stream around each launch
