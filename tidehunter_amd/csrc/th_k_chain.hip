@@ -224,7 +224,7 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
                         int *__restrict__ read_ch_base, int *__restrict__ read_ch_n, int *__restrict__ err)
 {
     __shared__ uint32_t s_key[TH_XFAST_MAX];
-    __shared__ int s_from[TH_XFAST_MAX];
+    __shared__ short s_from[TH_XFAST_MAX];
     __shared__ uint32_t s_trk[TH_XFAST_MAX / 32];
     __shared__ int ch_off[TH_TOPN], ch_len[TH_TOPN], ch_score[TH_TOPN], ch_fs[TH_TOPN], ch_ls[TH_TOPN], ch_le[TH_TOPN];
     __shared__ short ch_idx[TH_TOPN];
@@ -238,7 +238,7 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
         int *CL = cells + off;
         int N = 1; while (N < n) N <<= 1;
         for (int i = lane; i < N; i += TH_WAVE) s_key[i] = i < n ? ((uint32_t)S[i] << 13 | (uint32_t)i) : 0u;
-        for (int i = lane; i < n; i += TH_WAVE) s_from[i] = F[i];
+        for (int i = lane; i < n; i += TH_WAVE) s_from[i] = (short)F[i];
         for (int i = lane; i < (n + 31) / 32; i += TH_WAVE) s_trk[i] = 0;
         for (int i = lane; i < TH_TOPN; i += TH_WAVE) ch_idx[i] = (short)i;
         TH_WAVE_FENCE();
@@ -275,9 +275,26 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
                 }
                 if (!__any(open)) break;
             }
-            const unsigned long long m = __ballot(valid && !skip);
+            // Candidates whose backtrack stops at once -- no predecessor, or a predecessor that is already tracked
+            // (possibly by an earlier candidate of this very window) -- only get themselves tracked: the chain
+            // has one cell, is rejected (:107) and the sort_chain that follows changes nothing.  They are
+            // committed together up to the first candidate that needs a real walk.
+            const bool nonskip = valid && !skip;
+            const int pre0 = nonskip ? (int)s_from[cand] : -1;
+            bool trivial = nonskip && (pre0 == -1 || ((s_trk[pre0 >> 5] >> (pre0 & 31)) & 1));
+            const unsigned long long nsm = __ballot(nonskip);
+            if (nsm & (nsm - 1)) {                    // two or more live candidates: one may track another's predecessor
+                for (unsigned long long w = nsm; w; w &= w - 1) {
+                    const int k = th_ctz64(w);
+                    const int ck = TH_READLANE(cand, k);
+                    if (nonskip && k < lane && pre0 == ck) trivial = true;
+                }
+            }
+            const unsigned long long m = __ballot(nonskip && !trivial);
+            const int f = th_ctz64(m);               // 64 when every live candidate of the window is trivial
+            if (nonskip && trivial && lane < f) atomicOr(&s_trk[cand >> 5], 1u << (cand & 31));
+            TH_WAVE_FENCE();
             if (!m) { ci += TH_WAVE; continue; }
-            const int f = th_ctz64(m);
             const int c0 = TH_READLANE(cand, f);
             ci += f + 1;
             // ---- attempt: backtrack_dp into slot ch_n (wave-uniform scalar walk; cells written by lane 0) ----
