@@ -163,3 +163,15 @@ def test_gpu_multi_batch_file_run(tmp_path):
     """th_run_file with a small batch size: several device batches, output order = input order"""
     fq = os.path.join(U.DATA, "test.fq")
     assert _cli("-b", "7", "-f", "2", fq) == open(os.path.join(U.ROOT, "tests", "golden", "oracle_test_fq_tab.txt")).read()
+
+
+def test_gpu_large_batch_is_deterministic(th):
+    """a few thousand reads, three runs: identical records every time (persistent kernels pull work from
+    shared queues and chain records arrive in arbitrary order; nothing downstream may depend on that)"""
+    seqs = _synth(th.lib, 3072, 1000, 10, 0.10, 1)
+    runs = [th.process(seqs) for _ in range(3)]
+    assert runs[0] == runs[1] == runs[2]
+    para = O.default_para()
+    step = len(seqs) // 24
+    sample = list(range(0, len(seqs), step))
+    U.assert_records_equal([seqs[i] for i in sample], [runs[0][i] for i in sample], para, "sampled")

@@ -122,5 +122,21 @@ __device__ __forceinline__ int th_lane_shift(int v, int off, int fill)
     const int o = __shfl(v, src & 63);
     return (src >= 0 && src < TH_WAVE) ? o : fill;
 }
+// Plain load of a word that was updated with device-scope atomics earlier in the same kernel: atomics execute
+// in L2 and do not refresh the CU's vector L1, so the read-back must bypass L1 (global_load ... sc1).
+#ifdef TH_CPU_EMUL
+#define TH_LOAD_L2(p) (*(p))
+#else
+#define TH_LOAD_L2(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+
+// next index of a shared work queue, wave-uniform.  Every lane takes part in the atomic (lane 0 adds 1, the
+// others 0), so there is no divergent region around it: with the add under `if (lane == 0)` hipcc 7.2
+// restructured the surrounding persistent loop into one that never fetched a second item.
+__device__ __forceinline__ int th_queue_pop(int *queue)
+{
+    const int v = atomicAdd(queue, TH_LANE() == 0 ? 1 : 0);
+    return TH_READLANE(v, 0);
+}
 __device__ __forceinline__ int th_ctz64(unsigned long long m) { return m ? __ffsll((long long)m) - 1 : 64; }
 __device__ __forceinline__ int th_msb64(unsigned long long m) { return 63 - __clzll((long long)m); }   // m != 0

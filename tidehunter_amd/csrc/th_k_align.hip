@@ -12,12 +12,12 @@
 struct ThAlnItem { int task, which; };   // which >= 0: unit index in the run; -1 left extension; -2 right extension
 
 // Gathers the scattered per-chain par_pos regions into one compact array (host gives offsets).
-__global__ void th_k_gather_par(const ThChainRec *__restrict__ rec, int n_rec, const int *__restrict__ par, const int *__restrict__ par_n,
+__global__ void th_k_gather_par(int n_rec, const int *__restrict__ par, const int *__restrict__ par_off, const int *__restrict__ par_n,
                                 const int *__restrict__ dst_off, int *__restrict__ dst)
 {
     const int c = blockIdx.x;
     if (c >= n_rec) return;
-    const int *src = par + 2LL * rec[c].cell_off + 16LL * c;
+    const int *src = par + par_off[c];
     const int n = par_n[c], o = dst_off[c];
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[o + i] = src[i];
 }
@@ -26,12 +26,14 @@ __global__ void __launch_bounds__(TH_ALN_BLOCK)
 th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__restrict__ tasks, const int *__restrict__ pos,
            const uint32_t *__restrict__ roff, const uint8_t *__restrict__ bseq,
            const uint8_t *__restrict__ cons, const int *__restrict__ cons_len,
-           int *__restrict__ bnd, long long bnd_stride, int *__restrict__ iden, int *__restrict__ ext, int *__restrict__ err)
+           int *__restrict__ bnd, long long bnd_stride, int *__restrict__ iden, int *__restrict__ ext, int *__restrict__ err, int *__restrict__ queue)
 {
     const int lane = TH_LANE();
-    const int wave = blockIdx.x, nwave = gridDim.x;
+    const int wave = blockIdx.x;
     int *mybnd = bnd + (long long)wave * bnd_stride;
-    for (int it = wave; it < n_items; it += nwave) {
+    for (;;) {
+        const int it = th_queue_pop(queue);   // dynamic work queue: items range from a short extension to a full matrix
+        if (it >= n_items) break;
         const ThAlnItem I = items[it];
         const ThTask T = tasks[I.task];
         const int cl = cons_len[I.task];

@@ -15,7 +15,8 @@
 __global__ void __launch_bounds__(TH_PART_BLOCK)
 th_k_partition(const ThChainRec *__restrict__ rec, int n_rec, const uint32_t *__restrict__ roff, const uint8_t *__restrict__ bseq,
                const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ cells, ThDevPara P,
-               int *__restrict__ par, int *__restrict__ par_n, int *__restrict__ bnd, long long bnd_stride, int *__restrict__ err)
+               int *__restrict__ par, int par_cap, int *__restrict__ par_top, int *__restrict__ par_off, int *__restrict__ par_n,
+               int *__restrict__ bnd, long long bnd_stride, int *__restrict__ err)
 {
     const int lane = TH_LANE();
     const int wave = blockIdx.x, nwave = gridDim.x;
@@ -26,11 +27,16 @@ th_k_partition(const ThChainRec *__restrict__ rec, int n_rec, const uint32_t *__
         const uint32_t off = roff[R.read];
         const uint8_t *b = bseq + off;
         const int *E = hit_end + off, *Pd = hit_per + off, *CL = cells + R.cell_off;
-        int *out = par + 2LL * R.cell_off + 16LL * c;
+        // the chain's par_pos region is carved from a shared arena (chain records arrive in no particular order,
+        // so nothing derived from the record index may be used to keep regions apart)
         const int cap = 2 * R.len + 16;
-        int n = 0, bad = 0;
+        int base = 0;
+        { const int v = atomicAdd(par_top, lane == 0 ? cap : 0); base = TH_READLANE(v, 0); }
+        int n = 0, bad = base + cap > par_cap;
+        int *out = par + (bad ? 0 : base);
+        if (lane == 0) par_off[c] = base;
         int ch_i = 0, s = R.est_start, e = R.est_start + R.est_period;
-        if (lane == 0) { out[0] = s; out[1] = e; }
+        if (lane == 0 && !bad) { out[0] = s; out[1] = e; }
         n = 2;
         while (ch_i < R.len - 1 && e <= R.last_start && !bad) {
             // first cell beyond ch_i whose start is >= e (exists: last_start >= e)

@@ -220,16 +220,24 @@ __device__ unsigned long long th_poa_prof[8];
 // row-maximum columns in wave-uniform registers, so a row whose predecessors are among them -- nearly
 // all rows: the previous node and the members of the previous column -- issues no HBM load at all; its
 // own cells leave as fire-and-forget 16-byte stores (needed by the traceback and by far predecessors).
+// ring values are stored as int16 (half the LDS, so more waves per CU); anything below the int16 range is a
+// band-edge "minus infinity" and is widened back to TH_NEG on load.  Rows are cached only while every real
+// score fits (see cache16_ok below).
+#define TH_RING_LD(x) ((int)(x) == -32768 ? TH_NEG : (int)(x))
+#define TH_RING_ST(v) ((short)max((v), -32768))
 #define TH_SEL4(s, a0, a1, a2, a3) ((s) == 0 ? (a0) : (s) == 1 ? (a1) : (s) == 2 ? (a2) : (a3))
 #define TH_SET4(s, a0, a1, a2, a3, v) do { if ((s) == 0) a0 = (v); else if ((s) == 1) a1 = (v); else if ((s) == 2) a2 = (v); else a3 = (v); } while (0)
 
 template <bool LQ>
-__device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t *s_q, int (*s_ring)[3][TH_POA_RW], int (*s_rmeta)[8], int qlen, const ThDevPara &P)
+__device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t *s_q, short (*s_ring)[3][TH_POA_RW], int (*s_rmeta)[8], int qlen, const ThDevPara &P)
 {
     const int lane = TH_LANE();
     const int M = P.match, X = P.mismatch, O1 = P.go1, E1 = P.ge1, O2 = P.go2, E2 = P.ge2;
     const int n = g.n_node, w = TH_POA_WB + qlen / 100;
     long long ncell = 0;
+    // a real score is at most (largest per-step score or gap extension) * (columns + rows) + both gap opens away from 0:
+    // rows are cached as int16 only if that fits
+    const bool cache16_ok = (long long)max(max(M, X), max(E1, E2)) * (qlen + n) + O1 + O2 < 30000;
     int c_meta = 0, c_rem = 0, c_p0 = -1, c_p1 = -1, c_p2 = -1, c_p3 = -1, c_id = 0;   // row-table chunk cache
     // the previous row's band / row-maximum columns / LDS-cached flag stay in wave-uniform registers (the
     // common row has exactly that predecessor); older ring slots keep theirs in s_rmeta[slot][]:
@@ -278,7 +286,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         const long long my_off = ncell;
         ncell += e - b + 1;
         const int myslot = i & 3, lslot = (i - 1) & 3;
-        const bool cache_me = e - b < TH_POA_RW;
+        const bool cache_me = cache16_ok && e - b < TH_POA_RW;
         const bool store_full = needfull || !cache_me;     // otherwise only the direction word leaves the CU
         int rmax = TH_NEG - 0x10000000, left = b, right = b;
         int carry1 = TH_NEG + b * E1, carry2 = TH_NEG + b * E2;
@@ -290,8 +298,8 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             if (in && j >= 1) { const int qb = min(LQ ? (int)s_q[j - 1] : (int)q[j - 1], 4); sc = (qb == 4 || nb == 4) ? 0 : (qb == nb ? M : -X); }
             if (fast) {
                 if (in) {
-                    if (j >= 1) { m = ((j - 1 >= L_b && j - 1 <= L_e) ? s_ring[lslot][0][j - 1 - L_b] : TH_NEG) + sc; }
-                    if (j >= L_b && j <= L_e) { e1v = s_ring[lslot][1][j - L_b]; e2v = s_ring[lslot][2][j - L_b]; }
+                    if (j >= 1) { m = ((j - 1 >= L_b && j - 1 <= L_e) ? TH_RING_LD(s_ring[lslot][0][j - 1 - L_b]) : TH_NEG) + sc; }
+                    if (j >= L_b && j <= L_e) { e1v = TH_RING_LD(s_ring[lslot][1][j - L_b]); e2v = TH_RING_LD(s_ring[lslot][2][j - L_b]); }
                 }
             } else if (i > 0) {
                 for (int o = 0; o < inn; ++o) {
@@ -302,8 +310,8 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                     if (recent && s_rmeta[s][5]) {           // LDS ring: no HBM round trip
                         const int pb = s_rmeta[s][1], pe = s_rmeta[s][2];
                         if (in) {
-                            if (j >= 1 && j - 1 >= pb && j - 1 <= pe) hp = s_ring[s][0][j - 1 - pb];
-                            if (j >= pb && j <= pe) { c1 = s_ring[s][1][j - pb]; c2 = s_ring[s][2][j - pb]; }
+                            if (j >= 1 && j - 1 >= pb && j - 1 <= pe) hp = TH_RING_LD(s_ring[s][0][j - 1 - pb]);
+                            if (j >= pb && j <= pe) { c1 = TH_RING_LD(s_ring[s][1][j - pb]); c2 = TH_RING_LD(s_ring[s][2][j - pb]); }
                         }
                     } else {
                         int pb, pe; long long po;
@@ -348,7 +356,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 const int n1 = max(h - O1, e1v) - E1, n2 = max(h - O2, e2v) - E2;
                 drow[j - b] = (int)d;
                 if (store_full) { int4 cv; cv.x = h; cv.y = n1; cv.z = n2; cv.w = (int)d; row[j - b] = cv; }
-                if (cache_me) { s_ring[myslot][0][j - b] = h; s_ring[myslot][1][j - b] = n1; s_ring[myslot][2][j - b] = n2; }
+                if (cache_me) { s_ring[myslot][0][j - b] = TH_RING_ST(h); s_ring[myslot][1][j - b] = TH_RING_ST(n1); s_ring[myslot][2][j - b] = TH_RING_ST(n2); }
             }
             const int hm = th_wave_max(in ? h : TH_NEG * 2);
             const unsigned long long mm = __ballot(in && h == hm);
@@ -502,13 +510,13 @@ __device__ void th_poa_merge(ThPoaG &g, const uint8_t *__restrict__ q, int n_ops
     int shift = 0;
     for (int p0 = 0; p0 < n_old; p0 += TH_WAVE) {
         const int p = p0 + lane; const bool ok = p < n_old;
-        const int cb = ok ? g.cntB[p] : 0, af = ok ? (g.aft[p] >= 0) : 0;
+        const int cb = ok ? TH_LOAD_L2(&g.cntB[p]) : 0, af = ok ? (g.aft[p] >= 0) : 0;     // cntB/headB were built with atomics
         const int incB = th_wave_incl_sum(cb), incA = th_wave_incl_sum(af);
         if (ok) {
             const int np = p + shift + incB + (incA - af);
             const int id = g.order[p];
             g.order2[np] = id; g.pos[id] = np;
-            const int hb = g.headB[p];
+            const int hb = TH_LOAD_L2(&g.headB[p]);
             for (int x = 0; x < cb; ++x) { g.order2[np - cb + x] = hb + x; g.pos[hb + x] = np - cb + x; }
             if (af) { const int m = g.aft[p]; g.order2[np + 1] = m; g.pos[m] = np + 1; }
         }
@@ -566,15 +574,18 @@ template <bool LQ>
 __global__ void __launch_bounds__(TH_POA_BLOCK)
 th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict__ units, const uint32_t *__restrict__ roff,
          const uint8_t *__restrict__ bseq, ThDevPara P, int *__restrict__ scratch, long long scratch_ints,
-         uint8_t *__restrict__ cons, int *__restrict__ cov, int *__restrict__ cons_len, int *__restrict__ status)
+         uint8_t *__restrict__ cons, int *__restrict__ cov, int *__restrict__ cons_len, int *__restrict__ status, int *__restrict__ queue)
 {
     __shared__ uint8_t s_q[TH_POA_QCAP];
-    __shared__ int s_ring[TH_POA_RING][3][TH_POA_RW];
+    __shared__ short s_ring[TH_POA_RING][3][TH_POA_RW];
     __shared__ int s_rmeta[TH_POA_RING][8];
     const int lane = TH_LANE();
-    const int wave = blockIdx.x, nwave = gridDim.x;
+    const int wave = blockIdx.x;
     int *my = scratch + (long long)wave * scratch_ints;
-    for (int t = wave; t < n_tasks; t += nwave) {
+    for (;;) {
+        // jobs differ a lot in length (units, copies): waves pull the next job from a shared counter
+        const int t = th_queue_pop(queue);
+        if (t >= n_tasks) break;
         const ThTask T = tasks[t];
         const uint8_t *rb = bseq + roff[T.read];
         const ThUnit *U = units + T.unit_off;

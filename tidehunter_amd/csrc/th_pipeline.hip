@@ -48,7 +48,7 @@ struct th_gpu {
     DBuf<int> d_hit_end, d_hit_per, d_hit_n, d_score, d_from, d_cells, d_cnt, d_read_ch_base, d_read_ch_n;
     DBuf<unsigned long long> d_gsort; DBuf<long long> d_gsort_off;
     DBuf<ThChainRec> d_rec;
-    DBuf<int> d_par, d_par_n, d_par_dst, d_parc, d_bnd, d_scratch, d_cov, d_cons_len, d_status, d_iden, d_ext;
+    DBuf<int> d_par, d_par_off, d_par_n, d_par_dst, d_parc, d_bnd, d_scratch, d_cov, d_cons_len, d_status, d_iden, d_ext;
     DBuf<ThTask> d_tasks; DBuf<ThUnit> d_units; DBuf<ThAlnItem> d_items;
     int n_rec = 0;
     std::vector<ThChainRec> h_rec; std::vector<int> h_par_n, h_par_dst, h_parc, h_read_ch_base, h_read_ch_n;
@@ -89,7 +89,7 @@ extern "C" void th_gpu_destroy(th_gpu_t *g)
     g->d_seq.release(); g->d_bseq.release(); g->d_tracked.release(); g->d_cons.release(); g->d_roff.release(); g->d_tmp.release();
     g->d_hit_end.release(); g->d_hit_per.release(); g->d_hit_n.release(); g->d_score.release(); g->d_from.release(); g->d_cells.release();
     g->d_cnt.release(); g->d_read_ch_base.release(); g->d_read_ch_n.release(); g->d_gsort.release(); g->d_gsort_off.release(); g->d_rec.release();
-    g->d_par.release(); g->d_par_n.release(); g->d_par_dst.release(); g->d_parc.release(); g->d_bnd.release(); g->d_scratch.release();
+    g->d_par.release(); g->d_par_off.release(); g->d_par_n.release(); g->d_par_dst.release(); g->d_parc.release(); g->d_bnd.release(); g->d_scratch.release();
     g->d_cov.release(); g->d_cons_len.release(); g->d_status.release(); g->d_iden.release(); g->d_ext.release();
     g->d_tasks.release(); g->d_units.release(); g->d_items.release();
     if (g->h_seq) th_rt_host_free(g->h_seq);
@@ -251,12 +251,14 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         // ---- partition ----
         const long long bnd_part = (((long long)g->max_len + 128) * 6 + 3) & ~3LL;   // 16-byte aligned per-wave segments
         const int wp = std::min(n_rec, g->waves_part);
-        TRY(g->d_par.ensure(2 * padT + 16 * (size_t)rec_cap)); TRY(g->d_par_n.ensure(n_rec)); TRY(g->d_par_dst.ensure(n_rec));
+        const size_t par_cap = 2 * padT + 16 * (size_t)n_rec + 64;
+        if (par_cap >= (1ull << 31)) return th_fail("par_pos arena would exceed 2^31 entries; use a smaller batch");
+        TRY(g->d_par.ensure(par_cap)); TRY(g->d_par_off.ensure(n_rec)); TRY(g->d_par_n.ensure(n_rec)); TRY(g->d_par_dst.ensure(n_rec));
         TRY(g->d_bnd.ensure((size_t)(bnd_part * wp)));
         KT_BEGIN(TK_PART);
         TH_LAUNCH(th_k_partition, wp, TH_PART_BLOCK, g->stream, (const ThChainRec *)g->d_rec.p, n_rec, (const uint32_t *)g->d_roff.p,
                   (const uint8_t *)g->d_bseq.p, (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_cells.p, g->dp,
-                  g->d_par.p, g->d_par_n.p, g->d_bnd.p, bnd_part, g->d_cnt.p + 1);
+                  g->d_par.p, (int)par_cap, g->d_cnt.p + 5, g->d_par_off.p, g->d_par_n.p, g->d_bnd.p, bnd_part, g->d_cnt.p + 1);
         KT_END(TK_PART);
         TRY(th_rt_d2h(g->h_rec.data(), g->d_rec.p, (size_t)n_rec * sizeof(ThChainRec), g->stream));
         TRY(th_rt_d2h(g->h_par_n.data(), g->d_par_n.p, (size_t)n_rec * 4, g->stream));
@@ -268,12 +270,13 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         g->h_parc.resize((size_t)tot);
         TRY(g->d_parc.ensure((size_t)tot + 1));
         TRY(th_rt_h2d(g->d_par_dst.p, g->h_par_dst.data(), (size_t)n_rec * 4, g->stream));
-        TH_LAUNCH(th_k_gather_par, n_rec, 64, g->stream, (const ThChainRec *)g->d_rec.p, n_rec, (const int *)g->d_par.p, (const int *)g->d_par_n.p,
+        TH_LAUNCH(th_k_gather_par, n_rec, 64, g->stream, n_rec, (const int *)g->d_par.p, (const int *)g->d_par_off.p, (const int *)g->d_par_n.p,
                   (const int *)g->d_par_dst.p, g->d_parc.p);
         TRY(th_rt_d2h(g->h_parc.data(), g->d_parc.p, (size_t)tot * 4, g->stream));
         TRY(th_rt_sync(g->stream));
     } else TRY(th_rt_sync(g->stream));
 
+    if (getenv("TH_TRACE")) fprintf(stderr, "[th] stages 1-3 done, %d chains\n", n_rec);
     build_jobs(g);
     const int nt = (int)g->h_tasks.size();
     g->jobs.resize(nt);
@@ -309,14 +312,16 @@ extern "C" int th_gpu_run(th_gpu_t *g)
             }
             int max_unit = 0;
             for (int t : todo) max_unit = std::max(max_unit, g->h_tasks[t].max_len);
+            if (attempt > 0) TRY(th_rt_memset(g->d_cnt.p + 2, 0, 2 * sizeof(int), g->stream));      // job queue head (zeroed with the other counters for the first attempt)
             KT_BEGIN(TK_POA);
             if (max_unit <= TH_POA_QCAP)
                 TH_LAUNCH(th_k_poa<true>, wv, TH_POA_BLOCK, g->stream, dt, (int)todo.size(), (const ThUnit *)g->d_units.p, (const uint32_t *)g->d_roff.p,
-                          (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, dcl, dst);
+                          (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, dcl, dst, g->d_cnt.p + 2);
             else
                 TH_LAUNCH(th_k_poa<false>, wv, TH_POA_BLOCK, g->stream, dt, (int)todo.size(), (const ThUnit *)g->d_units.p, (const uint32_t *)g->d_roff.p,
-                          (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, dcl, dst);
+                          (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, dcl, dst, g->d_cnt.p + 2);
             KT_END(TK_POA);
+            if (getenv("TH_TRACE")) { th_rt_sync(g->stream); fprintf(stderr, "[th] poa done (%d jobs, %d waves)\n", (int)todo.size(), wv); }
             std::vector<int> cl(todo.size()), st(todo.size());
             TRY(th_rt_d2h(cl.data(), dcl, todo.size() * 4, g->stream));
             TRY(th_rt_d2h(st.data(), dst, todo.size() * 4, g->stream));
@@ -356,8 +361,9 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         KT_BEGIN(TK_ALIGN);
         TH_LAUNCH(th_k_align, wa, TH_ALN_BLOCK, g->stream, (const ThAlnItem *)g->d_items.p, ni, (const ThTask *)g->d_tasks.p, (const int *)g->d_parc.p,
                   (const uint32_t *)g->d_roff.p, (const uint8_t *)g->d_bseq.p, (const uint8_t *)g->d_cons.p, (const int *)g->d_cons_len.p,
-                  g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, g->d_cnt.p + 1);
+                  g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, g->d_cnt.p + 1, g->d_cnt.p + 4);   // queue head d_cnt[4] was zeroed with the other counters at the start of the run
         KT_END(TK_ALIGN);
+        if (getenv("TH_TRACE")) { th_rt_sync(g->stream); fprintf(stderr, "[th] align done (%d items)\n", ni); }
         g->h_iden.resize(aln_total); g->h_ext.resize((size_t)nt * 4); g->h_cons.resize((size_t)cons_total); g->h_cov.resize((size_t)cons_total);
         TRY(th_rt_d2h(g->h_iden.data(), g->d_iden.p, (size_t)aln_total * 4, g->stream));
         TRY(th_rt_d2h(g->h_ext.data(), g->d_ext.p, (size_t)nt * 16, g->stream));
