@@ -70,7 +70,7 @@ int main(int argc, char **argv)
     if (p.only_unit && (p.out_fmt == THO_FASTQ_FMT || p.out_fmt == THO_TAB_QUAL_FMT)) { fprintf(stderr, "\n[main] Error: unit sequences can only be ouput in FASTA or TAB format.\n"); return 0; }
     if (optind + 1 > argc) { fprintf(stderr, "\n[main] Error: please specify an input file.\n"); return 0; }
     if (p.only_full_length && (!five || !three)) { fprintf(stderr, "\n[main] Error: 5' and 3' adapter sequence need to be provided.\n"); return 0; }
-    if (p.w > 1) { fprintf(stderr, "[tho_oracle] minimizer seeding (-w > 1) is not restated yet\n"); return 2; }
+    if (p.w < 1 || p.w > 256) { fprintf(stderr, "[tho_oracle] -w must be in 1..256 (the reference's window array has 256 slots)\n"); return 2; }
     tho_para_load_adapters(&p, five, three);
     int n = tho_run_file(argv[optind], &p, out);
     struct rusage ru; getrusage(RUSAGE_SELF, &ru);

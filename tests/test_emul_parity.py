@@ -83,8 +83,33 @@ def test_emul_adapters_full_length(emu):
     th.close()
 
 
-def test_refuses_unimplemented_modes(emu):
-    for kw in (dict(w=5), dict(hpc=1)):
+def test_emul_hpc_kmers(emu):
+    """-H: homopolymer-compressed k-mers (src/tandem_hit.c:46), incl. N resets and long runs"""
+    th = TH.TideHunter(lib_path=emu, hpc=1)
+    seqs = _reads(th.lib, [(80, 7, 0.08), (150, 4, 0.10)], seed=9)
+    seqs += [(b"ACGGGGGTTTACGTNAACCCGTAGGA" * 3 + b"TTTTTTTTTT") * 5, b"AAAACCCCGGGGTTTT" * 30]
+    para = O.default_para(hpc=1)
+    got = th.process(seqs)
+    U.stage_compare(th, seqs, para)
+    U.assert_records_equal(seqs, got, para, "hpc")
+    th.close()
+
+
+def test_emul_minimizer_seeding(emu):
+    """-w > 1: the minimizer replay (src/tandem_hit.c:97-157), with N resets, ties in low-complexity sequence, and -H"""
+    for kw in (dict(w=5), dict(w=3, k=6), dict(w=4, hpc=1), dict(w=10, k=5)):
+        th = TH.TideHunter(lib_path=emu, **kw)
+        seqs = _reads(th.lib, [(80, 7, 0.08), (150, 4, 0.10)], seed=11)
+        seqs += [(b"ACGGGGGTTTACGTNAACCCGTAGGA" * 3 + b"TTTTTTTTTT") * 5, b"ACACACACACAC" * 30, b"ACGT", b"ACGTACGTACGTNNACGTACGTACGTACGT"]
+        para = O.default_para(**kw)
+        got = th.process(seqs)
+        U.stage_compare(th, seqs, para)
+        U.assert_records_equal(seqs, got, para, "minimizer %r" % (kw,))
+        th.close()
+
+
+def test_refuses_out_of_range_window(emu):
+    for kw in (dict(w=0), dict(w=257)):
         with pytest.raises(RuntimeError):
             TH.TideHunter(lib_path=emu, **kw)
 

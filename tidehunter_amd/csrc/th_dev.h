@@ -8,6 +8,8 @@
 // Parameters the kernels read (a device-friendly projection of mini_tandem_para, src/tidehunter.h:47-61)
 struct ThDevPara {
     int k;                       // k-mer length (-k)
+    int w;                       // -w: minimizer window (1 = every k-mer)
+    int hpc;                     // -H: homopolymer-compressed k-mers (src/tandem_hit.c:46)
     uint32_t min_p, max_p;       // period limits, cast as at src/tandem_hit.c:235
     double one_minus_div;        // 1 - max_div (src/partition.c:202,252: the one double product on the path)
     int min_copy;

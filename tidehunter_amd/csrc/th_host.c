@@ -289,11 +289,10 @@ static int edlib_hw(const char *q, int qlen, const char *t, int tlen, int *start
 th_handle_t *th_init(const th_para_t *p, int device)
 {
     g_err[0] = 0;
-    if (p->w > 1) { host_fail("-w > 1 (minimizer seeding, src/tandem_hit.c:97-157) is not implemented by the HIP path yet"); return NULL; }
-    if (p->hpc) { host_fail("-H (homopolymer-compressed k-mers, src/tandem_hit.c:46) is not implemented by the HIP path yet"); return NULL; }
+    if (p->w < 1 || p->w > 256) { host_fail("-w must be in 1..256 (the reference's minimizer window, src/tandem_hit.c:100, has 256 slots)"); return NULL; }
     if (p->k < 2 || p->k > 16) { host_fail("k-mer length must be in [2,16]"); return NULL; }
     th_gpu_para_t gp; memset(&gp, 0, sizeof(gp));
-    gp.k = (int)p->k; gp.min_p = (uint32_t)p->min_p; gp.max_p = (uint32_t)p->max_p; gp.one_minus_div = 1 - p->max_div; gp.min_copy = p->min_copy;
+    gp.k = (int)p->k; gp.w = (int)p->w; gp.hpc = p->hpc ? 1 : 0; gp.min_p = (uint32_t)p->min_p; gp.max_p = (uint32_t)p->max_p; gp.one_minus_div = 1 - p->max_div; gp.min_copy = p->min_copy;
     gp.match = p->match; gp.mismatch = p->mismatch; gp.go1 = p->gap_open1; gp.ge1 = p->gap_ext1; gp.go2 = p->gap_open2; gp.ge2 = p->gap_ext2;
     gp.only_unit = p->only_unit;
     th_gpu_t *g = th_gpu_create(&gp, device);

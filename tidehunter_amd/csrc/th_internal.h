@@ -9,7 +9,7 @@ extern "C" {
 #endif
 
 typedef struct {
-    int k; uint32_t min_p, max_p; double one_minus_div; int min_copy;
+    int k, w, hpc; uint32_t min_p, max_p; double one_minus_div; int min_copy;
     int match, mismatch, go1, ge1, go2, ge2;
     int only_unit;          /* -u: stop after partition (no POA, no alignment) */
 } th_gpu_para_t;

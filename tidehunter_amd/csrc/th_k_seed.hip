@@ -54,26 +54,93 @@ __global__ void th_k_encode(const uint8_t *__restrict__ seq, uint8_t *__restrict
 __global__ void __launch_bounds__(TH_SEED_BLOCK)
 th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, ThDevPara P,
           int *__restrict__ hit_end, int *__restrict__ hit_per, int *__restrict__ hit_n,
-          uint32_t *__restrict__ tmp, unsigned long long *__restrict__ gsort, const long long *__restrict__ gsort_off)
+          uint32_t *__restrict__ tmp, unsigned long long *__restrict__ gsort, const long long *__restrict__ gsort_off,
+          int *__restrict__ err)
 {
     __shared__ unsigned long long lds[TH_SORT_LDS];
     __shared__ int s_cnt[TH_SEED_BLOCK + 1];
+    __shared__ uint32_t s_wkey[256], s_wpos[256]; // -w > 1: the minimizer window (key, pos)
+    __shared__ int s_runs[32];                    // -w > 1 with -H: lengths of the last k runs
     const int tid = threadIdx.x, r = blockIdx.x;
     const uint32_t off = roff[r];
     const int L = (int)(roff[r + 1] - off), k = P.k;
     const uint8_t *b = bseq + off;
     const int ne = L - k + 1;                     // k-mer slots; slot e ends at position e+k-1
-    if (ne < 1) { if (tid == 0) hit_n[r] = 0; return; }
+    if (ne < 1 || L - P.w <= 0) { if (tid == 0) hit_n[r] = 0; return; }
     int N = 1; while (N < ne) N <<= 1;
     unsigned long long *buf = N <= TH_SORT_LDS ? lds : gsort + gsort_off[r];
 
+    if (P.w > 1) {
+        // 1m. minimizer words (src/tandem_hit.c:97-157).  The reference's selection is a sequential state machine
+        // whose first-window and post-N gating does not reduce to "minimum of every window", so lane 0 replays it
+        // exactly over an LDS window; the other lanes pre-fill the sort buffer.  Off by default (-w 1).
+        for (int e = tid; e < N; e += TH_SEED_BLOCK) buf[e] = ~0ull;
+        __syncthreads();
+        if (tid == 0) {
+            const int w = P.w;
+            const uint32_t mask = k >= 16 ? 0xffffffffu : (1u << (2 * k)) - 1u, NONE = 0xffffffffu;
+            uint32_t key = 0, sel_key = NONE, sel_pos = NONE;
+            int r_head = 0, r_cnt = 0, span = 0, count = 0, at = 0, sel_at = 0, n = 0;
+            auto put = [&](uint32_t kk, uint32_t pp) { if (n < N) buf[n] = (unsigned long long)kk << 32 | pp; ++n; };
+            auto sweep = [&](int lo, int hi) {
+                for (int j = lo; j < hi; ++j) { const uint32_t sk = s_wkey[j], sp = s_wpos[j]; if (sk == sel_key && sp != sel_pos) put(sk, sp); }
+            };
+            for (int i = 0; i < L; ++i) {
+                const int c = b[i];
+                uint32_t ck = NONE, cp = NONE;
+                if (c < 4) {
+                    if (P.hpc) {
+                        int run = 1;
+                        while (i + run < L && b[i + run] == c) ++run;
+                        i += run - 1;
+                        s_runs[(r_head + r_cnt++) & 31] = run; span += run;
+                        if (r_cnt > k) { span -= s_runs[r_head]; r_head = (r_head + 1) & 31; --r_cnt; }
+                    } else span = count + 1 < k ? count + 1 : k;
+                    key = (key << 2 | (uint32_t)c) & mask;
+                    ++count;
+                    if (count >= k && span < 256) { ck = key; cp = (uint32_t)i; }
+                } else { count = 0; r_head = r_cnt = 0; span = 0; key = 0; }
+                s_wkey[at] = ck; s_wpos[at] = cp;
+                if (count == w + k - 1 && sel_key != NONE) { sweep(at + 1, w); sweep(0, at); }
+                if (ck <= sel_key) {
+                    if (count >= w + k && sel_key != NONE) put(sel_key, sel_pos);
+                    sel_key = ck; sel_pos = cp; sel_at = at;
+                } else if (at == sel_at) {
+                    const bool open = count >= w + k - 1;
+                    if (open && sel_key != NONE) put(sel_key, sel_pos);
+                    sel_key = NONE;
+                    for (int j = at + 1; j < w; ++j) { const uint32_t sk = s_wkey[j]; if (sel_key >= sk) { sel_key = sk; sel_pos = s_wpos[j]; sel_at = j; } }
+                    for (int j = 0; j <= at; ++j) { const uint32_t sk = s_wkey[j]; if (sel_key >= sk) { sel_key = sk; sel_pos = s_wpos[j]; sel_at = j; } }
+                    if (open && sel_key != NONE) { sweep(at + 1, w); sweep(0, at + 1); }
+                }
+                if (++at == w) at = 0;
+            }
+            if (sel_key != NONE) put(sel_key, sel_pos);
+            if (n > N) atomicOr(err, 8);
+        }
+    } else
     // 1. words: key<<32 | pos of the k-mer's LAST base; any code >= 4 in the window kills the word
     for (int e = tid; e < N; e += TH_SEED_BLOCK) {
         unsigned long long v = ~0ull;
-        if (e < ne) {
+        if (e < ne && !P.hpc) {
             uint32_t key = 0; bool ok = true;
             for (int x = 0; x < k; ++x) { uint8_t c = b[e + x]; ok = ok && c < 4; key = key << 2 | (c & 3); }
             if (ok) v = (unsigned long long)key << 32 | (uint32_t)(e + k - 1);
+        } else if (e < ne) {
+            // -H (src/tandem_hit.c:46): a homopolymer run counts as one symbol and the word sits on the run's last
+            // base; it exists if the k most recent runs are all A/C/G/T (any other code resets the count)
+            const int p = e + k - 1;
+            const uint8_t c0 = b[p];
+            bool ok = c0 < 4 && (p == L - 1 || b[p + 1] != c0);
+            uint32_t key = 0; int x = p;
+            for (int rn = 0; rn < k && ok; ++rn) {
+                if (x < 0) { ok = false; break; }
+                const uint8_t cc = b[x];
+                if (cc >= 4) { ok = false; break; }
+                key |= (uint32_t)cc << (2 * rn);
+                while (x >= 0 && b[x] == cc) --x;
+            }
+            if (ok) v = (unsigned long long)key << 32 | (uint32_t)p;
         }
         buf[e] = v;
     }
@@ -97,6 +164,9 @@ th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, T
         unsigned long long v = buf[x];
         if (v == ~0ull) continue;
         uint32_t key = (uint32_t)(v >> 32), pos = (uint32_t)v, per = 0;
+        // one word per position is what makes step 4 a compaction; the minimizer replay never repeats a word in
+        // practice (tests/test_oracle_golden.py sweeps for it), but fail loudly rather than drop a hit if it does
+        if (x > 0 && buf[x - 1] == v) atomicOr(err, 8);
         for (int y = x - 1; y >= 0; --y) {
             unsigned long long w = buf[y];
             if ((uint32_t)(w >> 32) != key) break;

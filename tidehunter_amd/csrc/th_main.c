@@ -38,7 +38,6 @@ static int usage(void)
     fprintf(stderr, "Version: %s\n\nUsage:   TideHunter-amd [options] in.fa/fq > cons.fa\n\n", th_version());
     fprintf(stderr, "Options: as TideHunter 1.5.5 (-k -w -H -c -e -p -P -M -X -O -E -5 -3 -a -o -m -r -u -l -F -s -f -t -h -v)\n");
     fprintf(stderr, "         -g --gpu INT    HIP device ordinal [0];  -b --batch INT   reads per device batch [16384]\n");
-    fprintf(stderr, "         (-w > 1 and -H are not implemented by the HIP path yet and are refused)\n\n");
     return 1;
 }
 

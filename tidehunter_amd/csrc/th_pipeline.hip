@@ -65,7 +65,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
 {
     th_gpu *g = new th_gpu();
     g->para = *p;
-    g->dp.k = p->k; g->dp.min_p = p->min_p; g->dp.max_p = p->max_p; g->dp.one_minus_div = p->one_minus_div; g->dp.min_copy = p->min_copy;
+    g->dp.k = p->k; g->dp.w = p->w; g->dp.hpc = p->hpc; g->dp.min_p = p->min_p; g->dp.max_p = p->max_p; g->dp.one_minus_div = p->one_minus_div; g->dp.min_copy = p->min_copy;
     g->dp.match = p->match; g->dp.mismatch = p->mismatch; g->dp.go1 = p->go1; g->dp.ge1 = p->ge1; g->dp.go2 = p->go2; g->dp.ge2 = p->ge2;
     g->device = device;
 #ifdef TH_CPU_EMUL
@@ -223,7 +223,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
     KT_BEGIN(TK_SEED);
     TH_LAUNCH(th_k_encode, enc_blocks, 256, g->stream, (const uint8_t *)g->d_seq.p, g->d_bseq.p, (long long)T);
     TH_LAUNCH(th_k_hits, n, TH_SEED_BLOCK, g->stream, (const uint8_t *)g->d_bseq.p, (const uint32_t *)g->d_roff.p, g->dp,
-              g->d_hit_end.p, g->d_hit_per.p, g->d_hit_n.p, g->d_tmp.p, g->d_gsort.p, (const long long *)g->d_gsort_off.p);
+              g->d_hit_end.p, g->d_hit_per.p, g->d_hit_n.p, g->d_tmp.p, g->d_gsort.p, (const long long *)g->d_gsort_off.p, g->d_cnt.p + 1);
     KT_END(TK_SEED); KT_BEGIN(TK_CHAIN_DP);
     TH_LAUNCH(th_k_chain_dp, (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
               (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p);
@@ -241,6 +241,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
     int cnt[8];
     TRY(th_rt_d2h(cnt, g->d_cnt.p, sizeof(cnt), g->stream));
     TRY(th_rt_sync(g->stream));
+    if (cnt[1] & 8) return th_fail("minimizer selection repeated a word or overflowed its buffer");
     if (cnt[1]) return th_fail("chain record arena overflow");
     const int n_rec = cnt[0]; g->n_rec = n_rec;
     g->h_read_ch_base.resize(n); g->h_read_ch_n.resize(n);
