@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("TH_BENCH_BATCH", "16384")), help="reads per step per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("TH_BENCH_BATCH", "65536")), help="reads per step per GPU")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1: auto, 0: skip)")
     a = ap.parse_args()
 
@@ -126,8 +126,20 @@ def main():
         launch_s = kms[dom] / 1000.0 / a.steps             # one launch of it per step
         per_launch_bytes = alg_bytes / float(a.steps)
         ach = per_launch_bytes / launch_s / 1e9 if launch_s > 0 else 0.0
+        # traffic: HBM bytes of one launch of the dominant kernel from the PMC passes of this same command
+        # (tests/prof_round.sh -> profiles/r01_hbm_traffic.json); counters cannot be read from inside the process, so
+        # the committed profile is quoted when it was taken at the same batch size, else null
+        traffic, traffic_src = None, None
+        try:
+            prof = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")))
+            if prof.get("reads_per_launch") == B:
+                for kname, v in prof["kernels"].items():
+                    if kname.replace("void ", "").split("<")[0] == dom:
+                        traffic, traffic_src = v["hbm_bytes_per_launch_corrected"], "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+        except (OSError, ValueError, KeyError):
+            pass
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": None, "launch_ms": launch_s * 1000.0,
+                           "traffic": traffic, "traffic_source": traffic_src, "launch_ms": launch_s * 1000.0,
                            "kernel_ms_per_step": {k: v / a.steps for k, v in kms.items()},
                            "algorithmic_bytes_per_launch": per_launch_bytes}
         if world == 1 and a.cpu_sample != 0:

@@ -18,6 +18,7 @@
 #include <limits.h>
 #include <ctype.h>
 #include <zlib.h>
+#include <pthread.h>
 #include "tidehunter_amd.h"
 #include "th_internal.h"
 
@@ -522,30 +523,88 @@ void th_output(FILE *fp, int n, const char *const *names, const char *const *seq
 }
 
 /* ---------------------------------------------------------------- whole-file driver, src/main.c:375-436 */
+/* th_run_file = mini_tandem() (src/main.c:377-447).  The reference alternates "read a chunk / fan out / print"; here the
+ * three run as a pipeline over three batch slots so that parsing batch i+1 and formatting batch i-1 overlap the device
+ * work on batch i.  Output order = input order (src/main.c:217). */
+enum { SLOT_EMPTY = 0, SLOT_FILLED = 1, SLOT_DONE = 2 };
+typedef struct { char **names, **seqs; int *lens; int n, state; th_tandem_seq_t *ts; } th_slot_t;
+typedef struct {
+    th_slot_t slot[3];
+    pthread_mutex_t mu; pthread_cond_t cv;
+    th_reader_t *rd; FILE *out; const th_para_t *p; int batch_reads; volatile int stop;
+} th_pipe_t;
+
+static void slot_wait(th_pipe_t *q, th_slot_t *s, int state)
+{
+    pthread_mutex_lock(&q->mu);
+    while (s->state != state) pthread_cond_wait(&q->cv, &q->mu);
+    pthread_mutex_unlock(&q->mu);
+}
+static void slot_set(th_pipe_t *q, th_slot_t *s, int state)
+{
+    pthread_mutex_lock(&q->mu); s->state = state; pthread_cond_broadcast(&q->cv); pthread_mutex_unlock(&q->mu);
+}
+static void *pipe_reader(void *arg)
+{
+    th_pipe_t *q = (th_pipe_t *)arg;
+    const long long max_bases = 1LL << 30;
+    for (int i = 0;; ++i) {
+        th_slot_t *s = &q->slot[i % 3];
+        slot_wait(q, s, SLOT_EMPTY);
+        int n = 0; long long bases = 0;
+        if (!q->stop)
+            while (n < q->batch_reads && bases < max_bases && rd_next(q->rd, &s->names[n], &s->seqs[n], &s->lens[n])) { bases += s->lens[n]; ++n; }
+        s->n = n;
+        slot_set(q, s, SLOT_FILLED);
+        if (n == 0) return NULL;
+    }
+}
+static void *pipe_writer(void *arg)
+{
+    th_pipe_t *q = (th_pipe_t *)arg;
+    for (int i = 0;; ++i) {
+        th_slot_t *s = &q->slot[i % 3];
+        slot_wait(q, s, SLOT_DONE);
+        const int n = s->n;
+        if (n > 0 && q->out && !q->stop) th_output(q->out, n, (const char *const *)s->names, (const char *const *)s->seqs, s->lens, s->ts, q->p);
+        for (int k = 0; k < n; ++k) { free(s->names[k]); free(s->seqs[k]); }
+        slot_set(q, s, SLOT_EMPTY);
+        if (n == 0) return NULL;
+    }
+}
+
 int th_run_file(const char *read_fn, th_para_t *p, FILE *out, int device, int batch_reads)
 {
-    if (batch_reads <= 0) batch_reads = 16384;
+    if (batch_reads <= 0) batch_reads = 65536;
     if (p->five_fn && p->three_fn && !p->five_seq) if (th_load_adapters(p)) return -1;
     th_reader_t *r = rd_open(read_fn);
     if (!r) { char m[300]; snprintf(m, sizeof(m), "fail to open file '%s'", read_fn); return host_fail(m); }
     th_handle_t *h = th_init(p, device);
     if (!h) { rd_close(r); return -1; }
-    char **names = (char **)calloc(batch_reads, sizeof(char *)), **seqs = (char **)calloc(batch_reads, sizeof(char *));
-    int *lens = (int *)calloc(batch_reads, sizeof(int));
-    th_tandem_seq_t *ts = th_alloc_tandem_seq(batch_reads);
-    int total = 0, rc = 0;
-    const long long max_bases = 512LL << 20;
-    for (;;) {
-        int n = 0; long long bases = 0;
-        while (n < batch_reads && bases < max_bases && rd_next(r, &names[n], &seqs[n], &lens[n])) { bases += lens[n]; ++n; }
-        if (n == 0) break;
-        rc = th_process_batch(h, (const char *const *)seqs, lens, n, ts);
-        if (rc == 0 && out) th_output(out, n, (const char *const *)names, (const char *const *)seqs, lens, ts, p);
-        for (int i = 0; i < n; ++i) { free(names[i]); free(seqs[i]); }
-        if (rc) break;
-        total += n;
+    th_pipe_t q; memset(&q, 0, sizeof(q));
+    pthread_mutex_init(&q.mu, NULL); pthread_cond_init(&q.cv, NULL);
+    q.rd = r; q.out = out; q.p = p; q.batch_reads = batch_reads;
+    for (int i = 0; i < 3; ++i) {
+        q.slot[i].names = (char **)calloc(batch_reads, sizeof(char *)); q.slot[i].seqs = (char **)calloc(batch_reads, sizeof(char *));
+        q.slot[i].lens = (int *)calloc(batch_reads, sizeof(int)); q.slot[i].ts = th_alloc_tandem_seq(batch_reads);
     }
-    th_free_tandem_seq(ts, batch_reads); free(names); free(seqs); free(lens);
+    pthread_t t_rd, t_wr;
+    pthread_create(&t_rd, NULL, pipe_reader, &q); pthread_create(&t_wr, NULL, pipe_writer, &q);
+    int total = 0, rc = 0;
+    for (int i = 0;; ++i) {
+        th_slot_t *s = &q.slot[i % 3];
+        slot_wait(&q, s, SLOT_FILLED);
+        if (s->n > 0 && !rc) {
+            rc = th_process_batch(h, (const char *const *)s->seqs, s->lens, s->n, s->ts);
+            if (rc) q.stop = 1; else total += s->n;   /* never partial output: the failed batch and everything after it are dropped */
+        }
+        const int last = s->n == 0;
+        slot_set(&q, s, SLOT_DONE);
+        if (last) break;
+    }
+    pthread_join(t_rd, NULL); pthread_join(t_wr, NULL);
+    for (int i = 0; i < 3; ++i) { th_free_tandem_seq(q.slot[i].ts, batch_reads); free(q.slot[i].names); free(q.slot[i].seqs); free(q.slot[i].lens); }
+    pthread_mutex_destroy(&q.mu); pthread_cond_destroy(&q.cv);
     th_destroy(h); rd_close(r);
     return rc ? -1 : total;
 }

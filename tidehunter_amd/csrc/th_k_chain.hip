@@ -28,6 +28,10 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
               const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ hit_n,
               int *__restrict__ score, int *__restrict__ from)
 {
+    // Measured alternatives (batch 16384, config 3; this version 43 ms): a per-wave LDS ring of the last 1024 hits
+    // removes the window re-reads from HBM but its 48 KiB per workgroup cuts residency to 3 waves per SIMD (62 ms);
+    // a 512-hit ring 46 ms; scoring 2 or 4 chunks ahead of the resolution 49 / 85 ms.  The kernel is bound by VALU
+    // issue (about 90 instructions per 64 predecessors), not by the loads.
     const int lane = TH_LANE();
     const int r = blockIdx.x * (TH_CHAIN_BLOCK / TH_WAVE) + (threadIdx.x >> 6);
     const bool live = r < n_reads;
@@ -50,11 +54,14 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             const int ps = pe - pp;
             const bool dstop = !valid || pe < cs;                  // :331  predecessor ends before cur starts
             int type = TH_NO_CON, con = 0;
-            if (!dstop && !(cs <= ps || (double)cp >= pp * 1.8 || (double)pp >= cp * 1.8)) {   // :154
+            // :154 compares cp >= pp * 1.8 in double.  fl(1.8) exceeds 1.8 by a relative 2.5e-17, less than half an ulp,
+            // so pp * fl(1.8) rounds to exactly 1.8 pp whenever that is an integer and stays > 0.19 away from every
+            // integer otherwise: the comparison equals 5 cp >= 9 pp for all periods below 2^28 (th_gpu_upload checks).
+            if (!dstop && !(cs <= ps || 5u * (uint32_t)cp >= 9u * (uint32_t)pp || 5u * (uint32_t)pp >= 9u * (uint32_t)cp)) {
                 const int dis1 = abs(ce - pe), dis2 = abs(cs - ps);
                 const int matched = min(dis1, k) + min(dis2, k);
                 const int dp = abs(cp - pp);
-                const int gap = dp * dp / 2 + (31 - __clz(dis1 + dis2)) / 2;                   // :128-142
+                const int gap = (int)((uint32_t)(dp * dp) >> 1) + (max(31 - __clz(dis1 + dis2), 0) >> 1);   // :128-142
                 con = matched - gap;
                 type = dp == 0 ? (matched < 2 * k ? TH_OVL_CON : TH_SAME_CON) : TH_REG_CON;
             }
@@ -62,14 +69,16 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             const int rb = th_wave_excl_max(s, best);              // best as seen just before this lane
             const bool imp = type != TH_NO_CON && s > rb;
             const unsigned long long impm = __ballot(imp);
-            const unsigned long long A = __ballot(imp && (type == TH_SAME_CON || type == TH_OVL_CON));   // :342
-            const unsigned long long B = __ballot(!imp && type == TH_OVL_CON);                          // :344-346
-            const unsigned long long D = __ballot(dstop);
-            const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1);
-            const unsigned long long below = impm & upto;
-            const int iter_after = below ? lane - th_msb64(below) : iter + lane + 1;
-            const unsigned long long C = __ballot(!imp && !dstop && iter_after >= max_h);                // :349
-            const unsigned long long stopm = A | B | C | D;
+            // stop rules in scan order: :331 (dstop); :342 improving SAME/OVL and :344-346 non-improving OVL, so OVL
+            // always stops; :349 max_h consecutive non-improving predecessors (only evaluated when reachable)
+            bool stop = dstop || type == TH_OVL_CON || (imp && type == TH_SAME_CON);
+            if (iter + TH_WAVE >= max_h) {
+                const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1);
+                const unsigned long long below = impm & upto;
+                const int iter_after = below ? lane - th_msb64(below) : iter + lane + 1;
+                stop = stop || (!imp && iter_after >= max_h);
+            }
+            const unsigned long long stopm = __ballot(stop);
             const int f = th_ctz64(stopm);
             const unsigned long long lim = f >= 63 ? ~0ull : ((2ull << f) - 1);
             const unsigned long long taken = impm & lim;

@@ -37,7 +37,7 @@ static int usage(void)
     fprintf(stderr, "\nTideHunter-amd: Tandem repeats detection and consensus calling from noisy long reads (MI355X/HIP hot path)\n\n");
     fprintf(stderr, "Version: %s\n\nUsage:   TideHunter-amd [options] in.fa/fq > cons.fa\n\n", th_version());
     fprintf(stderr, "Options: as TideHunter 1.5.5 (-k -w -H -c -e -p -P -M -X -O -E -5 -3 -a -o -m -r -u -l -F -s -f -t -h -v)\n");
-    fprintf(stderr, "         -g --gpu INT    HIP device ordinal [0];  -b --batch INT   reads per device batch [16384]\n");
+    fprintf(stderr, "         -g --gpu INT    HIP device ordinal [0];  -b --batch INT   reads per device batch [65536]\n");
     return 1;
 }
 

@@ -107,6 +107,7 @@ extern "C" int th_gpu_upload(th_gpu_t *g, const char *const *seqs, const int *le
     long long T = 0; int mx = 0;
     for (int i = 0; i < n; ++i) { g->h_roff[i] = (uint32_t)T; T += lens[i]; mx = std::max(mx, lens[i]); }
     if (T >= (1LL << 31)) return th_fail("batch holds 2^31 bases or more; split it");
+    if (mx >= (1 << 28)) return th_fail("a read of 2^28 bases or more is not supported (32-bit period arithmetic in th_k_chain_dp)");
     g->h_roff[n] = (uint32_t)T; g->T = T; g->max_len = mx;
     size_t padT = (size_t)((T + 15) & ~15LL);
     if (padT + 16 > g->h_seq_cap) {
