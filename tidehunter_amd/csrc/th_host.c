@@ -19,6 +19,7 @@
 #include <ctype.h>
 #include <zlib.h>
 #include <pthread.h>
+#include <time.h>
 #include "tidehunter_amd.h"
 #include "th_internal.h"
 
@@ -68,6 +69,28 @@ static int rd_getc(th_reader_t *r)
     }
     return r->buf[r->beg++];
 }
+/* appends the rest of the current line to s (s may be NULL), consumes the '\n'; returns the byte count, -1 at end of file */
+static long rd_line(th_reader_t *r, th_str_t *s)
+{
+    long got = 0;
+    for (;;) {
+        if (r->beg >= r->end) {
+            if (r->eof) return got ? got : -1;
+            r->beg = 0; r->end = gzread(r->fp, r->buf, 1 << 18);
+            if (r->end <= 0) { r->eof = 1; r->end = 0; return got ? got : -1; }
+        }
+        const unsigned char *p = r->buf + r->beg;
+        const int avail = r->end - r->beg;
+        const unsigned char *nl = (const unsigned char *)memchr(p, '\n', (size_t)avail);
+        const int n = nl ? (int)(nl - p) : avail;
+        if (s && n) {
+            if (s->l + (size_t)n + 2 > s->m) { while (s->l + (size_t)n + 2 > s->m) s->m = s->m ? s->m * 2 : 256; s->s = (char *)realloc(s->s, s->m); }
+            memcpy(s->s + s->l, p, (size_t)n); s->l += (size_t)n; s->s[s->l] = 0;
+        }
+        got += n; r->beg += n + (nl ? 1 : 0);
+        if (nl) return got;
+    }
+}
 static th_reader_t *rd_open(const char *fn)
 {
     gzFile fp = strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(0, "r");
@@ -93,15 +116,14 @@ static int rd_next(th_reader_t *r, char **name, char **seq, int *len)
     while ((c = rd_getc(r)) != -1 && c != '>' && c != '+' && c != '@') {
         if (c == '\n') continue;
         str_putc(&sq, c);
-        int d;
-        while ((d = rd_getc(r)) != -1 && d != '\n') str_putc(&sq, d);
+        rd_line(r, &sq);
         if (sq.l > 1 && sq.s[sq.l - 1] == '\r') sq.s[--sq.l] = 0;
     }
     r->last = (c == '>' || c == '@') ? c : 0;
     if (c == '+') {
         while ((c = rd_getc(r)) != -1 && c != '\n') {}
-        size_t ql = 0;
-        while (ql < sq.l && (c = rd_getc(r)) != -1) if (c != '\n') ++ql;
+        size_t ql = 0; long n;
+        while (ql < sq.l && (n = rd_line(r, NULL)) >= 0) ql += (size_t)n;   /* quality lines until as long as the sequence */
         r->last = 0;
     }
     *name = nm.s; *seq = sq.s; *len = (int)sq.l;
@@ -532,7 +554,10 @@ typedef struct {
     th_slot_t slot[3];
     pthread_mutex_t mu; pthread_cond_t cv;
     th_reader_t *rd; FILE *out; const th_para_t *p; int batch_reads; volatile int stop;
+    double t_read, t_write;      /* busy seconds of the two side threads (TH_TRACE=1 prints them) */
 } th_pipe_t;
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 static void slot_wait(th_pipe_t *q, th_slot_t *s, int state)
 {
@@ -552,8 +577,10 @@ static void *pipe_reader(void *arg)
         th_slot_t *s = &q->slot[i % 3];
         slot_wait(q, s, SLOT_EMPTY);
         int n = 0; long long bases = 0;
+        const double t0 = now_s();
         if (!q->stop)
             while (n < q->batch_reads && bases < max_bases && rd_next(q->rd, &s->names[n], &s->seqs[n], &s->lens[n])) { bases += s->lens[n]; ++n; }
+        q->t_read += now_s() - t0;
         s->n = n;
         slot_set(q, s, SLOT_FILLED);
         if (n == 0) return NULL;
@@ -566,8 +593,10 @@ static void *pipe_writer(void *arg)
         th_slot_t *s = &q->slot[i % 3];
         slot_wait(q, s, SLOT_DONE);
         const int n = s->n;
+        const double t0 = now_s();
         if (n > 0 && q->out && !q->stop) th_output(q->out, n, (const char *const *)s->names, (const char *const *)s->seqs, s->lens, s->ts, q->p);
         for (int k = 0; k < n; ++k) { free(s->names[k]); free(s->seqs[k]); }
+        q->t_write += now_s() - t0;
         slot_set(q, s, SLOT_EMPTY);
         if (n == 0) return NULL;
     }
@@ -591,11 +620,14 @@ int th_run_file(const char *read_fn, th_para_t *p, FILE *out, int device, int ba
     pthread_t t_rd, t_wr;
     pthread_create(&t_rd, NULL, pipe_reader, &q); pthread_create(&t_wr, NULL, pipe_writer, &q);
     int total = 0, rc = 0;
+    double t_dev = 0; const double t_start = now_s();
     for (int i = 0;; ++i) {
         th_slot_t *s = &q.slot[i % 3];
         slot_wait(&q, s, SLOT_FILLED);
         if (s->n > 0 && !rc) {
+            const double t0 = now_s();
             rc = th_process_batch(h, (const char *const *)s->seqs, s->lens, s->n, s->ts);
+            t_dev += now_s() - t0;
             if (rc) q.stop = 1; else total += s->n;   /* never partial output: the failed batch and everything after it are dropped */
         }
         const int last = s->n == 0;
@@ -603,6 +635,9 @@ int th_run_file(const char *read_fn, th_para_t *p, FILE *out, int device, int ba
         if (last) break;
     }
     pthread_join(t_rd, NULL); pthread_join(t_wr, NULL);
+    if (getenv("TH_TRACE"))
+        fprintf(stderr, "[th_run_file] %d reads: wall %.3f s; busy: reader %.3f s, device batches %.3f s, writer %.3f s\n",
+                total, now_s() - t_start, q.t_read, t_dev, q.t_write);
     for (int i = 0; i < 3; ++i) { th_free_tandem_seq(q.slot[i].ts, batch_reads); free(q.slot[i].names); free(q.slot[i].seqs); free(q.slot[i].lens); }
     pthread_mutex_destroy(&q.mu); pthread_cond_destroy(&q.cv);
     th_destroy(h); rd_close(r);

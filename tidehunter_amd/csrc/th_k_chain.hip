@@ -224,18 +224,55 @@ th_k_chain_extract(const uint32_t *__restrict__ roff, ThDevPara P,
 //     sort_chain that follows is a no-op on an unchanged list), the first surviving lane is attempted;
 //   * backtracking follows from[] through an LDS copy, tracked flags are an LDS bitmap.
 // ---------------------------------------------------------------------------------------------
+// Candidate order for the one-wave extraction: (score << 13 | hit index) sorted descending by a whole workgroup
+// (the sort is the only data-parallel part of the extraction); the sorted hit indices and their (start, end)
+// coordinates go to HBM in candidate order so that the extraction wave reads its 64-candidate windows coalesced
+// and keeps only from[] and the tracked bitmap in LDS (4 waves per CU instead of 2).
+#define TH_XS_BLOCK 256
+__global__ void __launch_bounds__(TH_XS_BLOCK)
+th_k_chain_sort(const uint32_t *__restrict__ roff, ThDevPara P,
+                const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ hit_n,
+                const int *__restrict__ score, uint16_t *__restrict__ xorder, int *__restrict__ xstart, int *__restrict__ xend)
+{
+    __shared__ uint32_t s_key[TH_XFAST_MAX];
+    const int tid = threadIdx.x, r = blockIdx.x;
+    const uint32_t off = roff[r];
+    const int n = hit_n[r];
+    if (n > TH_XFAST_MAX || n < 2) return;
+    const int *E = hit_end + off, *Pd = hit_per + off, *S = score + off;
+    int N = 1; while (N < n) N <<= 1;
+    for (int i = tid; i < N; i += TH_XS_BLOCK) s_key[i] = i < n ? ((uint32_t)S[i] << 13 | (uint32_t)i) : 0u;
+    __syncthreads();
+    for (int size = 2; size <= N; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (N >> 1); t += TH_XS_BLOCK) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const uint32_t a = s_key[lo], c = s_key[hi];
+                if ((a < c) == desc) { s_key[lo] = c; s_key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (int x = tid; x < n; x += TH_XS_BLOCK) {
+        const int cand = (int)(s_key[x] & 0x1fff);
+        const int e = E[cand];
+        xorder[off + x] = (uint16_t)cand; xstart[off + x] = e - Pd[cand]; xend[off + x] = e;
+    }
+}
+
 #define TH_XW_BLOCK 64
 __global__ void __launch_bounds__(TH_XW_BLOCK)
 th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
                         const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ hit_n,
                         const int *__restrict__ score, const int *__restrict__ from, int *__restrict__ cells,
+                        const uint16_t *__restrict__ xorder, const int *__restrict__ xstart, const int *__restrict__ xend,
                         ThChainRec *__restrict__ rec, int rec_cap, int *__restrict__ rec_count,
                         int *__restrict__ read_ch_base, int *__restrict__ read_ch_n, int *__restrict__ err)
 {
-    __shared__ uint32_t s_key[TH_XFAST_MAX];
     __shared__ short s_from[TH_XFAST_MAX];
     __shared__ uint32_t s_trk[TH_XFAST_MAX / 32];
-    __shared__ int ch_off[TH_TOPN], ch_len[TH_TOPN], ch_score[TH_TOPN], ch_fs[TH_TOPN], ch_ls[TH_TOPN], ch_le[TH_TOPN];
+    __shared__ int ch_score[TH_TOPN], ch_fs[TH_TOPN], ch_ls[TH_TOPN], ch_le[TH_TOPN];
+    __shared__ unsigned short ch_off[TH_TOPN], ch_len[TH_TOPN];      // offsets / lengths in the read's cell list (<= 8192 hits)
     __shared__ short ch_idx[TH_TOPN];
     const int lane = TH_LANE();
     for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
@@ -245,22 +282,11 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
         if (n < 2) { if (lane == 0) { read_ch_base[r] = 0; read_ch_n[r] = 0; } continue; }     // src/tandem_chain.c:291
         const int *E = hit_end + off, *Pd = hit_per + off, *S = score + off, *F = from + off;
         int *CL = cells + off;
-        int N = 1; while (N < n) N <<= 1;
-        for (int i = lane; i < N; i += TH_WAVE) s_key[i] = i < n ? ((uint32_t)S[i] << 13 | (uint32_t)i) : 0u;
+        const uint16_t *XO = xorder + off; const int *XS = xstart + off, *XE = xend + off;
         for (int i = lane; i < n; i += TH_WAVE) s_from[i] = (short)F[i];
         for (int i = lane; i < (n + 31) / 32; i += TH_WAVE) s_trk[i] = 0;
         for (int i = lane; i < TH_TOPN; i += TH_WAVE) ch_idx[i] = (short)i;
         TH_WAVE_FENCE();
-        for (int size = 2; size <= N; size <<= 1)
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                for (int t = lane; t < (N >> 1); t += TH_WAVE) {
-                    const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
-                    const bool desc = (lo & size) == 0;
-                    const uint32_t a = s_key[lo], c = s_key[hi];
-                    if ((a < c) == desc) { s_key[lo] = c; s_key[hi] = a; }
-                }
-                TH_WAVE_FENCE();
-            }
         int ch_n = 0, top = 0, ci = 0;
         while (ci < n && ch_n < TH_TOPN) {
 #ifdef TH_CPU_EMUL
@@ -269,8 +295,8 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
             // ---- 64 candidates at once: covered by an accepted chain, or already tracked? ----
             const int x = ci + lane;
             const bool valid = x < n;
-            const int cand = valid ? (int)(s_key[x] & 0x1fff) : 0;
-            const int cell_end = valid ? E[cand] : 0, cell_start = valid ? cell_end - Pd[cand] : 0;
+            const int cand = valid ? (int)XO[x] : 0;
+            const int cell_end = valid ? XE[x] : 0, cell_start = valid ? XS[x] : 0;
             bool skip = !valid || ((s_trk[cand >> 5] >> (cand & 31)) & 1);
             bool open = !skip;                       // is_in_chain's scan is still running for this lane
             for (int q = 0; q < ch_n; ++q) {
@@ -341,7 +367,7 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
                 if (ok) {
                     // reverse the cells in place (they were written last-to-first)
                     for (int a = lane; a < len / 2; a += TH_WAVE) { const int b2 = len - 1 - a; const int t0 = CL[top + a], t1 = CL[top + b2]; CL[top + a] = t1; CL[top + b2] = t0; }
-                    if (lane == 0) { ch_off[nw] = top; ch_len[nw] = len; ch_score[nw] = sc; ch_fs[nw] = fs; ch_ls[nw] = ls; ch_le[nw] = le; }
+                    if (lane == 0) { ch_off[nw] = (unsigned short)top; ch_len[nw] = (unsigned short)len; ch_score[nw] = sc; ch_fs[nw] = fs; ch_ls[nw] = ls; ch_le[nw] = le; }
                     top += len; ++ch_n;
                 }
             }

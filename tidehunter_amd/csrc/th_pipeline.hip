@@ -45,6 +45,7 @@ struct th_gpu {
     std::vector<uint32_t> h_roff; std::vector<long long> h_gsort_off; long long gsort_total = 0;
     DBuf<uint8_t> d_seq, d_bseq, d_tracked, d_cons;
     DBuf<uint32_t> d_roff, d_tmp;
+    DBuf<uint16_t> d_xorder; DBuf<int> d_xstart, d_xend;   // candidates in extraction order (th_k_chain_sort)
     DBuf<int> d_hit_end, d_hit_per, d_hit_n, d_score, d_from, d_cells, d_cnt, d_read_ch_base, d_read_ch_n;
     DBuf<unsigned long long> d_gsort; DBuf<long long> d_gsort_off;
     DBuf<ThChainRec> d_rec;
@@ -86,7 +87,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
 extern "C" void th_gpu_destroy(th_gpu_t *g)
 {
     if (!g) return;
-    g->d_seq.release(); g->d_bseq.release(); g->d_tracked.release(); g->d_cons.release(); g->d_roff.release(); g->d_tmp.release();
+    g->d_seq.release(); g->d_bseq.release(); g->d_tracked.release(); g->d_xorder.release(); g->d_xstart.release(); g->d_xend.release(); g->d_cons.release(); g->d_roff.release(); g->d_tmp.release();
     g->d_hit_end.release(); g->d_hit_per.release(); g->d_hit_n.release(); g->d_score.release(); g->d_from.release(); g->d_cells.release();
     g->d_cnt.release(); g->d_read_ch_base.release(); g->d_read_ch_n.release(); g->d_gsort.release(); g->d_gsort_off.release(); g->d_rec.release();
     g->d_par.release(); g->d_par_off.release(); g->d_par_n.release(); g->d_par_dst.release(); g->d_parc.release(); g->d_bnd.release(); g->d_scratch.release();
@@ -217,6 +218,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
     const int rec_cap = n * 8 + 4096;
     TRY(g->d_tmp.ensure(padT)); TRY(g->d_hit_end.ensure(padT)); TRY(g->d_hit_per.ensure(padT)); TRY(g->d_hit_n.ensure(n));
     TRY(g->d_score.ensure(padT)); TRY(g->d_from.ensure(padT)); TRY(g->d_cells.ensure(padT)); TRY(g->d_tracked.ensure(padT));
+    TRY(g->d_xorder.ensure(padT)); TRY(g->d_xstart.ensure(padT)); TRY(g->d_xend.ensure(padT));
     TRY(g->d_cnt.ensure(8)); TRY(g->d_read_ch_base.ensure(n)); TRY(g->d_read_ch_n.ensure(n)); TRY(g->d_rec.ensure(rec_cap));
     TRY(th_rt_memset(g->d_cnt.p, 0, 8 * sizeof(int), g->stream));
 
@@ -234,9 +236,13 @@ extern "C" int th_gpu_run(th_gpu_t *g)
               (const int *)g->d_score.p, (const int *)g->d_from.p, g->d_tracked.p, g->d_cells.p,
               g->d_gsort.p, (const long long *)g->d_gsort_off.p, g->d_rec.p, rec_cap, g->d_cnt.p,
               g->d_read_ch_base.p, g->d_read_ch_n.p, g->d_cnt.p + 1);
+    TH_LAUNCH(th_k_chain_sort, n, TH_XS_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, g->dp,
+              (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, (const int *)g->d_score.p,
+              g->d_xorder.p, g->d_xstart.p, g->d_xend.p);
     TH_LAUNCH(th_k_chain_extract_wave, std::min(n, g->waves_xw), TH_XW_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
               (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p,
-              (const int *)g->d_score.p, (const int *)g->d_from.p, g->d_cells.p, g->d_rec.p, rec_cap, g->d_cnt.p,
+              (const int *)g->d_score.p, (const int *)g->d_from.p, g->d_cells.p,
+              (const uint16_t *)g->d_xorder.p, (const int *)g->d_xstart.p, (const int *)g->d_xend.p, g->d_rec.p, rec_cap, g->d_cnt.p,
               g->d_read_ch_base.p, g->d_read_ch_n.p, g->d_cnt.p + 1);
     KT_END(TK_CHAIN_X);
     int cnt[8];
