@@ -97,7 +97,7 @@ def test_emul_hpc_kmers(emu):
 
 def test_emul_minimizer_seeding(emu):
     """-w > 1: the minimizer replay (src/tandem_hit.c:97-157), with N resets, ties in low-complexity sequence, and -H"""
-    for kw in (dict(w=5), dict(w=3, k=6), dict(w=4, hpc=1), dict(w=10, k=5)):
+    for kw in (dict(w=5), dict(w=3, k=6), dict(w=4, hpc=1), dict(w=10, k=5), dict(w=3, k=11), dict(k=10)):   # k > 9: 64-bit sort words
         th = TH.TideHunter(lib_path=emu, **kw)
         seqs = _reads(th.lib, [(80, 7, 0.08), (150, 4, 0.10)], seed=11)
         seqs += [(b"ACGGGGGTTTACGTNAACCCGTAGGA" * 3 + b"TTTTTTTTTT") * 5, b"ACACACACACAC" * 30, b"ACGT", b"ACGTACGTACGTNNACGTACGTACGTACGT"]

@@ -51,13 +51,18 @@ __global__ void th_k_encode(const uint8_t *__restrict__ seq, uint8_t *__restrict
 }
 
 // hit_end/hit_per: per-read segments at roff[r]; tmp: per-position scratch (period or 0)
+// W = unsigned long long: words key<<32 | pos (any k <= 16, any read length; LDS up to 16384 k-mers, else HBM scratch).
+// W = uint32_t:           words key<<14 | pos when k <= 9 and every read of the batch has at most 16384 bases: half the
+//                         LDS footprint (two workgroups per CU) and half the LDS traffic of the sort.
+template <typename W, int PB>
 __global__ void __launch_bounds__(TH_SEED_BLOCK)
 th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, ThDevPara P,
           int *__restrict__ hit_end, int *__restrict__ hit_per, int *__restrict__ hit_n,
-          uint32_t *__restrict__ tmp, unsigned long long *__restrict__ gsort, const long long *__restrict__ gsort_off,
+          uint32_t *__restrict__ tmp, W *__restrict__ gsort, const long long *__restrict__ gsort_off,
           int *__restrict__ err)
 {
-    __shared__ unsigned long long lds[TH_SORT_LDS];
+    __shared__ W lds[TH_SORT_LDS];
+    const W NONE_W = (W)~(W)0;
     __shared__ int s_cnt[TH_SEED_BLOCK + 1];
     __shared__ uint32_t s_wkey[256], s_wpos[256]; // -w > 1: the minimizer window (key, pos)
     __shared__ int s_runs[32];                    // -w > 1 with -H: lengths of the last k runs
@@ -68,20 +73,20 @@ th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, T
     const int ne = L - k + 1;                     // k-mer slots; slot e ends at position e+k-1
     if (ne < 1 || L - P.w <= 0) { if (tid == 0) hit_n[r] = 0; return; }
     int N = 1; while (N < ne) N <<= 1;
-    unsigned long long *buf = N <= TH_SORT_LDS ? lds : gsort + gsort_off[r];
+    W *buf = N <= TH_SORT_LDS ? lds : gsort + gsort_off[r];
 
     if (P.w > 1) {
         // 1m. minimizer words (src/tandem_hit.c:97-157).  The reference's selection is a sequential state machine
         // whose first-window and post-N gating does not reduce to "minimum of every window", so lane 0 replays it
         // exactly over an LDS window; the other lanes pre-fill the sort buffer.  Off by default (-w 1).
-        for (int e = tid; e < N; e += TH_SEED_BLOCK) buf[e] = ~0ull;
+        for (int e = tid; e < N; e += TH_SEED_BLOCK) buf[e] = NONE_W;
         __syncthreads();
         if (tid == 0) {
             const int w = P.w;
             const uint32_t mask = k >= 16 ? 0xffffffffu : (1u << (2 * k)) - 1u, NONE = 0xffffffffu;
             uint32_t key = 0, sel_key = NONE, sel_pos = NONE;
             int r_head = 0, r_cnt = 0, span = 0, count = 0, at = 0, sel_at = 0, n = 0;
-            auto put = [&](uint32_t kk, uint32_t pp) { if (n < N) buf[n] = (unsigned long long)kk << 32 | pp; ++n; };
+            auto put = [&](uint32_t kk, uint32_t pp) { if (n < N) buf[n] = (W)((W)kk << PB | pp); ++n; };
             auto sweep = [&](int lo, int hi) {
                 for (int j = lo; j < hi; ++j) { const uint32_t sk = s_wkey[j], sp = s_wpos[j]; if (sk == sel_key && sp != sel_pos) put(sk, sp); }
             };
@@ -121,11 +126,11 @@ th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, T
     } else
     // 1. words: key<<32 | pos of the k-mer's LAST base; any code >= 4 in the window kills the word
     for (int e = tid; e < N; e += TH_SEED_BLOCK) {
-        unsigned long long v = ~0ull;
+        W v = NONE_W;
         if (e < ne && !P.hpc) {
             uint32_t key = 0; bool ok = true;
             for (int x = 0; x < k; ++x) { uint8_t c = b[e + x]; ok = ok && c < 4; key = key << 2 | (c & 3); }
-            if (ok) v = (unsigned long long)key << 32 | (uint32_t)(e + k - 1);
+            if (ok) v = (W)((W)key << PB | (uint32_t)(e + k - 1));
         } else if (e < ne) {
             // -H (src/tandem_hit.c:46): a homopolymer run counts as one symbol and the word sits on the run's last
             // base; it exists if the k most recent runs are all A/C/G/T (any other code resets the count)
@@ -140,7 +145,7 @@ th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, T
                 key |= (uint32_t)cc << (2 * rn);
                 while (x >= 0 && b[x] == cc) --x;
             }
-            if (ok) v = (unsigned long long)key << 32 | (uint32_t)p;
+            if (ok) v = (W)((W)key << PB | (uint32_t)p);
         }
         buf[e] = v;
     }
@@ -153,7 +158,7 @@ th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, T
             for (int t = tid; t < (N >> 1); t += TH_SEED_BLOCK) {
                 int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
                 bool asc = (lo & size) == 0;
-                unsigned long long a = buf[lo], c = buf[hi];
+                W a = buf[lo], c = buf[hi];
                 if ((a > c) == asc) { buf[lo] = c; buf[hi] = a; }
             }
             __syncthreads();
@@ -161,16 +166,17 @@ th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, T
 
     // 3. nearest earlier occurrence at distance >= min_p (src/tandem_hit.c:192-196)
     for (int x = tid; x < ne; x += TH_SEED_BLOCK) {
-        unsigned long long v = buf[x];
-        if (v == ~0ull) continue;
-        uint32_t key = (uint32_t)(v >> 32), pos = (uint32_t)v, per = 0;
+        const W v = buf[x];
+        if (v == NONE_W) continue;
+        const W PM = ((W)1 << PB) - 1;
+        uint32_t key = (uint32_t)(v >> PB), pos = (uint32_t)(v & PM), per = 0;
         // one word per position is what makes step 4 a compaction; the minimizer replay never repeats a word in
         // practice (tests/test_oracle_golden.py sweeps for it), but fail loudly rather than drop a hit if it does
         if (x > 0 && buf[x - 1] == v) atomicOr(err, 8);
         for (int y = x - 1; y >= 0; --y) {
-            unsigned long long w = buf[y];
-            if ((uint32_t)(w >> 32) != key) break;
-            uint32_t p = pos - (uint32_t)w;
+            const W w = buf[y];
+            if ((uint32_t)(w >> PB) != key) break;
+            uint32_t p = pos - (uint32_t)(w & PM);
             if (p >= P.min_p) { per = p; break; }
         }
         if (per > P.max_p) per = 0;

@@ -81,6 +81,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
     g->waves_part = env_int("TH_WAVES_PART", g->waves_part);
     g->waves_poa = env_int("TH_WAVES_POA", g->waves_poa);
     g->waves_aln = env_int("TH_WAVES_ALN", g->waves_aln);
+    g->waves_xw = env_int("TH_WAVES_XW", g->waves_xw);
     return g;
 }
 
@@ -225,8 +226,12 @@ extern "C" int th_gpu_run(th_gpu_t *g)
     const int enc_blocks = (int)std::min<long long>(2048, (T / 16 + 255) / 256 + 1);
     KT_BEGIN(TK_SEED);
     TH_LAUNCH(th_k_encode, enc_blocks, 256, g->stream, (const uint8_t *)g->d_seq.p, g->d_bseq.p, (long long)T);
-    TH_LAUNCH(th_k_hits, n, TH_SEED_BLOCK, g->stream, (const uint8_t *)g->d_bseq.p, (const uint32_t *)g->d_roff.p, g->dp,
-              g->d_hit_end.p, g->d_hit_per.p, g->d_hit_n.p, g->d_tmp.p, g->d_gsort.p, (const long long *)g->d_gsort_off.p, g->d_cnt.p + 1);
+    if (g->dp.k <= 9 && g->max_len < TH_SORT_LDS)       // every word fits key<<14 | pos and stays below the all-ones sentinel
+        TH_LAUNCH((th_k_hits<uint32_t, 14>), n, TH_SEED_BLOCK, g->stream, (const uint8_t *)g->d_bseq.p, (const uint32_t *)g->d_roff.p, g->dp,
+                  g->d_hit_end.p, g->d_hit_per.p, g->d_hit_n.p, g->d_tmp.p, (uint32_t *)nullptr, (const long long *)g->d_gsort_off.p, g->d_cnt.p + 1);
+    else
+        TH_LAUNCH((th_k_hits<unsigned long long, 32>), n, TH_SEED_BLOCK, g->stream, (const uint8_t *)g->d_bseq.p, (const uint32_t *)g->d_roff.p, g->dp,
+                  g->d_hit_end.p, g->d_hit_per.p, g->d_hit_n.p, g->d_tmp.p, g->d_gsort.p, (const long long *)g->d_gsort_off.p, g->d_cnt.p + 1);
     KT_END(TK_SEED); KT_BEGIN(TK_CHAIN_DP);
     TH_LAUNCH(th_k_chain_dp, (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
               (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p);
