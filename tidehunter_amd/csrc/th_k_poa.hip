@@ -393,6 +393,7 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
     int no = 0, ci = bi, cj = qlen, st = 0;
     int ti = -1000000, tj = 0;              // tile anchor; lane l = 4*k + o holds cell (ti - k, tj - k + o - 1)
     int t_d = 0, t_p0 = -1, t_p1 = -1, t_p2 = -1, t_p3 = -1, t_ok = 0;
+    unsigned long long t_run = 0;           // tile cells that are plain diagonal steps: match state, predecessor = the row above
     while (ci > 0) {
         int k = ti - ci, o = cj - (tj - k) + 1;
         bool hit0 = k >= 0 && k <= 15 && o >= 0 && o <= 3;
@@ -406,9 +407,25 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
                 t_p0 = g.r_p[row * 4]; t_p1 = g.r_p[row * 4 + 1]; t_p2 = g.r_p[row * 4 + 2]; t_p3 = g.r_p[row * 4 + 3];
                 if (col >= rb && col <= re) { t_d = g.dcell[g.r_off[row] + (col - rb)]; t_ok = 1; }
             }
+            {
+                const int want = (int)TH_D_PM((uint32_t)t_d);
+                const int pr = want == 0 ? t_p0 : want == 1 ? t_p1 : want == 2 ? t_p2 : t_p3;
+                t_run = __ballot(t_ok && TH_D_SRC((uint32_t)t_d) == 0 && want < TH_POA_INL && pr == row - 1);
+            }
             k = 0; o = 1;
         }
         const int tl = k * 4 + o;
+        if (st == 0) {
+            // a run of plain diagonal steps down this tile column is emitted in one go (most of the path at 10 % error)
+            const unsigned long long col_bits = (t_run >> tl) & 0x1111111111111111ull;      // bit 4x: step x of the run is plain
+            const int run = th_ctz64(~col_bits & 0x1111111111111111ull) >> 2;              // 16 when the column is plain to the tile's end
+            const int lim = min(run, 16 - k);
+            if (lim > 0) {
+                if (lane < lim) { g.ops[2 * (no + lane)] = 0 | (ci - lane) << 2; g.ops[2 * (no + lane) + 1] = cj - 1 - lane; }
+                no += lim; ci -= lim; cj -= lim;
+                continue;
+            }
+        }
         const uint32_t d = (uint32_t)TH_READLANE(t_d, tl);
         const int a0 = TH_READLANE(t_p0, tl), a1 = TH_READLANE(t_p1, tl), a2 = TH_READLANE(t_p2, tl), a3 = TH_READLANE(t_p3, tl);
         if (st == 0) st = TH_D_SRC(d);
