@@ -142,3 +142,48 @@ __device__ __forceinline__ int th_queue_pop(int *queue)
 }
 __device__ __forceinline__ int th_ctz64(unsigned long long m) { return m ? __ffsll((long long)m) - 1 : 64; }
 __device__ __forceinline__ int th_msb64(unsigned long long m) { return 63 - __clzll((long long)m); }   // m != 0
+
+// ---- packed int16 pairs (two DP cells per lane): v_pk_add_i16 clamp / v_pk_sub_i16 clamp / v_pk_max_i16 ----
+#define TH_PK_NEG 0x80008000u            // (-32768, -32768): "minus infinity" in both halves
+#define TH_PK_LO(x) ((int)(short)((x) & 0xffffu))
+#define TH_PK_HI(x) ((int)(short)((uint32_t)(x) >> 16))
+#define TH_PK(lo, hi) (((uint32_t)(lo) & 0xffffu) | ((uint32_t)(hi) << 16))
+#define TH_PK_DUP(v) TH_PK((v), (v))
+#ifdef TH_CPU_EMUL
+static inline int th_sat16_(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
+static inline uint32_t th_pk_add(uint32_t a, uint32_t b) { return TH_PK(th_sat16_(TH_PK_LO(a) + TH_PK_LO(b)), th_sat16_(TH_PK_HI(a) + TH_PK_HI(b))); }
+static inline uint32_t th_pk_sub(uint32_t a, uint32_t b) { return TH_PK(th_sat16_(TH_PK_LO(a) - TH_PK_LO(b)), th_sat16_(TH_PK_HI(a) - TH_PK_HI(b))); }
+static inline uint32_t th_pk_max(uint32_t a, uint32_t b) { return TH_PK(TH_PK_LO(a) > TH_PK_LO(b) ? TH_PK_LO(a) : TH_PK_LO(b), TH_PK_HI(a) > TH_PK_HI(b) ? TH_PK_HI(a) : TH_PK_HI(b)); }
+static inline uint32_t th_pk_negmask(uint32_t a) { return (TH_PK_LO(a) < 0 ? 0xffffu : 0u) | (TH_PK_HI(a) < 0 ? 0xffff0000u : 0u); }
+static inline uint32_t th_alignbit16(uint32_t hi, uint32_t lo) { return (lo >> 16) | (hi << 16); }   // (lo.hi, hi.lo)
+static inline uint32_t th_ubfe(uint32_t v, uint32_t off, uint32_t w) { return (v >> (off & 31)) & ((1u << w) - 1); }
+__device__ __forceinline__ uint32_t th_wave_incl_pkmax(uint32_t v)
+{
+    const int lane = TH_LANE();
+    for (int d = 1; d < TH_WAVE; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)v, d); if (lane >= d) v = th_pk_max(v, o); }
+    return v;
+}
+#else
+typedef short th_s2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t th_pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(th_s2_t, a), __builtin_bit_cast(th_s2_t, b))); }
+__device__ __forceinline__ uint32_t th_pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(th_s2_t, a), __builtin_bit_cast(th_s2_t, b))); }
+__device__ __forceinline__ uint32_t th_pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(th_s2_t, a), __builtin_bit_cast(th_s2_t, b))); }
+__device__ __forceinline__ uint32_t th_pk_negmask(uint32_t a) { const th_s2_t v = __builtin_bit_cast(th_s2_t, a); const th_s2_t r = v >> (th_s2_t)(15); return __builtin_bit_cast(uint32_t, r); }
+__device__ __forceinline__ uint32_t th_alignbit16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
+__device__ __forceinline__ uint32_t th_ubfe(uint32_t v, uint32_t off, uint32_t w) { return __builtin_amdgcn_ubfe(v, off, w); }
+__device__ __forceinline__ uint32_t th_wave_incl_pkmax(uint32_t v)
+{
+    const int id = (int)TH_PK_NEG;
+    uint32_t x = v;
+    x = th_pk_max(x, (uint32_t)TH_DPP(id, (int)v, 0x111, 0xf, 0xf));     // row_shr:1
+    x = th_pk_max(x, (uint32_t)TH_DPP(id, (int)v, 0x112, 0xf, 0xf));     // row_shr:2
+    x = th_pk_max(x, (uint32_t)TH_DPP(id, (int)v, 0x113, 0xf, 0xf));     // row_shr:3
+    x = th_pk_max(x, (uint32_t)TH_DPP(id, (int)x, 0x114, 0xf, 0xe));     // row_shr:4, banks 1-3
+    x = th_pk_max(x, (uint32_t)TH_DPP(id, (int)x, 0x118, 0xf, 0xc));     // row_shr:8, banks 2-3
+    x = th_pk_max(x, (uint32_t)TH_DPP(id, (int)x, 0x142, 0xa, 0xf));     // row_bcast:15 into rows 1,3
+    x = th_pk_max(x, (uint32_t)TH_DPP(id, (int)x, 0x143, 0xc, 0xf));     // row_bcast:31 into rows 2,3
+    return x;
+}
+#endif
+// (a & m) | (b & ~m): v_bfi_b32
+__device__ __forceinline__ uint32_t th_sel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }

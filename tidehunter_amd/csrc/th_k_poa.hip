@@ -38,7 +38,9 @@
 
 #define TH_POA_INL 4
 #define TH_POA_RING 4      // recent rows kept in LDS (a row can read the three before it)
-#define TH_POA_RW 192      // columns per cached row
+#define TH_POA_RW 192      // widest cached band
+#define TH_POA_PAD 4       // minus-infinity shorts in front of every ring row (columns left of the band; clamp target)
+#define TH_POA_RS (TH_POA_PAD + TH_POA_RW + 4)   // shorts per ring array: pad + band (from its even base) + the odd-edge pair
 #define TH_BIG 0x3fffffff
 
 struct ThPoaG {
@@ -216,34 +218,50 @@ __device__ unsigned long long th_poa_prof[8];
 #endif
 
 // ---- banded DP; returns the row of the sink's best predecessor (>= 0) or a negative status ----
-// The three most recent rows stay in an LDS ring (H, E1', E2' per column) together with their band and
-// row-maximum columns in wave-uniform registers, so a row whose predecessors are among them -- nearly
-// all rows: the previous node and the members of the previous column -- issues no HBM load at all; its
-// own cells leave as fire-and-forget 16-byte stores (needed by the traceback and by far predecessors).
-// ring values are stored as int16 (half the LDS, so more waves per CU); anything below the int16 range is a
-// band-edge "minus infinity" and is widened back to TH_NEG on load.  Rows are cached only while every real
-// score fits (see cache16_ok below).
-#define TH_RING_LD(x) ((int)(x) == -32768 ? TH_NEG : (int)(x))
+// The three most recent rows stay in an LDS ring (H, E1', E2' per column, int16) together with their band and
+// row-maximum columns in wave-uniform registers, so a row whose predecessors are among them -- nearly all rows:
+// the previous node and the members of the previous column -- issues no HBM load at all.
+//
+// Ring layout: a row with band [b, e] keeps column j at index j - (b & ~1) + TH_POA_PAD of each of its three arrays,
+// so columns pair up (even, odd) in aligned 32-bit words.  -32768 is "minus infinity".
+//
+// PACKED ROWS.  A row whose only predecessor is the previous row (97 % of rows) and whose band fits the ring is
+// computed two columns per lane on packed int16 pairs (v_pk_add_i16 clamp / v_pk_max_i16): 128 columns per trip,
+// F1 and F2 share ONE packed max-plus DPP scan, comparisons are sign bits of saturating differences, selections are
+// v_bfi.  Such a row rewrites its whole ring slot (minus infinity outside its band), which is what lets the next
+// packed row read its predecessor without bounds checks ("clean" slot).  Exactness: all real scores stay inside
+// int16 (pk_ok below); an unreachable in-band cell may drift upwards from -32768 by at most M per row, which pk_ok
+// keeps below every real score, and readers that work in 32 bits widen anything below `neg_thr` back to TH_NEG.
+#define TH_RING_LD(x) ((int)(x) < neg_thr ? TH_NEG : (int)(x))
 #define TH_RING_ST(v) ((short)max((v), -32768))
-#define TH_SEL4(s, a0, a1, a2, a3) ((s) == 0 ? (a0) : (s) == 1 ? (a1) : (s) == 2 ? (a2) : (a3))
-#define TH_SET4(s, a0, a1, a2, a3, v) do { if ((s) == 0) a0 = (v); else if ((s) == 1) a1 = (v); else if ((s) == 2) a2 = (v); else a3 = (v); } while (0)
+#define TH_RIDX(j, beg) ((j) - ((beg) & ~1) + TH_POA_PAD)
 
 template <bool LQ>
-__device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t *s_q, short (*s_ring)[3][TH_POA_RW], int (*s_rmeta)[8], int qlen, const ThDevPara &P)
+__device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t *s_qs, short (*s_ring)[3][TH_POA_RS], int (*s_rmeta)[8], int qlen, const ThDevPara &P)
 {
     const int lane = TH_LANE();
     const int M = P.match, X = P.mismatch, O1 = P.go1, E1 = P.ge1, O2 = P.go2, E2 = P.ge2;
     const int n = g.n_node, w = TH_POA_WB + qlen / 100;
     long long ncell = 0;
-    // a real score is at most (largest per-step score or gap extension) * (columns + rows) + both gap opens away from 0:
-    // rows are cached as int16 only if that fits
-    const bool cache16_ok = (long long)max(max(M, X), max(E1, E2)) * (qlen + n) + O1 + O2 < 30000;
+    // Every real score lies within +-real_b: a path to (i, j) has at most i + j unit steps, the dearest of which is a
+    // mismatch (X for two units) or a one-base gap (open + extend for one unit); E'/F carry one more open + extend.
+    // Rows are cached as int16 (and packed rows are used) only if that, the upward drift of unreachable cells (M per
+    // row) and the column offsets of the F scan (2 * ring width * extension) all fit below 32000.
+    const int maxE = max(E1, E2), gap1 = min(O1 + E1, O2 + E2);
+    const long long real_b = (long long)max(max(M, X), gap1) * (qlen + n) + O1 + O2 + 2 * maxE;
+    const bool cache16_ok = M <= 31 && X <= 31 && real_b + (long long)M * n + 2LL * (TH_POA_RW + 64) * maxE < 32000;
+    const int neg_thr = cache16_ok ? -(int)real_b - 1 : -32768;
+    // packed constants
+    const uint32_t O1P = TH_PK_DUP(O1), O2P = TH_PK_DUP(O2), E1P = TH_PK_DUP(E1), E2P = TH_PK_DUP(E2);
+    uint32_t TX = 32u << 24;                                         // score table, 6 bits per query code (x 6), biased by 32
+    for (int c = 0; c < 4; ++c) TX |= (uint32_t)(32 - X) << (6 * c);
     int c_meta = 0, c_rem = 0, c_p0 = -1, c_p1 = -1, c_p2 = -1, c_p3 = -1, c_id = 0;   // row-table chunk cache
-    // the previous row's band / row-maximum columns / LDS-cached flag stay in wave-uniform registers (the
-    // common row has exactly that predecessor); older ring slots keep theirs in s_rmeta[slot][]:
-    //   0 row, 1 beg, 2 end, 3 left, 4 right, 5 cached, 6..7 cell offset
+    // the previous row's band / row-maximum columns / cache state stay in wave-uniform registers (the common row has
+    // exactly that predecessor); older ring slots keep theirs in s_rmeta[slot][]:
+    //   0 row, 1 beg, 2 end, 3 left, 4 right, 5 cache state (0 none, 3 cached; every cached slot is clean), 6..7 cell offset
     int L_b = 0, L_e = -1, L_l = 0, L_r = 0, L_c = 0;
     if (lane < TH_POA_RING) s_rmeta[lane][0] = -1;
+    for (int x = lane; x < TH_POA_RING * 3 * TH_POA_PAD; x += TH_WAVE) s_ring[x / (3 * TH_POA_PAD)][(x / TH_POA_PAD) % 3][x % TH_POA_PAD] = -32768;
     TH_WAVE_FENCE();
     for (int i = 0; i + 1 < n; ++i) {
         if ((i & 63) == 0) {
@@ -281,25 +299,110 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             e = min(qlen, max(mpr, qlen - rm) + w);
         }
         if (b > e) return -2;
-        if (ncell + (e - b + 1) > g.cell_cap) return -3;
-        int4 *row = g.cell + ncell; int *drow = g.dcell + ncell;
-        const long long my_off = ncell;
-        ncell += e - b + 1;
+        // a row owns the cells of columns (b & ~1) .. (e | 1): packed rows store column pairs
+        const int B0 = b & ~1, span = (e | 1) - B0 + 1;
+        if (ncell + span > g.cell_cap) return -3;
+        const long long my_off = ncell + (b - B0);               // offset of column b, as every reader expects
+        int4 *row = g.cell + my_off; int *drow = g.dcell + my_off;
+        ncell += span;
         const int myslot = i & 3, lslot = (i - 1) & 3;
         const bool cache_me = cache16_ok && e - b < TH_POA_RW;
         const bool store_full = needfull || !cache_me;     // otherwise only the direction word leaves the CU
         int rmax = TH_NEG - 0x10000000, left = b, right = b;
+        const bool pk = LQ && fast && L_c == 3 && cache_me;
+#ifdef TH_CPU_EMUL
+        if (lane == 0 && getenv("TH_DEBUG_PK")) { static long n_pk, n_all; n_all++; n_pk += pk; if ((n_all & 4095) == 0) fprintf(stderr, "[poa] packed rows %ld of %ld\n", n_pk, n_all); }
+#endif
+        if (pk) {
+            // ================= packed row: lane l owns columns B0 + 128 t + 2 l and the next one =================
+            const int PB0 = L_b & ~1;
+            const uint32_t T = nb == 4 ? 0x20820820u : ((TX & ~(63u << (6 * nb))) | (uint32_t)(32 + M) << (6 * nb));
+            const uint32_t *rH = (const uint32_t *)s_ring[lslot][0], *rE1 = (const uint32_t *)s_ring[lslot][1], *rE2 = (const uint32_t *)s_ring[lslot][2];
+            uint32_t *wH = (uint32_t *)s_ring[myslot][0], *wE1 = (uint32_t *)s_ring[myslot][1], *wE2 = (uint32_t *)s_ring[myslot][2];
+            uint32_t carry = TH_PK_NEG;                              // (F1, F2) running maxima in the column-offset domain
+            for (int t0 = 0; t0 < 256; t0 += 128) {
+                const int jr = t0 + 2 * lane, j0 = B0 + jr;
+                const int wi = (jr + TH_POA_PAD) >> 1;              // this lane's pair in the row being written
+                if (t0 && B0 + t0 > e) {                             // one trip was enough: clear the rest of the slot
+                    if (wi < TH_POA_RS / 2) { wH[wi] = TH_PK_NEG; wE1[wi] = TH_PK_NEG; wE2[wi] = TH_PK_NEG; }
+                    break;
+                }
+                const bool lo_ok = j0 >= b && j0 <= e, hi_ok = j0 + 1 <= e;
+                const uint32_t IM = (lo_ok ? 0xffffu : 0u) | (hi_ok ? 0xffff0000u : 0u);
+                // substitution scores of the two columns from the row's table
+                const uint32_t qx = *(const unsigned short *)(s_qs + min(j0, TH_POA_QCAP));
+                const uint32_t SC = th_pk_sub(th_ubfe(T, qx & 0xffu, 6) | th_ubfe(T, qx >> 8, 6) << 16, 0x00200020u);
+                // predecessor row: diagonal pair (j0-1, j0) and vertical pairs (j0, j0+1); anything outside its band reads -inf
+                int pi = j0 - PB0 + TH_POA_PAD;
+                pi = pi <= TH_POA_RS - 2 ? pi : 2;
+                const uint32_t Hm = rH[(pi >> 1) - 1], Hc = rH[pi >> 1], e1v = rE1[pi >> 1], e2v = rE2[pi >> 1];
+                const uint32_t m = th_pk_add(th_alignbit16(Hc, Hm), SC);
+                const uint32_t hnf1 = th_pk_max(m, e1v), g1 = th_pk_negmask(th_pk_sub(m, e1v));
+                const uint32_t hnf = th_pk_max(hnf1, e2v), g2 = th_pk_negmask(th_pk_sub(hnf1, e2v));
+                // F1 / F2: max-plus prefix over the row in the domain value + column * extension
+                const uint32_t JR = TH_PK(jr, jr + 1);
+                const uint32_t JE1 = TH_PK(TH_PK_LO(JR) * E1, TH_PK_HI(JR) * E1), JE2 = TH_PK(TH_PK_LO(JR) * E2, TH_PK_HI(JR) * E2);
+                const uint32_t a1 = th_sel(IM, th_pk_add(th_pk_sub(hnf, O1P), JE1), TH_PK_NEG);
+                const uint32_t a2 = th_sel(IM, th_pk_add(th_pk_sub(hnf, O2P), JE2), TH_PK_NEG);
+                const uint32_t t1 = th_pk_max(a1, th_alignbit16(a1, a1)), t2 = th_pk_max(a2, th_alignbit16(a2, a2));
+                const uint32_t inc = th_wave_incl_pkmax((t1 & 0xffffu) | (t2 << 16));         // (F1 | F2) lane totals, inclusive
+                const uint32_t exc = th_pk_max((uint32_t)th_shr1_inject((int)inc, (int)carry), carry);
+                carry = th_pk_max(carry, (uint32_t)TH_READLANE((int)inc, 63));
+                const uint32_t x1 = th_pk_max(TH_PK_DUP(exc & 0xffffu), (a1 << 16) | 0x8000u);     // (before lo, before hi)
+                const uint32_t x2 = th_pk_max(TH_PK_DUP(exc >> 16), (a2 << 16) | 0x8000u);
+                const uint32_t f1 = th_pk_sub(x1, JE1), f2 = th_pk_sub(x2, JE2);
+                const uint32_t h3 = th_pk_max(hnf, f1), g3 = th_pk_negmask(th_pk_sub(hnf, f1));
+                const uint32_t h = th_pk_max(h3, f2), g4 = th_pk_negmask(th_pk_sub(h3, f2));
+                // direction codes (src | flags << 3 per half) and the next row's E1', E2'
+                const uint32_t hO1 = th_pk_sub(h, O1P), hO2 = th_pk_sub(h, O2P);
+                uint32_t code = g1 & 0x00010001u;
+                code = th_sel(g2, 0x00020002u, code); code = th_sel(g3, 0x00030003u, code); code = th_sel(g4, 0x00040004u, code);
+                code |= th_pk_negmask(th_pk_sub(hO1, e1v)) & 0x00080008u;
+                code |= th_pk_negmask(th_pk_sub(hO2, e2v)) & 0x00100010u;
+                code |= th_pk_negmask(th_pk_sub(hO1, f1)) & 0x00200020u;
+                code |= th_pk_negmask(th_pk_sub(hO2, f2)) & 0x00400040u;
+                const uint32_t n1 = th_pk_sub(th_pk_max(hO1, e1v), E1P), n2 = th_pk_sub(th_pk_max(hO2, e2v), E2P);
+                const uint32_t d_lo = (code & 7u) | ((code << 24) & 0x78000000u), d_hi = ((code >> 16) & 7u) | ((code << 8) & 0x78000000u);
+                if (j0 <= e) {
+                    *(unsigned long long *)(drow + (j0 - b)) = (unsigned long long)d_hi << 32 | d_lo;   // column b-1 / e+1 of an odd edge land in the row's own padding
+                    if (store_full) {
+                        const int hl = TH_PK_LO(h), hh = TH_PK_HI(h), n1l = TH_PK_LO(n1), n1h = TH_PK_HI(n1), n2l = TH_PK_LO(n2), n2h = TH_PK_HI(n2);
+                        int4 cv;
+                        if (lo_ok) { cv.x = hl < neg_thr ? TH_NEG : hl; cv.y = n1l < neg_thr ? TH_NEG : n1l; cv.z = n2l < neg_thr ? TH_NEG : n2l; cv.w = (int)d_lo; row[j0 - b] = cv; }
+                        if (hi_ok) { cv.x = hh < neg_thr ? TH_NEG : hh; cv.y = n1h < neg_thr ? TH_NEG : n1h; cv.z = n2h < neg_thr ? TH_NEG : n2h; cv.w = (int)d_hi; row[j0 + 1 - b] = cv; }
+                    }
+                }
+                if (wi < TH_POA_RS / 2) { wH[wi] = th_sel(IM, h, TH_PK_NEG); wE1[wi] = th_sel(IM, n1, TH_PK_NEG); wE2[wi] = th_sel(IM, n2, TH_PK_NEG); }
+                // row maximum and its first / last column: the maximum of H is a maximum of hnf (an F value is always
+                // below the hnf it came from), and H == max only where hnf == max
+                const uint32_t hm2 = th_sel(IM, hnf, TH_PK_NEG);
+                const uint32_t red = th_wave_incl_pkmax(th_pk_max(hm2, th_alignbit16(hm2, hm2)));
+                const int hm = TH_PK_LO((uint32_t)TH_READLANE((int)red, 63));
+                const uint32_t eqx = hm2 ^ TH_PK_DUP(hm);
+                const unsigned long long mlo = __ballot((eqx & 0xffffu) == 0), mhi = __ballot((eqx >> 16) == 0);
+                if (hm >= rmax && (mlo | mhi)) {
+                    const int fl = B0 + t0 + min(mlo ? 2 * th_ctz64(mlo) : 1 << 20, mhi ? 2 * th_ctz64(mhi) + 1 : 1 << 20);
+                    const int lr = B0 + t0 + max(mlo ? 2 * th_msb64(mlo) : -1, mhi ? 2 * th_msb64(mhi) + 1 : -1);
+                    if (hm > rmax) { rmax = hm; left = fl; right = lr; } else right = lr;
+                }
+            }
+        } else {
+        if (cache_me) {      // leave the slot clean for a packed successor: minus infinity wherever this row stores nothing
+            uint32_t *wH = (uint32_t *)s_ring[myslot][0], *wE1 = (uint32_t *)s_ring[myslot][1], *wE2 = (uint32_t *)s_ring[myslot][2];
+            for (int x = TH_POA_PAD / 2 + lane; x < TH_POA_RS / 2; x += TH_WAVE) { wH[x] = TH_PK_NEG; wE1[x] = TH_PK_NEG; wE2[x] = TH_PK_NEG; }
+            TH_WAVE_FENCE();
+        }
         int carry1 = TH_NEG + b * E1, carry2 = TH_NEG + b * E2;
         for (int c0 = b; c0 <= e; c0 += TH_WAVE) {
             const int j = c0 + lane;
             const bool in = j <= e;
             int m = TH_NEG, e1v = TH_NEG, e2v = TH_NEG, pm = 0, pe1 = 0, pe2 = 0;
             int sc = 0;
-            if (in && j >= 1) { const int qb = min(LQ ? (int)s_q[j - 1] : (int)q[j - 1], 4); sc = (qb == 4 || nb == 4) ? 0 : (qb == nb ? M : -X); }
+            if (in && j >= 1) { const int qb = LQ ? (int)s_qs[j] : 6 * min((int)q[j - 1], 4); sc = (qb == 24 || nb == 4) ? 0 : (qb == 6 * nb ? M : -X); }
             if (fast) {
                 if (in) {
-                    if (j >= 1) { m = ((j - 1 >= L_b && j - 1 <= L_e) ? TH_RING_LD(s_ring[lslot][0][j - 1 - L_b]) : TH_NEG) + sc; }
-                    if (j >= L_b && j <= L_e) { e1v = TH_RING_LD(s_ring[lslot][1][j - L_b]); e2v = TH_RING_LD(s_ring[lslot][2][j - L_b]); }
+                    if (j >= 1) { m = ((j - 1 >= L_b && j - 1 <= L_e) ? TH_RING_LD(s_ring[lslot][0][TH_RIDX(j - 1, L_b)]) : TH_NEG) + sc; }
+                    if (j >= L_b && j <= L_e) { e1v = TH_RING_LD(s_ring[lslot][1][TH_RIDX(j, L_b)]); e2v = TH_RING_LD(s_ring[lslot][2][TH_RIDX(j, L_b)]); }
                 }
             } else if (i > 0) {
                 for (int o = 0; o < inn; ++o) {
@@ -310,8 +413,8 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                     if (recent && s_rmeta[s][5]) {           // LDS ring: no HBM round trip
                         const int pb = s_rmeta[s][1], pe = s_rmeta[s][2];
                         if (in) {
-                            if (j >= 1 && j - 1 >= pb && j - 1 <= pe) hp = TH_RING_LD(s_ring[s][0][j - 1 - pb]);
-                            if (j >= pb && j <= pe) { c1 = TH_RING_LD(s_ring[s][1][j - pb]); c2 = TH_RING_LD(s_ring[s][2][j - pb]); }
+                            if (j >= 1 && j - 1 >= pb && j - 1 <= pe) hp = TH_RING_LD(s_ring[s][0][TH_RIDX(j - 1, pb)]);
+                            if (j >= pb && j <= pe) { c1 = TH_RING_LD(s_ring[s][1][TH_RIDX(j, pb)]); c2 = TH_RING_LD(s_ring[s][2][TH_RIDX(j, pb)]); }
                         }
                     } else {
                         int pb, pe; long long po;
@@ -356,19 +459,21 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 const int n1 = max(h - O1, e1v) - E1, n2 = max(h - O2, e2v) - E2;
                 drow[j - b] = (int)d;
                 if (store_full) { int4 cv; cv.x = h; cv.y = n1; cv.z = n2; cv.w = (int)d; row[j - b] = cv; }
-                if (cache_me) { s_ring[myslot][0][j - b] = TH_RING_ST(h); s_ring[myslot][1][j - b] = TH_RING_ST(n1); s_ring[myslot][2][j - b] = TH_RING_ST(n2); }
+                if (cache_me) { s_ring[myslot][0][TH_RIDX(j, b)] = TH_RING_ST(h); s_ring[myslot][1][TH_RIDX(j, b)] = TH_RING_ST(n1); s_ring[myslot][2][TH_RIDX(j, b)] = TH_RING_ST(n2); }
             }
             const int hm = th_wave_max(in ? h : TH_NEG * 2);
             const unsigned long long mm = __ballot(in && h == hm);
             if (hm > rmax) { rmax = hm; left = c0 + th_ctz64(mm); right = c0 + th_msb64(mm); }
             else if (hm == rmax) right = c0 + th_msb64(mm);
         }
+        }
+        const int cstate = cache_me ? 3 : 0;
         if (lane == 0) {
             g.r_beg[i] = b; g.r_end[i] = e; g.r_off[i] = my_off; g.r_mpl[i] = left; g.r_mpr[i] = right;
             s_rmeta[myslot][0] = i; s_rmeta[myslot][1] = b; s_rmeta[myslot][2] = e; s_rmeta[myslot][3] = left; s_rmeta[myslot][4] = right;
-            s_rmeta[myslot][5] = cache_me ? 1 : 0; s_rmeta[myslot][6] = (int)(uint32_t)my_off; s_rmeta[myslot][7] = (int)(my_off >> 32);
+            s_rmeta[myslot][5] = cstate; s_rmeta[myslot][6] = (int)(uint32_t)my_off; s_rmeta[myslot][7] = (int)(my_off >> 32);
         }
-        L_b = b; L_e = e; L_l = left; L_r = right; L_c = cache_me ? 1 : 0;
+        L_b = b; L_e = e; L_l = left; L_r = right; L_c = cstate;
         TH_WAVE_FENCE();
     }
     // global end: best predecessor row of the sink (row n-1) at column qlen, first in edge order
@@ -593,8 +698,8 @@ th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict
          const uint8_t *__restrict__ bseq, ThDevPara P, int *__restrict__ scratch, long long scratch_ints,
          uint8_t *__restrict__ cons, int *__restrict__ cov, int *__restrict__ cons_len, int *__restrict__ status, int *__restrict__ queue)
 {
-    __shared__ uint8_t s_q[TH_POA_QCAP];
-    __shared__ short s_ring[TH_POA_RING][3][TH_POA_RW];
+    __shared__ __attribute__((aligned(4))) uint8_t s_qs[TH_POA_QCAP + 4];     // s_qs[j] = 6 * code(q[j-1]): the column's query base, pre-scaled for the score table
+    __shared__ __attribute__((aligned(4))) short s_ring[TH_POA_RING][3][TH_POA_RS];
     __shared__ int s_rmeta[TH_POA_RING][8];
     const int lane = TH_LANE();
     const int wave = blockIdx.x;
@@ -634,13 +739,13 @@ th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict
         if (!st) th_poa_seed(g, rb + U[0].start, U[0].len);
         for (int s = 1; s < T.n_units && !st; ++s) {
             const uint8_t *q = rb + U[s].start; const int qlen = U[s].len;
-            if (LQ) for (int x = lane; x < qlen; x += TH_WAVE) s_q[x] = q[x];
+            if (LQ) for (int x = lane; x < qlen + 3; x += TH_WAVE) s_qs[x] = (x >= 1 && x <= qlen) ? (uint8_t)(6 * min((int)q[x - 1], 4)) : (uint8_t)24;
             TH_WAVE_FENCE();
             TH_PROF_T0();
             const int deg = th_poa_rows(g);
             TH_PROF(0);
             if (deg > 255) { st = 5; break; }
-            const int bi = th_poa_dp<LQ>(g, q, s_q, s_ring, s_rmeta, qlen, P);
+            const int bi = th_poa_dp<LQ>(g, q, s_qs, s_ring, s_rmeta, qlen, P);
             TH_PROF(1);
             if (bi < 0) { st = bi == -3 ? 2 : 4; break; }
             const int no = th_poa_traceback(g, bi, qlen);
