@@ -132,6 +132,15 @@ __device__ __forceinline__ int th_lane_shift(int v, int off, int fill)
 #define TH_LOAD_L2(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif
 
+// Explicit "all my vector-memory loads have landed".  gfx9 counts loads AND stores in vmcnt, and the compiler places its
+// wait at the first use of a loaded register; when that use sits in a loop whose body also issues fire-and-forget
+// stores, the wait it inserts there drains the stores of the previous trip on every trip.  Waiting right after the
+// (rare) loads instead leaves the steady-state trips without any vmcnt wait.
+#ifdef TH_CPU_EMUL
+#define TH_VM_WAIT0() ((void)0)
+#else
+#define TH_VM_WAIT0() __builtin_amdgcn_s_waitcnt(0x0F70)      // vmcnt(0), expcnt and lgkmcnt untouched
+#endif
 // next index of a shared work queue, wave-uniform.  Every lane takes part in the atomic (lane 0 adds 1, the
 // others 0), so there is no divergent region around it: with the add under `if (lane == 0)` hipcc 7.2
 // restructured the surrounding persistent loop into one that never fetched a second item.

@@ -227,7 +227,7 @@ __device__ unsigned long long th_poa_prof[8];
 //
 // PACKED ROWS.  A row whose only predecessor is the previous row (97 % of rows) and whose band fits the ring is
 // computed two columns per lane on packed int16 pairs (v_pk_add_i16 clamp / v_pk_max_i16): 128 columns per trip,
-// F1 and F2 share ONE packed max-plus DPP scan, comparisons are sign bits of saturating differences, selections are
+// F1 and F2 are scanned once per lane PAIR, comparisons are sign bits of saturating differences, selections are
 // v_bfi.  Such a row rewrites its whole ring slot (minus infinity outside its band), which is what lets the next
 // packed row read its predecessor without bounds checks ("clean" slot).  Exactness: all real scores stay inside
 // int16 (pk_ok below); an unreachable in-band cell may drift upwards from -32768 by at most M per row, which pk_ok
@@ -270,6 +270,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 c_meta = g.r_meta[r]; c_rem = g.r_rem[r]; c_id = g.order[r];
                 c_p0 = g.r_p[r * 4]; c_p1 = g.r_p[r * 4 + 1]; c_p2 = g.r_p[r * 4 + 2]; c_p3 = g.r_p[r * 4 + 3];
             }
+            TH_VM_WAIT0();      // here, once per 64 rows -- not at the first use below, where it would drain every row's stores
         }
         const int sl = i & 63;
         const int meta = TH_READLANE(c_meta, sl), rm = TH_READLANE(c_rem, sl);
@@ -319,7 +320,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             const uint32_t T = nb == 4 ? 0x20820820u : ((TX & ~(63u << (6 * nb))) | (uint32_t)(32 + M) << (6 * nb));
             const uint32_t *rH = (const uint32_t *)s_ring[lslot][0], *rE1 = (const uint32_t *)s_ring[lslot][1], *rE2 = (const uint32_t *)s_ring[lslot][2];
             uint32_t *wH = (uint32_t *)s_ring[myslot][0], *wE1 = (uint32_t *)s_ring[myslot][1], *wE2 = (uint32_t *)s_ring[myslot][2];
-            uint32_t carry = TH_PK_NEG;                              // (F1, F2) running maxima in the column-offset domain
+            int carry1 = -32768, carry2 = -32768;                   // F1 / F2 running maxima in the column-offset domain
             for (int t0 = 0; t0 < 256; t0 += 128) {
                 const int jr = t0 + 2 * lane, j0 = B0 + jr;
                 const int wi = (jr + TH_POA_PAD) >> 1;              // this lane's pair in the row being written
@@ -344,12 +345,13 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 const uint32_t JE1 = TH_PK(TH_PK_LO(JR) * E1, TH_PK_HI(JR) * E1), JE2 = TH_PK(TH_PK_LO(JR) * E2, TH_PK_HI(JR) * E2);
                 const uint32_t a1 = th_sel(IM, th_pk_add(th_pk_sub(hnf, O1P), JE1), TH_PK_NEG);
                 const uint32_t a2 = th_sel(IM, th_pk_add(th_pk_sub(hnf, O2P), JE2), TH_PK_NEG);
-                const uint32_t t1 = th_pk_max(a1, th_alignbit16(a1, a1)), t2 = th_pk_max(a2, th_alignbit16(a2, a2));
-                const uint32_t inc = th_wave_incl_pkmax((t1 & 0xffffu) | (t2 << 16));         // (F1 | F2) lane totals, inclusive
-                const uint32_t exc = th_pk_max((uint32_t)th_shr1_inject((int)inc, (int)carry), carry);
-                carry = th_pk_max(carry, (uint32_t)TH_READLANE((int)inc, 63));
-                const uint32_t x1 = th_pk_max(TH_PK_DUP(exc & 0xffffu), (a1 << 16) | 0x8000u);     // (before lo, before hi)
-                const uint32_t x2 = th_pk_max(TH_PK_DUP(exc >> 16), (a2 << 16) | 0x8000u);
+                // lane totals are scanned as two 32-bit values: v_max_i32 takes the DPP operand directly (one instruction per
+                // step), a packed max would need a move and an identity fill per step
+                const int a1l = TH_PK_LO(a1), a2l = TH_PK_LO(a2);
+                const int i1 = th_wave_incl_max(max(a1l, TH_PK_HI(a1))), i2 = th_wave_incl_max(max(a2l, TH_PK_HI(a2)));
+                const int b1 = max(th_shr1(i1, carry1), carry1), b2 = max(th_shr1(i2, carry2), carry2);    // best before this lane's pair
+                carry1 = max(carry1, TH_READLANE(i1, 63)); carry2 = max(carry2, TH_READLANE(i2, 63));
+                const uint32_t x1 = TH_PK(b1, max(b1, a1l)), x2 = TH_PK(b2, max(b2, a2l));                 // (before lo, before hi)
                 const uint32_t f1 = th_pk_sub(x1, JE1), f2 = th_pk_sub(x2, JE2);
                 const uint32_t h3 = th_pk_max(hnf, f1), g3 = th_pk_negmask(th_pk_sub(hnf, f1));
                 const uint32_t h = th_pk_max(h3, f2), g4 = th_pk_negmask(th_pk_sub(h3, f2));
@@ -376,8 +378,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 // row maximum and its first / last column: the maximum of H is a maximum of hnf (an F value is always
                 // below the hnf it came from), and H == max only where hnf == max
                 const uint32_t hm2 = th_sel(IM, hnf, TH_PK_NEG);
-                const uint32_t red = th_wave_incl_pkmax(th_pk_max(hm2, th_alignbit16(hm2, hm2)));
-                const int hm = TH_PK_LO((uint32_t)TH_READLANE((int)red, 63));
+                const int hm = th_wave_max(max(TH_PK_LO(hm2), TH_PK_HI(hm2)));
                 const uint32_t eqx = hm2 ^ TH_PK_DUP(hm);
                 const unsigned long long mlo = __ballot((eqx & 0xffffu) == 0), mhi = __ballot((eqx >> 16) == 0);
                 if (hm >= rmax && (mlo | mhi)) {
