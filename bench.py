@@ -53,7 +53,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)   # two: device buffers reach their steady size (a batch that grows one is first-touched inside a kernel)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TH_BENCH_BATCH", "65536")), help="reads per step per GPU")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1: auto, 0: skip)")
     a = ap.parse_args()
@@ -127,7 +127,7 @@ def main():
         per_launch_bytes = alg_bytes / float(a.steps)
         ach = per_launch_bytes / launch_s / 1e9 if launch_s > 0 else 0.0
         # traffic: HBM bytes of one launch of the dominant kernel from the PMC passes of this same command
-        # (tests/prof_round.sh -> profiles/r01_hbm_traffic.json); counters cannot be read from inside the process, so
+        # (tools/prof_round.sh -> profiles/r01_hbm_traffic.json); counters cannot be read from inside the process, so
         # the committed profile is quoted when it was taken at the same batch size, else null
         traffic, traffic_src = None, None
         try:

@@ -108,6 +108,16 @@ def test_emul_minimizer_seeding(emu):
         th.close()
 
 
+def test_emul_poa_scoring_options(emu):
+    """-M -X -O -E: the packed int16 POA rows read their scores from a per-row table (match, mismatch <= 31); larger
+    scores take the 32-bit rows"""
+    for kw in (dict(match=3, mismatch=5), dict(gap_open1=6, gap_ext1=3, gap_open2=30, gap_ext2=1), dict(match=40, mismatch=50)):
+        th = TH.TideHunter(lib_path=emu, **kw)
+        seqs = _reads(th.lib, [(120, 6, 0.10), (260, 4, 0.12)], seed=17)
+        U.assert_records_equal(seqs, th.process(seqs), O.default_para(**kw), "scoring %r" % (kw,))
+        th.close()
+
+
 def test_refuses_out_of_range_window(emu):
     for kw in (dict(w=0), dict(w=257)):
         with pytest.raises(RuntimeError):

@@ -81,7 +81,8 @@ def test_gpu_ragged_and_degenerate_inputs(th):
 def test_gpu_options(th):
     seqs = _synth(th.lib, 6, 150, 8, 0.1, 21)
     for kw in (dict(only_unit=1), dict(min_len=160), dict(only_longest=1), dict(min_copy=5), dict(out_fmt=3),
-               dict(min_cov=4, out_fmt=4), dict(k=12), dict(max_div=0.05), dict(min_p=200), dict(max_p=100), dict(hpc=1), dict(hpc=1, k=6), dict(w=5), dict(w=10, k=5), dict(w=4, hpc=1)):
+               dict(min_cov=4, out_fmt=4), dict(k=12), dict(max_div=0.05), dict(min_p=200), dict(max_p=100), dict(hpc=1), dict(hpc=1, k=6), dict(w=5), dict(w=10, k=5), dict(w=4, hpc=1),
+               dict(match=3, mismatch=5), dict(gap_open1=6, gap_ext1=3, gap_open2=30, gap_ext2=1), dict(match=40, mismatch=50), dict(mismatch=1, gap_ext1=1)):
         t = TH.TideHunter(device=0, **kw)
         U.assert_records_equal(seqs, t.process(seqs), O.default_para(**kw), str(kw))
         t.close()

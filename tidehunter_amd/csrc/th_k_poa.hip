@@ -13,11 +13,12 @@
 //                register relaxation (no memory round trips);
 //   row tables : per row (order index) base, degrees, predecessor / successor ROW indices, so the DP
 //                loop never chases node ids;
-//   DP         : band cells one lane each, F1/F2 as max-plus prefix scans; the previous row stays
-//                in registers (lane shuffles) when it is the only predecessor, so the common
-//                row has no dependent HBM load; cells {H,E1',E2',dir} go to HBM as 16-byte vectors;
-//   traceback  : sequential, but reads its direction words from 16-row x 4-diagonal tiles
-//                prefetched by the whole wave;
+//   DP         : rows whose only predecessor is the cached previous row run two columns per lane on packed int16
+//                pairs, other rows one column per lane; F1/F2 are max-plus prefix scans (DPP); the three previous
+//                rows live in an LDS int16 ring, so the common row has no dependent HBM load; only the 4-byte
+//                direction word of a cell goes to HBM unless a far row needs {H,E1',E2'};
+//   traceback  : sequential, but reads its direction words from 16-row x 4-diagonal tiles loaded by the whole
+//                wave, and emits plain diagonal runs of a tile column in one step;
 //   merge      : one alignment column per lane (node choice, ring splice, new ids by prefix sum,
 //                edges: every node is `from` once and `to` once per path, so lanes never collide);
 //   order      : positions of new nodes by a prefix sum over the old order.

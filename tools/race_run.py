@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0,'.')
+sys.path.insert(0, '.')
 import numpy as np
 import tidehunter_amd as TH
 lib = sys.argv[2] if len(sys.argv) > 2 else None
