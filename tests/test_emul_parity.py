@@ -118,6 +118,19 @@ def test_emul_poa_scoring_options(emu):
         th.close()
 
 
+def test_emul_unpacked_chain_records(emu, monkeypatch):
+    """batches holding a read of 65536+ bases use the unpacked chain-DP records; TH_CHAIN_UNPACKED forces that path on a
+    small batch (the real trigger is covered on the GPU: test_gpu_batch_with_a_long_read)"""
+    monkeypatch.setenv("TH_CHAIN_UNPACKED", "1")
+    th = TH.TideHunter(lib_path=emu)
+    seqs = _reads(th.lib, [(90, 6, 0.08), (200, 4, 0.1)], seed=23)
+    para = O.default_para()
+    got = th.process(seqs)
+    U.stage_compare(th, seqs, para)
+    U.assert_records_equal(seqs, got, para, "unpacked chain records")
+    th.close()
+
+
 def test_refuses_out_of_range_window(emu):
     for kw in (dict(w=0), dict(w=257)):
         with pytest.raises(RuntimeError):

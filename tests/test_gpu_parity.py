@@ -88,6 +88,18 @@ def test_gpu_options(th):
         t.close()
 
 
+def test_gpu_batch_with_a_long_read(th):
+    """a read of 65536+ bases switches the whole batch to the unpacked chain-DP records, the 64-bit sort words and the
+    HBM sort scratch"""
+    rng = np.random.default_rng(5)
+    long_read = bytes(b"ACGT"[i] for i in rng.integers(0, 4, 66000))
+    seqs = [long_read] + _synth(th.lib, 4, 90, 6, 0.08, 23) + _synth(th.lib, 2, 1000, 5, 0.1, 24)
+    para = O.default_para()
+    got = th.process(seqs)
+    U.stage_compare(th, seqs, para)
+    U.assert_records_equal(seqs, got, para, "long read in batch")
+
+
 def test_gpu_adapters_full_length(th):
     ad = (os.path.join(U.DATA, "5prime.fa"), os.path.join(U.DATA, "3prime.fa"))
     para = O.default_para()

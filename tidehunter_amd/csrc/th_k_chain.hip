@@ -23,15 +23,19 @@ enum { TH_NO_CON = 0, TH_REG_CON = 1, TH_SAME_CON = 2, TH_OVL_CON = 3 };
 // would have improved the best in sequential order; ballots of the four stop rules give the
 // first lane (in scan order) that ends the scan, and lanes beyond it are discarded.
 // ---------------------------------------------------------------------------------------------
+// PK: every read of the batch is shorter than 65536 bases, so a hit's (end, period) fit one 32-bit word; the window
+// scan then reads one 8-byte {end<<16|period, score} record per predecessor instead of three 4-byte words.
+template <bool PK>
 __global__ void __launch_bounds__(TH_CHAIN_BLOCK)
 th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
               const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ hit_n,
-              int *__restrict__ score, int *__restrict__ from)
+              int *__restrict__ score, int *__restrict__ from, unsigned long long *__restrict__ eps)
 {
     // Measured alternatives (batch 16384, config 3; this version 43 ms): a per-wave LDS ring of the last 1024 hits
     // removes the window re-reads from HBM but its 48 KiB per workgroup cuts residency to 3 waves per SIMD (62 ms);
-    // a 512-hit ring 46 ms; scoring 2 or 4 chunks ahead of the resolution 49 / 85 ms.  The kernel is bound by VALU
-    // issue (about 90 instructions per 64 predecessors), not by the loads.
+    // a 512-hit ring 46 ms; scoring 2 or 4 chunks ahead of the resolution 49 / 85 ms.  Each hit is re-read ~250 times by
+    // the sliding window (881 GB of L2/Infinity-Cache fabric traffic per 65536 reads = 5.5 TB/s), with VALU issue
+    // (about 90 instructions per 64 predecessors) right behind; hence the packed 8-byte records.
     const int lane = TH_LANE();
     const int r = blockIdx.x * (TH_CHAIN_BLOCK / TH_WAVE) + (threadIdx.x >> 6);
     const bool live = r < n_reads;
@@ -39,8 +43,13 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
     const int n = live ? hit_n[r] : 0, k = P.k;
     const int *E = hit_end + off, *Pd = hit_per + off;
     int *S = score + off, *F = from + off;
+    unsigned long long *R = eps + off;
     // init_dp (src/tandem_chain.c:113-126): score = k + min(k, period), no predecessor
-    for (int i = lane; i < n; i += TH_WAVE) { S[i] = k + min(k, Pd[i]); F[i] = -1; }
+    for (int i = lane; i < n; i += TH_WAVE) {
+        const int e = E[i], p = Pd[i], s0 = k + min(k, p);
+        S[i] = s0; F[i] = -1;
+        if (PK) R[i] = (unsigned long long)(uint32_t)s0 << 32 | (uint32_t)e << 16 | (uint32_t)p;
+    }
     TH_WAVE_FENCE();
     for (int cur = 1; cur < n; ++cur) {
         const int ce = E[cur], cp = Pd[cur], cs = ce - cp;
@@ -50,7 +59,11 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
         for (int base = cur - 1; base >= 0; base -= TH_WAVE) {
             const int idx = base - lane;
             const bool valid = idx >= 0;
-            const int pe = valid ? E[idx] : 0, pp = valid ? Pd[idx] : 1, psc = valid ? S[idx] : 0;
+            int pe, pp, psc;
+            if (PK) {
+                const unsigned long long rec = valid ? R[idx] : 1ull;
+                pe = (int)((uint32_t)rec >> 16); pp = (int)((uint32_t)rec & 0xffffu); psc = (int)(rec >> 32);
+            } else { pe = valid ? E[idx] : 0; pp = valid ? Pd[idx] : 1; psc = valid ? S[idx] : 0; }
             const int ps = pe - pp;
             const bool dstop = !valid || pe < cs;                  // :331  predecessor ends before cur starts
             int type = TH_NO_CON, con = 0;
@@ -86,7 +99,10 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             if (f < 64) break;
             iter = impm ? 63 - th_msb64(impm) : iter + TH_WAVE;
         }
-        if (lane == 0 && best > init) { S[cur] = best; F[cur] = bi; }                                   // :352-354
+        if (lane == 0 && best > init) {                                                                 // :352-354
+            S[cur] = best; F[cur] = bi;
+            if (PK) ((int *)(R + cur))[1] = best;
+        }
         TH_WAVE_FENCE();
     }
 }

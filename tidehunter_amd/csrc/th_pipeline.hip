@@ -47,7 +47,7 @@ struct th_gpu {
     DBuf<uint32_t> d_roff, d_tmp;
     DBuf<uint16_t> d_xorder; DBuf<int> d_xstart, d_xend;   // candidates in extraction order (th_k_chain_sort)
     DBuf<int> d_hit_end, d_hit_per, d_hit_n, d_score, d_from, d_cells, d_cnt, d_read_ch_base, d_read_ch_n;
-    DBuf<unsigned long long> d_gsort; DBuf<long long> d_gsort_off;
+    DBuf<unsigned long long> d_gsort, d_eps; DBuf<long long> d_gsort_off;
     DBuf<ThChainRec> d_rec;
     DBuf<int> d_par, d_par_off, d_par_n, d_par_dst, d_parc, d_bnd, d_scratch, d_cov, d_cons_len, d_status, d_iden, d_ext;
     DBuf<ThTask> d_tasks; DBuf<ThUnit> d_units; DBuf<ThAlnItem> d_items;
@@ -88,7 +88,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
 extern "C" void th_gpu_destroy(th_gpu_t *g)
 {
     if (!g) return;
-    g->d_seq.release(); g->d_bseq.release(); g->d_tracked.release(); g->d_xorder.release(); g->d_xstart.release(); g->d_xend.release(); g->d_cons.release(); g->d_roff.release(); g->d_tmp.release();
+    g->d_seq.release(); g->d_bseq.release(); g->d_tracked.release(); g->d_eps.release(); g->d_xorder.release(); g->d_xstart.release(); g->d_xend.release(); g->d_cons.release(); g->d_roff.release(); g->d_tmp.release();
     g->d_hit_end.release(); g->d_hit_per.release(); g->d_hit_n.release(); g->d_score.release(); g->d_from.release(); g->d_cells.release();
     g->d_cnt.release(); g->d_read_ch_base.release(); g->d_read_ch_n.release(); g->d_gsort.release(); g->d_gsort_off.release(); g->d_rec.release();
     g->d_par.release(); g->d_par_off.release(); g->d_par_n.release(); g->d_par_dst.release(); g->d_parc.release(); g->d_bnd.release(); g->d_scratch.release();
@@ -233,8 +233,13 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         TH_LAUNCH((th_k_hits<unsigned long long, 32>), n, TH_SEED_BLOCK, g->stream, (const uint8_t *)g->d_bseq.p, (const uint32_t *)g->d_roff.p, g->dp,
                   g->d_hit_end.p, g->d_hit_per.p, g->d_hit_n.p, g->d_tmp.p, g->d_gsort.p, (const long long *)g->d_gsort_off.p, g->d_cnt.p + 1);
     KT_END(TK_SEED); KT_BEGIN(TK_CHAIN_DP);
-    TH_LAUNCH(th_k_chain_dp, (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
-              (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p);
+    if (g->max_len < 65536 && !getenv("TH_CHAIN_UNPACKED")) {      // (the environment knob exists for the CPU tests)
+        TRY(g->d_eps.ensure(padT));
+        TH_LAUNCH((th_k_chain_dp<true>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
+                  (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p, g->d_eps.p);
+    } else
+        TH_LAUNCH((th_k_chain_dp<false>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
+                  (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p, (unsigned long long *)nullptr);
     KT_END(TK_CHAIN_DP); KT_BEGIN(TK_CHAIN_X);
     TH_LAUNCH(th_k_chain_extract, n, TH_XBLOCK, g->stream, (const uint32_t *)g->d_roff.p, g->dp,
               (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p,
