@@ -28,6 +28,7 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
            const uint8_t *__restrict__ cons, const int *__restrict__ cons_len,
            int *__restrict__ bnd, long long bnd_stride, int *__restrict__ iden, int *__restrict__ ext, int *__restrict__ err, int *__restrict__ queue)
 {
+    __shared__ __attribute__((aligned(16))) int s_in[2][TH_WAVE][8];      // left-border inbox of the banded sweep (two 64-row blocks)
     const int lane = TH_LANE();
     const int wave = blockIdx.x;
     int *mybnd = bnd + (long long)wave * bnd_stride;
@@ -50,7 +51,7 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                     // banded pass with an exactness certificate first; the full matrix only when it cannot be certified
                     const int W = cl / 8 + 32, D = cl - len;
                     v = -1;
-                    if (64 + 2 * W + (D < 0 ? -D : D) < (cl * 3) / 4) v = th_ksw_global_band_wave(rb + start + 1, len, cs, cl, W, mybnd);
+                    if (64 + 2 * W + (D < 0 ? -D : D) < (cl * 3) / 4) v = th_ksw_global_band_wave(rb + start + 1, len, cs, cl, W, mybnd, s_in);
                     if (v < 0) v = th_ksw_global_wave<false>(rb + start + 1, len, cs, cl, 0, mybnd, nullptr);
                 }
             }

@@ -130,7 +130,7 @@ __device__ int th_ksw_global_wave(const uint8_t *__restrict__ q, int qlen, const
 // the traceback -- lies inside the band, hence H, the tie-breaks and the '=' count along ksw_backtrack's
 // path are those of the full computation.  Returns -1 when the certificate fails (the caller then
 // runs the full matrix).  Strip geometry: columns j0..j0+63 need rows [j0+lo, j0+63+hi] only.
-__device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, int W, int *__restrict__ bnd)
+__device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, int W, int *__restrict__ bnd, int (*s_in)[TH_WAVE][8])
 {
     const int lane = TH_LANE();
     const int D = tlen - qlen;
@@ -154,23 +154,32 @@ __device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, 
             if (row < tlen) { nt = t[row]; if (!first && row <= pre) nb = bnd4[row]; }
         }
         for (int s0 = 0; s0 < nsteps; s0 += TH_WAVE) {
-            int ibH, ibF, ibCH, ibT2, ibT = nt;
-            if (first) {
-                const int row = rs + s0 + lane;
-                const bool inb = row + 1 <= hi;                     // border column -1 has d = row + 1
-                ibH = inb ? -(TH_KQ + (row + 1) * TH_KE) : TH_NEG; ibF = inb ? ibH - TH_KQ - TH_KE : TH_NEG; ibCH = 0; ibT2 = 0;
-            } else { ibH = nb.x; ibF = nb.y; ibCH = nb.z; ibT2 = nb.w; }
+            // the 64 rows' left-border cells (previous strip's last column, or the matrix border) are parked in LDS, one
+            // entry per row; every step all lanes read the entry of their step (one broadcast ds_read, issued a step
+            // ahead) and wave_shr:1 injects it at lane 0 -- no rotating copy of the border in registers
+            int (*inbox)[8] = s_in[(s0 >> 6) & 1];
+            {
+                int4 ib; const int ibT = nt;
+                if (first) {
+                    const int row = rs + s0 + lane;
+                    const bool inb = row + 1 <= hi;                     // border column -1 has d = row + 1
+                    ib.x = inb ? -(TH_KQ + (row + 1) * TH_KE) : TH_NEG; ib.y = inb ? ib.x - TH_KQ - TH_KE : TH_NEG; ib.z = 0; ib.w = 0;
+                } else ib = nb;
+                *(int4 *)&inbox[lane][0] = ib; inbox[lane][4] = ibT;
+            }
+            TH_WAVE_FENCE();
             {
                 const int row = rs + s0 + TH_WAVE + lane;
                 nt = 4; nb.x = TH_NEG; nb.y = TH_NEG; nb.z = 0; nb.w = 0;
                 if (row < tlen) { nt = t[row]; if (!first && row <= pre) nb = bnd4[row]; }
             }
             const int kend = min(TH_WAVE, nsteps - s0);
+            int4 in = *(const int4 *)&inbox[0][0]; int inT = inbox[0][4];
             for (int k = 0; k < kend; ++k) {
                 const int i = rs + s0 + k - lane;
-                const int lH = th_shr1_inject(oH, ibH), lF = th_shr1_inject(oF, ibF), lCH = th_shr1_inject(oCH, ibCH), lT2 = th_shr1_inject(oT2, ibT2);
-                const int ti = th_shr1_inject(tcur, ibT);
-                ibH = th_rol1(ibH); ibF = th_rol1(ibF); ibCH = th_rol1(ibCH); ibT2 = th_rol1(ibT2); ibT = th_rol1(ibT);
+                const int lH = th_shr1_inject(oH, in.x), lF = th_shr1_inject(oF, in.y), lCH = th_shr1_inject(oCH, in.z), lT2 = th_shr1_inject(oT2, in.w);
+                const int ti = th_shr1_inject(tcur, inT);
+                { const int kn = min(k + 1, TH_WAVE - 1); in = *(const int4 *)&inbox[kn][0]; inT = inbox[kn][4]; }
                 tcur = ti;
                 if (i == 0) {   // top border (row -1) where it lies inside the band
                     Hup = (-1 - j >= lo) ? -(TH_KQ + (j + 1) * TH_KE) : TH_NEG; Ein = Hup > TH_NEG ? Hup - TH_KQ - TH_KE : TH_NEG; T1up = 0;
