@@ -175,11 +175,13 @@ __device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, 
             }
             const int kend = min(TH_WAVE, nsteps - s0);
             int4 in = *(const int4 *)&inbox[0][0]; int inT = inbox[0][4];
-            for (int k = 0; k < kend; ++k) {
+            // one sweep step; `cin` / `cinT` hold this step's inbox entry, the next one is fetched into `nin` / `ninT`.
+            // The loop below alternates two register sets so that no copy is needed between steps.
+            auto step = [&](int k, int4 &cin, int &cinT, int4 &nin, int &ninT) {
                 const int i = rs + s0 + k - lane;
-                const int lH = th_shr1_inject(oH, in.x), lF = th_shr1_inject(oF, in.y), lCH = th_shr1_inject(oCH, in.z), lT2 = th_shr1_inject(oT2, in.w);
-                const int ti = th_shr1_inject(tcur, inT);
-                { const int kn = min(k + 1, TH_WAVE - 1); in = *(const int4 *)&inbox[kn][0]; inT = inbox[kn][4]; }
+                const int lH = th_shr1_inject(oH, cin.x), lF = th_shr1_inject(oF, cin.y), lCH = th_shr1_inject(oCH, cin.z), lT2 = th_shr1_inject(oT2, cin.w);
+                const int ti = th_shr1_inject(tcur, cinT);
+                { const int kn = min(k + 1, TH_WAVE - 1); nin = *(const int4 *)&inbox[kn][0]; ninT = inbox[kn][4]; }
                 tcur = ti;
                 if (i == 0) {   // top border (row -1) where it lies inside the band
                     Hup = (-1 - j >= lo) ? -(TH_KQ + (j + 1) * TH_KE) : TH_NEG; Ein = Hup > TH_NEG ? Hup - TH_KQ - TH_KE : TH_NEG; T1up = 0;
@@ -200,7 +202,11 @@ __device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, 
                 oH = inb ? h : TH_NEG; oF = inb ? max(lF, h - TH_KQ) - TH_KE : TH_NEG; oCH = ch; oT2 = t2;
                 if (owner && i == tlen - 1) { res_iden = ch; res_h = h; }
                 if (!last && lane == 63 && i >= 0 && i < tlen) { int4 o; o.x = oH; o.y = oF; o.z = oCH; o.w = oT2; bnd4[i] = o; }
-            }
+            };
+            int4 in2; int in2T;
+            int k = 0;
+            for (; k + 1 < kend; k += 2) { step(k, in, inT, in2, in2T); step(k + 1, in2, in2T, in, inT); }
+            if (k < kend) step(k, in, inT, in2, in2T);
         }
         TH_WAVE_FENCE();
     }
