@@ -177,18 +177,18 @@ __device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, 
             int4 in = *(const int4 *)&inbox[0][0]; int inT = inbox[0][4];
             // one sweep step; `cin` / `cinT` hold this step's inbox entry, the next one is fetched into `nin` / `ninT`.
             // The loop below alternates two register sets so that no copy is needed between steps.
+            const bool top_ok = rs + s0 < TH_WAVE;               // row 0 can only be met in a block that starts above row 64
             auto step = [&](int k, int4 &cin, int &cinT, int4 &nin, int &ninT) {
                 const int i = rs + s0 + k - lane;
                 const int lH = th_shr1_inject(oH, cin.x), lF = th_shr1_inject(oF, cin.y), lCH = th_shr1_inject(oCH, cin.z), lT2 = th_shr1_inject(oT2, cin.w);
                 const int ti = th_shr1_inject(tcur, cinT);
                 { const int kn = min(k + 1, TH_WAVE - 1); nin = *(const int4 *)&inbox[kn][0]; ninT = inbox[kn][4]; }
                 tcur = ti;
-                if (i == 0) {   // top border (row -1) where it lies inside the band
+                if (top_ok && i == 0) {   // top border (row -1) where it lies inside the band
                     Hup = (-1 - j >= lo) ? -(TH_KQ + (j + 1) * TH_KE) : TH_NEG; Ein = Hup > TH_NEG ? Hup - TH_KQ - TH_KE : TH_NEG; T1up = 0;
                     Hdiag = j == 0 ? 0 : ((-j >= lo) ? -(TH_KQ + j * TH_KE) : TH_NEG); CHdiag = 0;
                 }
-                const int dd = i - j;
-                const bool inb = colok && i >= 0 && i < tlen && dd >= lo && dd <= hi;
+                const bool inb = colok && (unsigned)i < (unsigned)tlen && (unsigned)(i - j - lo) <= (unsigned)(hi - lo);
                 const int diag = Hdiag + th_ksw_sc(ti, qj);
                 int d = Ein > diag ? 1 : 0;
                 int h = max(diag, Ein);
@@ -200,7 +200,7 @@ __device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, 
                 Hup = h; T1up = t1;
                 Ein = inb ? max(Ein, h - TH_KQ) - TH_KE : TH_NEG;
                 oH = inb ? h : TH_NEG; oF = inb ? max(lF, h - TH_KQ) - TH_KE : TH_NEG; oCH = ch; oT2 = t2;
-                if (owner && i == tlen - 1) { res_iden = ch; res_h = h; }
+                if (last && owner && i == tlen - 1) { res_iden = ch; res_h = h; }
                 if (!last && lane == 63 && i >= 0 && i < tlen) { int4 o; o.x = oH; o.y = oF; o.z = oCH; o.w = oT2; bnd4[i] = o; }
             };
             int4 in2; int in2T;
