@@ -189,12 +189,15 @@ __device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, 
                     Hdiag = j == 0 ? 0 : ((-j >= lo) ? -(TH_KQ + j * TH_KE) : TH_NEG); CHdiag = 0;
                 }
                 const bool inb = colok && (unsigned)i < (unsigned)tlen && (unsigned)(i - j - lo) <= (unsigned)(hi - lo);
+                // ties prefer the diagonal over E over F (ksw2_extz2_sse.c:177-195); written as selects so that no lane diverges
                 const int diag = Hdiag + th_ksw_sc(ti, qj);
-                int d = Ein > diag ? 1 : 0;
-                int h = max(diag, Ein);
-                if (lF > h) { d = 2; h = lF; }
+                const bool e_gt = Ein > diag;
+                const int h1 = max(diag, Ein);
+                const bool f_gt = lF > h1;
+                const int h = max(h1, lF);
                 const bool xe = Ein > h - TH_KQ, xf = lF > h - TH_KQ;
-                const int ch = d == 0 ? CHdiag + (ti == qj) : d == 1 ? T1up : lT2;
+                const int ch01 = e_gt ? T1up : CHdiag + (ti == qj ? 1 : 0);
+                const int ch = f_gt ? lT2 : ch01;
                 const int t1 = xe ? T1up : ch, t2 = xf ? lT2 : ch;
                 Hdiag = lH; CHdiag = lCH;
                 Hup = h; T1up = t1;
