@@ -108,6 +108,17 @@ def test_emul_minimizer_seeding(emu):
         th.close()
 
 
+def test_emul_config5_adapters(emu, tmp_path):
+    """adapter-bounded units on both strands through the host-side adapter search (edlib restatement)"""
+    seqs, ad = U.config5_reads(tmp_path, 2, periods=(200, 240))
+    for kw in (dict(), dict(only_full_length=1)):
+        para = O.default_para(**kw)
+        O.load().tho_para_load_adapters(para, ad[0].encode(), ad[1].encode())
+        th = TH.TideHunter(lib_path=emu, adapters=ad, **kw)
+        U.assert_records_equal(seqs, th.process(seqs), para, "config5 %r" % (kw,))
+        th.close()
+
+
 def test_emul_poa_scoring_options(emu):
     """-M -X -O -E: the packed int16 POA rows read their scores from a per-row table (match, mismatch <= 31); larger
     scores take the 32-bit rows"""

@@ -112,6 +112,21 @@ def test_gpu_adapters_full_length(th):
     t.close()
 
 
+def test_gpu_config5_adapters(tmp_path):
+    """config 5 shape: adapter-bounded units of mixed periods, both strands, with and without -F (full length only)"""
+    seqs, ad = U.config5_reads(tmp_path, 24)
+    for kw in (dict(), dict(only_full_length=1), dict(only_full_length=1, single_copy=1)):
+        para = O.default_para(**kw)
+        O.load().tho_para_load_adapters(para, ad[0].encode(), ad[1].encode())
+        t = TH.TideHunter(device=0, adapters=ad, **kw)
+        got = t.process(seqs)
+        n = U.assert_records_equal(seqs, got, para, "config5 %r" % (kw,))
+        assert n >= 12
+        if not kw:
+            assert sum(1 for rr in got for r in rr if r["full_length"] > 0) >= 8
+        t.close()
+
+
 def test_gpu_batch_order_and_idempotence(th):
     """results do not depend on what else is in the batch or on running it twice"""
     seqs = _synth(th.lib, 12, 250, 6, 0.1, 33)

@@ -87,3 +87,36 @@ def stage_compare(th, seqs, para):
             assert list(cells[m[1]:m[1] + m[2]]) == c["cells"], r
             assert (m[3], m[4]) == (c["est_start"], c["est_period"]), r
             assert list(parc[m[5]:m[5] + m[6]]) == c["par_pos"], "par_pos differs, read %d" % r
+
+
+def config5_reads(tmpdir, n, seed=5, err=0.10, periods=(200, 500, 1000)):
+    """SURVEY 8(d) config 5 shape: unit = 5' adapter (84 nt) + random insert + revcomp(3' adapter, 25 nt), tandemly repeated
+    with substitutions / insertions / deletions; half of the reads reverse-complemented.  Writes 5p.fa / 3p.fa into tmpdir and
+    returns (reads, (five_fn, three_fn))."""
+    rng = np.random.default_rng(seed)
+    rnd = lambda k: bytes(b"ACGT"[i] for i in rng.integers(0, 4, k))
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    rc = lambda s: s.translate(comp)[::-1]
+    five, three = rnd(84), rnd(25)
+    fns = (os.path.join(str(tmpdir), "5p.fa"), os.path.join(str(tmpdir), "3p.fa"))
+    open(fns[0], "wb").write(b">5p\n" + five + b"\n")
+    open(fns[1], "wb").write(b">3p\n" + three + b"\n")
+    reads = []
+    for r in range(n):
+        period = periods[r % len(periods)]
+        unit = five + rnd(period - 84 - 25) + rc(three)
+        copies = max(3, 3000 // period)
+        out = bytearray(rnd(int(rng.integers(0, 40))))           # a little flank
+        for b in unit * copies:
+            x = rng.random()
+            if x < err / 3:
+                out.append(b"ACGT"[(b"ACGT".index(b) + 1 + int(rng.integers(0, 3))) & 3])
+            elif x < 2 * err / 3:
+                out.append(b); out.append(b"ACGT"[int(rng.integers(0, 4))])
+            elif x < err:
+                pass
+            else:
+                out.append(b)
+        s = bytes(out)
+        reads.append(rc(s) if r & 1 else s)
+    return reads, fns
