@@ -318,6 +318,7 @@ th_handle_t *th_init(const th_para_t *p, int device)
     gp.k = (int)p->k; gp.w = (int)p->w; gp.hpc = p->hpc ? 1 : 0; gp.min_p = (uint32_t)p->min_p; gp.max_p = (uint32_t)p->max_p; gp.one_minus_div = 1 - p->max_div; gp.min_copy = p->min_copy;
     gp.match = p->match; gp.mismatch = p->mismatch; gp.go1 = p->gap_open1; gp.ge1 = p->gap_ext1; gp.go2 = p->gap_open2; gp.ge2 = p->gap_ext2;
     gp.only_unit = p->only_unit;
+    gp.want_cov = (p->min_cov > 0 || p->min_frac > 0.0 || p->out_fmt == TH_FASTQ_FMT || p->out_fmt == TH_TAB_QUAL_FMT) ? 1 : 0;
     th_gpu_t *g = th_gpu_create(&gp, device);
     if (!g) return NULL;
     th_handle_t *h = (th_handle_t *)calloc(1, sizeof(*h));
@@ -399,7 +400,7 @@ static void finish_job(const th_handle_t *h, const th_gpu_out_t *o, const th_job
     if (p->only_unit) { write_unit(t, pos, pos_n); return; }
     int cons_len = j->cons_len, n_seqs = j->n_seqs;
     if (cons_len <= 0) return;
-    const uint8_t *cb = o->cons + j->cons_off; const int *cov = o->cov + j->cons_off;
+    const uint8_t *cb = o->cons + j->cons_off; const int *cov = o->cov ? o->cov + j->cons_off : NULL;
     const int want_q = p->out_fmt == TH_FASTQ_FMT || p->out_fmt == TH_TAB_QUAL_FMT;
     int min_cov = 0;
     if (p->min_frac > 0.0) min_cov = (int)(n_seqs * p->min_frac); else if (p->min_cov > 0) min_cov = p->min_cov;
@@ -475,17 +476,41 @@ WRITE:
     free(cons_seq); free(qual);
 }
 
+/* Record arithmetic of a batch (src/gen_cons.c:208-301 per consensus job): reads are independent and each writes only its
+ * own tandem_seq_t slot, so the batch is cut into contiguous read ranges for a few worker threads. */
+typedef struct { th_handle_t *h; const th_gpu_out_t *o; th_tandem_seq_t *out; int r0, r1; } collect_arg_t;
+static void *collect_range(void *arg)
+{
+    collect_arg_t *a = (collect_arg_t *)arg;
+    th_handle_t *h = a->h; const th_gpu_out_t *o = a->o; const th_para_t *p = &h->para;
+    int lo = 0, hi = o->n_jobs;                  /* first job of read >= r0 (jobs are ordered by read) */
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (o->jobs[mid].read < a->r0) lo = mid + 1; else hi = mid; }
+    int ji = lo;
+    for (int r = a->r0; r < a->r1; ++r) {
+        th_tandem_seq_t *t = &a->out[r];
+        t->cons_n = 0; t->cons_seq_l = 0; t->cons_qual_l = 0;
+        while (ji < o->n_jobs && o->jobs[ji].read == r) { finish_job(h, o, &o->jobs[ji], t); ++ji; }
+        if (h->lens[r] >= p->k && p->single_copy == 1 && p->only_full_length && p->five_seq != NULL && p->three_seq != NULL)
+            single_copy(h->lens[r], h->seqs[r], t, p);   /* src/tidehunter.c:24,49-51 */
+    }
+    return NULL;
+}
 int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out)
 {
     th_gpu_out_t o; th_gpu_get(h->gpu, &o);
-    const th_para_t *p = &h->para;
-    for (int i = 0; i < h->n; ++i) { out[i].cons_n = 0; out[i].cons_seq_l = 0; out[i].cons_qual_l = 0; }
-    int ji = 0;
-    for (int r = 0; r < h->n; ++r) {
-        while (ji < o.n_jobs && o.jobs[ji].read == r) { finish_job(h, &o, &o.jobs[ji], &out[r]); ++ji; }
-        if (h->lens[r] >= p->k && p->single_copy == 1 && p->only_full_length && p->five_seq != NULL && p->three_seq != NULL)
-            single_copy(h->lens[r], h->seqs[r], &out[r], p);   /* src/tidehunter.c:24,49-51 */
+    int nth = 8;
+    const char *e = getenv("TH_HOST_THREADS");
+    if (e && atoi(e) > 0) nth = atoi(e);
+    if (nth > 64) nth = 64;
+    if (h->n < 256 * nth) nth = 1;
+    collect_arg_t arg[64]; pthread_t tid[64];
+    for (int t = 0; t < nth; ++t) {
+        arg[t].h = h; arg[t].o = &o; arg[t].out = out;
+        arg[t].r0 = (int)((long long)h->n * t / nth); arg[t].r1 = (int)((long long)h->n * (t + 1) / nth);
     }
+    for (int t = 1; t < nth; ++t) pthread_create(&tid[t], NULL, collect_range, &arg[t]);
+    collect_range(&arg[0]);
+    for (int t = 1; t < nth; ++t) pthread_join(tid[t], NULL);
     return 0;
 }
 

@@ -12,6 +12,7 @@ typedef struct {
     int k, w, hpc; uint32_t min_p, max_p; double one_minus_div; int min_copy;
     int match, mismatch, go1, ge1, go2, ge2;
     int only_unit;          /* -u: stop after partition (no POA, no alignment) */
+    int want_cov;           /* per-base coverage is needed on the host (-r / -c filters, FASTQ / -f 4 qualities) */
 } th_gpu_para_t;
 
 /* one consensus job as the host sees it after the device run */
@@ -28,7 +29,7 @@ typedef struct {
 typedef struct {
     int n_jobs; const th_job_t *jobs;
     const int *par;         /* compact par_pos values */
-    const uint8_t *cons; const int *cov; const int *iden;
+    const uint8_t *cons; const int *cov; const int *iden;   /* cov is NULL unless want_cov */
     double ms_kernels;      /* device time of the last run (HIP events), all kernels */
     double ms_dominant;     /* device time of the slowest kernel of the last run */
     double ms_kernel[8];    /* per kernel: 0 encode+hits, 1 chain_dp, 2 chain_extract, 3 partition, 4 poa, 5 align */

@@ -45,7 +45,8 @@ struct th_gpu {
     std::vector<uint32_t> h_roff; std::vector<long long> h_gsort_off; long long gsort_total = 0;
     DBuf<uint8_t> d_seq, d_bseq, d_tracked, d_cons;
     DBuf<uint32_t> d_roff, d_tmp;
-    DBuf<uint16_t> d_xorder; DBuf<int> d_xstart, d_xend;   // candidates in extraction order (th_k_chain_sort)
+    DBuf<uint16_t> d_xorder; DBuf<int> d_xstart, d_xend;
+    DBuf<uint8_t> d_cons_c; DBuf<int> d_cov_c, d_cc_len, d_cc_off;   // compacted results   // candidates in extraction order (th_k_chain_sort)
     DBuf<int> d_hit_end, d_hit_per, d_hit_n, d_score, d_from, d_cells, d_cnt, d_read_ch_base, d_read_ch_n;
     DBuf<unsigned long long> d_gsort, d_eps; DBuf<long long> d_gsort_off;
     DBuf<ThChainRec> d_rec;
@@ -88,7 +89,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
 extern "C" void th_gpu_destroy(th_gpu_t *g)
 {
     if (!g) return;
-    g->d_seq.release(); g->d_bseq.release(); g->d_tracked.release(); g->d_eps.release(); g->d_xorder.release(); g->d_xstart.release(); g->d_xend.release(); g->d_cons.release(); g->d_roff.release(); g->d_tmp.release();
+    g->d_seq.release(); g->d_bseq.release(); g->d_tracked.release(); g->d_cons_c.release(); g->d_cov_c.release(); g->d_cc_len.release(); g->d_cc_off.release(); g->d_eps.release(); g->d_xorder.release(); g->d_xstart.release(); g->d_xend.release(); g->d_cons.release(); g->d_roff.release(); g->d_tmp.release();
     g->d_hit_end.release(); g->d_hit_per.release(); g->d_hit_n.release(); g->d_score.release(); g->d_from.release(); g->d_cells.release();
     g->d_cnt.release(); g->d_read_ch_base.release(); g->d_read_ch_n.release(); g->d_gsort.release(); g->d_gsort_off.release(); g->d_rec.release();
     g->d_par.release(); g->d_par_off.release(); g->d_par_n.release(); g->d_par_dst.release(); g->d_parc.release(); g->d_bnd.release(); g->d_scratch.release();
@@ -382,11 +383,21 @@ extern "C" int th_gpu_run(th_gpu_t *g)
                   g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, g->d_cnt.p + 1, g->d_cnt.p + 4);   // queue head d_cnt[4] was zeroed with the other counters at the start of the run
         KT_END(TK_ALIGN);
         if (getenv("TH_TRACE")) { th_rt_sync(g->stream); fprintf(stderr, "[th] align done (%d items)\n", ni); }
-        g->h_iden.resize(aln_total); g->h_ext.resize((size_t)nt * 4); g->h_cons.resize((size_t)cons_total); g->h_cov.resize((size_t)cons_total);
+        // results: consensus strings compacted to their lengths (the slots are sized for the worst case), coverage only on request
+        std::vector<int> cc_off(nt); long long cc_total = 0;
+        for (int t = 0; t < nt; ++t) { cc_off[t] = (int)cc_total; cc_total += (g->h_cons_len[t] + 3) & ~3; }
+        TRY(g->d_cc_len.ensure(nt)); TRY(g->d_cc_off.ensure(nt)); TRY(g->d_cons_c.ensure((size_t)cc_total + 4));
+        if (g->para.want_cov) TRY(g->d_cov_c.ensure((size_t)cc_total + 4));
+        TRY(th_rt_h2d(g->d_cc_len.p, g->h_cons_len.data(), (size_t)nt * 4, g->stream));
+        TRY(th_rt_h2d(g->d_cc_off.p, cc_off.data(), (size_t)nt * 4, g->stream));
+        TH_LAUNCH(th_k_gather_cons, nt, 128, g->stream, nt, (const ThTask *)g->d_tasks.p, (const int *)g->d_cc_len.p, (const int *)g->d_cc_off.p,
+                  (const uint8_t *)g->d_cons.p, (const int *)g->d_cov.p, g->d_cons_c.p, g->para.want_cov ? g->d_cov_c.p : (int *)nullptr);
+        g->h_iden.resize(aln_total); g->h_ext.resize((size_t)nt * 4); g->h_cons.resize((size_t)cc_total + 4);
         TRY(th_rt_d2h(g->h_iden.data(), g->d_iden.p, (size_t)aln_total * 4, g->stream));
         TRY(th_rt_d2h(g->h_ext.data(), g->d_ext.p, (size_t)nt * 16, g->stream));
-        TRY(th_rt_d2h(g->h_cons.data(), g->d_cons.p, (size_t)cons_total, g->stream));
-        TRY(th_rt_d2h(g->h_cov.data(), g->d_cov.p, (size_t)cons_total * 4, g->stream));
+        TRY(th_rt_d2h(g->h_cons.data(), g->d_cons_c.p, (size_t)cc_total, g->stream));
+        if (g->para.want_cov) { g->h_cov.resize((size_t)cc_total + 4); TRY(th_rt_d2h(g->h_cov.data(), g->d_cov_c.p, (size_t)cc_total * 4, g->stream)); }
+        for (int t = 0; t < nt; ++t) g->jobs[t].cons_off = cc_off[t];
         TRY(th_rt_d2h(cnt, g->d_cnt.p, sizeof(cnt), g->stream));
         TRY(th_rt_sync(g->stream));
         if (cnt[1]) return th_fail("alignment boundary buffer overflow");
@@ -408,7 +419,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
 extern "C" int th_gpu_get(th_gpu_t *g, th_gpu_out_t *out)
 {
     out->n_jobs = (int)g->jobs.size(); out->jobs = g->jobs.data(); out->par = g->h_parc.data();
-    out->cons = g->h_cons.data(); out->cov = g->h_cov.data(); out->iden = g->h_iden.data();
+    out->cons = g->h_cons.data(); out->cov = g->para.want_cov ? g->h_cov.data() : nullptr; out->iden = g->h_iden.data();
     out->ms_kernels = g->ms_kernels; out->ms_dominant = g->ms_dominant;
     for (int k = 0; k < TK_N; ++k) out->ms_kernel[k] = g->ms_k[k];
     return 0;
