@@ -138,8 +138,10 @@ __device__ __forceinline__ int th_lane_shift(int v, int off, int fill)
 // (rare) loads instead leaves the steady-state trips without any vmcnt wait.
 #ifdef TH_CPU_EMUL
 #define TH_VM_WAIT0() ((void)0)
+#define TH_WAVES_PER_SIMD(n)
 #else
 #define TH_VM_WAIT0() __builtin_amdgcn_s_waitcnt(0x0F70)      // vmcnt(0), expcnt and lgkmcnt untouched
+#define TH_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))   // caps the VGPR budget so that n waves fit a SIMD
 #endif
 // next index of a shared work queue, wave-uniform.  Every lane takes part in the atomic (lane 0 adds 1, the
 // others 0), so there is no divergent region around it: with the add under `if (lane == 0)` hipcc 7.2

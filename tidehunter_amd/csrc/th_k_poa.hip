@@ -26,7 +26,7 @@
 
 #define TH_POA_BLOCK 64
 #define TH_POA_WB 10
-#define TH_POA_QCAP 4096        // query bases staged in LDS (jobs with longer units use the LQ=false instantiation)
+#define TH_POA_QCAP 3072        // query bases staged in LDS (jobs with longer units use the LQ=false instantiation)
 
 #define TH_D_SRC(d)  ((d) & 7)
 #define TH_D_PM(d)   (((d) >> 3) & 0xff)
@@ -695,7 +695,8 @@ __device__ __forceinline__ int *th_carve(int *&p, long long cnt) { int *r = p; p
 //         5 in-degree > 255, 6 consensus longer than cons_cap
 // LQ = true: the query of every alignment fits the LDS staging buffer (the common case); LQ = false reads it from HBM
 template <bool LQ>
-__global__ void __launch_bounds__(TH_POA_BLOCK)
+// 5 waves per SIMD: 96 VGPRs (9 dwords of scratch) and 8016 B of LDS per wave; measured 588 -> 557 ms per 65536 reads against 4 waves
+__global__ void __launch_bounds__(TH_POA_BLOCK) TH_WAVES_PER_SIMD(5)
 th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict__ units, const uint32_t *__restrict__ roff,
          const uint8_t *__restrict__ bseq, ThDevPara P, int *__restrict__ scratch, long long scratch_ints,
          uint8_t *__restrict__ cons, int *__restrict__ cov, int *__restrict__ cons_len, int *__restrict__ status, int *__restrict__ queue)

@@ -12,7 +12,7 @@
 #include "th_dev.h"
 
 #define TH_SORT_LDS 16384
-#define TH_SEED_BLOCK 256
+#define TH_SEED_BLOCK 512
 
 __device__ __forceinline__ uint8_t th_code(uint8_t c)
 {
