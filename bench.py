@@ -11,8 +11,8 @@ different batch of the 100k-read set (read index = rank_offset + step * batch + 
 For N > 1 the driver launches one rank per GPU with torch.distributed.run; reads shard across ranks
 (no data-path collective; RCCL is used for the barrier and the max-over-ranks of the time only).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel th_k_align, HIP-event timed on the
-kernel's own stream inside the library) and `cpu_baseline` (the CPU oracle, a scalar C port of the
+Prints ONE JSON line (rank 0) with `roofline` (the kernel with the largest device time -- th_k_poa --, HIP-event
+timed on the kernel's own stream inside the library) and `cpu_baseline` (the CPU oracle, a scalar C port of the
 reference's algorithm, timed on the host cores on a bounded sample of the same workload; N=1 only).
 """
 import argparse
