@@ -60,9 +60,20 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                 if ((long long)((cl + 63) & ~63) * 4 > bnd_stride) { if (lane == 0) atomicOr(err, 4); }
                 else if (len > 0) {
                     // banded pass with an exactness certificate first; the full matrix only when it cannot be certified
-                    const int W = cl / 8 + 32, D = cl - len;
+                    const int W = cl / 8 + 32, D = cl - len, aD = D < 0 ? -D : D;
                     v = -1;
-                    if (64 + 2 * W + (D < 0 ? -D : D) < (cl * 3) / 4) v = th_ksw_global_band_wave(rb + start + 1, len, cs, cl, W, mybnd, s_in);
+                    if (64 + 2 * W + aD < (cl * 3) / 4) {
+                        int s1 = 0;
+                        v = th_ksw_global_band_wave(rb + start + 1, len, cs, cl, W, mybnd, s_in, &s1);
+                        if (v < 0) {
+                            // not certified (more divergent than ~12 %): the banded score s1 bounds the optimum from below, and a band
+                            // whose Gmin exceeds (m + n - 2 s1 - 4q) / (1 + 2e) is certified for any optimum >= s1; run that band if
+                            // it is still clearly narrower than the matrix
+                            const long long g2 = ((long long)len + cl - 2LL * s1 - 4 * TH_KQ) / (1 + 2 * TH_KE) + 2;
+                            const long long W2 = (g2 - 2 - aD + 1) / 2 + 8;
+                            if (W2 > W && 64 + 2 * W2 + aD < (cl * 3) / 4) v = th_ksw_global_band_wave(rb + start + 1, len, cs, cl, (int)W2, mybnd, s_in, &s1);
+                        }
+                    }
                     if (v < 0) v = th_ksw_global_wave<false>(rb + start + 1, len, cs, cl, 0, mybnd, nullptr);
                 }
             }

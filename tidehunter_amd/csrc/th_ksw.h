@@ -130,7 +130,7 @@ __device__ int th_ksw_global_wave(const uint8_t *__restrict__ q, int qlen, const
 // the traceback -- lies inside the band, hence H, the tie-breaks and the '=' count along ksw_backtrack's
 // path are those of the full computation.  Returns -1 when the certificate fails (the caller then
 // runs the full matrix).  Strip geometry: columns j0..j0+63 need rows [j0+lo, j0+63+hi] only.
-__device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, int W, int *__restrict__ bnd, int (*s_in)[TH_WAVE][8])
+__device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, int W, int *__restrict__ bnd, int (*s_in)[TH_WAVE][8], int *band_score)
 {
     const int lane = TH_LANE();
     const int D = tlen - qlen;
@@ -217,6 +217,7 @@ __device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, 
     res_iden = TH_READLANE(res_iden, ol); res_h = TH_READLANE(res_h, ol);
     const int gmin = 2 * W + 2 + (D < 0 ? -D : D);
     // S > (m + n - Gmin)/2 - 2q - Gmin*e   <=>   2S > (m + n - Gmin) - 4q - 2*Gmin*e
+    *band_score = res_h;          // the banded optimum is a lower bound of the true optimum: it sizes a second, wider band
     if (2LL * res_h > (long long)(qlen + tlen - gmin) - 4 * TH_KQ - 2LL * gmin * TH_KE) return res_iden;
     return -1;
 }
