@@ -26,7 +26,8 @@
 
 #define TH_POA_BLOCK 64
 #define TH_POA_WB 10
-#define TH_POA_QCAP 3072        // query bases staged in LDS (jobs with longer units use the LQ=false instantiation)
+#define TH_POA_QCAP 3072        // query bases staged in LDS by the int16-ring variant
+#define TH_POA_QCAP_WIDE 8192   // ... by the 32-bit-ring variant (longer units read the query from HBM: QCAP = 0)
 
 #define TH_D_SRC(d)  ((d) & 7)
 #define TH_D_PM(d)   (((d) >> 3) & 0xff)
@@ -233,13 +234,16 @@ __device__ unsigned long long th_poa_prof[8];
 // packed row read its predecessor without bounds checks ("clean" slot).  Exactness: all real scores stay inside
 // int16 (pk_ok below); an unreachable in-band cell may drift upwards from -32768 by at most M per row, which pk_ok
 // keeps below every real score, and readers that work in 32 bits widen anything below `neg_thr` back to TH_NEG.
-#define TH_RING_LD(x) ((int)(x) < neg_thr ? TH_NEG : (int)(x))
-#define TH_RING_ST(v) ((short)max((v), -32768))
+#define TH_RING_LD(x) (WIDE ? (int)(x) : ((int)(x) < neg_thr ? TH_NEG : (int)(x)))
+#define TH_RING_ST(v) ((RT)(WIDE ? (v) : max((v), -32768)))
 #define TH_RIDX(j, beg) ((j) - ((beg) & ~1) + TH_POA_PAD)
 
-template <bool LQ>
-__device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t *s_qs, short (*s_ring)[3][TH_POA_RS], int (*s_rmeta)[8], int qlen, const ThDevPara &P)
+// QCAP > 0: the query is staged in LDS (s_qs); RT = short: int16 ring with packed rows, RT = int: 32-bit ring (exact for any
+// score range, one column per lane).  The int16 variant returns -5 when the alignment's scores may not fit.
+template <int QCAP, typename RT>
+__device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t *s_qs, RT (*s_ring)[3][TH_POA_RS], int (*s_rmeta)[8], int qlen, const ThDevPara &P)
 {
+    constexpr bool LQ = QCAP > 0, WIDE = sizeof(RT) == 4;
     const int lane = TH_LANE();
     const int M = P.match, X = P.mismatch, O1 = P.go1, E1 = P.ge1, O2 = P.go2, E2 = P.ge2;
     const int n = g.n_node, w = TH_POA_WB + qlen / 100;
@@ -250,8 +254,9 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     // row) and the column offsets of the F scan (2 * ring width * extension) all fit below 32000.
     const int maxE = max(E1, E2), gap1 = min(O1 + E1, O2 + E2);
     const long long real_b = (long long)max(max(M, X), gap1) * (qlen + n) + O1 + O2 + 2 * maxE;
-    const bool cache16_ok = M <= 31 && X <= 31 && real_b + (long long)M * n + 2LL * (TH_POA_RW + 64) * maxE < 32000;
-    const int neg_thr = cache16_ok ? -(int)real_b - 1 : -32768;
+    const bool cache16_ok = WIDE || (M <= 31 && X <= 31 && real_b + (long long)M * n + 2LL * (TH_POA_RW + 64) * maxE < 32000);
+    if (!cache16_ok) return -5;
+    const int neg_thr = -(int)real_b - 1;
     // packed constants
     const uint32_t O1P = TH_PK_DUP(O1), O2P = TH_PK_DUP(O2), E1P = TH_PK_DUP(E1), E2P = TH_PK_DUP(E2);
     uint32_t TX = 32u << 24;                                         // score table, 6 bits per query code (x 6), biased by 32
@@ -262,7 +267,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     //   0 row, 1 beg, 2 end, 3 left, 4 right, 5 cache state (0 none, 3 cached; every cached slot is clean), 6..7 cell offset
     int L_b = 0, L_e = -1, L_l = 0, L_r = 0, L_c = 0;
     if (lane < TH_POA_RING) s_rmeta[lane][0] = -1;
-    for (int x = lane; x < TH_POA_RING * 3 * TH_POA_PAD; x += TH_WAVE) s_ring[x / (3 * TH_POA_PAD)][(x / TH_POA_PAD) % 3][x % TH_POA_PAD] = -32768;
+    for (int x = lane; x < TH_POA_RING * 3 * TH_POA_PAD; x += TH_WAVE) s_ring[x / (3 * TH_POA_PAD)][(x / TH_POA_PAD) % 3][x % TH_POA_PAD] = (RT)(WIDE ? TH_NEG : -32768);
     TH_WAVE_FENCE();
     for (int i = 0; i + 1 < n; ++i) {
         if ((i & 63) == 0) {
@@ -311,7 +316,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         const bool cache_me = cache16_ok && e - b < TH_POA_RW;
         const bool store_full = needfull || !cache_me;     // otherwise only the direction word leaves the CU
         int rmax = TH_NEG - 0x10000000, left = b, right = b;
-        const bool pk = LQ && fast && L_c == 3 && cache_me;
+        const bool pk = !WIDE && LQ && fast && L_c == 3 && cache_me;
 #ifdef TH_CPU_EMUL
         if (lane == 0 && getenv("TH_DEBUG_PK")) { static long n_pk, n_all; n_all++; n_pk += pk; if ((n_all & 4095) == 0) fprintf(stderr, "[poa] packed rows %ld of %ld\n", n_pk, n_all); }
 #endif
@@ -332,7 +337,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 const bool lo_ok = j0 >= b && j0 <= e, hi_ok = j0 + 1 <= e;
                 const uint32_t IM = (lo_ok ? 0xffffu : 0u) | (hi_ok ? 0xffff0000u : 0u);
                 // substitution scores of the two columns from the row's table
-                const uint32_t qx = *(const unsigned short *)(s_qs + min(j0, TH_POA_QCAP));
+                const uint32_t qx = *(const unsigned short *)(s_qs + min(j0, QCAP));
                 const uint32_t SC = th_pk_sub(th_ubfe(T, qx & 0xffu, 6) | th_ubfe(T, qx >> 8, 6) << 16, 0x00200020u);
                 // predecessor row: diagonal pair (j0-1, j0) and vertical pairs (j0, j0+1); anything outside its band reads -inf
                 int pi = j0 - PB0 + TH_POA_PAD;
@@ -389,7 +394,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 }
             }
         } else {
-        if (cache_me) {      // leave the slot clean for a packed successor: minus infinity wherever this row stores nothing
+        if (!WIDE && cache_me) {      // leave the slot clean for a packed successor: minus infinity wherever this row stores nothing
             uint32_t *wH = (uint32_t *)s_ring[myslot][0], *wE1 = (uint32_t *)s_ring[myslot][1], *wE2 = (uint32_t *)s_ring[myslot][2];
             for (int x = TH_POA_PAD / 2 + lane; x < TH_POA_RS / 2; x += TH_WAVE) { wH[x] = TH_PK_NEG; wE1[x] = TH_PK_NEG; wE2[x] = TH_PK_NEG; }
             TH_WAVE_FENCE();
@@ -692,17 +697,18 @@ __device__ int th_poa_consensus(ThPoaG &g, int n_seqs, uint8_t *__restrict__ con
 __device__ __forceinline__ int *th_carve(int *&p, long long cnt) { int *r = p; p += (cnt + 3) & ~3LL; return r; }
 
 // status: 0 ok, 1 scratch too small for the graph, 2 band cells overflow, 3 internal order error, 4 band lost the path,
-//         5 in-degree > 255, 6 consensus longer than cons_cap
-// LQ = true: the query of every alignment fits the LDS staging buffer (the common case); LQ = false reads it from HBM
-template <bool LQ>
+//         5 in-degree > 255, 6 consensus longer than cons_cap, 7 scores may not fit the int16 ring (rerun on the 32-bit variant)
+// QCAP: query bases staged in LDS (0: read from HBM); RT: element type of the LDS ring of recent rows (see th_poa_dp)
+template <int QCAP, typename RT>
 // 5 waves per SIMD: 96 VGPRs (9 dwords of scratch) and 8016 B of LDS per wave; measured 588 -> 557 ms per 65536 reads against 4 waves
 __global__ void __launch_bounds__(TH_POA_BLOCK) TH_WAVES_PER_SIMD(5)
 th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict__ units, const uint32_t *__restrict__ roff,
          const uint8_t *__restrict__ bseq, ThDevPara P, int *__restrict__ scratch, long long scratch_ints,
          uint8_t *__restrict__ cons, int *__restrict__ cov, int *__restrict__ cons_len, int *__restrict__ status, int *__restrict__ queue)
 {
-    __shared__ __attribute__((aligned(4))) uint8_t s_qs[TH_POA_QCAP + 4];     // s_qs[j] = 6 * code(q[j-1]): the column's query base, pre-scaled for the score table
-    __shared__ __attribute__((aligned(4))) short s_ring[TH_POA_RING][3][TH_POA_RS];
+    constexpr bool LQ = QCAP > 0;
+    __shared__ __attribute__((aligned(4))) uint8_t s_qs[QCAP + 4];     // s_qs[j] = 6 * code(q[j-1]): the column's query base, pre-scaled for the score table
+    __shared__ __attribute__((aligned(4))) RT s_ring[TH_POA_RING][3][TH_POA_RS];
     __shared__ int s_rmeta[TH_POA_RING][8];
     const int lane = TH_LANE();
     const int wave = blockIdx.x;
@@ -748,9 +754,9 @@ th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict
             const int deg = th_poa_rows(g);
             TH_PROF(0);
             if (deg > 255) { st = 5; break; }
-            const int bi = th_poa_dp<LQ>(g, q, s_qs, s_ring, s_rmeta, qlen, P);
+            const int bi = th_poa_dp<QCAP, RT>(g, q, s_qs, s_ring, s_rmeta, qlen, P);
             TH_PROF(1);
-            if (bi < 0) { st = bi == -3 ? 2 : 4; break; }
+            if (bi < 0) { st = bi == -3 ? 2 : bi == -5 ? 7 : 4; break; }
             const int no = th_poa_traceback(g, bi, qlen);
             TH_PROF(2);
             th_poa_merge(g, q, no);

@@ -51,7 +51,7 @@ struct th_gpu {
     DBuf<unsigned long long> d_gsort, d_eps; DBuf<long long> d_gsort_off;
     DBuf<ThChainRec> d_rec;
     DBuf<int> d_par, d_par_off, d_par_n, d_par_dst, d_parc, d_bnd, d_scratch, d_cov, d_cons_len, d_status, d_iden, d_ext;
-    DBuf<ThTask> d_tasks; DBuf<ThUnit> d_units; DBuf<ThAlnItem> d_items;
+    DBuf<ThTask> d_tasks, d_sub; DBuf<ThUnit> d_units; DBuf<ThAlnItem> d_items; DBuf<int> d_scl, d_sst;   // d_sub/d_scl/d_sst: task subsets of POA relaunches
     int n_rec = 0;
     std::vector<ThChainRec> h_rec; std::vector<int> h_par_n, h_par_dst, h_parc, h_read_ch_base, h_read_ch_n;
     std::vector<ThTask> h_tasks; std::vector<ThUnit> h_units; std::vector<ThAlnItem> h_items;
@@ -89,7 +89,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
 extern "C" void th_gpu_destroy(th_gpu_t *g)
 {
     if (!g) return;
-    g->d_seq.release(); g->d_bseq.release(); g->d_tracked.release(); g->d_cons_c.release(); g->d_cov_c.release(); g->d_cc_len.release(); g->d_cc_off.release(); g->d_eps.release(); g->d_xorder.release(); g->d_xstart.release(); g->d_xend.release(); g->d_cons.release(); g->d_roff.release(); g->d_tmp.release();
+    g->d_seq.release(); g->d_bseq.release(); g->d_tracked.release(); g->d_sub.release(); g->d_scl.release(); g->d_sst.release(); g->d_cons_c.release(); g->d_cov_c.release(); g->d_cc_len.release(); g->d_cc_off.release(); g->d_eps.release(); g->d_xorder.release(); g->d_xstart.release(); g->d_xend.release(); g->d_cons.release(); g->d_roff.release(); g->d_tmp.release();
     g->d_hit_end.release(); g->d_hit_per.release(); g->d_hit_n.release(); g->d_score.release(); g->d_from.release(); g->d_cells.release();
     g->d_cnt.release(); g->d_read_ch_base.release(); g->d_read_ch_n.release(); g->d_gsort.release(); g->d_gsort_off.release(); g->d_rec.release();
     g->d_par.release(); g->d_par_off.release(); g->d_par_n.release(); g->d_par_dst.release(); g->d_parc.release(); g->d_bnd.release(); g->d_scratch.release();
@@ -315,51 +315,66 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         // ---- POA: persistent waves with private scratch; tasks that outgrow it are retried with more ----
         g->h_cons_len.assign(nt, 0); g->h_status.assign(nt, 0);
         std::vector<int> todo(nt); for (int t = 0; t < nt; ++t) todo[t] = t;
-        std::vector<ThTask> sub; double factor = 1.5;
-        for (int attempt = 0; attempt < 5 && !todo.empty(); ++attempt, factor *= 4) {
-            long long need = 1024;
-            for (int t : todo) need = std::max(need, poa_need_ints(g->h_tasks[t], factor));
-            const int wv = (int)std::min<long long>(std::min<long long>((long long)todo.size(), g->waves_poa), std::max<long long>(1, (64LL << 30) / (need * 4)));
+        // Two kernel variants: the common one keeps recent rows as int16 in LDS (packed rows, 5 waves per SIMD) and gives a job
+        // back with status 7 when an alignment's scores may not fit int16 (long units, unusual scoring); those jobs, and jobs
+        // whose units exceed its query staging buffer, run on the 32-bit-ring variant.
+        std::vector<int> todo_n, todo_w;
+        for (int t : todo) (g->h_tasks[t].max_len <= TH_POA_QCAP ? todo_n : todo_w).push_back(t);
+        double factor = 1.5; bool patched = false;   // patched: some results live in subset arrays
+        auto run_group = [&](const std::vector<int> &grp, bool wide, std::vector<int> &again, std::vector<int> &to_wide) -> int {
+            if (grp.empty()) return 0;
+            long long need = 1024; int max_unit = 0;
+            for (int t : grp) { need = std::max(need, poa_need_ints(g->h_tasks[t], factor)); max_unit = std::max(max_unit, g->h_tasks[t].max_len); }
+            const int wv = (int)std::min<long long>(std::min<long long>((long long)grp.size(), g->waves_poa), std::max<long long>(1, (64LL << 30) / (need * 4)));
             TRY(g->d_scratch.ensure((size_t)(need * wv)));
             const ThTask *dt = g->d_tasks.p; int *dcl = g->d_cons_len.p, *dst = g->d_status.p;
-            DBuf<ThTask> d_sub; DBuf<int> d_scl, d_sst;
-            if (attempt > 0) {
-                sub.clear(); for (int t : todo) sub.push_back(g->h_tasks[t]);
+            DBuf<ThTask> &d_sub = g->d_sub; DBuf<int> &d_scl = g->d_scl, &d_sst = g->d_sst;
+            const bool whole = (int)grp.size() == nt;            // every task in its original order: the main arrays serve
+            if (!whole) {
+                patched = true;
+                std::vector<ThTask> sub; sub.reserve(grp.size());
+                for (int t : grp) sub.push_back(g->h_tasks[t]);
                 TRY(d_sub.ensure(sub.size())); TRY(d_scl.ensure(sub.size())); TRY(d_sst.ensure(sub.size()));
                 TRY(th_rt_h2d(d_sub.p, sub.data(), sub.size() * sizeof(ThTask), g->stream));
+                TRY(th_rt_sync(g->stream));
                 dt = d_sub.p; dcl = d_scl.p; dst = d_sst.p;
             }
-            int max_unit = 0;
-            for (int t : todo) max_unit = std::max(max_unit, g->h_tasks[t].max_len);
-            if (attempt > 0) TRY(th_rt_memset(g->d_cnt.p + 2, 0, 2 * sizeof(int), g->stream));      // job queue head (zeroed with the other counters for the first attempt)
+            TRY(th_rt_memset(g->d_cnt.p + 2, 0, 2 * sizeof(int), g->stream));      // job queue head
             KT_BEGIN(TK_POA);
-            if (max_unit <= TH_POA_QCAP)
-                TH_LAUNCH(th_k_poa<true>, wv, TH_POA_BLOCK, g->stream, dt, (int)todo.size(), (const ThUnit *)g->d_units.p, (const uint32_t *)g->d_roff.p,
-                          (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, dcl, dst, g->d_cnt.p + 2);
-            else
-                TH_LAUNCH(th_k_poa<false>, wv, TH_POA_BLOCK, g->stream, dt, (int)todo.size(), (const ThUnit *)g->d_units.p, (const uint32_t *)g->d_roff.p,
-                          (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, dcl, dst, g->d_cnt.p + 2);
+#define POA_LAUNCH(QC, RT) TH_LAUNCH((th_k_poa<QC, RT>), wv, TH_POA_BLOCK, g->stream, dt, (int)grp.size(), (const ThUnit *)g->d_units.p, (const uint32_t *)g->d_roff.p, \
+                          (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, dcl, dst, g->d_cnt.p + 2)
+            if (!wide) POA_LAUNCH(TH_POA_QCAP, short);
+            else if (max_unit <= TH_POA_QCAP_WIDE) POA_LAUNCH(TH_POA_QCAP_WIDE, int);
+            else POA_LAUNCH(0, int);
             KT_END(TK_POA);
-            if (getenv("TH_TRACE")) { th_rt_sync(g->stream); fprintf(stderr, "[th] poa done (%d jobs, %d waves)\n", (int)todo.size(), wv); }
-            std::vector<int> cl(todo.size()), st(todo.size());
-            TRY(th_rt_d2h(cl.data(), dcl, todo.size() * 4, g->stream));
-            TRY(th_rt_d2h(st.data(), dst, todo.size() * 4, g->stream));
+            if (getenv("TH_TRACE")) { th_rt_sync(g->stream); fprintf(stderr, "[th] poa done (%d jobs, %d waves, %s ring)\n", (int)grp.size(), wv, wide ? "32-bit" : "int16"); }
+            std::vector<int> cl(grp.size()), st(grp.size());
+            TRY(th_rt_d2h(cl.data(), dcl, grp.size() * 4, g->stream));
+            TRY(th_rt_d2h(st.data(), dst, grp.size() * 4, g->stream));
             TRY(th_rt_sync(g->stream));
-            std::vector<int> again;
-            for (size_t x = 0; x < todo.size(); ++x) {
-                const int t = todo[x];
+            for (size_t x = 0; x < grp.size(); ++x) {
+                const int t = grp[x];
                 g->h_cons_len[t] = cl[x]; g->h_status[t] = st[x];
                 if (st[x] == 1 || st[x] == 2) again.push_back(t);
-                else if (st[x] != 0) { d_sub.release(); d_scl.release(); d_sst.release(); return th_fail("POA kernel failed with status " + std::to_string(st[x])); }
+                else if (st[x] == 7 && !wide) to_wide.push_back(t);
+                else if (st[x] != 0) return th_fail("POA kernel failed with status " + std::to_string(st[x]));
             }
-            if (attempt > 0) {   // results of a retried subset live in the subset arrays: patch the main ones
-                TRY(th_rt_h2d(g->d_cons_len.p, g->h_cons_len.data(), (size_t)nt * 4, g->stream));
-                TRY(th_rt_sync(g->stream));
-            }
-            d_sub.release(); d_scl.release(); d_sst.release();
-            todo.swap(again);
+            return 0;
+        };
+        for (int attempt = 0; attempt < 6 && (!todo_n.empty() || !todo_w.empty()); ++attempt, factor *= 4) {
+            std::vector<int> again_n, again_w, to_wide;
+            TRY(run_group(todo_n, false, again_n, to_wide));
+            todo_w.insert(todo_w.end(), to_wide.begin(), to_wide.end());     // same scratch factor: they have not run yet
+            std::sort(todo_w.begin(), todo_w.end());
+            TRY(run_group(todo_w, true, again_w, to_wide));
+            todo_n.swap(again_n); todo_w.swap(again_w);
         }
-        if (!todo.empty()) return th_fail("POA scratch still too small after 5 attempts");
+        todo.clear(); todo.insert(todo.end(), todo_n.begin(), todo_n.end()); todo.insert(todo.end(), todo_w.begin(), todo_w.end());
+        if (patched) {   // some results live in subset arrays: the alignment kernel reads the main one
+            TRY(th_rt_h2d(g->d_cons_len.p, g->h_cons_len.data(), (size_t)nt * 4, g->stream));
+            TRY(th_rt_sync(g->stream));
+        }
+        if (!todo.empty()) return th_fail("POA scratch still too small after 6 attempts");
 #if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
         { unsigned long long pr[8]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(th_poa_prof), sizeof(pr)); 
           fprintf(stderr, "[poa_prof] rows %llu dp %llu traceback %llu merge %llu (cycles summed over waves); dp rows %llu slow %llu chunks %llu preds %llu\n", pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7]);
