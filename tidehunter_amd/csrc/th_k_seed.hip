@@ -52,16 +52,17 @@ __global__ void th_k_encode(const uint8_t *__restrict__ seq, uint8_t *__restrict
 
 // hit_end/hit_per: per-read segments at roff[r]; tmp: per-position scratch (period or 0)
 // W = unsigned long long: words key<<32 | pos (any k <= 16, any read length; LDS up to 16384 k-mers, else HBM scratch).
-// W = uint32_t:           words key<<14 | pos when k <= 9 and every read of the batch has at most 16384 bases: half the
-//                         LDS footprint (two workgroups per CU) and half the LDS traffic of the sort.
-template <typename W, int PB>
+// W = uint32_t:           words key<<PB | pos when every word of the batch fits 32 bits and every read fits the LDS buffer:
+//                         PB 14 / CAP 16384 (k <= 9, reads < 16384 bases: 64 KiB, two workgroups per CU) or
+//                         PB 15 / CAP 32768 (k <= 8, reads < 32768 bases: 128 KiB); half the LDS traffic of the 64-bit sort.
+template <typename W, int PB, int CAP>
 __global__ void __launch_bounds__(TH_SEED_BLOCK)
 th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, ThDevPara P,
           int *__restrict__ hit_end, int *__restrict__ hit_per, int *__restrict__ hit_n,
           uint32_t *__restrict__ tmp, W *__restrict__ gsort, const long long *__restrict__ gsort_off,
           int *__restrict__ err)
 {
-    __shared__ W lds[TH_SORT_LDS];
+    __shared__ W lds[CAP];
     const W NONE_W = (W)~(W)0;
     __shared__ int s_cnt[TH_SEED_BLOCK + 1];
     __shared__ uint32_t s_wkey[256], s_wpos[256]; // -w > 1: the minimizer window (key, pos)
@@ -73,7 +74,7 @@ th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, T
     const int ne = L - k + 1;                     // k-mer slots; slot e ends at position e+k-1
     if (ne < 1 || L - P.w <= 0) { if (tid == 0) hit_n[r] = 0; return; }
     int N = 1; while (N < ne) N <<= 1;
-    W *buf = N <= TH_SORT_LDS ? lds : gsort + gsort_off[r];
+    W *buf = N <= CAP ? lds : gsort + gsort_off[r];
 
     if (P.w > 1) {
         // 1m. minimizer words (src/tandem_hit.c:97-157).  The reference's selection is a sequential state machine

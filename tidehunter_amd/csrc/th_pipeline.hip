@@ -227,12 +227,12 @@ extern "C" int th_gpu_run(th_gpu_t *g)
     const int enc_blocks = (int)std::min<long long>(2048, (T / 16 + 255) / 256 + 1);
     KT_BEGIN(TK_SEED);
     TH_LAUNCH(th_k_encode, enc_blocks, 256, g->stream, (const uint8_t *)g->d_seq.p, g->d_bseq.p, (long long)T);
-    if (g->dp.k <= 9 && g->max_len < TH_SORT_LDS)       // every word fits key<<14 | pos and stays below the all-ones sentinel
-        TH_LAUNCH((th_k_hits<uint32_t, 14>), n, TH_SEED_BLOCK, g->stream, (const uint8_t *)g->d_bseq.p, (const uint32_t *)g->d_roff.p, g->dp,
-                  g->d_hit_end.p, g->d_hit_per.p, g->d_hit_n.p, g->d_tmp.p, (uint32_t *)nullptr, (const long long *)g->d_gsort_off.p, g->d_cnt.p + 1);
-    else
-        TH_LAUNCH((th_k_hits<unsigned long long, 32>), n, TH_SEED_BLOCK, g->stream, (const uint8_t *)g->d_bseq.p, (const uint32_t *)g->d_roff.p, g->dp,
-                  g->d_hit_end.p, g->d_hit_per.p, g->d_hit_n.p, g->d_tmp.p, g->d_gsort.p, (const long long *)g->d_gsort_off.p, g->d_cnt.p + 1);
+#define HITS_LAUNCH(W, PB, CAP, GS) TH_LAUNCH((th_k_hits<W, PB, CAP>), n, TH_SEED_BLOCK, g->stream, (const uint8_t *)g->d_bseq.p, (const uint32_t *)g->d_roff.p, g->dp, \
+                  g->d_hit_end.p, g->d_hit_per.p, g->d_hit_n.p, g->d_tmp.p, GS, (const long long *)g->d_gsort_off.p, g->d_cnt.p + 1)
+    // 32-bit sort words when key << PB | pos stays below the all-ones sentinel and every read sorts in LDS
+    if (g->dp.k <= 9 && g->max_len < 16384) HITS_LAUNCH(uint32_t, 14, 16384, (uint32_t *)nullptr);
+    else if (g->dp.k <= 8 && g->max_len < 32768) HITS_LAUNCH(uint32_t, 15, 32768, (uint32_t *)nullptr);
+    else HITS_LAUNCH(unsigned long long, 32, TH_SORT_LDS, g->d_gsort.p);
     KT_END(TK_SEED); KT_BEGIN(TK_CHAIN_DP);
     if (g->max_len < 65536 && !getenv("TH_CHAIN_UNPACKED")) {      // (the environment knob exists for the CPU tests)
         TRY(g->d_eps.ensure(padT));
