@@ -35,7 +35,9 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
     // removes the window re-reads from HBM but its 48 KiB per workgroup cuts residency to 3 waves per SIMD (62 ms);
     // a 512-hit ring 46 ms; scoring 2 or 4 chunks ahead of the resolution 49 / 85 ms.  Each hit is re-read ~250 times by
     // the sliding window (881 GB of L2/Infinity-Cache fabric traffic per 65536 reads = 5.5 TB/s), with VALU issue
-    // (about 90 instructions per 64 predecessors) right behind; hence the packed 8-byte records.
+    // (about 90 instructions per 64 predecessors) right behind; hence the packed 8-byte records (161 -> 151 ms per
+    // 65536 reads).  Two predecessors per lane (128 per trip, shared scan and ballots) measured 154 ms: the per-predecessor
+    // scoring, not the scan, is what issues.
     const int lane = TH_LANE();
     const int r = blockIdx.x * (TH_CHAIN_BLOCK / TH_WAVE) + (threadIdx.x >> 6);
     const bool live = r < n_reads;
