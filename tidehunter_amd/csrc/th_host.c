@@ -52,6 +52,8 @@ void th_free_para(th_para_t *p)
     free(p);
 }
 
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
 /* ---------------------------------------------------------------- FASTA/FASTQ(.gz) reader (kseq grammar, src/kseq.h:176-215) */
 typedef struct { gzFile fp; unsigned char *buf; int beg, end, eof, last; } th_reader_t;
 typedef struct { char *s; size_t l, m; } th_str_t;
@@ -100,8 +102,10 @@ static th_reader_t *rd_open(const char *fn)
     return r;
 }
 static void rd_close(th_reader_t *r) { if (r) { gzclose(r->fp); free(r->buf); free(r); } }
-/* 1 = record read (name/seq malloc'd), 0 = end of file */
-static int rd_next(th_reader_t *r, char **name, char **seq, int *len)
+/* Appends one record to the arena `a` as name\0sequence\0 and returns its offsets (the arena may move while it grows, so
+ * callers turn offsets into pointers when the batch is complete).  1 = record read, 0 = end of file.  One arena per batch
+ * slot, reused from batch to batch: no per-read malloc/free, and no page-fault storm next to the device allocations. */
+static int rd_next_into(th_reader_t *r, th_str_t *a, size_t *name_off, size_t *seq_off, int *len)
 {
     int c;
     if (r->last == 0) {
@@ -109,24 +113,36 @@ static int rd_next(th_reader_t *r, char **name, char **seq, int *len)
         if (c == -1) return 0;
         r->last = c;
     }
-    th_str_t nm = { 0, 0, 0 }, sq = { 0, 0, 0 };
-    str_putc(&nm, 0); nm.l = 0; str_putc(&sq, 0); sq.l = 0;
-    while ((c = rd_getc(r)) != -1 && !isspace(c)) str_putc(&nm, c);
+    *name_off = a->l;
+    while ((c = rd_getc(r)) != -1 && !isspace(c)) str_putc(a, c);
+    str_putc(a, 0);
     if (c != '\n' && c != -1) while ((c = rd_getc(r)) != -1 && c != '\n') {}
+    *seq_off = a->l;
     while ((c = rd_getc(r)) != -1 && c != '>' && c != '+' && c != '@') {
         if (c == '\n') continue;
-        str_putc(&sq, c);
-        rd_line(r, &sq);
-        if (sq.l > 1 && sq.s[sq.l - 1] == '\r') sq.s[--sq.l] = 0;
+        str_putc(a, c);
+        rd_line(r, a);
+        if (a->l - *seq_off > 1 && a->s[a->l - 1] == '\r') a->s[--a->l] = 0;
     }
+    const size_t sl = a->l - *seq_off;
+    str_putc(a, 0);
     r->last = (c == '>' || c == '@') ? c : 0;
     if (c == '+') {
         while ((c = rd_getc(r)) != -1 && c != '\n') {}
         size_t ql = 0; long n;
-        while (ql < sq.l && (n = rd_line(r, NULL)) >= 0) ql += (size_t)n;   /* quality lines until as long as the sequence */
+        while (ql < sl && (n = rd_line(r, NULL)) >= 0) ql += (size_t)n;   /* quality lines until as long as the sequence */
         r->last = 0;
     }
-    *name = nm.s; *seq = sq.s; *len = (int)sq.l;
+    *len = (int)sl;
+    return 1;
+}
+/* 1 = record read (name/seq malloc'd), 0 = end of file */
+static int rd_next(th_reader_t *r, char **name, char **seq, int *len)
+{
+    th_str_t a = { 0, 0, 0 }; size_t no, so;
+    if (!rd_next_into(r, &a, &no, &so, len)) { free(a.s); return 0; }
+    *name = strdup(a.s + no); *seq = (char *)malloc((size_t)*len + 1); memcpy(*seq, a.s + so, (size_t)*len + 1);
+    free(a.s);
     return 1;
 }
 
@@ -516,9 +532,17 @@ int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out)
 
 int th_process_batch(th_handle_t *h, const char *const *seqs, const int *lens, int n, th_tandem_seq_t *out)
 {
+    const double t0 = now_s();
     if (th_batch_upload(h, seqs, lens, n)) return -1;
+    const double t1 = now_s();
     if (th_batch_run(h)) return -1;
-    return th_batch_collect(h, out);
+    const double t2 = now_s();
+    const int rc = th_batch_collect(h, out);
+    if (getenv("TH_TRACE")) {
+        th_gpu_out_t o; th_gpu_get(h->gpu, &o);
+        fprintf(stderr, "[th_process_batch] %d reads: upload %.3f s, device run %.3f s (kernels %.3f s), collect %.3f s\n", n, t1 - t0, t2 - t1, o.ms_kernels / 1000.0, now_s() - t2);
+    }
+    return rc;
 }
 
 /* ---------------------------------------------------------------- output, src/main.c:214-271 */
@@ -574,7 +598,7 @@ void th_output(FILE *fp, int n, const char *const *names, const char *const *seq
  * three run as a pipeline over three batch slots so that parsing batch i+1 and formatting batch i-1 overlap the device
  * work on batch i.  Output order = input order (src/main.c:217). */
 enum { SLOT_EMPTY = 0, SLOT_FILLED = 1, SLOT_DONE = 2 };
-typedef struct { char **names, **seqs; int *lens; int n, state; th_tandem_seq_t *ts; } th_slot_t;
+typedef struct { char **names, **seqs; int *lens; int n, state; th_tandem_seq_t *ts; th_str_t arena; size_t *noff, *soff; } th_slot_t;
 typedef struct {
     th_slot_t slot[3];
     pthread_mutex_t mu; pthread_cond_t cv;
@@ -582,7 +606,6 @@ typedef struct {
     double t_read, t_write;      /* busy seconds of the two side threads (TH_TRACE=1 prints them) */
 } th_pipe_t;
 
-static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 static void slot_wait(th_pipe_t *q, th_slot_t *s, int state)
 {
@@ -603,8 +626,10 @@ static void *pipe_reader(void *arg)
         slot_wait(q, s, SLOT_EMPTY);
         int n = 0; long long bases = 0;
         const double t0 = now_s();
+        s->arena.l = 0;
         if (!q->stop)
-            while (n < q->batch_reads && bases < max_bases && rd_next(q->rd, &s->names[n], &s->seqs[n], &s->lens[n])) { bases += s->lens[n]; ++n; }
+            while (n < q->batch_reads && bases < max_bases && rd_next_into(q->rd, &s->arena, &s->noff[n], &s->soff[n], &s->lens[n])) { bases += s->lens[n]; ++n; }
+        for (int k = 0; k < n; ++k) { s->names[k] = s->arena.s + s->noff[k]; s->seqs[k] = s->arena.s + s->soff[k]; }
         q->t_read += now_s() - t0;
         s->n = n;
         slot_set(q, s, SLOT_FILLED);
@@ -620,7 +645,6 @@ static void *pipe_writer(void *arg)
         const int n = s->n;
         const double t0 = now_s();
         if (n > 0 && q->out && !q->stop) th_output(q->out, n, (const char *const *)s->names, (const char *const *)s->seqs, s->lens, s->ts, q->p);
-        for (int k = 0; k < n; ++k) { free(s->names[k]); free(s->seqs[k]); }
         q->t_write += now_s() - t0;
         slot_set(q, s, SLOT_EMPTY);
         if (n == 0) return NULL;
@@ -641,6 +665,7 @@ int th_run_file(const char *read_fn, th_para_t *p, FILE *out, int device, int ba
     for (int i = 0; i < 3; ++i) {
         q.slot[i].names = (char **)calloc(batch_reads, sizeof(char *)); q.slot[i].seqs = (char **)calloc(batch_reads, sizeof(char *));
         q.slot[i].lens = (int *)calloc(batch_reads, sizeof(int)); q.slot[i].ts = th_alloc_tandem_seq(batch_reads);
+        q.slot[i].noff = (size_t *)calloc(batch_reads, sizeof(size_t)); q.slot[i].soff = (size_t *)calloc(batch_reads, sizeof(size_t));
     }
     pthread_t t_rd, t_wr;
     pthread_create(&t_rd, NULL, pipe_reader, &q); pthread_create(&t_wr, NULL, pipe_writer, &q);
@@ -663,7 +688,7 @@ int th_run_file(const char *read_fn, th_para_t *p, FILE *out, int device, int ba
     if (getenv("TH_TRACE"))
         fprintf(stderr, "[th_run_file] %d reads: wall %.3f s; busy: reader %.3f s, device batches %.3f s, writer %.3f s\n",
                 total, now_s() - t_start, q.t_read, t_dev, q.t_write);
-    for (int i = 0; i < 3; ++i) { th_free_tandem_seq(q.slot[i].ts, batch_reads); free(q.slot[i].names); free(q.slot[i].seqs); free(q.slot[i].lens); }
+    for (int i = 0; i < 3; ++i) { th_free_tandem_seq(q.slot[i].ts, batch_reads); free(q.slot[i].names); free(q.slot[i].seqs); free(q.slot[i].lens); free(q.slot[i].noff); free(q.slot[i].soff); free(q.slot[i].arena.s); }
     pthread_mutex_destroy(&q.mu); pthread_cond_destroy(&q.cv);
     th_destroy(h); rd_close(r);
     return rc ? -1 : total;

@@ -9,6 +9,7 @@
 #include <vector>
 #include <string>
 #include <algorithm>
+#include <chrono>
 #include "th_internal.h"
 #include "th_dev.h"
 #include "th_k_seed.hip"
@@ -20,6 +21,8 @@
 static std::string g_th_err;
 extern "C" const char *th_gpu_error(void) { return g_th_err.c_str(); }
 static int th_fail(const std::string &m) { g_th_err = m; fprintf(stderr, "[tidehunter_amd] %s\n", m.c_str()); return -1; }
+
+static double th_wall_s() { using namespace std::chrono; return duration<double>(steady_clock::now().time_since_epoch()).count(); }
 
 template <class T> struct DBuf {
     T *p = nullptr; size_t cap = 0;
@@ -210,6 +213,7 @@ struct KTimer {
 extern "C" int th_gpu_run(th_gpu_t *g)
 {
     const int n = g->n; const long long T = g->T; const size_t padT = (size_t)((T + 15) & ~15LL);
+    const double t_run0 = th_wall_s(); (void)t_run0;
     g->jobs.clear(); g->ms_kernels = g->ms_dominant = 0; g->n_rec = 0;
     g->h_tasks.clear(); g->h_parc.clear();
     if (n == 0) return 0;
@@ -295,7 +299,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         TRY(th_rt_sync(g->stream));
     } else TRY(th_rt_sync(g->stream));
 
-    if (getenv("TH_TRACE")) fprintf(stderr, "[th] stages 1-3 done, %d chains\n", n_rec);
+    if (getenv("TH_TRACE")) fprintf(stderr, "[th] %.3f s: stages 1-3 done, %d chains\n", th_wall_s() - t_run0, n_rec);
     build_jobs(g);
     const int nt = (int)g->h_tasks.size();
     g->jobs.resize(nt);
@@ -347,7 +351,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
             else if (max_unit <= TH_POA_QCAP_WIDE) POA_LAUNCH(TH_POA_QCAP_WIDE, int);
             else POA_LAUNCH(0, int);
             KT_END(TK_POA);
-            if (getenv("TH_TRACE")) { th_rt_sync(g->stream); fprintf(stderr, "[th] poa done (%d jobs, %d waves, %s ring)\n", (int)grp.size(), wv, wide ? "32-bit" : "int16"); }
+            if (getenv("TH_TRACE")) { th_rt_sync(g->stream); fprintf(stderr, "[th] %.3f s: poa done (%d jobs, %d waves, %s ring, %lld MB scratch)\n", th_wall_s() - t_run0, (int)grp.size(), wv, wide ? "32-bit" : "int16", (long long)(need * wv * 4 >> 20)); }
             std::vector<int> cl(grp.size()), st(grp.size());
             TRY(th_rt_d2h(cl.data(), dcl, grp.size() * 4, g->stream));
             TRY(th_rt_d2h(st.data(), dst, grp.size() * 4, g->stream));
@@ -397,7 +401,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
                   (const uint32_t *)g->d_roff.p, (const uint8_t *)g->d_bseq.p, (const uint8_t *)g->d_cons.p, (const int *)g->d_cons_len.p,
                   g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, g->d_cnt.p + 1, g->d_cnt.p + 4);   // queue head d_cnt[4] was zeroed with the other counters at the start of the run
         KT_END(TK_ALIGN);
-        if (getenv("TH_TRACE")) { th_rt_sync(g->stream); fprintf(stderr, "[th] align done (%d items)\n", ni); }
+        if (getenv("TH_TRACE")) { th_rt_sync(g->stream); fprintf(stderr, "[th] %.3f s: align done (%d items)\n", th_wall_s() - t_run0, ni); }
         // results: consensus strings compacted to their lengths (the slots are sized for the worst case), coverage only on request
         std::vector<int> cc_off(nt); long long cc_total = 0;
         for (int t = 0; t < nt; ++t) { cc_off[t] = (int)cc_total; cc_total += (g->h_cons_len[t] + 3) & ~3; }
