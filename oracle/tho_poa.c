@@ -194,8 +194,6 @@ static int align_to_graph(graph_t *g, const uint8_t *q, int qlen, const tho_para
             f2 = imax(h - O2, f2) - E2;
             if (h > rmax) { rmax = h; left = right = j; } else if (h == rmax) right = j;
         }
-        if (getenv("THO_DEBUG2") && i < 9) { fprintf(stderr, "[tho_H] i %d:", i); for (int j = b; j <= e; ++j) fprintf(stderr, " %d/%d/%d", AT(H,i,j), AT(N1,i,j), AT(N2,i,j)); fprintf(stderr, "\n"); }
-        if (getenv("THO_DEBUG2")) fprintf(stderr, "[tho_row] i %d v %d b %d e %d rmax %d l %d r %d\n", i, v, b, e, rmax, left, right);
         for (int ed = g->node[v].out_head; ed >= 0; ed = g->edge[ed].next_out) {
             int u = g->edge[ed].to;
             if (right + 1 > mpr[u]) mpr[u] = right + 1;
@@ -208,7 +206,6 @@ static int align_to_graph(graph_t *g, const uint8_t *q, int qlen, const tho_para
         int pi = g->index[g->edge[ed].from], c = RD(H, pi, qlen);
         if (ord == 0 || c > bs) { bs = c; bi = pi; }
     }
-    if (getenv("THO_DEBUG")) fprintf(stderr, "[tho_poa] n_node %d qlen %d best %d at row %d\n", n, qlen, bs, bi);
     if (bs <= NEG / 2) { fprintf(stderr, "[tho_poa] band lost the global path (score %d)\n", bs); exit(1); }
     /* traceback */
     aop_t *ops = (aop_t *)malloc(sizeof(aop_t) * (size_t)(n + qlen + 2));

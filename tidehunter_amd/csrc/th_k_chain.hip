@@ -307,9 +307,6 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
         TH_WAVE_FENCE();
         int ch_n = 0, top = 0, ci = 0;
         while (ci < n && ch_n < TH_TOPN) {
-#ifdef TH_CPU_EMUL
-            if (lane == 0 && getenv("TH_DEBUG_X")) fprintf(stderr, "[xw] r %d ci %d n %d ch_n %d top %d\n", r, ci, n, ch_n, top);
-#endif
             // ---- 64 candidates at once: covered by an accepted chain, or already tracked? ----
             const int x = ci + lane;
             const bool valid = x < n;

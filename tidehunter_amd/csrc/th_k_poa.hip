@@ -317,9 +317,6 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         const bool store_full = needfull || !cache_me;     // otherwise only the direction word leaves the CU
         int rmax = TH_NEG - 0x10000000, left = b, right = b;
         const bool pk = !WIDE && LQ && fast && L_c == 3 && cache_me;
-#ifdef TH_CPU_EMUL
-        if (lane == 0 && getenv("TH_DEBUG_PK")) { static long n_pk, n_all; n_all++; n_pk += pk; if ((n_all & 4095) == 0) fprintf(stderr, "[poa] packed rows %ld of %ld\n", n_pk, n_all); }
-#endif
         if (pk) {
             // ================= packed row: lane l owns columns B0 + 128 t + 2 l and the next one =================
             const int PB0 = L_b & ~1;

@@ -422,7 +422,6 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         if (cnt[1]) return th_fail("alignment boundary buffer overflow");
         for (int t = 0; t < nt; ++t) {
             th_job_t &j = g->jobs[t];
-            if (getenv("TH_DEBUG")) fprintf(stderr, "[th] job %d read %d pos_n %d n_units %d cons_len %d status %d\n", t, g->h_tasks[t].read, g->h_tasks[t].pos_n, g->h_tasks[t].n_units, g->h_cons_len[t], g->h_status[t]);
             j.cons_len = g->h_cons_len[t]; j.status = g->h_status[t];
             j.max_q_l = g->h_ext[4 * t]; j.max_t_l = g->h_ext[4 * t + 1]; j.max_q_r = g->h_ext[4 * t + 2]; j.max_t_r = g->h_ext[4 * t + 3];
         }
