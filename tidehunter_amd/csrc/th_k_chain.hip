@@ -73,10 +73,12 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             // so pp * fl(1.8) rounds to exactly 1.8 pp whenever that is an integer and stays > 0.19 away from every
             // integer otherwise: the comparison equals 5 cp >= 9 pp for all periods below 2^28 (th_gpu_upload checks).
             if (!dstop && !(cs <= ps || 5u * (uint32_t)cp >= 9u * (uint32_t)pp || 5u * (uint32_t)pp >= 9u * (uint32_t)cp)) {
-                const int dis1 = abs(ce - pe), dis2 = abs(cs - ps);
+                // hits are sorted by end, so pe <= ce, and cs > ps was just tested: both distances are plain differences and
+                // their sum is positive (ilog2 needs no guard)
+                const int dis1 = ce - pe, dis2 = cs - ps;
                 const int matched = min(dis1, k) + min(dis2, k);
                 const int dp = abs(cp - pp);
-                const int gap = (int)((uint32_t)(dp * dp) >> 1) + (max(31 - __clz(dis1 + dis2), 0) >> 1);   // :128-142
+                const int gap = (int)((uint32_t)(dp * dp) >> 1) + ((31 - __clz(dis1 + dis2)) >> 1);   // :128-142
                 con = matched - gap;
                 type = dp == 0 ? (matched < 2 * k ? TH_OVL_CON : TH_SAME_CON) : TH_REG_CON;
             }
