@@ -129,6 +129,31 @@ def test_emul_poa_scoring_options(emu):
         th.close()
 
 
+def test_emul_chain_record_arena_grows(emu, monkeypatch):
+    """a batch with more chains than the record arena holds reruns the extraction with a larger arena (TH_REC_CAP forces it)"""
+    monkeypatch.setenv("TH_REC_CAP", "1")
+    th = TH.TideHunter(lib_path=emu)
+    seqs = _reads(th.lib, [(90, 6, 0.08), (200, 4, 0.1)], seed=29)
+    para = O.default_para()
+    got = th.process(seqs)
+    U.stage_compare(th, seqs, para)
+    assert U.assert_records_equal(seqs, got, para, "arena growth") >= 2
+    th.close()
+
+
+def test_emul_partition_regions_grow(emu, monkeypatch):
+    """a chain whose par_pos outgrows its region makes the partition rerun with larger regions (TH_PAR_MUL forces a first
+    pass with four-entry regions)"""
+    monkeypatch.setenv("TH_PAR_MUL", "1")
+    th = TH.TideHunter(lib_path=emu)
+    seqs = _reads(th.lib, [(90, 6, 0.08), (200, 4, 0.1)], seed=31)
+    para = O.default_para()
+    got = th.process(seqs)
+    U.stage_compare(th, seqs, para)
+    assert U.assert_records_equal(seqs, got, para, "partition regrow") >= 2
+    th.close()
+
+
 def test_emul_unpacked_chain_records(emu, monkeypatch):
     """batches holding a read of 65536+ bases use the unpacked chain-DP records; TH_CHAIN_UNPACKED forces that path on a
     small batch (the real trigger is covered on the GPU: test_gpu_batch_with_a_long_read)"""

@@ -16,7 +16,7 @@ __global__ void __launch_bounds__(TH_PART_BLOCK)
 th_k_partition(const ThChainRec *__restrict__ rec, int n_rec, const uint32_t *__restrict__ roff, const uint8_t *__restrict__ bseq,
                const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ cells, ThDevPara P,
                int *__restrict__ par, int par_cap, int *__restrict__ par_top, int *__restrict__ par_off, int *__restrict__ par_n,
-               int *__restrict__ bnd, long long bnd_stride, int *__restrict__ err)
+               int *__restrict__ bnd, long long bnd_stride, int *__restrict__ err, int cap_mul)
 {
     const int lane = TH_LANE();
     const int wave = blockIdx.x, nwave = gridDim.x;
@@ -29,7 +29,7 @@ th_k_partition(const ThChainRec *__restrict__ rec, int n_rec, const uint32_t *__
         const int *E = hit_end + off, *Pd = hit_per + off, *CL = cells + R.cell_off;
         // the chain's par_pos region is carved from a shared arena (chain records arrive in no particular order,
         // so nothing derived from the record index may be used to keep regions apart)
-        const int cap = 2 * R.len + 16;
+        const int cap = cap_mul > 0 ? cap_mul * (2 * R.len + 16) : 4;      // (cap_mul 0: test knob, regions of four entries)
         int base = 0;
         { const int v = atomicAdd(par_top, lane == 0 ? cap : 0); base = TH_READLANE(v, 0); }
         int n = 0, bad = base + cap > par_cap;

@@ -221,7 +221,8 @@ extern "C" int th_gpu_run(th_gpu_t *g)
 #ifndef TH_CPU_EMUL
     KTimer kt; kt.s = g->stream;
 #endif
-    const int rec_cap = n * 8 + 4096;
+    int rec_cap = n * 8 + 4096;
+    if (getenv("TH_REC_CAP")) rec_cap = std::max(1, atoi(getenv("TH_REC_CAP")));      // test knob: forces the arena-growth path
     TRY(g->d_tmp.ensure(padT)); TRY(g->d_hit_end.ensure(padT)); TRY(g->d_hit_per.ensure(padT)); TRY(g->d_hit_n.ensure(n));
     TRY(g->d_score.ensure(padT)); TRY(g->d_from.ensure(padT)); TRY(g->d_cells.ensure(padT)); TRY(g->d_tracked.ensure(padT));
     TRY(g->d_xorder.ensure(padT)); TRY(g->d_xstart.ensure(padT)); TRY(g->d_xend.ensure(padT));
@@ -246,25 +247,38 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         TH_LAUNCH((th_k_chain_dp<false>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
                   (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p, (unsigned long long *)nullptr);
     KT_END(TK_CHAIN_DP); KT_BEGIN(TK_CHAIN_X);
-    TH_LAUNCH(th_k_chain_extract, n, TH_XBLOCK, g->stream, (const uint32_t *)g->d_roff.p, g->dp,
-              (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p,
-              (const int *)g->d_score.p, (const int *)g->d_from.p, g->d_tracked.p, g->d_cells.p,
-              g->d_gsort.p, (const long long *)g->d_gsort_off.p, g->d_rec.p, rec_cap, g->d_cnt.p,
-              g->d_read_ch_base.p, g->d_read_ch_n.p, g->d_cnt.p + 1);
     TH_LAUNCH(th_k_chain_sort, n, TH_XS_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, g->dp,
               (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, (const int *)g->d_score.p,
               g->d_xorder.p, g->d_xstart.p, g->d_xend.p);
-    TH_LAUNCH(th_k_chain_extract_wave, std::min(n, g->waves_xw), TH_XW_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
-              (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p,
-              (const int *)g->d_score.p, (const int *)g->d_from.p, g->d_cells.p,
-              (const uint16_t *)g->d_xorder.p, (const int *)g->d_xstart.p, (const int *)g->d_xend.p, g->d_rec.p, rec_cap, g->d_cnt.p,
-              g->d_read_ch_base.p, g->d_read_ch_n.p, g->d_cnt.p + 1);
     KT_END(TK_CHAIN_X);
     int cnt[8];
-    TRY(th_rt_d2h(cnt, g->d_cnt.p, sizeof(cnt), g->stream));
-    TRY(th_rt_sync(g->stream));
+    // chain extraction fills an arena of chain records with one atomic per read; a batch with more chains than the arena
+    // holds (8 per read on average) reruns the extraction with a larger one -- the kernels only read stage 1-2 results
+    for (int attempt = 0;; ++attempt) {
+        KT_BEGIN(TK_CHAIN_X);
+        TH_LAUNCH(th_k_chain_extract, n, TH_XBLOCK, g->stream, (const uint32_t *)g->d_roff.p, g->dp,
+                  (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p,
+                  (const int *)g->d_score.p, (const int *)g->d_from.p, g->d_tracked.p, g->d_cells.p,
+                  g->d_gsort.p, (const long long *)g->d_gsort_off.p, g->d_rec.p, rec_cap, g->d_cnt.p,
+                  g->d_read_ch_base.p, g->d_read_ch_n.p, g->d_cnt.p + 1);
+        TH_LAUNCH(th_k_chain_extract_wave, std::min(n, g->waves_xw), TH_XW_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
+                  (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p,
+                  (const int *)g->d_score.p, (const int *)g->d_from.p, g->d_cells.p,
+                  (const uint16_t *)g->d_xorder.p, (const int *)g->d_xstart.p, (const int *)g->d_xend.p, g->d_rec.p, rec_cap, g->d_cnt.p,
+                  g->d_read_ch_base.p, g->d_read_ch_n.p, g->d_cnt.p + 1);
+        KT_END(TK_CHAIN_X);
+        TRY(th_rt_d2h(cnt, g->d_cnt.p, sizeof(cnt), g->stream));
+        TRY(th_rt_sync(g->stream));
+        if (!(cnt[1] & 1)) break;
+        if (attempt == 4 || (long long)rec_cap * 4 > (1LL << 30)) return th_fail("chain record arena overflow");
+        rec_cap = std::max(rec_cap * 4, cnt[0] + 4096);
+        TRY(g->d_rec.ensure(rec_cap));
+        const int keep = cnt[1] & ~1;
+        TRY(th_rt_memset(g->d_cnt.p, 0, sizeof(int), g->stream));
+        TRY(th_rt_h2d(g->d_cnt.p + 1, &keep, sizeof(int), g->stream));
+    }
     if (cnt[1] & 8) return th_fail("minimizer selection repeated a word or overflowed its buffer");
-    if (cnt[1]) return th_fail("chain record arena overflow");
+    if (cnt[1]) return th_fail("stage 1-2 kernels reported error flags " + std::to_string(cnt[1]));
     const int n_rec = cnt[0]; g->n_rec = n_rec;
     g->h_read_ch_base.resize(n); g->h_read_ch_n.resize(n);
     TRY(th_rt_d2h(g->h_read_ch_base.data(), g->d_read_ch_base.p, (size_t)n * 4, g->stream));
@@ -274,20 +288,31 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         // ---- partition ----
         const long long bnd_part = (((long long)g->max_len + 128) * 6 + 3) & ~3LL;   // 16-byte aligned per-wave segments
         const int wp = std::min(n_rec, g->waves_part);
-        const size_t par_cap = 2 * padT + 16 * (size_t)n_rec + 64;
-        if (par_cap >= (1ull << 31)) return th_fail("par_pos arena would exceed 2^31 entries; use a smaller batch");
-        TRY(g->d_par.ensure(par_cap)); TRY(g->d_par_off.ensure(n_rec)); TRY(g->d_par_n.ensure(n_rec)); TRY(g->d_par_dst.ensure(n_rec));
+        TRY(g->d_par_off.ensure(n_rec)); TRY(g->d_par_n.ensure(n_rec)); TRY(g->d_par_dst.ensure(n_rec));
         TRY(g->d_bnd.ensure((size_t)(bnd_part * wp)));
-        KT_BEGIN(TK_PART);
-        TH_LAUNCH(th_k_partition, wp, TH_PART_BLOCK, g->stream, (const ThChainRec *)g->d_rec.p, n_rec, (const uint32_t *)g->d_roff.p,
-                  (const uint8_t *)g->d_bseq.p, (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_cells.p, g->dp,
-                  g->d_par.p, (int)par_cap, g->d_cnt.p + 5, g->d_par_off.p, g->d_par_n.p, g->d_bnd.p, bnd_part, g->d_cnt.p + 1);
-        KT_END(TK_PART);
+        // a chain's par_pos region holds cap_mul * (2 * cells + 16) entries; the sum over chains is bounded by the hits of the
+        // batch, so the arena cannot overflow -- a single chain that needs more (the reference allows up to the read length,
+        // src/partition.c:173) makes the partition rerun with larger regions
+        for (int cap_mul = getenv("TH_PAR_MUL") ? -1 : 1;; cap_mul = cap_mul < 0 ? 1 : cap_mul * 4) {
+            const int mul = cap_mul < 0 ? 0 : cap_mul;     // (TH_PAR_MUL: test knob, a first pass with empty regions)
+            const size_t par_cap = (size_t)std::max(mul, 1) * (2 * padT + 16 * (size_t)n_rec) + 64;
+            if (par_cap >= (1ull << 31)) return th_fail("par_pos arena would exceed 2^31 entries; use a smaller batch");
+            TRY(g->d_par.ensure(par_cap));
+            KT_BEGIN(TK_PART);
+            TH_LAUNCH(th_k_partition, wp, TH_PART_BLOCK, g->stream, (const ThChainRec *)g->d_rec.p, n_rec, (const uint32_t *)g->d_roff.p,
+                      (const uint8_t *)g->d_bseq.p, (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_cells.p, g->dp,
+                      g->d_par.p, (int)par_cap, g->d_cnt.p + 5, g->d_par_off.p, g->d_par_n.p, g->d_bnd.p, bnd_part, g->d_cnt.p + 1, mul);
+            KT_END(TK_PART);
+            TRY(th_rt_d2h(cnt, g->d_cnt.p, sizeof(cnt), g->stream));
+            TRY(th_rt_sync(g->stream));
+            if (!cnt[1]) break;
+            if (cap_mul >= 64) return th_fail("partition scratch overflow (par_pos region or boundary buffer)");
+            TRY(th_rt_memset(g->d_cnt.p + 1, 0, sizeof(int), g->stream));
+            TRY(th_rt_memset(g->d_cnt.p + 5, 0, sizeof(int), g->stream));
+        }
         TRY(th_rt_d2h(g->h_rec.data(), g->d_rec.p, (size_t)n_rec * sizeof(ThChainRec), g->stream));
         TRY(th_rt_d2h(g->h_par_n.data(), g->d_par_n.p, (size_t)n_rec * 4, g->stream));
-        TRY(th_rt_d2h(cnt, g->d_cnt.p, sizeof(cnt), g->stream));
         TRY(th_rt_sync(g->stream));
-        if (cnt[1]) return th_fail("partition scratch overflow (par_pos region or boundary buffer)");
         long long tot = 0;
         for (int c = 0; c < n_rec; ++c) { g->h_par_dst[c] = (int)tot; tot += g->h_par_n[c]; }
         g->h_parc.resize((size_t)tot);
