@@ -316,7 +316,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         const bool cache_me = cache16_ok && e - b < TH_POA_RW;
         const bool store_full = needfull || !cache_me;     // otherwise only the direction word leaves the CU
         int rmax = TH_NEG - 0x10000000, left = b, right = b;
-        const bool pk = !WIDE && LQ && fast && L_c == 3 && cache_me;
+        const bool pk = !WIDE && LQ && fast && L_c == 3 && cache_me && !needfull;    // rows some far row will read take the 32-bit path (they store whole cells)
         if (pk) {
             // ================= packed row: lane l owns columns B0 + 128 t + 2 l and the next one =================
             const int PB0 = L_b & ~1;
@@ -370,12 +370,6 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 const uint32_t d_lo = (code & 7u) | ((code << 24) & 0x78000000u), d_hi = ((code >> 16) & 7u) | ((code << 8) & 0x78000000u);
                 if (j0 <= e) {
                     *(unsigned long long *)(drow + (j0 - b)) = (unsigned long long)d_hi << 32 | d_lo;   // column b-1 / e+1 of an odd edge land in the row's own padding
-                    if (store_full) {
-                        const int hl = TH_PK_LO(h), hh = TH_PK_HI(h), n1l = TH_PK_LO(n1), n1h = TH_PK_HI(n1), n2l = TH_PK_LO(n2), n2h = TH_PK_HI(n2);
-                        int4 cv;
-                        if (lo_ok) { cv.x = hl < neg_thr ? TH_NEG : hl; cv.y = n1l < neg_thr ? TH_NEG : n1l; cv.z = n2l < neg_thr ? TH_NEG : n2l; cv.w = (int)d_lo; row[j0 - b] = cv; }
-                        if (hi_ok) { cv.x = hh < neg_thr ? TH_NEG : hh; cv.y = n1h < neg_thr ? TH_NEG : n1h; cv.z = n2h < neg_thr ? TH_NEG : n2h; cv.w = (int)d_hi; row[j0 + 1 - b] = cv; }
-                    }
                 }
                 if (wi < TH_POA_RS / 2) { wH[wi] = th_sel(IM, h, TH_PK_NEG); wE1[wi] = th_sel(IM, n1, TH_PK_NEG); wE2[wi] = th_sel(IM, n2, TH_PK_NEG); }
                 // row maximum and its first / last column: the maximum of H is a maximum of hnf (an F value is always
