@@ -95,6 +95,9 @@ void th_output(FILE *fp, int n, const char *const *names, const char *const *seq
 
 /* mini_tandem(), src/main.c:375-436: whole-file driver (FASTA/FASTQ, optionally gzipped) */
 int th_run_file(const char *read_fn, th_para_t *p, FILE *out, int device, int batch_reads);
+/* the same over several devices of one node: batch i runs on devices[i % n_dev] (reads are independent, src/tidehunter.c:23-60,
+ * so the shards exchange nothing); output order = input order.  1 <= n_dev <= 16. */
+int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *devices, int n_dev, int batch_reads);
 
 /* deterministic synthetic tandem-repeat reads; returns read length, writes at most cap bases */
 int th_synth_read(uint64_t seed, uint64_t read_index, int period, int copies, double err, char *dst, int cap);

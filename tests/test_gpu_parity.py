@@ -193,6 +193,15 @@ def test_gpu_multi_batch_file_run(tmp_path):
     assert _cli("-b", "7", "-f", "2", fq) == open(os.path.join(U.ROOT, "tests", "golden", "oracle_test_fq_tab.txt")).read()
 
 
+def test_gpu_multi_device_file_run():
+    """th_run_file_multi: batches go round a device list (here two workers on the one GPU of the box), the writer restores
+    input order; same bytes as the single-device run and as the oracle"""
+    fq = os.path.join(U.DATA, "test.fq")
+    want = open(os.path.join(U.ROOT, "tests", "golden", "oracle_test_fq_tab.txt")).read()
+    assert _cli("-g", "0,0", "-b", "7", "-f", "2", fq) == want
+    assert _cli("-g", "0,0,0", "-b", "64", "-f", "2", fq) == want
+
+
 def test_gpu_large_batch_is_deterministic(th):
     """a few thousand reads, three runs: identical records every time (persistent kernels pull work from
     shared queues and chain records arrive in arbitrary order; nothing downstream may depend on that)"""

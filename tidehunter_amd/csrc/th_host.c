@@ -598,20 +598,30 @@ void th_output(FILE *fp, int n, const char *const *names, const char *const *seq
  * three run as a pipeline over three batch slots so that parsing batch i+1 and formatting batch i-1 overlap the device
  * work on batch i.  Output order = input order (src/main.c:217). */
 enum { SLOT_EMPTY = 0, SLOT_FILLED = 1, SLOT_DONE = 2 };
-typedef struct { char **names, **seqs; int *lens; int n, state; th_tandem_seq_t *ts; th_str_t arena; size_t *noff, *soff; } th_slot_t;
+#define TH_MAX_DEV 16
+#define TH_MAX_SLOT (2 * TH_MAX_DEV + 1)
+typedef struct { char **names, **seqs; int *lens; int n, state, batch; th_tandem_seq_t *ts; th_str_t arena; size_t *noff, *soff; } th_slot_t;   /* batch: index of the batch the slot holds */
 typedef struct {
-    th_slot_t slot[3];
+    th_slot_t slot[TH_MAX_SLOT]; int n_slot, n_dev;
     pthread_mutex_t mu; pthread_cond_t cv;
-    th_reader_t *rd; FILE *out; const th_para_t *p; int batch_reads; volatile int stop;
+    th_reader_t *rd; FILE *out; th_para_t *p; int batch_reads; volatile int stop;
+    int eof_batch;               /* index of the empty batch that ends the input (-1 until the reader meets it) */
     double t_read, t_write;      /* busy seconds of the two side threads (TH_TRACE=1 prints them) */
 } th_pipe_t;
+typedef struct { th_pipe_t *q; int dev_index, device; int rc, total; double busy; } th_dev_worker_t;
 
-
-static void slot_wait(th_pipe_t *q, th_slot_t *s, int state)
+/* waits until the slot holds batch `batch` in state `state` (batch < 0: any occupant -- the reader waiting for a free slot);
+ * returns 0 if that batch lies beyond the end of the input instead */
+static int slot_wait(th_pipe_t *q, th_slot_t *s, int state, int batch)
 {
+    int ok = 1;
     pthread_mutex_lock(&q->mu);
-    while (s->state != state) pthread_cond_wait(&q->cv, &q->mu);
+    while (!(s->state == state && (batch < 0 || s->batch == batch))) {
+        if (batch >= 0 && q->eof_batch >= 0 && batch > q->eof_batch) { ok = 0; break; }
+        pthread_cond_wait(&q->cv, &q->mu);
+    }
     pthread_mutex_unlock(&q->mu);
+    return ok;
 }
 static void slot_set(th_pipe_t *q, th_slot_t *s, int state)
 {
@@ -622,8 +632,8 @@ static void *pipe_reader(void *arg)
     th_pipe_t *q = (th_pipe_t *)arg;
     const long long max_bases = 1LL << 30;
     for (int i = 0;; ++i) {
-        th_slot_t *s = &q->slot[i % 3];
-        slot_wait(q, s, SLOT_EMPTY);
+        th_slot_t *s = &q->slot[i % q->n_slot];
+        slot_wait(q, s, SLOT_EMPTY, -1);
         int n = 0; long long bases = 0;
         const double t0 = now_s();
         s->arena.l = 0;
@@ -631,7 +641,8 @@ static void *pipe_reader(void *arg)
             while (n < q->batch_reads && bases < max_bases && rd_next_into(q->rd, &s->arena, &s->noff[n], &s->soff[n], &s->lens[n])) { bases += s->lens[n]; ++n; }
         for (int k = 0; k < n; ++k) { s->names[k] = s->arena.s + s->noff[k]; s->seqs[k] = s->arena.s + s->soff[k]; }
         q->t_read += now_s() - t0;
-        s->n = n;
+        s->n = n; s->batch = i;
+        if (n == 0) { pthread_mutex_lock(&q->mu); q->eof_batch = i; pthread_mutex_unlock(&q->mu); }
         slot_set(q, s, SLOT_FILLED);
         if (n == 0) return NULL;
     }
@@ -640,8 +651,8 @@ static void *pipe_writer(void *arg)
 {
     th_pipe_t *q = (th_pipe_t *)arg;
     for (int i = 0;; ++i) {
-        th_slot_t *s = &q->slot[i % 3];
-        slot_wait(q, s, SLOT_DONE);
+        th_slot_t *s = &q->slot[i % q->n_slot];
+        slot_wait(q, s, SLOT_DONE, i);
         const int n = s->n;
         const double t0 = now_s();
         if (n > 0 && q->out && !q->stop) th_output(q->out, n, (const char *const *)s->names, (const char *const *)s->seqs, s->lens, s->ts, q->p);
@@ -650,48 +661,63 @@ static void *pipe_writer(void *arg)
         if (n == 0) return NULL;
     }
 }
-
-int th_run_file(const char *read_fn, th_para_t *p, FILE *out, int device, int batch_reads)
+/* one worker per device: batches dev_index, dev_index + n_dev, ... (reads are independent, so the shards need no exchange;
+ * the writer restores input order) */
+static void *pipe_device(void *arg)
 {
+    th_dev_worker_t *w = (th_dev_worker_t *)arg; th_pipe_t *q = w->q;
+    th_handle_t *h = th_init(q->p, w->device);
+    if (!h) { w->rc = -1; q->stop = 1; }
+    for (int i = w->dev_index;; i += q->n_dev) {
+        th_slot_t *s = &q->slot[i % q->n_slot];
+        if (!slot_wait(q, s, SLOT_FILLED, i)) break;
+        if (s->n > 0 && h && !q->stop) {
+            const double t0 = now_s();
+            const int rc = th_process_batch(h, (const char *const *)s->seqs, s->lens, s->n, s->ts);
+            w->busy += now_s() - t0;
+            if (rc) { w->rc = -1; q->stop = 1; } else w->total += s->n;   /* never partial output: a failed batch and everything after it are dropped */
+        }
+        const int last = s->n == 0;
+        slot_set(q, s, SLOT_DONE);
+        if (last) break;
+    }
+    if (h) th_destroy(h);
+    return NULL;
+}
+
+int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *devices, int n_dev, int batch_reads)
+{
+    if (n_dev < 1 || n_dev > TH_MAX_DEV) return host_fail("between 1 and 16 devices");
     if (batch_reads <= 0) batch_reads = 65536;
     if (p->five_fn && p->three_fn && !p->five_seq) if (th_load_adapters(p)) return -1;
     th_reader_t *r = rd_open(read_fn);
     if (!r) { char m[300]; snprintf(m, sizeof(m), "fail to open file '%s'", read_fn); return host_fail(m); }
-    th_handle_t *h = th_init(p, device);
-    if (!h) { rd_close(r); return -1; }
-    th_pipe_t q; memset(&q, 0, sizeof(q));
-    pthread_mutex_init(&q.mu, NULL); pthread_cond_init(&q.cv, NULL);
-    q.rd = r; q.out = out; q.p = p; q.batch_reads = batch_reads;
-    for (int i = 0; i < 3; ++i) {
-        q.slot[i].names = (char **)calloc(batch_reads, sizeof(char *)); q.slot[i].seqs = (char **)calloc(batch_reads, sizeof(char *));
-        q.slot[i].lens = (int *)calloc(batch_reads, sizeof(int)); q.slot[i].ts = th_alloc_tandem_seq(batch_reads);
-        q.slot[i].noff = (size_t *)calloc(batch_reads, sizeof(size_t)); q.slot[i].soff = (size_t *)calloc(batch_reads, sizeof(size_t));
+    th_pipe_t *q = (th_pipe_t *)calloc(1, sizeof(th_pipe_t));
+    pthread_mutex_init(&q->mu, NULL); pthread_cond_init(&q->cv, NULL);
+    q->rd = r; q->out = out; q->p = p; q->batch_reads = batch_reads; q->n_dev = n_dev; q->n_slot = 2 * n_dev + 1; q->eof_batch = -1;
+    for (int i = 0; i < q->n_slot; ++i) {
+        q->slot[i].names = (char **)calloc(batch_reads, sizeof(char *)); q->slot[i].seqs = (char **)calloc(batch_reads, sizeof(char *));
+        q->slot[i].lens = (int *)calloc(batch_reads, sizeof(int)); q->slot[i].ts = th_alloc_tandem_seq(batch_reads);
+        q->slot[i].noff = (size_t *)calloc(batch_reads, sizeof(size_t)); q->slot[i].soff = (size_t *)calloc(batch_reads, sizeof(size_t));
     }
-    pthread_t t_rd, t_wr;
-    pthread_create(&t_rd, NULL, pipe_reader, &q); pthread_create(&t_wr, NULL, pipe_writer, &q);
-    int total = 0, rc = 0;
-    double t_dev = 0; const double t_start = now_s();
-    for (int i = 0;; ++i) {
-        th_slot_t *s = &q.slot[i % 3];
-        slot_wait(&q, s, SLOT_FILLED);
-        if (s->n > 0 && !rc) {
-            const double t0 = now_s();
-            rc = th_process_batch(h, (const char *const *)s->seqs, s->lens, s->n, s->ts);
-            t_dev += now_s() - t0;
-            if (rc) q.stop = 1; else total += s->n;   /* never partial output: the failed batch and everything after it are dropped */
-        }
-        const int last = s->n == 0;
-        slot_set(&q, s, SLOT_DONE);
-        if (last) break;
-    }
+    pthread_t t_rd, t_wr, t_dev[TH_MAX_DEV]; th_dev_worker_t w[TH_MAX_DEV];
+    const double t_start = now_s();
+    pthread_create(&t_rd, NULL, pipe_reader, q); pthread_create(&t_wr, NULL, pipe_writer, q);
+    for (int d = 0; d < n_dev; ++d) { memset(&w[d], 0, sizeof(w[d])); w[d].q = q; w[d].dev_index = d; w[d].device = devices[d]; pthread_create(&t_dev[d], NULL, pipe_device, &w[d]); }
+    int total = 0, rc = 0; double busy = 0;
+    for (int d = 0; d < n_dev; ++d) { pthread_join(t_dev[d], NULL); total += w[d].total; rc |= w[d].rc; busy += w[d].busy; }
     pthread_join(t_rd, NULL); pthread_join(t_wr, NULL);
     if (getenv("TH_TRACE"))
-        fprintf(stderr, "[th_run_file] %d reads: wall %.3f s; busy: reader %.3f s, device batches %.3f s, writer %.3f s\n",
-                total, now_s() - t_start, q.t_read, t_dev, q.t_write);
-    for (int i = 0; i < 3; ++i) { th_free_tandem_seq(q.slot[i].ts, batch_reads); free(q.slot[i].names); free(q.slot[i].seqs); free(q.slot[i].lens); free(q.slot[i].noff); free(q.slot[i].soff); free(q.slot[i].arena.s); }
-    pthread_mutex_destroy(&q.mu); pthread_cond_destroy(&q.cv);
-    th_destroy(h); rd_close(r);
+        fprintf(stderr, "[th_run_file] %d reads on %d device(s): wall %.3f s; busy: reader %.3f s, device batches %.3f s (summed), writer %.3f s\n",
+                total, n_dev, now_s() - t_start, q->t_read, busy, q->t_write);
+    for (int i = 0; i < q->n_slot; ++i) { th_free_tandem_seq(q->slot[i].ts, batch_reads); free(q->slot[i].names); free(q->slot[i].seqs); free(q->slot[i].lens); free(q->slot[i].noff); free(q->slot[i].soff); free(q->slot[i].arena.s); }
+    pthread_mutex_destroy(&q->mu); pthread_cond_destroy(&q->cv);
+    free(q); rd_close(r);
     return rc ? -1 : total;
+}
+int th_run_file(const char *read_fn, th_para_t *p, FILE *out, int device, int batch_reads)
+{
+    return th_run_file_multi(read_fn, p, out, &device, 1, batch_reads);
 }
 
 /* ---------------------------------------------------------------- synthetic reads */

@@ -37,7 +37,7 @@ static int usage(void)
     fprintf(stderr, "\nTideHunter-amd: Tandem repeats detection and consensus calling from noisy long reads (MI355X/HIP hot path)\n\n");
     fprintf(stderr, "Version: %s\n\nUsage:   TideHunter-amd [options] in.fa/fq > cons.fa\n\n", th_version());
     fprintf(stderr, "Options: as TideHunter 1.5.5 (-k -w -H -c -e -p -P -M -X -O -E -5 -3 -a -o -m -r -u -l -F -s -f -t -h -v)\n");
-    fprintf(stderr, "         -g --gpu INT    HIP device ordinal [0];  -b --batch INT   reads per device batch [65536]\n");
+    fprintf(stderr, "         -g --gpu LIST   HIP device ordinal(s), e.g. 0 or 0,1,2,3: batches go round the listed devices [0];  -b --batch INT   reads per device batch [65536]\n");
     return 1;
 }
 
@@ -47,7 +47,8 @@ int main(int argc, char **argv)
 {
     th_para_t *p = th_init_para();
     FILE *out = stdout; char *s; double x, t0 = now();
-    int c, device = getenv("TH_DEVICE") ? atoi(getenv("TH_DEVICE")) : 0, batch = 0, rc = 0;
+    int c, batch = 0, rc = 0;
+    int devices[16] = { getenv("TH_DEVICE") ? atoi(getenv("TH_DEVICE")) : 0 }, n_dev = 1;
     while ((c = getopt_long(argc, argv, "k:w:m:Hhvc:e:p:P:M:X:E:O:5:3:a:o:ur:qslFf:t:g:b:", lopt, NULL)) >= 0) {
         switch (c) {
         case 'h': return usage();
@@ -75,7 +76,7 @@ int main(int argc, char **argv)
         case 's': p->single_copy = 1; break;
         case 'f': p->out_fmt = atoi(optarg); if (p->out_fmt < 1 || p->out_fmt > 4) { fprintf(stderr, "\n[main] Error: unknown format number. (-%c)\n", c); goto END; } break;
         case 't': p->n_thread = atoi(optarg); break;
-        case 'g': device = atoi(optarg); break;
+        case 'g': n_dev = 0; for (char *tok = strtok(optarg, ","); tok && n_dev < 16; tok = strtok(NULL, ",")) devices[n_dev++] = atoi(tok); if (n_dev == 0) { devices[0] = 0; n_dev = 1; } break;
         case 'b': batch = atoi(optarg); break;
         default: goto END;
         }
@@ -87,7 +88,7 @@ int main(int argc, char **argv)
     if (p->five_fn != NULL && p->three_fn == NULL) fprintf(stderr, "\n[main] Warning: only 5' adapter sequence is provided. Full-length sequence cannot be determined.\n");
     p->div_exp = exp(2 * p->k * p->max_div);
     {
-        int n = th_run_file(argv[optind], p, out, device, batch);
+        int n = th_run_file_multi(argv[optind], p, out, devices, n_dev, batch);
         if (n < 0) { fprintf(stderr, "[main] Error: %s\n", th_last_error()); rc = 1; goto END; }
         struct rusage ru; getrusage(RUSAGE_SELF, &ru);
         fprintf(stderr, "[main] Real time: %.3f sec; CPU: %.3f sec; Peak RSS: %.3f GB\n", now() - t0,
