@@ -193,6 +193,21 @@ def test_gpu_multi_batch_file_run(tmp_path):
     assert _cli("-b", "7", "-f", "2", fq) == open(os.path.join(U.ROOT, "tests", "golden", "oracle_test_fq_tab.txt")).read()
 
 
+def test_gpu_variant_boundaries(th):
+    """read lengths on both sides of the per-batch kernel-variant thresholds (32-bit sort words below 16384 / 32768 bases,
+    packed chain-DP records below 65536): a tandem repeat embedded in a random read of exactly that length"""
+    rng = np.random.default_rng(11)
+    para = O.default_para()
+    for L in (16383, 16384, 32767, 32768, 65535, 65536):
+        core = _synth(th.lib, 1, 300, 6, 0.08, L)[0]
+        pad = bytes(b"ACGT"[i] for i in rng.integers(0, 4, L - len(core)))
+        seqs = [pad[:L // 3] + core + pad[L // 3:], _synth(th.lib, 1, 120, 5, 0.1, L + 1)[0]]
+        assert len(seqs[0]) == L
+        got = th.process(seqs)
+        U.stage_compare(th, seqs, para)
+        assert U.assert_records_equal(seqs, got, para, "L=%d" % L) >= 2
+
+
 def test_gpu_multi_device_file_run():
     """th_run_file_multi: batches go round a device list (here two workers on the one GPU of the box), the writer restores
     input order; same bytes as the single-device run and as the oracle"""
