@@ -19,6 +19,7 @@
 #include <ctype.h>
 #include <zlib.h>
 #include <pthread.h>
+#include <unistd.h>
 #include <time.h>
 #include "tidehunter_amd.h"
 #include "th_internal.h"
@@ -514,7 +515,10 @@ static void *collect_range(void *arg)
 int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out)
 {
     th_gpu_out_t o; th_gpu_get(h->gpu, &o);
-    int nth = 8;
+    /* worker threads for the record arithmetic (adapter searches are the heavy part): -t if given above the reference's
+     * default of 4, else 16 on hosts with 32 or more cores, else 8; TH_HOST_THREADS overrides */
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    int nth = h->para.n_thread > 4 ? h->para.n_thread : (ncpu >= 32 ? 16 : 8);
     const char *e = getenv("TH_HOST_THREADS");
     if (e && atoi(e) > 0) nth = atoi(e);
     if (nth > 64) nth = 64;
