@@ -5,7 +5,7 @@ One "step" = one pass of the whole hot path (encode -> self-hits -> chain -> par
 unit/consensus alignments -> host record arithmetic) over one batch of synthetic reads of the
 headline configuration (BASELINE.json configs[2]: period 1000 x 10 copies, 10 % error, ~10 kb reads).
 The batch is uploaded to HBM before the timed region (inputs resident), every step processes a
-different batch of the 100k-read set (read index = rank_offset + step * batch + i).
+different batch (read index = (rank_offset + step * batch + i) mod 100000); the default batch is the whole 100k-read set.
 
   python bench.py --gpus N --steps K --warmup W
 For N > 1 the driver launches one rank per GPU with torch.distributed.run; reads shard across ranks
@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=2)   # two: device buffers reach their steady size (a batch that grows one is first-touched inside a kernel)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("TH_BENCH_BATCH", "65536")), help="reads per step per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("TH_BENCH_BATCH", "100000")), help="reads per step per GPU")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1: auto, 0: skip)")
     a = ap.parse_args()
 

@@ -290,12 +290,16 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         const int wp = std::min(n_rec, g->waves_part);
         TRY(g->d_par_off.ensure(n_rec)); TRY(g->d_par_n.ensure(n_rec)); TRY(g->d_par_dst.ensure(n_rec));
         TRY(g->d_bnd.ensure((size_t)(bnd_part * wp)));
-        // a chain's par_pos region holds cap_mul * (2 * cells + 16) entries; the sum over chains is bounded by the hits of the
-        // batch, so the arena cannot overflow -- a single chain that needs more (the reference allows up to the read length,
+        TRY(th_rt_d2h(g->h_rec.data(), g->d_rec.p, (size_t)n_rec * sizeof(ThChainRec), g->stream));
+        TRY(th_rt_sync(g->stream));
+        size_t par_base = 0;                                     // the regions the kernel will carve: 2 * cells + 16 per chain
+        for (int c = 0; c < n_rec; ++c) par_base += 2 * (size_t)g->h_rec[c].len + 16;
+        // a chain's par_pos region holds cap_mul * (2 * cells + 16) entries and the arena is sized to exactly their sum, so the
+        // arena cannot overflow -- a single chain that needs more (the reference allows up to the read length,
         // src/partition.c:173) makes the partition rerun with larger regions
         for (int cap_mul = getenv("TH_PAR_MUL") ? -1 : 1;; cap_mul = cap_mul < 0 ? 1 : cap_mul * 4) {
             const int mul = cap_mul < 0 ? 0 : cap_mul;     // (TH_PAR_MUL: test knob, a first pass with empty regions)
-            const size_t par_cap = (size_t)std::max(mul, 1) * (2 * padT + 16 * (size_t)n_rec) + 64;
+            const size_t par_cap = (size_t)std::max(mul, 1) * par_base + 64;
             if (par_cap >= (1ull << 31)) return th_fail("par_pos arena would exceed 2^31 entries; use a smaller batch");
             TRY(g->d_par.ensure(par_cap));
             KT_BEGIN(TK_PART);
@@ -310,7 +314,6 @@ extern "C" int th_gpu_run(th_gpu_t *g)
             TRY(th_rt_memset(g->d_cnt.p + 1, 0, sizeof(int), g->stream));
             TRY(th_rt_memset(g->d_cnt.p + 5, 0, sizeof(int), g->stream));
         }
-        TRY(th_rt_d2h(g->h_rec.data(), g->d_rec.p, (size_t)n_rec * sizeof(ThChainRec), g->stream));
         TRY(th_rt_d2h(g->h_par_n.data(), g->d_par_n.p, (size_t)n_rec * 4, g->stream));
         TRY(th_rt_sync(g->stream));
         long long tot = 0;
