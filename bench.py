@@ -61,10 +61,17 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    # TH_BENCH_BACKEND / TH_BENCH_DEVICE exist to rehearse the multi-rank path on a one-GPU box (gloo, every rank on device 0)
+    backend = os.environ.get("TH_BENCH_BACKEND", "nccl")
+    if "TH_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["TH_BENCH_DEVICE"])
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     import tidehunter_amd as TH
     lib = TH.load_library()
     th = TH.TideHunter(device=local)
@@ -106,7 +113,7 @@ def main():
                 n_cons += 1
     sync_all()
     if dist is not None:
-        t = torch.tensor([t_total], device="cuda", dtype=torch.float64)
+        t = torch.tensor([t_total], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_total = float(t.item())
     reads = B * a.steps * world
