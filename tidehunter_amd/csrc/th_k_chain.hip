@@ -281,21 +281,39 @@ th_k_chain_sort(const uint32_t *__restrict__ roff, ThDevPara P,
 }
 
 #define TH_XW_BLOCK 64
+#ifndef TH_TOPL
+#define TH_TOPL 256             // chain-table slots kept in LDS by the one-wave extraction (the CPU test build uses 2)
+#endif
+template <class T> struct ThTier {
+    T *lds; int *ovf;
+    __device__ __forceinline__ int get(int i) const { return i < TH_TOPL ? (int)lds[i] : TH_LOAD_L2(ovf + (i - TH_TOPL)); }
+    __device__ __forceinline__ void set(int i, int v) const { if (i < TH_TOPL) lds[i] = (T)v; else ovf[i - TH_TOPL] = v; }
+};
 __global__ void __launch_bounds__(TH_XW_BLOCK)
 th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
                         const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ hit_n,
                         const int *__restrict__ score, const int *__restrict__ from, int *__restrict__ cells,
-                        const uint16_t *__restrict__ xorder, const int *__restrict__ xstart, const int *__restrict__ xend,
+                        const uint16_t *__restrict__ xorder, const int *__restrict__ xstart, const int *__restrict__ xend, int *__restrict__ xovf,
                         ThChainRec *__restrict__ rec, int rec_cap, int *__restrict__ rec_count,
-                        int *__restrict__ read_ch_base, int *__restrict__ read_ch_n, int *__restrict__ err)
+                        int *__restrict__ read_ch_base, int *__restrict__ read_ch_n, int *__restrict__ err, int *__restrict__ queue)
 {
     __shared__ short s_from[TH_XFAST_MAX];
     __shared__ uint32_t s_trk[TH_XFAST_MAX / 32];
-    __shared__ int ch_score[TH_TOPN], ch_fs[TH_TOPN], ch_ls[TH_TOPN], ch_le[TH_TOPN];
-    __shared__ unsigned short ch_off[TH_TOPN], ch_len[TH_TOPN];      // offsets / lengths in the read's cell list (<= 8192 hits)
-    __shared__ short ch_idx[TH_TOPN];
+    // chain table: the first TH_TOPL slots in LDS, the rest (up to the reference's cap of 1000 chains) in the wave's HBM
+    // overflow segment -- a read rarely keeps more than a few dozen chains, and 22 KB of LDS per wave for the full table
+    // held the kernel at 4 waves per CU (it is bound by the latency of its sequential attempts)
+    __shared__ int l_score[TH_TOPL], l_fs[TH_TOPL], l_ls[TH_TOPL], l_le[TH_TOPL];
+    __shared__ unsigned short l_off[TH_TOPL], l_len[TH_TOPL];      // offsets / lengths in the read's cell list (<= 8192 hits)
+    __shared__ short l_idx[TH_TOPL];
+    int *ovf = xovf + (long long)blockIdx.x * (7 * (TH_TOPN - TH_TOPL));
+    const ThTier<int> ch_score = { l_score, ovf }, ch_fs = { l_fs, ovf + (TH_TOPN - TH_TOPL) }, ch_ls = { l_ls, ovf + 2 * (TH_TOPN - TH_TOPL) },
+                      ch_le = { l_le, ovf + 3 * (TH_TOPN - TH_TOPL) };
+    const ThTier<unsigned short> ch_off = { l_off, ovf + 4 * (TH_TOPN - TH_TOPL) }, ch_len = { l_len, ovf + 5 * (TH_TOPN - TH_TOPL) };
+    const ThTier<short> ch_idx = { l_idx, ovf + 6 * (TH_TOPN - TH_TOPL) };
     const int lane = TH_LANE();
-    for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
+    for (;;) {
+        const int r = th_queue_pop(queue);            // reads differ in hits and chains: waves pull the next read
+        if (r >= n_reads) break;
         const uint32_t off = roff[r];
         const int n = hit_n[r];
         if (n > TH_XFAST_MAX) continue;
@@ -305,7 +323,7 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
         const uint16_t *XO = xorder + off; const int *XS = xstart + off, *XE = xend + off;
         for (int i = lane; i < n; i += TH_WAVE) s_from[i] = (short)F[i];
         for (int i = lane; i < (n + 31) / 32; i += TH_WAVE) s_trk[i] = 0;
-        for (int i = lane; i < TH_TOPN; i += TH_WAVE) ch_idx[i] = (short)i;
+        for (int i = lane; i < TH_TOPN; i += TH_WAVE) ch_idx.set(i, i);
         TH_WAVE_FENCE();
         int ch_n = 0, top = 0, ci = 0;
         while (ci < n && ch_n < TH_TOPN) {
@@ -317,9 +335,9 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
             bool skip = !valid || ((s_trk[cand >> 5] >> (cand & 31)) & 1);
             bool open = !skip;                       // is_in_chain's scan is still running for this lane
             for (int q = 0; q < ch_n; ++q) {
-                const int c = ch_idx[q];
-                if (ch_len[c] <= 0) continue;
-                const int cst = ch_fs[c], cen = ch_le[c];
+                const int c = ch_idx.get(q);
+                if (ch_len.get(c) <= 0) continue;
+                const int cst = ch_fs.get(c), cen = ch_le.get(c);
                 if (open) {
                     if (cen < cell_start) open = false;
                     else if (cst > cell_end) {}
@@ -368,23 +386,23 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
                 const int fs = E[cfirst] - Pd[cfirst], ls = E[clast] - Pd[clast], le = E[clast];
                 int loses = 0, kill = -1;
                 for (int i = ch_n - 1; i >= 0; --i) {            // is_overlap_chain, :68-83
-                    if (ch_len[i] <= 0) continue;
-                    if (ch_le[i] <= ls) break;
-                    const int s1 = ch_fs[i], e1 = ch_ls[i];
+                    if (ch_len.get(i) <= 0) continue;
+                    if (ch_le.get(i) <= ls) break;
+                    const int s1 = ch_fs.get(i), e1 = ch_ls.get(i);
                     const int mn = min(e1 - s1, ls - fs), ov = min(e1, ls) - max(s1, fs);
                     if (ov / (mn + 0.0) >= 0.5) {
-                        if (ch_score[i] > sc) loses = 1; else kill = i;
+                        if (ch_score.get(i) > sc) loses = 1; else kill = i;
                         break;
                     }
                 }
                 TH_WAVE_FENCE();
-                if (lane == 0 && kill >= 0) ch_len[kill] = 0;    // the older chain loses
+                if (lane == 0 && kill >= 0) ch_len.set(kill, 0);    // the older chain loses
                 TH_WAVE_FENCE();
                 ok = !loses;
                 if (ok) {
                     // reverse the cells in place (they were written last-to-first)
                     for (int a = lane; a < len / 2; a += TH_WAVE) { const int b2 = len - 1 - a; const int t0 = CL[top + a], t1 = CL[top + b2]; CL[top + a] = t1; CL[top + b2] = t0; }
-                    if (lane == 0) { ch_off[nw] = (unsigned short)top; ch_len[nw] = (unsigned short)len; ch_score[nw] = sc; ch_fs[nw] = fs; ch_ls[nw] = ls; ch_le[nw] = le; }
+                    if (lane == 0) { ch_off.set(nw, top); ch_len.set(nw, len); ch_score.set(nw, sc); ch_fs.set(nw, fs); ch_ls.set(nw, ls); ch_le.set(nw, le); }
                     top += len; ++ch_n;
                 }
             }
@@ -392,14 +410,14 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
             // sort_chain, src/tandem_chain.c:188-207 (selection pass with the reference's stale `i`), by lane 0
             if (lane == 0) {
                 for (int a = 0; a + 1 < ch_n; ++a) {
-                    const int i = ch_idx[a];
-                    if (ch_len[i] <= 0) continue;
-                    int e1 = ch_le[i];
+                    const int i = ch_idx.get(a);
+                    if (ch_len.get(i) <= 0) continue;
+                    int e1 = ch_le.get(i);
                     for (int b = a + 1; b < ch_n; ++b) {
-                        const int j = ch_idx[b];
-                        if (ch_len[j] <= 0) continue;
-                        const int e2 = ch_le[j];
-                        if (e1 < e2) { ch_idx[a] = (short)j; ch_idx[b] = (short)i; e1 = e2; }
+                        const int j = ch_idx.get(b);
+                        if (ch_len.get(j) <= 0) continue;
+                        const int e2 = ch_le.get(j);
+                        if (e1 < e2) { ch_idx.set(a, j); ch_idx.set(b, i); e1 = e2; }
                     }
                 }
             }
@@ -407,7 +425,7 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
         }
         // copy_chain in reverse rank order (ascending end), chains with >= 3 cells; seed = first cell (:251-255)
         int cnt = 0;
-        for (int q = ch_n - 1; q >= 0; --q) if (ch_len[ch_idx[q]] >= 3) ++cnt;
+        for (int q = ch_n - 1; q >= 0; --q) if (ch_len.get(ch_idx.get(q)) >= 3) ++cnt;
         int base = 0;
         if (lane == 0 && cnt) base = atomicAdd(rec_count, cnt);
         base = TH_READLANE(base, 0);
@@ -417,13 +435,13 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
             if (cnt) {
                 int o = base;
                 for (int q = ch_n - 1; q >= 0; --q) {
-                    const int c = ch_idx[q];
-                    if (ch_len[c] < 3) continue;
-                    const int cc0 = CL[ch_off[c]];
+                    const int c = ch_idx.get(q);
+                    if (ch_len.get(c) < 3) continue;
+                    const int cc0 = CL[ch_off.get(c)];
                     ThChainRec xr;
-                    xr.read = r; xr.cell_off = (int)off + ch_off[c]; xr.len = ch_len[c];
-                    xr.est_start = ch_fs[c]; xr.est_period = E[cc0] - ch_fs[c];
-                    xr.first_end = E[cc0]; xr.last_start = ch_ls[c]; xr.pad = 0;
+                    xr.read = r; xr.cell_off = (int)off + ch_off.get(c); xr.len = ch_len.get(c);
+                    xr.est_start = ch_fs.get(c); xr.est_period = E[cc0] - ch_fs.get(c);
+                    xr.first_end = E[cc0]; xr.last_start = ch_ls.get(c); xr.pad = 0;
                     rec[o++] = xr;
                 }
             }

@@ -48,7 +48,7 @@ struct th_gpu {
     std::vector<uint32_t> h_roff; std::vector<long long> h_gsort_off; long long gsort_total = 0;
     DBuf<uint8_t> d_seq, d_bseq, d_tracked, d_cons;
     DBuf<uint32_t> d_roff, d_tmp;
-    DBuf<uint16_t> d_xorder; DBuf<int> d_xstart, d_xend;
+    DBuf<uint16_t> d_xorder; DBuf<int> d_xstart, d_xend, d_xovf;
     DBuf<uint8_t> d_cons_c; DBuf<int> d_cov_c, d_cc_len, d_cc_off;   // compacted results   // candidates in extraction order (th_k_chain_sort)
     DBuf<int> d_hit_end, d_hit_per, d_hit_n, d_score, d_from, d_cells, d_cnt, d_read_ch_base, d_read_ch_n;
     DBuf<unsigned long long> d_gsort, d_eps; DBuf<long long> d_gsort_off;
@@ -61,7 +61,7 @@ struct th_gpu {
     std::vector<int> h_cons_len, h_status, h_iden, h_ext, h_cov; std::vector<uint8_t> h_cons;
     std::vector<th_job_t> jobs;
     double ms_kernels = 0, ms_dominant = 0, ms_k[8] = { 0 };
-    int waves_part = 4096, waves_poa = 5120, waves_aln = 8192, waves_xw = 1024;   // persistent grids: 256 CUs x 4 SIMDs x resident waves
+    int waves_part = 4096, waves_poa = 5120, waves_aln = 8192, waves_xw = 1536;   // persistent grids: 256 CUs x 4 SIMDs x resident waves
 };
 
 static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
@@ -92,7 +92,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
 extern "C" void th_gpu_destroy(th_gpu_t *g)
 {
     if (!g) return;
-    g->d_seq.release(); g->d_bseq.release(); g->d_tracked.release(); g->d_sub.release(); g->d_scl.release(); g->d_sst.release(); g->d_cons_c.release(); g->d_cov_c.release(); g->d_cc_len.release(); g->d_cc_off.release(); g->d_eps.release(); g->d_xorder.release(); g->d_xstart.release(); g->d_xend.release(); g->d_cons.release(); g->d_roff.release(); g->d_tmp.release();
+    g->d_seq.release(); g->d_bseq.release(); g->d_tracked.release(); g->d_sub.release(); g->d_scl.release(); g->d_sst.release(); g->d_cons_c.release(); g->d_cov_c.release(); g->d_cc_len.release(); g->d_cc_off.release(); g->d_eps.release(); g->d_xovf.release(); g->d_xorder.release(); g->d_xstart.release(); g->d_xend.release(); g->d_cons.release(); g->d_roff.release(); g->d_tmp.release();
     g->d_hit_end.release(); g->d_hit_per.release(); g->d_hit_n.release(); g->d_score.release(); g->d_from.release(); g->d_cells.release();
     g->d_cnt.release(); g->d_read_ch_base.release(); g->d_read_ch_n.release(); g->d_gsort.release(); g->d_gsort_off.release(); g->d_rec.release();
     g->d_par.release(); g->d_par_off.release(); g->d_par_n.release(); g->d_par_dst.release(); g->d_parc.release(); g->d_bnd.release(); g->d_scratch.release();
@@ -226,6 +226,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
     TRY(g->d_tmp.ensure(padT)); TRY(g->d_hit_end.ensure(padT)); TRY(g->d_hit_per.ensure(padT)); TRY(g->d_hit_n.ensure(n));
     TRY(g->d_score.ensure(padT)); TRY(g->d_from.ensure(padT)); TRY(g->d_cells.ensure(padT)); TRY(g->d_tracked.ensure(padT));
     TRY(g->d_xorder.ensure(padT)); TRY(g->d_xstart.ensure(padT)); TRY(g->d_xend.ensure(padT));
+    TRY(g->d_xovf.ensure((size_t)std::min(n, g->waves_xw) * 7 * (TH_TOPN - TH_TOPL)));
     TRY(g->d_cnt.ensure(8)); TRY(g->d_read_ch_base.ensure(n)); TRY(g->d_read_ch_n.ensure(n)); TRY(g->d_rec.ensure(rec_cap));
     TRY(th_rt_memset(g->d_cnt.p, 0, 8 * sizeof(int), g->stream));
 
@@ -264,8 +265,8 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         TH_LAUNCH(th_k_chain_extract_wave, std::min(n, g->waves_xw), TH_XW_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
                   (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p,
                   (const int *)g->d_score.p, (const int *)g->d_from.p, g->d_cells.p,
-                  (const uint16_t *)g->d_xorder.p, (const int *)g->d_xstart.p, (const int *)g->d_xend.p, g->d_rec.p, rec_cap, g->d_cnt.p,
-                  g->d_read_ch_base.p, g->d_read_ch_n.p, g->d_cnt.p + 1);
+                  (const uint16_t *)g->d_xorder.p, (const int *)g->d_xstart.p, (const int *)g->d_xend.p, g->d_xovf.p, g->d_rec.p, rec_cap, g->d_cnt.p,
+                  g->d_read_ch_base.p, g->d_read_ch_n.p, g->d_cnt.p + 1, g->d_cnt.p + 6);
         KT_END(TK_CHAIN_X);
         TRY(th_rt_d2h(cnt, g->d_cnt.p, sizeof(cnt), g->stream));
         TRY(th_rt_sync(g->stream));
@@ -275,6 +276,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         TRY(g->d_rec.ensure(rec_cap));
         const int keep = cnt[1] & ~1;
         TRY(th_rt_memset(g->d_cnt.p, 0, sizeof(int), g->stream));
+        TRY(th_rt_memset(g->d_cnt.p + 6, 0, sizeof(int), g->stream));      // read queue of the extraction waves
         TRY(th_rt_h2d(g->d_cnt.p + 1, &keep, sizeof(int), g->stream));
     }
     if (cnt[1] & 8) return th_fail("minimizer selection repeated a word or overflowed its buffer");
