@@ -334,8 +334,8 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 const bool lo_ok = j0 >= b && j0 <= e, hi_ok = j0 + 1 <= e;
                 const uint32_t IM = (lo_ok ? 0xffffu : 0u) | (hi_ok ? 0xffff0000u : 0u);
                 // substitution scores of the two columns from the row's table
-                const uint32_t qx = *(const unsigned short *)(s_qs + min(j0, QCAP));
-                const uint32_t SC = th_pk_sub(th_ubfe(T, qx & 0xffu, 6) | th_ubfe(T, qx >> 8, 6) << 16, 0x00200020u);
+                const uint32_t qx = s_qs[min(j0, QCAP) >> 1];                        // the pair's two 4-bit query codes
+                const uint32_t SC = th_pk_sub(th_ubfe(T, 6u * (qx & 15u), 6) | th_ubfe(T, 6u * (qx >> 4), 6) << 16, 0x00200020u);
                 // predecessor row: diagonal pair (j0-1, j0) and vertical pairs (j0, j0+1); anything outside its band reads -inf
                 int pi = j0 - PB0 + TH_POA_PAD;
                 pi = pi <= TH_POA_RS - 2 ? pi : 2;
@@ -396,7 +396,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             const bool in = j <= e;
             int m = TH_NEG, e1v = TH_NEG, e2v = TH_NEG, pm = 0, pe1 = 0, pe2 = 0;
             int sc = 0;
-            if (in && j >= 1) { const int qb = LQ ? (int)s_qs[j] : 6 * min((int)q[j - 1], 4); sc = (qb == 24 || nb == 4) ? 0 : (qb == 6 * nb ? M : -X); }
+            if (in && j >= 1) { const int qb = LQ ? (int)((s_qs[j >> 1] >> ((j & 1) * 4)) & 15) : min((int)q[j - 1], 4); sc = (qb == 4 || nb == 4) ? 0 : (qb == nb ? M : -X); }
             if (fast) {
                 if (in) {
                     if (j >= 1) { m = ((j - 1 >= L_b && j - 1 <= L_e) ? TH_RING_LD(s_ring[lslot][0][TH_RIDX(j - 1, L_b)]) : TH_NEG) + sc; }
@@ -691,14 +691,15 @@ __device__ __forceinline__ int *th_carve(int *&p, long long cnt) { int *r = p; p
 //         5 in-degree > 255, 6 consensus longer than cons_cap, 7 scores may not fit the int16 ring (rerun on the 32-bit variant)
 // QCAP: query bases staged in LDS (0: read from HBM); RT: element type of the LDS ring of recent rows (see th_poa_dp)
 template <int QCAP, typename RT>
-// 5 waves per SIMD: 96 VGPRs (9 dwords of scratch) and 8016 B of LDS per wave; measured 588 -> 557 ms per 65536 reads against 4 waves
-__global__ void __launch_bounds__(TH_POA_BLOCK) TH_WAVES_PER_SIMD(5)
+// 6 waves per SIMD: 80 VGPRs (21 dwords of scratch) and 6.5 KB of LDS per wave (query codes packed two per byte); measured per
+// 65536 reads: 4 waves 588 ms, 5 waves 557 ms
+__global__ void __launch_bounds__(TH_POA_BLOCK) TH_WAVES_PER_SIMD(6)
 th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict__ units, const uint32_t *__restrict__ roff,
          const uint8_t *__restrict__ bseq, ThDevPara P, int *__restrict__ scratch, long long scratch_ints,
          uint8_t *__restrict__ cons, int *__restrict__ cov, int *__restrict__ cons_len, int *__restrict__ status, int *__restrict__ queue)
 {
     constexpr bool LQ = QCAP > 0;
-    __shared__ __attribute__((aligned(4))) uint8_t s_qs[QCAP + 4];     // s_qs[j] = 6 * code(q[j-1]): the column's query base, pre-scaled for the score table
+    __shared__ __attribute__((aligned(4))) uint8_t s_qs[QCAP / 2 + 4]; // column j's query code (0..4, code of q[j-1]; 4 for j = 0 and j > qlen) in nibble j & 1 of byte j >> 1
     __shared__ __attribute__((aligned(4))) RT s_ring[TH_POA_RING][3][TH_POA_RS];
     __shared__ int s_rmeta[TH_POA_RING][8];
     const int lane = TH_LANE();
@@ -739,7 +740,11 @@ th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict
         if (!st) th_poa_seed(g, rb + U[0].start, U[0].len);
         for (int s = 1; s < T.n_units && !st; ++s) {
             const uint8_t *q = rb + U[s].start; const int qlen = U[s].len;
-            if (LQ) for (int x = lane; x < qlen + 3; x += TH_WAVE) s_qs[x] = (x >= 1 && x <= qlen) ? (uint8_t)(6 * min((int)q[x - 1], 4)) : (uint8_t)24;
+            if (LQ) for (int x = lane; 2 * x < qlen + 3; x += TH_WAVE) {
+                const int j0 = 2 * x, j1 = j0 + 1;
+                const int c0 = (j0 >= 1 && j0 <= qlen) ? min((int)q[j0 - 1], 4) : 4, c1 = j1 <= qlen ? min((int)q[j1 - 1], 4) : 4;
+                s_qs[x] = (uint8_t)(c0 | c1 << 4);
+            }
             TH_WAVE_FENCE();
             TH_PROF_T0();
             const int deg = th_poa_rows(g);

@@ -61,7 +61,7 @@ struct th_gpu {
     std::vector<int> h_cons_len, h_status, h_iden, h_ext, h_cov; std::vector<uint8_t> h_cons;
     std::vector<th_job_t> jobs;
     double ms_kernels = 0, ms_dominant = 0, ms_k[8] = { 0 };
-    int waves_part = 4096, waves_poa = 5120, waves_aln = 8192, waves_xw = 2048;   // persistent grids: 256 CUs x 4 SIMDs x resident waves
+    int waves_part = 4096, waves_poa = 6144, waves_aln = 8192, waves_xw = 2048;   // persistent grids: 256 CUs x 4 SIMDs x resident waves
 };
 
 static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
