@@ -16,13 +16,15 @@ __global__ void __launch_bounds__(TH_PART_BLOCK)
 th_k_partition(const ThChainRec *__restrict__ rec, int n_rec, const uint32_t *__restrict__ roff, const uint8_t *__restrict__ bseq,
                const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ cells, ThDevPara P,
                int *__restrict__ par, int par_cap, int *__restrict__ par_top, int *__restrict__ par_off, int *__restrict__ par_n,
-               int *__restrict__ bnd, long long bnd_stride, int *__restrict__ err, int cap_mul)
+               int *__restrict__ bnd, long long bnd_stride, int *__restrict__ err, int cap_mul, int *__restrict__ queue)
 {
     const int lane = TH_LANE();
-    const int wave = blockIdx.x, nwave = gridDim.x;
+    const int wave = blockIdx.x;
     int *mybnd = bnd + (long long)wave * bnd_stride;
     const int k = P.k;
-    for (int c = wave; c < n_rec; c += nwave) {
+    for (;;) {
+        const int c = th_queue_pop(queue);            // chains differ in length and in bridging alignments
+        if (c >= n_rec) break;
         const ThChainRec R = rec[c];
         const uint32_t off = roff[R.read];
         const uint8_t *b = bseq + off;

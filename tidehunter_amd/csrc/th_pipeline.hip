@@ -61,7 +61,7 @@ struct th_gpu {
     std::vector<int> h_cons_len, h_status, h_iden, h_ext, h_cov; std::vector<uint8_t> h_cons;
     std::vector<th_job_t> jobs;
     double ms_kernels = 0, ms_dominant = 0, ms_k[8] = { 0 };
-    int waves_part = 4096, waves_poa = 6144, waves_aln = 8192, waves_xw = 2048;   // persistent grids: 256 CUs x 4 SIMDs x resident waves
+    int waves_part = 8192, waves_poa = 6144, waves_aln = 8192, waves_xw = 2048;   // persistent grids: 256 CUs x 4 SIMDs x resident waves
 };
 
 static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
@@ -307,7 +307,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
             KT_BEGIN(TK_PART);
             TH_LAUNCH(th_k_partition, wp, TH_PART_BLOCK, g->stream, (const ThChainRec *)g->d_rec.p, n_rec, (const uint32_t *)g->d_roff.p,
                       (const uint8_t *)g->d_bseq.p, (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_cells.p, g->dp,
-                      g->d_par.p, (int)par_cap, g->d_cnt.p + 5, g->d_par_off.p, g->d_par_n.p, g->d_bnd.p, bnd_part, g->d_cnt.p + 1, mul);
+                      g->d_par.p, (int)par_cap, g->d_cnt.p + 5, g->d_par_off.p, g->d_par_n.p, g->d_bnd.p, bnd_part, g->d_cnt.p + 1, mul, g->d_cnt.p + 7);
             KT_END(TK_PART);
             TRY(th_rt_d2h(cnt, g->d_cnt.p, sizeof(cnt), g->stream));
             TRY(th_rt_sync(g->stream));
@@ -315,6 +315,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
             if (cap_mul >= 64) return th_fail("partition scratch overflow (par_pos region or boundary buffer)");
             TRY(th_rt_memset(g->d_cnt.p + 1, 0, sizeof(int), g->stream));
             TRY(th_rt_memset(g->d_cnt.p + 5, 0, sizeof(int), g->stream));
+            TRY(th_rt_memset(g->d_cnt.p + 7, 0, sizeof(int), g->stream));      // chain queue of the partition waves
         }
         TRY(th_rt_d2h(g->h_par_n.data(), g->d_par_n.p, (size_t)n_rec * 4, g->stream));
         TRY(th_rt_sync(g->stream));
