@@ -37,7 +37,8 @@ __global__ void __launch_bounds__(TH_ALN_BLOCK)
 th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__restrict__ tasks, const int *__restrict__ pos,
            const uint32_t *__restrict__ roff, const uint8_t *__restrict__ bseq,
            const uint8_t *__restrict__ cons, const int *__restrict__ cons_len,
-           int *__restrict__ bnd, long long bnd_stride, int *__restrict__ iden, int *__restrict__ ext, int *__restrict__ err, int *__restrict__ queue)
+           int *__restrict__ bnd, long long bnd_stride, int *__restrict__ iden, int *__restrict__ ext, int *__restrict__ err, int *__restrict__ queue,
+           int wdiv, int wadd)
 {
     __shared__ __attribute__((aligned(16))) int s_in[2][TH_WAVE][8];      // left-border inbox of the banded sweep (two 64-row blocks)
     const int lane = TH_LANE();
@@ -60,7 +61,10 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                 if ((long long)((cl + 63) & ~63) * 4 > bnd_stride) { if (lane == 0) atomicOr(err, 4); }
                 else if (len > 0) {
                     // banded pass with an exactness certificate first; the full matrix only when it cannot be certified
-                    const int W = cl / 8 + 32, D = cl - len, aD = D < 0 ? -D : D;
+                    // first band (cons_len / 10 + 24 by default): wide enough to be certified for units up to ~11 % away from the consensus;
+                    // more divergent units fail the certificate and get a band sized from their banded score.  Measured on config 3
+                    // (10 % read error), alignment ms per 100 000 reads: /8+32 393, /9+24 367, /10+24 353, /11+24 358, /12+24 389
+                    const int W = cl / wdiv + wadd, D = cl - len, aD = D < 0 ? -D : D;
                     v = -1;
                     if (64 + 2 * W + aD < (cl * 3) / 4) {
                         int s1 = 0;

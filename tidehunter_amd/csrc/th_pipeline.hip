@@ -61,6 +61,7 @@ struct th_gpu {
     std::vector<int> h_cons_len, h_status, h_iden, h_ext, h_cov; std::vector<uint8_t> h_cons;
     std::vector<th_job_t> jobs;
     double ms_kernels = 0, ms_dominant = 0, ms_k[8] = { 0 };
+    int aln_wdiv = 10, aln_wadd = 24;     // first certified band of the unit alignments: half-width cons_len / wdiv + wadd
     int waves_part = 8192, waves_poa = 6144, waves_aln = 8192, waves_xw = 2048;   // persistent grids: 256 CUs x 4 SIMDs x resident waves
 };
 
@@ -86,6 +87,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
     g->waves_poa = env_int("TH_WAVES_POA", g->waves_poa);
     g->waves_aln = env_int("TH_WAVES_ALN", g->waves_aln);
     g->waves_xw = env_int("TH_WAVES_XW", g->waves_xw);
+    g->aln_wdiv = std::max(1, env_int("TH_ALN_WDIV", g->aln_wdiv)); g->aln_wadd = std::max(0, env_int("TH_ALN_WADD", g->aln_wadd));
     return g;
 }
 
@@ -430,7 +432,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         KT_BEGIN(TK_ALIGN);
         TH_LAUNCH(th_k_align, wa, TH_ALN_BLOCK, g->stream, (const ThAlnItem *)g->d_items.p, ni, (const ThTask *)g->d_tasks.p, (const int *)g->d_parc.p,
                   (const uint32_t *)g->d_roff.p, (const uint8_t *)g->d_bseq.p, (const uint8_t *)g->d_cons.p, (const int *)g->d_cons_len.p,
-                  g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, g->d_cnt.p + 1, g->d_cnt.p + 4);   // queue head d_cnt[4] was zeroed with the other counters at the start of the run
+                  g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, g->d_cnt.p + 1, g->d_cnt.p + 4, g->aln_wdiv, g->aln_wadd);   // queue head d_cnt[4] was zeroed with the other counters at the start of the run
         KT_END(TK_ALIGN);
         if (getenv("TH_TRACE")) { th_rt_sync(g->stream); fprintf(stderr, "[th] %.3f s: align done (%d items)\n", th_wall_s() - t_run0, ni); }
         // results: consensus strings compacted to their lengths (the slots are sized for the worst case), coverage only on request
