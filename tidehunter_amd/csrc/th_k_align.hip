@@ -33,14 +33,52 @@ __global__ void th_k_gather_cons(int n_tasks, const ThTask *__restrict__ tasks, 
     for (int i = threadIdx.x; i < n; i += blockDim.x) { cons_out[o + i] = cons[so + i]; if (cov_out) cov_out[o + i] = cov[so + i]; }
 }
 
+// Anti-diagonal band engine (th_ksw_band_ad_wave): NP registers per lane cover 256 NP diagonals.  th_ad_pick returns the
+// smallest NP <= npmax whose band reaches `want` diagonals beyond both 0 and D, or 0 when none does or the staging area is too small.
+__device__ __forceinline__ int th_ad_pick(int qlen, int tlen, int want, int lds_bytes, int npmax)
+{
+    const int D = tlen - qlen, aD = D < 0 ? -D : D;
+    if (qlen + tlen >= 30000) return 0;
+    for (int np = 1; np <= npmax; ++np)
+        if ((256 * np - 2 - aD) / 2 >= want) return qlen + tlen + 512 * np + 16 <= lds_bytes ? np : 0;
+    return 0;
+}
+template <int NP>
+__device__ __forceinline__ int th_ad_run(bool has_n, const uint8_t *st, const uint8_t *sq, int qlen, int tlen, int lo, int hi, int *score)
+{
+    return has_n ? th_ksw_band_ad_wave<NP, true>(st, sq, qlen, tlen, lo, hi, score) : th_ksw_band_ad_wave<NP, false>(st, sq, qlen, tlen, lo, hi, score);
+}
+template <int NPMAX>
+__device__ __forceinline__ int th_ad_align(int np, const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, uint8_t *s_seq, int *score)
+{
+    const int D = tlen - qlen, aD = D < 0 ? -D : D;
+    const int W = (256 * np - 2 - aD) / 2;
+    int lo = min(0, D) - W; lo -= lo & 1;                   // even; the band is as wide as the registers allow
+    const int hi = lo + 256 * np - 1;
+    const uint8_t *st, *sq;
+    const bool has_n = th_ad_stage(q, qlen, t, tlen, 128 * np, s_seq, &st, &sq);
+    int v = -1;
+    if (np == 1) v = th_ad_run<1>(has_n, st, sq, qlen, tlen, lo, hi, score);
+    else if (np == 2) v = th_ad_run<2>(has_n, st, sq, qlen, tlen, lo, hi, score);
+    else if (NPMAX >= 3 && np == 3) v = th_ad_run<(NPMAX >= 3 ? 3 : 1)>(has_n, st, sq, qlen, tlen, lo, hi, score);
+    else if (NPMAX >= 4 && np == 4) v = th_ad_run<(NPMAX >= 4 ? 4 : 1)>(has_n, st, sq, qlen, tlen, lo, hi, score);
+    else if (NPMAX >= 5 && np == 5) v = th_ad_run<(NPMAX >= 5 ? 5 : 1)>(has_n, st, sq, qlen, tlen, lo, hi, score);
+    else if (NPMAX >= 6 && np == 6) v = th_ad_run<(NPMAX >= 6 ? 6 : 1)>(has_n, st, sq, qlen, tlen, lo, hi, score);
+    TH_WAVE_FENCE();
+    return v;
+}
+
+// mode: 0 strip engine only (th_ksw_global_band_wave), 1 anti-diagonal engine first (default), 2 both and compare (err bit 64 on a difference)
+template <int LDSB, int NPMAX>
 __global__ void __launch_bounds__(TH_ALN_BLOCK)
 th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__restrict__ tasks, const int *__restrict__ pos,
            const uint32_t *__restrict__ roff, const uint8_t *__restrict__ bseq,
            const uint8_t *__restrict__ cons, const int *__restrict__ cons_len,
            int *__restrict__ bnd, long long bnd_stride, int *__restrict__ iden, int *__restrict__ ext, int *__restrict__ err, int *__restrict__ queue,
-           int wdiv, int wadd)
+           int wdiv, int wadd, int wtol, int mode)
 {
-    __shared__ __attribute__((aligned(16))) int s_in[2][TH_WAVE][8];      // left-border inbox of the banded sweep (two 64-row blocks)
+    __shared__ __attribute__((aligned(16))) int s_in[2][TH_WAVE][8];      // left-border inbox of the strip sweep (two 64-row blocks)
+    __shared__ __attribute__((aligned(16))) uint8_t s_seq[LDSB];          // staged bases of the anti-diagonal engine
     const int lane = TH_LANE();
     const int wave = blockIdx.x;
     int *mybnd = bnd + (long long)wave * bnd_stride;
@@ -63,22 +101,36 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                     // banded pass with an exactness certificate first; the full matrix only when it cannot be certified
                     // first band (cons_len / 10 + 24 by default): wide enough to be certified for units up to ~11 % away from the consensus;
                     // more divergent units fail the certificate and get a band sized from their banded score.  Measured on config 3
-                    // (10 % read error), alignment ms per 100 000 reads: /8+32 393, /9+24 367, /10+24 353, /11+24 358, /12+24 389
+                    // (10 % read error) with the strip engine, alignment ms per 100 000 reads: /8+32 393, /9+24 367, /10+24 353, /11+24 358, /12+24 389
                     const int W = cl / wdiv + wadd, D = cl - len, aD = D < 0 ? -D : D;
+                    const uint8_t *qp = rb + start + 1;
                     v = -1;
-                    if (64 + 2 * W + aD < (cl * 3) / 4) {
-                        int s1 = 0;
-                        v = th_ksw_global_band_wave(rb + start + 1, len, cs, cl, W, mybnd, s_in, &s1);
-                        if (v < 0) {
-                            // not certified (more divergent than ~12 %): the banded score s1 bounds the optimum from below, and a band
-                            // whose Gmin exceeds (m + n - 2 s1 - 4q) / (1 + 2e) is certified for any optimum >= s1; run that band if
-                            // it is still clearly narrower than the matrix
-                            const long long g2 = ((long long)len + cl - 2LL * s1 - 4 * TH_KQ) / (1 + 2 * TH_KE) + 2;
-                            const long long W2 = (g2 - 2 - aD + 1) / 2 + 8;
-                            if (W2 > W && 64 + 2 * W2 + aD < (cl * 3) / 4) v = th_ksw_global_band_wave(rb + start + 1, len, cs, cl, (int)W2, mybnd, s_in, &s1);
-                        }
+                    int s1 = 0; bool have_s1 = false;
+                    // anti-diagonal engine: its band is as wide as its registers (>= W - wtol), so it also serves matrices narrower than the band
+                    int np = mode ? th_ad_pick(len, cl, max(W - wtol, 0), LDSB, NPMAX) : 0;
+                    const bool ad_first = np != 0;
+                    while (np) {
+                        v = th_ad_align<NPMAX>(np, qp, len, cs, cl, s_seq, &s1); have_s1 = true;
+                        if (v >= 0) break;
+                        // not certified: the banded score s1 bounds the optimum from below, and a band whose Gmin exceeds
+                        // (m + n - 2 s1 - 4q) / (1 + 2e) is certified for any optimum >= s1
+                        const long long g2 = ((long long)len + cl - 2LL * s1 - 4 * TH_KQ) / (1 + 2 * TH_KE) + 2;
+                        const long long W2 = (g2 - 2 - aD + 1) / 2 + 8;
+                        const int np2 = W2 < 4096 ? th_ad_pick(len, cl, (int)W2, LDSB, NPMAX) : 0;
+                        np = np2 > np ? np2 : 0;
                     }
-                    if (v < 0) v = th_ksw_global_wave<false>(rb + start + 1, len, cs, cl, 0, mybnd, nullptr);
+                    if (!ad_first && 64 + 2 * W + aD < (cl * 3) / 4) { v = th_ksw_global_band_wave(qp, len, cs, cl, W, mybnd, s_in, &s1); have_s1 = true; }
+                    if (v < 0 && have_s1) {
+                        // strip engine for the second, wider certified band (more divergent than ~12 %) if it is still clearly narrower than the matrix
+                        const long long g2 = ((long long)len + cl - 2LL * s1 - 4 * TH_KQ) / (1 + 2 * TH_KE) + 2;
+                        const long long W2 = (g2 - 2 - aD + 1) / 2 + 8;
+                        if (W2 > W && 64 + 2 * W2 + aD < (cl * 3) / 4) v = th_ksw_global_band_wave(qp, len, cs, cl, (int)W2, mybnd, s_in, &s1);
+                    }
+                    if (v < 0) v = th_ksw_global_wave<false>(qp, len, cs, cl, 0, mybnd, nullptr);
+                    if (mode == 2) {
+                        const int v0 = th_ksw_global_wave<false>(qp, len, cs, cl, 0, mybnd, nullptr);
+                        if (v0 != v && lane == 0) atomicOr(err, 64);
+                    }
                 }
             }
             if (lane == 0) iden[T.aln_off + I.which] = v;

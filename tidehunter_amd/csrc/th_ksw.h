@@ -222,6 +222,167 @@ __device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, 
     return -1;
 }
 
+// ---- Banded global alignment, anti-diagonal formulation: the whole band of one anti-diagonal in one wave ----
+//
+// Same recurrence, tie rules, band semantics and certificate as th_ksw_global_band_wave above (so the two are
+// interchangeable bit for bit), different geometry.  The strip sweep above spends a third of its lanes on the skew of
+// every 64-column strip and moves five values one lane per step; here the wave holds one whole anti-diagonal
+// r' = i' + j' of the band (i' = row + 1, j' = column + 1: row 0 / column 0 are the matrix borders) and walks r' = 0 ..
+// tlen + qlen.  Cell position u on an anti-diagonal is its diagonal, d = i' - j' = lo + 2u + c with c = r' & 1 (lo is
+// even), so that
+//     the diagonal predecessor (i'-1, j'-1) is position u of anti-diagonal r'-2        -> stays in its register,
+//     even r': the left neighbour is position u of r'-1, the upper one position u-1     -> one shift of (E', T1),
+//     odd  r': the upper neighbour is position u of r'-1, the left one position u+1     -> one shift of (F', T2),
+// and there is no skew, no parked strip border, no inbox.  Two positions share a lane as packed int16 halves
+// (v_pk_add_i16 clamp / v_pk_max_i16 / v_pk_ashrrev_i16 / v_bfi, as in the POA rows): lane l, register k holds
+// positions 2 (NP l + k) and the next one, so a shift by one position is one v_alignbit per register plus one DPP move
+// per quantity.  NP registers cover diagonals lo .. lo + 256 NP - 1.  -32768 is minus infinity: every real value lies
+// within +-(qlen + tlen + 8) (the caller guarantees qlen + tlen < 30000), saturating arithmetic keeps minus infinity
+// below all of them, and positions outside the band or the matrix are reset to it after every step.
+// Bases come from an LDS staging area (one byte per base): row codes at s_t[NPOS + i'], column codes REVERSED at
+// s_q[qlen + NPOS - j'], both padded, so the two bases of a lane's pair are adjacent bytes for every r'.
+// Steps come in three kinds: A (r' <= max(hi, -lo): border cells present, general validity mask), B (the band lies
+// inside the matrix: constant masks), C (the rest: general mask).
+#define TH_AD_ONE 0x00010001u
+template <int NP> struct ThAdState {
+    uint32_t E1[NP], TE[NP], F1[NP], TF[NP], Tp[NP], Qp[NP], NT[NP], NQ[NP], POS[NP];
+};
+__device__ __forceinline__ uint32_t th_ad_pair(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 16; }
+__device__ __forceinline__ uint32_t th_ad_is4(uint32_t v) { return th_pk_negmask_op(th_pk_sub(v ^ 0x00040004u, TH_AD_ONE)); }
+
+// one anti-diagonal.  C = r' & 1; PH = 0 (A) / 1 (B) / 2 (C); Hd / Cd: H and CH of anti-diagonal r'-2, replaced by those of r'
+template <int NP, bool HASN, int C, int PH>
+__device__ __forceinline__ void th_ad_step(ThAdState<NP> &S, uint32_t (&Hd)[NP], uint32_t (&Cd)[NP], const uint8_t *s_t, const uint8_t *s_q,
+                                          int rp, int ib, int jb, int qlen, int tlen, int uhb)
+{
+    const int lane = TH_LANE();
+    // bases: the sequence whose index advanced since r'-1 (rows on odd r', columns on even r')
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int u0 = 2 * (NP * lane + k);
+        if (C) { S.Tp[k] = th_ad_pair(s_t + 128 * NP + ib + u0); if (HASN) S.NT[k] = th_ad_is4(S.Tp[k]); }
+        else { S.Qp[k] = th_ad_pair(s_q + qlen + 128 * NP - jb + u0); if (HASN) S.NQ[k] = th_ad_is4(S.Qp[k]); }
+    }
+    uint32_t up[NP], upT[NP], lf[NP], lfT[NP];
+    if (C == 0) {
+        const uint32_t pe = (uint32_t)th_shr1((int)S.E1[NP - 1], (int)TH_PK_NEG), pt = (uint32_t)th_shr1((int)S.TE[NP - 1], 0);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            up[k] = th_alignbit16(S.E1[k], k ? S.E1[k - 1] : pe); upT[k] = th_alignbit16(S.TE[k], k ? S.TE[k - 1] : pt);
+            lf[k] = S.F1[k]; lfT[k] = S.TF[k];
+        }
+    } else {
+        const uint32_t nf = (uint32_t)th_shl1((int)S.F1[0], (int)TH_PK_NEG), nt = (uint32_t)th_shl1((int)S.TF[0], 0);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            lf[k] = th_alignbit16(k + 1 < NP ? S.F1[k + 1] : nf, S.F1[k]); lfT[k] = th_alignbit16(k + 1 < NP ? S.TF[k + 1] : nt, S.TF[k]);
+            up[k] = S.E1[k]; upT[k] = S.TE[k];
+        }
+    }
+    // validity of a position: inside the matrix (borders included) and inside the band
+    uint32_t ULO = 0, UHI = 0, BT = 0, BL = 0, HBd = 0, EBd = 0;
+    if (PH != 1) {
+        const int ulo = max(0, max(-ib, jb - qlen)), uhi = min(min(tlen - ib, jb), uhb);
+        ULO = TH_PK_DUP(ulo); UHI = TH_PK_DUP(uhi);
+    }
+    if (PH == 0) {
+        const int ut = -ib >= 0 ? -ib : 0x7fff, ul = jb >= 0 ? jb : 0x7fff;     // positions of the border cells (0, r') and (r', 0)
+        BT = TH_PK_DUP(ut); BL = TH_PK_DUP(ul);
+        const int hb = rp == 0 ? 0 : -(TH_KQ + rp * TH_KE);
+        HBd = TH_PK_DUP(hb); EBd = TH_PK_DUP(hb - TH_KQ - TH_KE);
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const uint32_t EM = th_pk_negmask_op(th_pk_sub(S.Tp[k] ^ S.Qp[k], TH_AD_ONE));        // 0xffff where the bases are equal
+        uint32_t sc = th_sel(EM, TH_AD_ONE, 0xfffefffeu);                                    // 1 / -2
+        if (HASN) sc = th_sel(S.NT[k] | S.NQ[k], 0xffffffffu, sc);                           // either base N: -e
+        const uint32_t diag = th_pk_add(Hd[k], sc);
+        const uint32_t g_e = th_pk_negmask_op(th_pk_sub(diag, up[k]));                         // E > diagonal
+        const uint32_t h1 = th_pk_max(diag, up[k]);
+        const uint32_t g_f = th_pk_negmask_op(th_pk_sub(h1, lf[k]));                           // F > both
+        uint32_t h = th_pk_max(h1, lf[k]);
+        const uint32_t hq = th_pk_sub(h, TH_PK_DUP(TH_KQ));
+        const uint32_t xe = th_pk_negmask_op(th_pk_sub(hq, up[k])), xf = th_pk_negmask_op(th_pk_sub(hq, lf[k]));
+        uint32_t ch = th_sel(g_f, lfT[k], th_sel(g_e, upT[k], th_pk_sub(Cd[k], EM)));       // '=' count along ksw_backtrack's path
+        uint32_t t1 = th_sel(xe, upT[k], ch), t2 = th_sel(xf, lfT[k], ch);
+        uint32_t nE = th_pk_sub(th_pk_max(up[k], hq), TH_PK_DUP(TH_KE)), nF = th_pk_sub(th_pk_max(lf[k], hq), TH_PK_DUP(TH_KE));
+        if (PH == 0) {          // border cells take their closed-form values
+            const uint32_t BM = th_pk_negmask_op(th_pk_sub(S.POS[k] ^ BT, TH_AD_ONE)) | th_pk_negmask_op(th_pk_sub(S.POS[k] ^ BL, TH_AD_ONE));
+            h = th_sel(BM, HBd, h); nE = th_sel(BM, EBd, nE); nF = th_sel(BM, EBd, nF);
+            ch &= ~BM; t1 &= ~BM; t2 &= ~BM;
+        }
+        if (PH != 1) {      // phase B: the band fills the registers exactly (hi - lo = 256 NP - 1), every position is a cell of the band
+            const uint32_t IM = th_pk_negmask_op(th_pk_sub(S.POS[k], ULO) | th_pk_sub(UHI, S.POS[k]));
+            h = th_sel(IM, TH_PK_NEG, h); nE = th_sel(IM, TH_PK_NEG, nE); nF = th_sel(IM, TH_PK_NEG, nF);
+        }
+        Hd[k] = h; Cd[k] = ch; S.E1[k] = nE; S.TE[k] = t1; S.F1[k] = nF; S.TF[k] = t2;
+    }
+}
+
+// two anti-diagonals (even r', then r' + 1)
+template <int NP, bool HASN, int PH>
+__device__ __forceinline__ void th_ad_pair_steps(ThAdState<NP> &S, uint32_t (&HA)[NP], uint32_t (&HB)[NP], uint32_t (&CA)[NP], uint32_t (&CB)[NP],
+                                                const uint8_t *s_t, const uint8_t *s_q, int rp, int lo2, int qlen, int tlen, int uhb0, int uhb1)
+{
+    const int m = rp >> 1;
+    th_ad_step<NP, HASN, 0, PH>(S, HA, CA, s_t, s_q, rp, m + lo2, m - lo2, qlen, tlen, uhb0);
+    th_ad_step<NP, HASN, 1, PH>(S, HB, CB, s_t, s_q, rp + 1, m + 1 + lo2, m - lo2, qlen, tlen, uhb1);
+}
+
+// bases into the staging area; returns whether either sequence holds an N (code 4).  Needs tlen + qlen + 512 NP + 16 bytes.
+__device__ __forceinline__ bool th_ad_stage(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, int npos, uint8_t *s, const uint8_t **st, const uint8_t **sq)
+{
+    const int lane = TH_LANE();
+    const int ST = (tlen + 2 * npos + 8) & ~3, SQ = qlen + 2 * npos + 4;
+    bool n4 = false;
+#pragma unroll 4
+    for (int x = lane; x < ST; x += TH_WAVE) { const int i = x - npos; uint8_t c = 4; if (i >= 1 && i <= tlen) { c = t[i - 1]; n4 |= c == 4; } s[x] = c; }
+#pragma unroll 4
+    for (int y = lane; y < SQ; y += TH_WAVE) { const int j = qlen + npos - y; uint8_t c = 4; if (j >= 1 && j <= qlen) { c = q[j - 1]; n4 |= c == 4; } s[ST + y] = c; }
+    *st = s; *sq = s + ST;
+    TH_WAVE_FENCE();
+    return __ballot(n4) != 0;
+}
+
+// lo even, lo <= min(0, D), hi = lo + 256 NP - 1 >= max(0, D) (D = tlen - qlen); returns iden_n or -1 (not certified)
+template <int NP, bool HASN>
+__device__ __forceinline__ int th_ksw_band_ad_wave(const uint8_t *s_t, const uint8_t *s_q, int qlen, int tlen, int lo, int hi, int *band_score)
+{
+    const int lane = TH_LANE();
+    const int lo2 = lo / 2, R = tlen + qlen, D = tlen - qlen;
+    const int uhb0 = (hi - lo) >> 1, uhb1 = (hi - lo - 1) >> 1;
+    ThAdState<NP> S;
+    uint32_t HA[NP], HB[NP], CA[NP], CB[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int u0 = 2 * (NP * lane + k);
+        HA[k] = HB[k] = TH_PK_NEG; CA[k] = CB[k] = 0; S.E1[k] = S.F1[k] = TH_PK_NEG; S.TE[k] = S.TF[k] = 0;
+        S.POS[k] = TH_PK(u0, u0 + 1);
+        S.Tp[k] = th_ad_pair(s_t + 128 * NP + lo2 + u0); S.Qp[k] = 0x00040004u;      // rows of r' = 0 (the even step loads its columns itself)
+        S.NT[k] = HASN ? th_ad_is4(S.Tp[k]) : 0u; S.NQ[k] = 0u;
+    }
+    // phase limits (each phase runs whole pairs of anti-diagonals)
+    const int endA = max(hi, -lo);                                        // last r' with a border cell
+    const int limB = min(min(2 * tlen - hi, 2 * qlen + lo), R);           // last r' whose band lies inside the matrix
+    int rp = 0;
+    for (; rp <= endA && rp <= R; rp += 2) th_ad_pair_steps<NP, HASN, 0>(S, HA, HB, CA, CB, s_t, s_q, rp, lo2, qlen, tlen, uhb0, uhb1);
+    for (; rp + 1 <= limB; rp += 2) th_ad_pair_steps<NP, HASN, 1>(S, HA, HB, CA, CB, s_t, s_q, rp, lo2, qlen, tlen, uhb0, uhb1);
+    for (; rp <= R; rp += 2) th_ad_pair_steps<NP, HASN, 2>(S, HA, HB, CA, CB, s_t, s_q, rp, lo2, qlen, tlen, uhb0, uhb1);
+    // cell (tlen, qlen) sits on anti-diagonal R at position tlen - ib(R)
+    const int ibR = (R & 1) ? (R >> 1) + 1 + lo2 : (R >> 1) + lo2;
+    const int us = tlen - ibR, ps = us >> 1, ks = ps % NP, ls = ps / NP;
+    uint32_t hv = 0, cv = 0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) if (k == ks) { hv = (R & 1) ? HB[k] : HA[k]; cv = (R & 1) ? CB[k] : CA[k]; }
+    hv = (uint32_t)TH_READLANE((int)hv, ls); cv = (uint32_t)TH_READLANE((int)cv, ls);
+    const int res_h = (us & 1) ? TH_PK_HI(hv) : TH_PK_LO(hv), res_iden = (us & 1) ? TH_PK_HI(cv) : TH_PK_LO(cv);
+    *band_score = res_h;
+    if (lo <= -qlen && hi >= tlen) return res_iden;                      // the band is the whole matrix
+    const int gmin = min(2 * hi + 2 - D, -2 * lo + 2 + D);
+    if (2LL * res_h > (long long)(qlen + tlen - gmin) - 4 * TH_KQ - 2LL * gmin * TH_KE) return res_iden;
+    return -1;
+}
+
 // Extension, score only: returns (max_q, max_t) of the first strictly greater H over anti-diagonals
 // r = 0,1,..., candidates inside one anti-diagonal ranked as ksw2's SSE code visits them
 // (ksw2_extz2_sse.c:228-260): t = en0 first, then four interleaved lanes over [st0,en1), then the

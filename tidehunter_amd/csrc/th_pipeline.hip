@@ -62,6 +62,7 @@ struct th_gpu {
     std::vector<th_job_t> jobs;
     double ms_kernels = 0, ms_dominant = 0, ms_k[8] = { 0 };
     int aln_wdiv = 10, aln_wadd = 24;     // first certified band of the unit alignments: half-width cons_len / wdiv + wadd
+    int aln_wtol = 16, aln_mode = 1;      // anti-diagonal engine: accepted shortfall of its band against that half-width; 0 = strip engine only, 2 = verify against the full matrix
     int waves_part = 8192, waves_poa = 6144, waves_aln = 8192, waves_xw = 2048;   // persistent grids: 256 CUs x 4 SIMDs x resident waves
 };
 
@@ -88,6 +89,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
     g->waves_aln = env_int("TH_WAVES_ALN", g->waves_aln);
     g->waves_xw = env_int("TH_WAVES_XW", g->waves_xw);
     g->aln_wdiv = std::max(1, env_int("TH_ALN_WDIV", g->aln_wdiv)); g->aln_wadd = std::max(0, env_int("TH_ALN_WADD", g->aln_wadd));
+    g->aln_wtol = std::max(0, env_int("TH_ALN_WTOL", g->aln_wtol)); g->aln_mode = env_int("TH_ALN_MODE", g->aln_mode);
     return g;
 }
 
@@ -418,21 +420,34 @@ extern "C" int th_gpu_run(th_gpu_t *g)
           unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(th_poa_prof), z, sizeof(z)); }
 #endif
         // ---- unit-vs-consensus alignments and flank extensions ----
+        // Items whose two sequences fit the small staging area of the anti-diagonal engine (4 KB: 5 waves per SIMD) go first;
+        // tasks with longer units / consensus form a second list for the kernel variant with a 24 KB area and up to 6 registers per lane.
         int max_cl = 0;
+        const int ALN_SMALL = 4096, ALN_BIG = 24576;
+        std::vector<ThAlnItem> big_items;
         for (int t = 0; t < nt; ++t) {
             max_cl = std::max(max_cl, g->h_cons_len[t]);
-            for (int u = 0; u < g->h_tasks[t].pos_n - 1; ++u) { ThAlnItem it = { t, u }; g->h_items.push_back(it); }
+            const bool big = (long long)g->h_tasks[t].max_len + g->h_cons_len[t] + 512 * 2 + 16 > ALN_SMALL;
+            for (int u = 0; u < g->h_tasks[t].pos_n - 1; ++u) { ThAlnItem it = { t, u }; (big ? big_items : g->h_items).push_back(it); }
             ThAlnItem l = { t, -1 }, r = { t, -2 }; g->h_items.push_back(l); g->h_items.push_back(r);
         }
+        const int ns = (int)g->h_items.size();
+        g->h_items.insert(g->h_items.end(), big_items.begin(), big_items.end());
         const int ni = (int)g->h_items.size();
         const long long bnd_aln = (std::max<long long>(((long long)max_cl + 128) * 4, ((long long)g->max_len + 128) * 2) + 3) & ~3LL;
         const int wa = std::min(ni, g->waves_aln);
         TRY(g->d_items.ensure(ni)); TRY(g->d_bnd.ensure((size_t)(bnd_aln * wa)));
         TRY(th_rt_h2d(g->d_items.p, g->h_items.data(), (size_t)ni * sizeof(ThAlnItem), g->stream));
+        TRY(th_rt_memset(g->d_cnt.p + 7, 0, sizeof(int), g->stream));      // queue head of the second list (d_cnt[4], the first one's, was zeroed at the start of the run)
         KT_BEGIN(TK_ALIGN);
-        TH_LAUNCH(th_k_align, wa, TH_ALN_BLOCK, g->stream, (const ThAlnItem *)g->d_items.p, ni, (const ThTask *)g->d_tasks.p, (const int *)g->d_parc.p,
-                  (const uint32_t *)g->d_roff.p, (const uint8_t *)g->d_bseq.p, (const uint8_t *)g->d_cons.p, (const int *)g->d_cons_len.p,
-                  g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, g->d_cnt.p + 1, g->d_cnt.p + 4, g->aln_wdiv, g->aln_wadd);   // queue head d_cnt[4] was zeroed with the other counters at the start of the run
+        {
+#define TH_ALN_ARGS(first, n, q) (const ThAlnItem *)g->d_items.p + (first), (n), (const ThTask *)g->d_tasks.p, (const int *)g->d_parc.p, \
+                  (const uint32_t *)g->d_roff.p, (const uint8_t *)g->d_bseq.p, (const uint8_t *)g->d_cons.p, (const int *)g->d_cons_len.p, \
+                  g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, g->d_cnt.p + 1, g->d_cnt.p + (q), g->aln_wdiv, g->aln_wadd, g->aln_wtol, g->aln_mode
+            if (ns) TH_LAUNCH((th_k_align<ALN_SMALL, 2>), std::min(ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(0, ns, 4));
+            if (ni > ns) TH_LAUNCH((th_k_align<ALN_BIG, 6>), std::min(ni - ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(ns, ni - ns, 7));
+#undef TH_ALN_ARGS
+        }
         KT_END(TK_ALIGN);
         if (getenv("TH_TRACE")) { th_rt_sync(g->stream); fprintf(stderr, "[th] %.3f s: align done (%d items)\n", th_wall_s() - t_run0, ni); }
         // results: consensus strings compacted to their lengths (the slots are sized for the worst case), coverage only on request
@@ -452,6 +467,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         for (int t = 0; t < nt; ++t) g->jobs[t].cons_off = cc_off[t];
         TRY(th_rt_d2h(cnt, g->d_cnt.p, sizeof(cnt), g->stream));
         TRY(th_rt_sync(g->stream));
+        if (cnt[1] & 64) return th_fail("TH_ALN_MODE=2: a banded alignment differs from the full matrix");
         if (cnt[1]) return th_fail("alignment boundary buffer overflow");
         for (int t = 0; t < nt; ++t) {
             th_job_t &j = g->jobs[t];
