@@ -151,6 +151,14 @@ __device__ __forceinline__ int th_queue_pop(int *queue)
     const int v = atomicAdd(queue, TH_LANE() == 0 ? 1 : 0);
     return TH_READLANE(v, 0);
 }
+// A value that is the same in every lane but that the compiler cannot prove uniform (it came from a per-lane load or an LDS
+// read): v_readfirstlane moves it to an SGPR, so that what depends on it is scalar code and scalar branches instead of
+// vector code under execution masks.
+#ifdef TH_CPU_EMUL
+#define TH_UNI(x) (x)
+#else
+#define TH_UNI(x) __builtin_amdgcn_readfirstlane(x)
+#endif
 __device__ __forceinline__ int th_ctz64(unsigned long long m) { return m ? __ffsll((long long)m) - 1 : 64; }
 __device__ __forceinline__ int th_msb64(unsigned long long m) { return 63 - __clzll((long long)m); }   // m != 0
 

@@ -246,7 +246,8 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     constexpr bool LQ = QCAP > 0, WIDE = sizeof(RT) == 4;
     const int lane = TH_LANE();
     const int M = P.match, X = P.mismatch, O1 = P.go1, E1 = P.ge1, O2 = P.go2, E2 = P.ge2;
-    const int n = g.n_node, w = TH_POA_WB + qlen / 100;
+    qlen = TH_UNI(qlen);
+    const int n = TH_UNI(g.n_node), w = TH_POA_WB + qlen / 100;
     long long ncell = 0;
     // Every real score lies within +-real_b: a path to (i, j) has at most i + j unit steps, the dearest of which is a
     // mismatch (X for two units) or a one-base gap (open + extend for one unit); E'/F carry one more open + extend.
@@ -305,6 +306,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             if (i > 0) { b = max(0, min(mpl, qlen - rm) - w); b = max(b, mb); }
             e = min(qlen, max(mpr, qlen - rm) + w);
         }
+        b = TH_UNI(b); e = TH_UNI(e);
         if (b > e) return -2;
         // a row owns the cells of columns (b & ~1) .. (e | 1): packed rows store column pairs
         const int B0 = b & ~1, span = (e | 1) - B0 + 1;
@@ -471,7 +473,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             s_rmeta[myslot][0] = i; s_rmeta[myslot][1] = b; s_rmeta[myslot][2] = e; s_rmeta[myslot][3] = left; s_rmeta[myslot][4] = right;
             s_rmeta[myslot][5] = cstate; s_rmeta[myslot][6] = (int)(uint32_t)my_off; s_rmeta[myslot][7] = (int)(my_off >> 32);
         }
-        L_b = b; L_e = e; L_l = left; L_r = right; L_c = cstate;
+        L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = cstate;
         TH_WAVE_FENCE();
     }
     // global end: best predecessor row of the sink (row n-1) at column qlen, first in edge order
