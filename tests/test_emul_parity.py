@@ -180,3 +180,31 @@ def test_emul_banded_alignment_long_units(emu):
     para = O.default_para()
     assert U.assert_records_equal(seqs, th.process(seqs), para, "band") >= 1
     th.close()
+
+
+@pytest.mark.parametrize("wadd", ["24", "200", "330"])
+def test_emul_antidiagonal_band_engine(emu, monkeypatch, wadd):
+    """th_ksw_band_ad_wave (one anti-diagonal of the band per wave, packed int16 pairs): TH_ALN_MODE=2 recomputes every
+    alignment with the full matrix on the device and fails the run on a difference; TH_ALN_WADD widens the requested band so
+    that 1, 2 and 3 registers per lane are used; units of 330-500 bases reach the steady-state steps (band inside the
+    matrix), one read carries Ns (the N-aware variant)"""
+    monkeypatch.setenv("TH_ALN_MODE", "2")
+    monkeypatch.setenv("TH_ALN_WADD", wadd)
+    th = TH.TideHunter(lib_path=emu)
+    seqs = [TH.synth_read(th.lib, 5, i, p, c, e) for i, (p, c, e) in enumerate([(400, 4, 0.10), (330, 5, 0.12), (500, 3, 0.05)])]
+    s = bytearray(seqs[0])
+    for x in (100, 101, 555, 900):
+        s[x] = ord("N")
+    seqs.append(bytes(s))
+    assert U.assert_records_equal(seqs, th.process(seqs), O.default_para(), "anti-diagonal band, wadd " + wadd) >= 4
+    th.close()
+
+
+def test_emul_strip_engine_still_matches(emu, monkeypatch):
+    """TH_ALN_MODE=0: the strip engine (th_ksw_global_band_wave), which remains the fallback for pairs the anti-diagonal
+    engine cannot take"""
+    monkeypatch.setenv("TH_ALN_MODE", "0")
+    th = TH.TideHunter(lib_path=emu)
+    seqs = [TH.synth_read(th.lib, 5, 0, 500, 4, 0.10), TH.synth_read(th.lib, 5, 2, 520, 3, 0.16)]
+    assert U.assert_records_equal(seqs, th.process(seqs), O.default_para(), "strip") >= 1
+    th.close()

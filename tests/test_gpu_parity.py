@@ -227,3 +227,23 @@ def test_gpu_large_batch_is_deterministic(th):
     step = len(seqs) // 24
     sample = list(range(0, len(seqs), step))
     U.assert_records_equal([seqs[i] for i in sample], [runs[0][i] for i in sample], para, "sampled")
+
+
+@pytest.mark.parametrize("env", [dict(TH_ALN_MODE="2"), dict(TH_ALN_MODE="2", TH_ALN_WADD="200"), dict(TH_ALN_MODE="2", TH_ALN_WADD="600"),
+                                 dict(TH_ALN_MODE="2", TH_ALN_WTOL="0"), dict(TH_ALN_MODE="0")])
+def test_gpu_alignment_engines(monkeypatch, env):
+    """unit-vs-consensus alignments: the anti-diagonal band engine with 1..6 registers per lane (TH_ALN_WADD widens the
+    requested band), verified on the device against the full matrix (TH_ALN_MODE=2 fails the run on any difference), and the
+    strip engine alone (TH_ALN_MODE=0); records compared with the oracle as everywhere else"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    t = TH.TideHunter(device=0)
+    para = O.default_para()
+    seqs = _synth(t.lib, 12, 1000, 10, 0.10, 1) + _synth(t.lib, 6, 200, 20, 0.10, 2) + _synth(t.lib, 3, 2500, 4, 0.15, 3) + _synth(t.lib, 4, 700, 6, 0.2, 6)
+    s = bytearray(seqs[0])
+    for x in range(1500, 1510):
+        s[x] = ord("N")
+    seqs.append(bytes(s))
+    got = t.process(seqs)
+    assert U.assert_records_equal(seqs, got, para, "alignment engines %r" % (env,)) >= 20
+    t.close()

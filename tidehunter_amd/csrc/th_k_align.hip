@@ -8,6 +8,9 @@
 #include "th_ksw.h"
 
 #define TH_ALN_BLOCK 64
+#ifndef TH_ALN_OCC
+#define TH_ALN_OCC
+#endif
 
 struct ThAlnItem { int task, which; };   // which >= 0: unit index in the run; -1 left extension; -2 right extension
 
@@ -70,15 +73,18 @@ __device__ __forceinline__ int th_ad_align(int np, const uint8_t *__restrict__ q
 
 // mode: 0 strip engine only (th_ksw_global_band_wave), 1 anti-diagonal engine first (default), 2 both and compare (err bit 64 on a difference)
 template <int LDSB, int NPMAX>
-__global__ void __launch_bounds__(TH_ALN_BLOCK)
+__global__ void __launch_bounds__(TH_ALN_BLOCK) TH_ALN_OCC
 th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__restrict__ tasks, const int *__restrict__ pos,
            const uint32_t *__restrict__ roff, const uint8_t *__restrict__ bseq,
            const uint8_t *__restrict__ cons, const int *__restrict__ cons_len,
            int *__restrict__ bnd, long long bnd_stride, int *__restrict__ iden, int *__restrict__ ext, int *__restrict__ err, int *__restrict__ queue,
            int wdiv, int wadd, int wtol, int mode)
 {
-    __shared__ __attribute__((aligned(16))) int s_in[2][TH_WAVE][8];      // left-border inbox of the strip sweep (two 64-row blocks)
-    __shared__ __attribute__((aligned(16))) uint8_t s_seq[LDSB];          // staged bases of the anti-diagonal engine
+    // one LDS area, used either as the left-border inbox of the strip sweep (two 64-row blocks, 4 KB) or as the staged bases
+    // of the anti-diagonal engine (never both at once)
+    static_assert(LDSB >= 2 * TH_WAVE * 8 * 4, "the staging area doubles as the strip engine's inbox");
+    __shared__ __attribute__((aligned(16))) uint8_t s_seq[LDSB];
+    int (*s_in)[TH_WAVE][8] = (int (*)[TH_WAVE][8])s_seq;
     const int lane = TH_LANE();
     const int wave = blockIdx.x;
     int *mybnd = bnd + (long long)wave * bnd_stride;
