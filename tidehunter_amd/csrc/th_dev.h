@@ -58,6 +58,7 @@ struct ThUnit { int start, len; };   // start = index of the unit's first base i
 // implements the same semantics with its rendezvous shuffles.
 #ifdef TH_CPU_EMUL
 #define TH_READLANE(v, l) __shfl((v), (l))
+#define TH_WRITELANE(old, v, l) (TH_LANE() == (l) ? (v) : (old))
 __device__ __forceinline__ int th_shr1(int v, int fill) { int o = __shfl_up(v, 1); return TH_LANE() == 0 ? fill : o; }
 __device__ __forceinline__ int th_shl1(int v, int fill) { int o = __shfl_down(v, 1); return TH_LANE() == 63 ? fill : o; }
 // lane l <- lane l-1, lane 0 <- lane 0 of `inj` (a per-lane register: only its lane 0 matters)
@@ -78,6 +79,10 @@ __device__ __forceinline__ int th_wave_incl_sum(int v)
 }
 #else
 #define TH_READLANE(v, l) __builtin_amdgcn_readlane((v), (l))
+// lane l of `old` replaced by the wave-uniform v (v_writelane_b32: value and lane select are scalar operands)
+// gfx9 reads one SGPR per vector instruction, so the lane select travels in m0
+__device__ __forceinline__ int th_writelane(int old, int v, int l) { asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(v), "s"(l) : "m0"); return old; }
+#define TH_WRITELANE(old, v, l) th_writelane((old), (v), (l))
 #define TH_DPP(old, src, ctrl, rmask, bmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), (bmask), false)
 __device__ __forceinline__ int th_shr1(int v, int fill) { return TH_DPP(fill, v, 0x138, 0xf, 0xf); }   // wave_shr:1
 __device__ __forceinline__ int th_shl1(int v, int fill) { return TH_DPP(fill, v, 0x130, 0xf, 0xf); }   // wave_shl:1

@@ -267,7 +267,10 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     // exactly that predecessor); older ring slots keep theirs in s_rmeta[slot][]:
     //   0 row, 1 beg, 2 end, 3 left, 4 right, 5 cache state (0 none, 3 cached; every cached slot is clean), 6..7 cell offset
     int L_b = 0, L_e = -1, L_l = 0, L_r = 0, L_c = 0;
-    if (lane < TH_POA_RING) s_rmeta[lane][0] = -1;
+    // band, row-maximum columns and cell offset of the rows of the current 64-row chunk: lane (row & 63) of these registers
+    // (one v_writelane each per row); they go to the row tables in HBM 64 rows at a time, so the common row issues no
+    // metadata store at all.  A predecessor inside the chunk is read back with v_readlane, an older one from the tables.
+    int m_beg = 0, m_end = 0, m_left = 0, m_right = 0, m_offlo = 0, m_offhi = 0;
     for (int x = lane; x < TH_POA_RING * 3 * TH_POA_PAD; x += TH_WAVE) s_ring[x / (3 * TH_POA_PAD)][(x / TH_POA_PAD) % 3][x % TH_POA_PAD] = (RT)(WIDE ? TH_NEG : -32768);
     TH_WAVE_FENCE();
     for (int i = 0; i + 1 < n; ++i) {
@@ -299,7 +302,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 const int s = pi & 3;
                 int pb, pl, pr;
                 if (pi == i - 1) { pb = L_b; pl = L_l; pr = L_r; }
-                else if (i - pi < TH_POA_RING && s_rmeta[s][0] == pi) { pb = s_rmeta[s][1]; pl = s_rmeta[s][3]; pr = s_rmeta[s][4]; }
+                else if (pi >= (i & ~63)) { pb = TH_READLANE(m_beg, pi & 63); pl = TH_READLANE(m_left, pi & 63); pr = TH_READLANE(m_right, pi & 63); }
                 else { pb = g.r_beg[pi]; pl = g.r_mpl[pi]; pr = g.r_mpr[pi]; }
                 mpl = min(mpl, pl + 1); mpr = max(mpr, pr + 1); mb = min(mb, pb);
             }
@@ -409,17 +412,19 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                     const int pi = o == 0 ? p0 : o == 1 ? p1 : o == 2 ? p2 : o == 3 ? p3 : g.pos[th_poa_in(g, vid, o)];
                     const int s = pi & 3;
                     int hp = TH_NEG, c1 = TH_NEG, c2 = TH_NEG;
-                    const bool recent = i - pi < TH_POA_RING && s_rmeta[s][0] == pi;
-                    if (recent && s_rmeta[s][5]) {           // LDS ring: no HBM round trip
-                        const int pb = s_rmeta[s][1], pe = s_rmeta[s][2];
+                    // the predecessor row's band and cell offset: chunk registers or row tables
+                    int pb, pe; long long po;
+                    if (pi >= (i & ~63)) {
+                        pb = TH_READLANE(m_beg, pi & 63); pe = TH_READLANE(m_end, pi & 63);
+                        po = ((long long)TH_READLANE(m_offhi, pi & 63) << 32) | (uint32_t)TH_READLANE(m_offlo, pi & 63);
+                    } else { pb = g.r_beg[pi]; pe = g.r_end[pi]; po = g.r_off[pi]; }
+                    // the three rows before this one are still in the LDS ring if their band fitted it (every cached slot is clean)
+                    if (i - pi < TH_POA_RING && cache16_ok && pe - pb < TH_POA_RW) {           // LDS ring: no HBM round trip
                         if (in) {
                             if (j >= 1 && j - 1 >= pb && j - 1 <= pe) hp = TH_RING_LD(s_ring[s][0][TH_RIDX(j - 1, pb)]);
                             if (j >= pb && j <= pe) { c1 = TH_RING_LD(s_ring[s][1][TH_RIDX(j, pb)]); c2 = TH_RING_LD(s_ring[s][2][TH_RIDX(j, pb)]); }
                         }
                     } else {
-                        int pb, pe; long long po;
-                        if (recent) { pb = s_rmeta[s][1]; pe = s_rmeta[s][2]; po = ((long long)s_rmeta[s][7] << 32) | (uint32_t)s_rmeta[s][6]; }
-                        else { pb = g.r_beg[pi]; pe = g.r_end[pi]; po = g.r_off[pi]; }
                         const int4 *prow = g.cell + po;
                         if (in) {
                             if (j >= 1 && j - 1 >= pb && j - 1 <= pe) hp = prow[j - 1 - pb].x;
@@ -468,12 +473,13 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         }
         }
         const int cstate = cache_me ? 3 : 0;
-        if (lane == 0) {
-            g.r_beg[i] = b; g.r_end[i] = e; g.r_off[i] = my_off; g.r_mpl[i] = left; g.r_mpr[i] = right;
-            s_rmeta[myslot][0] = i; s_rmeta[myslot][1] = b; s_rmeta[myslot][2] = e; s_rmeta[myslot][3] = left; s_rmeta[myslot][4] = right;
-            s_rmeta[myslot][5] = cstate; s_rmeta[myslot][6] = (int)(uint32_t)my_off; s_rmeta[myslot][7] = (int)(my_off >> 32);
-        }
         L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = cstate;
+        m_beg = TH_WRITELANE(m_beg, b, sl); m_end = TH_WRITELANE(m_end, e, sl); m_left = TH_WRITELANE(m_left, L_l, sl); m_right = TH_WRITELANE(m_right, L_r, sl);
+        m_offlo = TH_WRITELANE(m_offlo, (int)(uint32_t)my_off, sl); m_offhi = TH_WRITELANE(m_offhi, (int)(my_off >> 32), sl);
+        if (sl == 63 || i + 2 >= n) {          // chunk complete (or last row): its rows' metadata to the tables, coalesced
+            const int r = (i & ~63) + lane;
+            if (r <= i) { g.r_beg[r] = m_beg; g.r_end[r] = m_end; g.r_off[r] = ((long long)m_offhi << 32) | (uint32_t)m_offlo; g.r_mpl[r] = m_left; g.r_mpr[r] = m_right; }
+        }
         TH_WAVE_FENCE();
     }
     // global end: best predecessor row of the sink (row n-1) at column qlen, first in edge order
