@@ -79,9 +79,14 @@ __device__ __forceinline__ int th_wave_incl_sum(int v)
 }
 #else
 #define TH_READLANE(v, l) __builtin_amdgcn_readlane((v), (l))
-// lane l of `old` replaced by the wave-uniform v (v_writelane_b32: value and lane select are scalar operands)
-// gfx9 reads one SGPR per vector instruction, so the lane select travels in m0
-__device__ __forceinline__ int th_writelane(int old, int v, int l) { asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(v), "s"(l) : "m0"); return old; }
+// lane l of `old` replaced by the wave-uniform v (v_writelane_b32: value and lane select are scalar operands; gfx9 reads one
+// SGPR per vector instruction, so the lane select travels in m0, which is saved and restored around the instruction)
+__device__ __forceinline__ int th_writelane(int old, int v, int l)
+{
+    int keep;
+    asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(old), "=&s"(keep) : "s"(v), "s"(l));
+    return old;
+}
 #define TH_WRITELANE(old, v, l) th_writelane((old), (v), (l))
 #define TH_DPP(old, src, ctrl, rmask, bmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), (bmask), false)
 __device__ __forceinline__ int th_shr1(int v, int fill) { return TH_DPP(fill, v, 0x138, 0xf, 0xf); }   // wave_shr:1

@@ -209,7 +209,7 @@ __device__ int th_poa_rows(ThPoaG &g)
 }
 
 #if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
-__device__ unsigned long long th_poa_prof[8];
+__device__ unsigned long long th_poa_prof[18];
 #define TH_PROF_CNT(k, v) ((void)0)
 #define TH_PROF_T0() unsigned long long pt_ = __builtin_amdgcn_s_memtime()
 #define TH_PROF(k) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (TH_LANE() == 0) atomicAdd(&th_poa_prof[k], n_ - pt_); pt_ = n_; } while (0)
@@ -273,6 +273,9 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     int m_beg = 0, m_end = 0, m_left = 0, m_right = 0, m_offlo = 0, m_offhi = 0;
     for (int x = lane; x < TH_POA_RING * 3 * TH_POA_PAD; x += TH_WAVE) s_ring[x / (3 * TH_POA_PAD)][(x / TH_POA_PAD) % 3][x % TH_POA_PAD] = (RT)(WIDE ? TH_NEG : -32768);
     TH_WAVE_FENCE();
+#if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
+    unsigned long long pf_n[5] = { 0, 0, 0, 0, 0 }, pf_t[5] = { 0, 0, 0, 0, 0 };
+#endif
     for (int i = 0; i + 1 < n; ++i) {
         if ((i & 63) == 0) {
             const int r = i + lane;
@@ -282,6 +285,9 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             }
             TH_VM_WAIT0();      // here, once per 64 rows -- not at the first use below, where it would drain every row's stores
         }
+#if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
+        const unsigned long long row_t0 = __builtin_amdgcn_s_memtime();
+#endif
         const int sl = i & 63;
         const int meta = TH_READLANE(c_meta, sl), rm = TH_READLANE(c_rem, sl);
         const int nb = meta & 0xff, inn = (meta >> 8) & 0xff;
@@ -289,6 +295,10 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         const int p0 = TH_READLANE(c_p0, sl);
         const bool fast = inn == 1 && p0 == i - 1 && L_c;        // one predecessor, the previous row, cached in LDS
         int p1 = -1, p2 = -1, p3 = -1, vid = 0;
+        // predecessors as the packed row reads them: ring slot and even band base of each; ring_all: every predecessor is one of
+        // the three rows before this one and sits (clean) in its ring slot
+        int q_slot0 = (i - 1) & 3, q_slot1 = 0, q_slot2 = 0, q_slot3 = 0, q_pb0 = L_b & ~1, q_pb1 = 0, q_pb2 = 0, q_pb3 = 0;
+        bool ring_all = fast && L_c == 3;
         // ---- band: pull the predecessors' band start and row-maximum columns ----
         int b = 0, e;
         if (fast) {
@@ -297,14 +307,17 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         } else {
             p1 = TH_READLANE(c_p1, sl); p2 = TH_READLANE(c_p2, sl); p3 = TH_READLANE(c_p3, sl); vid = TH_READLANE(c_id, sl);
             int mpl = 0x7fffffff, mpr = 0, mb = 0x7fffffff;
+            ring_all = i > 0 && inn >= 1 && inn <= 4;
             for (int o = 0; o < inn; ++o) {
                 const int pi = o == 0 ? p0 : o == 1 ? p1 : o == 2 ? p2 : o == 3 ? p3 : g.pos[th_poa_in(g, vid, o)];
                 const int s = pi & 3;
-                int pb, pl, pr;
-                if (pi == i - 1) { pb = L_b; pl = L_l; pr = L_r; }
-                else if (pi >= (i & ~63)) { pb = TH_READLANE(m_beg, pi & 63); pl = TH_READLANE(m_left, pi & 63); pr = TH_READLANE(m_right, pi & 63); }
-                else { pb = g.r_beg[pi]; pl = g.r_mpl[pi]; pr = g.r_mpr[pi]; }
+                int pb, pl, pr, pe;
+                if (pi == i - 1) { pb = L_b; pl = L_l; pr = L_r; pe = L_c == 3 ? L_b : L_b + TH_POA_RW; }
+                else if (pi >= (i & ~63)) { pb = TH_READLANE(m_beg, pi & 63); pl = TH_READLANE(m_left, pi & 63); pr = TH_READLANE(m_right, pi & 63); pe = TH_READLANE(m_end, pi & 63); }
+                else { pb = TH_UNI(g.r_beg[pi]); pl = TH_UNI(g.r_mpl[pi]); pr = TH_UNI(g.r_mpr[pi]); pe = pb + TH_POA_RW; }     // a row of the previous chunk: not worth a fourth load
                 mpl = min(mpl, pl + 1); mpr = max(mpr, pr + 1); mb = min(mb, pb);
+                ring_all = ring_all && i - pi >= 1 && i - pi < TH_POA_RING && pe - pb < TH_POA_RW;
+                if (o == 0) { q_slot0 = s; q_pb0 = pb & ~1; } else if (o == 1) { q_slot1 = s; q_pb1 = pb & ~1; } else if (o == 2) { q_slot2 = s; q_pb2 = pb & ~1; } else if (o == 3) { q_slot3 = s; q_pb3 = pb & ~1; }
             }
             if (i > 0) { b = max(0, min(mpl, qlen - rm) - w); b = max(b, mb); }
             e = min(qlen, max(mpr, qlen - rm) + w);
@@ -321,12 +334,11 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         const bool cache_me = cache16_ok && e - b < TH_POA_RW;
         const bool store_full = needfull || !cache_me;     // otherwise only the direction word leaves the CU
         int rmax = TH_NEG - 0x10000000, left = b, right = b;
-        const bool pk = !WIDE && LQ && fast && L_c == 3 && cache_me && !needfull;    // rows some far row will read take the 32-bit path (they store whole cells)
+        const bool pk = !WIDE && LQ && ring_all && cache_me && !needfull;    // rows some far row will read take the 32-bit path (they store whole cells)
+        const int npk = fast ? 1 : inn;
         if (pk) {
             // ================= packed row: lane l owns columns B0 + 128 t + 2 l and the next one =================
-            const int PB0 = L_b & ~1;
             const uint32_t T = nb == 4 ? 0x20820820u : ((TX & ~(63u << (6 * nb))) | (uint32_t)(32 + M) << (6 * nb));
-            const uint32_t *rH = (const uint32_t *)s_ring[lslot][0], *rE1 = (const uint32_t *)s_ring[lslot][1], *rE2 = (const uint32_t *)s_ring[lslot][2];
             uint32_t *wH = (uint32_t *)s_ring[myslot][0], *wE1 = (uint32_t *)s_ring[myslot][1], *wE2 = (uint32_t *)s_ring[myslot][2];
             int carry1 = -32768, carry2 = -32768;                   // F1 / F2 running maxima in the column-offset domain
             for (int t0 = 0; t0 < 256; t0 += 128) {
@@ -341,11 +353,29 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 // substitution scores of the two columns from the row's table
                 const uint32_t qx = s_qs[min(j0, QCAP) >> 1];                        // the pair's two 4-bit query codes
                 const uint32_t SC = th_pk_sub(th_ubfe(T, 6u * (qx & 15u), 6) | th_ubfe(T, 6u * (qx >> 4), 6) << 16, 0x00200020u);
-                // predecessor row: diagonal pair (j0-1, j0) and vertical pairs (j0, j0+1); anything outside its band reads -inf
-                int pi = j0 - PB0 + TH_POA_PAD;
-                pi = pi <= TH_POA_RS - 2 ? pi : 2;
-                const uint32_t Hm = rH[(pi >> 1) - 1], Hc = rH[pi >> 1], e1v = rE1[pi >> 1], e2v = rE2[pi >> 1];
-                const uint32_t m = th_pk_add(th_alignbit16(Hc, Hm), SC);
+                // predecessor rows (all in the ring): diagonal pair (j0-1, j0) and vertical pairs (j0, j0+1) of each; anything outside
+                // a row's band reads -inf (its slot is clean, indices beyond either end are sent to the padding).  The first
+                // predecessor in edge order wins ties, as in the one-column-per-lane path; PMV / PE1V / PE2V hold the winners' edge
+                // indices, already shifted to their place in the direction word (PE2V 16 bits lower)
+                uint32_t m = 0, e1v = 0, e2v = 0, PMV = 0, PE1V = 0, PE2V = 0;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    if (o < npk) {
+                        const int qs = o == 0 ? q_slot0 : o == 1 ? q_slot1 : o == 2 ? q_slot2 : q_slot3, qb = o == 0 ? q_pb0 : o == 1 ? q_pb1 : o == 2 ? q_pb2 : q_pb3;
+                        const uint32_t *rH = (const uint32_t *)s_ring[qs][0], *rE1 = (const uint32_t *)s_ring[qs][1], *rE2 = (const uint32_t *)s_ring[qs][2];
+                        int pi = j0 - qb + TH_POA_PAD;
+                        pi = pi <= TH_POA_RS - 2 ? pi : 2;
+                        pi = max(pi, 2);
+                        const uint32_t Hm = rH[(pi >> 1) - 1], Hc = rH[pi >> 1], c1 = rE1[pi >> 1], c2 = rE2[pi >> 1];
+                        const uint32_t mo = th_pk_add(th_alignbit16(Hc, Hm), SC);
+                        if (o == 0) { m = mo; e1v = c1; e2v = c2; }
+                        else {
+                            const uint32_t gm = th_pk_negmask_op(th_pk_sub(m, mo)), ge1 = th_pk_negmask_op(th_pk_sub(e1v, c1)), ge2 = th_pk_negmask_op(th_pk_sub(e2v, c2));
+                            m = th_pk_max(m, mo); e1v = th_pk_max(e1v, c1); e2v = th_pk_max(e2v, c2);
+                            PMV = th_sel(gm, TH_PK_DUP(o << 3), PMV); PE1V = th_sel(ge1, TH_PK_DUP(o << 11), PE1V); PE2V = th_sel(ge2, TH_PK_DUP(o << 3), PE2V);
+                        }
+                    }
+                }
                 const uint32_t hnf1 = th_pk_max(m, e1v), g1 = th_pk_negmask(th_pk_sub(m, e1v));
                 const uint32_t hnf = th_pk_max(hnf1, e2v), g2 = th_pk_negmask(th_pk_sub(hnf1, e2v));
                 // F1 / F2: max-plus prefix over the row in the domain value + column * extension
@@ -372,7 +402,11 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 code |= th_pk_negmask(th_pk_sub(hO1, f1)) & 0x00200020u;
                 code |= th_pk_negmask(th_pk_sub(hO2, f2)) & 0x00400040u;
                 const uint32_t n1 = th_pk_sub(th_pk_max(hO1, e1v), E1P), n2 = th_pk_sub(th_pk_max(hO2, e2v), E2P);
-                const uint32_t d_lo = (code & 7u) | ((code << 24) & 0x78000000u), d_hi = ((code >> 16) & 7u) | ((code << 8) & 0x78000000u);
+                uint32_t d_lo = (code & 7u) | ((code << 24) & 0x78000000u), d_hi = ((code >> 16) & 7u) | ((code << 8) & 0x78000000u);
+                if (npk > 1) {
+                    const uint32_t X = PMV | PE1V;
+                    d_lo |= (X & 0xffffu) | (PE2V << 16); d_hi |= (X >> 16) | (PE2V & 0xffff0000u);
+                }
                 if (j0 <= e) {
                     *(unsigned long long *)(drow + (j0 - b)) = (unsigned long long)d_hi << 32 | d_lo;   // column b-1 / e+1 of an odd edge land in the row's own padding
                 }
@@ -474,6 +508,11 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         }
         const int cstate = cache_me ? 3 : 0;
         L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = cstate;
+#if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
+        { const unsigned long long dt = __builtin_amdgcn_s_memtime() - row_t0;
+          const int cat = pk ? 0 : inn != 1 ? 1 : p0 != i - 1 ? 2 : needfull ? 3 : 4;     // packed / several predecessors / one far predecessor / stores full cells / other
+          pf_n[cat] += 1; pf_t[cat] += dt; }
+#endif
         m_beg = TH_WRITELANE(m_beg, b, sl); m_end = TH_WRITELANE(m_end, e, sl); m_left = TH_WRITELANE(m_left, L_l, sl); m_right = TH_WRITELANE(m_right, L_r, sl);
         m_offlo = TH_WRITELANE(m_offlo, (int)(uint32_t)my_off, sl); m_offhi = TH_WRITELANE(m_offhi, (int)(my_off >> 32), sl);
         if (sl == 63 || i + 2 >= n) {          // chunk complete (or last row): its rows' metadata to the tables, coalesced
@@ -482,6 +521,9 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         }
         TH_WAVE_FENCE();
     }
+#if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
+    if (lane == 0) for (int c = 0; c < 5; ++c) { atomicAdd(&th_poa_prof[8 + c], pf_n[c]); atomicAdd(&th_poa_prof[13 + c], pf_t[c]); }
+#endif
     // global end: best predecessor row of the sink (row n-1) at column qlen, first in edge order
     int bi = -1, bs = 0;
     {
