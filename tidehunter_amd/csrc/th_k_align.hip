@@ -71,6 +71,26 @@ __device__ __forceinline__ int th_ad_align(int np, const uint8_t *__restrict__ q
     return v;
 }
 
+// Flank extension on the anti-diagonal engine (th_ksw_ext_ad_wave); false when the result could not be certified.
+template <int NP>
+__device__ __forceinline__ bool th_adx_run(bool has_n, const uint8_t *st, const uint8_t *sq, int qlen, int tlen, int *mq, int *mt)
+{
+    return has_n ? th_ksw_ext_ad_wave<NP, true>(st, sq, qlen, tlen, mq, mt) : th_ksw_ext_ad_wave<NP, false>(st, sq, qlen, tlen, mq, mt);
+}
+template <int NPXMAX>
+__device__ __forceinline__ bool th_adx_align(int np, const uint8_t *__restrict__ q, int qs, int qlen, const uint8_t *__restrict__ t, int ts, int tlen, uint8_t *s_seq, int *mq, int *mt)
+{
+    const uint8_t *st, *sq;
+    const bool has_n = th_ad_stage(q, qlen, t, tlen, 128 * np, s_seq, &st, &sq, qs, ts);
+    bool ok = false;
+    if (np == 1) ok = th_adx_run<1>(has_n, st, sq, qlen, tlen, mq, mt);
+    else if (np == 2) ok = th_adx_run<2>(has_n, st, sq, qlen, tlen, mq, mt);
+    else if (NPXMAX >= 3 && np == 3) ok = th_adx_run<(NPXMAX >= 3 ? 3 : 1)>(has_n, st, sq, qlen, tlen, mq, mt);
+    else if (NPXMAX >= 4 && np == 4) ok = th_adx_run<(NPXMAX >= 4 ? 4 : 1)>(has_n, st, sq, qlen, tlen, mq, mt);
+    TH_WAVE_FENCE();
+    return ok;
+}
+
 // mode: 0 strip engine only (th_ksw_global_band_wave), 1 anti-diagonal engine first (default), 2 both and compare (err bit 64 on a difference)
 template <int LDSB, int NPMAX>
 __global__ void __launch_bounds__(TH_ALN_BLOCK) TH_ALN_OCC
@@ -78,7 +98,7 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
            const uint32_t *__restrict__ roff, const uint8_t *__restrict__ bseq,
            const uint8_t *__restrict__ cons, const int *__restrict__ cons_len,
            int *__restrict__ bnd, long long bnd_stride, int *__restrict__ iden, int *__restrict__ ext, int *__restrict__ err, int *__restrict__ queue,
-           int wdiv, int wadd, int wtol, int mode)
+           int wdiv, int wadd, int wtol, int mode, int xpct)
 {
     // one LDS area, used either as the left-border inbox of the strip sweep (two 64-row blocks, 4 KB) or as the staged bases
     // of the anti-diagonal engine (never both at once)
@@ -148,7 +168,23 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                 else { const int lastp = ps[T.pos_n - 1]; tlen = L - lastp - 1; tp = rb + lastp + 1; qp = cs; st = 1; }   // :221
                 if (tlen > 0) {
                     if ((long long)((tlen + 63) & ~63) * 2 > bnd_stride) { if (lane == 0) atomicOr(err, 4); }
-                    else th_ksw_ext_wave(qp, st, cl, tp, st, tlen, mybnd, &mq, &mt);
+                    else {
+                        // anti-diagonal engine first: a band of 128 NP diagonals either side, wide enough to be certified when the flank
+                        // continues the repeat (banded maximum ~0.6 min(m, n) > min(m, n) - 3 - W); the strip engine otherwise
+                        bool done = false;
+                        if (mode && cl + tlen < 30000) {
+                            const int need = (min(cl, tlen) * xpct) / 100 + 8;
+                            int np = 0;
+                            for (int c = 1; c <= 4; ++c) if (128 * c - 1 >= need) { np = c; break; }
+                            if (np && cl + tlen + 512 * np + 16 <= LDSB) done = th_adx_align<4>(np, qp, st, cl, tp, st, tlen, s_seq, &mq, &mt);
+                        }
+                        if (!done) th_ksw_ext_wave(qp, st, cl, tp, st, tlen, mybnd, &mq, &mt);
+                        else if (mode == 2) {
+                            int mq2 = -1, mt2 = -1;
+                            th_ksw_ext_wave(qp, st, cl, tp, st, tlen, mybnd, &mq2, &mt2);
+                            if ((mq2 != mq || mt2 != mt) && lane == 0) atomicOr(err, 64);
+                        }
+                    }
                 }
             }
             if (lane == 0) { const int o = 4 * I.task + (I.which == -1 ? 0 : 2); ext[o] = mq; ext[o + 1] = mt; }

@@ -259,7 +259,12 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     if (!cache16_ok) return -5;
     const int neg_thr = -(int)real_b - 1;
     // packed constants
-    const uint32_t O1P = TH_PK_DUP(O1), O2P = TH_PK_DUP(O2), E1P = TH_PK_DUP(E1), E2P = TH_PK_DUP(E2);
+    uint32_t O1P = TH_PK_DUP(O1), O2P = TH_PK_DUP(O2), E1P = TH_PK_DUP(E1), E2P = TH_PK_DUP(E2);
+#ifndef TH_CPU_EMUL
+    // the scalar register file of this kernel is full (the graph descriptor alone is ~35 pointer pairs), and a spilled scalar costs a
+    // v_readlane -- a vector instruction -- at every use: the four constants every packed row uses several times live in VGPRs instead
+    asm volatile("" : "+v"(O1P), "+v"(O2P), "+v"(E1P), "+v"(E2P));
+#endif
     uint32_t TX = 32u << 24;                                         // score table, 6 bits per query code (x 6), biased by 32
     for (int c = 0; c < 4; ++c) TX |= (uint32_t)(32 - X) << (6 * c);
     int c_meta = 0, c_rem = 0, c_p0 = -1, c_p1 = -1, c_p2 = -1, c_p3 = -1, c_id = 0;   // row-table chunk cache

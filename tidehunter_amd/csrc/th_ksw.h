@@ -330,15 +330,16 @@ __device__ __forceinline__ void th_ad_pair_steps(ThAdState<NP> &S, uint32_t (&HA
 }
 
 // bases into the staging area; returns whether either sequence holds an N (code 4).  Needs tlen + qlen + 512 NP + 16 bytes.
-__device__ __forceinline__ bool th_ad_stage(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, int npos, uint8_t *s, const uint8_t **st, const uint8_t **sq)
+__device__ __forceinline__ bool th_ad_stage(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, int npos, uint8_t *s, const uint8_t **st, const uint8_t **sq,
+                                            int qs = 1, int ts = 1)      // qs / ts = +1 or -1: walk q / t forwards or backwards (left extension)
 {
     const int lane = TH_LANE();
     const int ST = (tlen + 2 * npos + 8) & ~3, SQ = qlen + 2 * npos + 4;
     bool n4 = false;
 #pragma unroll 4
-    for (int x = lane; x < ST; x += TH_WAVE) { const int i = x - npos; uint8_t c = 4; if (i >= 1 && i <= tlen) { c = t[i - 1]; n4 |= c == 4; } s[x] = c; }
+    for (int x = lane; x < ST; x += TH_WAVE) { const int i = x - npos; uint8_t c = 4; if (i >= 1 && i <= tlen) { c = t[(long long)(i - 1) * ts]; n4 |= c == 4; } s[x] = c; }
 #pragma unroll 4
-    for (int y = lane; y < SQ; y += TH_WAVE) { const int j = qlen + npos - y; uint8_t c = 4; if (j >= 1 && j <= qlen) { c = q[j - 1]; n4 |= c == 4; } s[ST + y] = c; }
+    for (int y = lane; y < SQ; y += TH_WAVE) { const int j = qlen + npos - y; uint8_t c = 4; if (j >= 1 && j <= qlen) { c = q[(long long)(j - 1) * qs]; n4 |= c == 4; } s[ST + y] = c; }
     *st = s; *sq = s + ST;
     TH_WAVE_FENCE();
     return __ballot(n4) != 0;
@@ -381,6 +382,135 @@ __device__ __forceinline__ int th_ksw_band_ad_wave(const uint8_t *s_t, const uin
     const int gmin = min(2 * hi + 2 - D, -2 * lo + 2 + D);
     if (2LL * res_h > (long long)(qlen + tlen - gmin) - 4 * TH_KQ - 2LL * gmin * TH_KE) return res_iden;
     return -1;
+}
+
+// ---- Extension (score only) on the anti-diagonal engine ----
+// Same geometry as th_ksw_band_ad_wave with the band [lo, hi] = [-128 NP, 128 NP - 1] around the main diagonal, the recurrence of
+// th_ksw_ext_wave below (no path functionals), and per position a running best (H, anti-diagonal): within one position the
+// anti-diagonal only grows, so a strict '>' keeps the earliest one; the final arg-max ranks candidates by (H desc, anti-diagonal
+// asc, ksw2's SSE visiting order asc) exactly as th_ksw_ext_wave does.  Exactness certificate: a path that reaches a diagonal
+// outside the band holds at least W + 1 gap bases (W = 128 NP - 1) and at most min(qlen, tlen) matches, so every cell whose
+// true H differs from the banded one, and every cell outside the band, has H <= min(qlen, tlen) - 3 - W; if the banded maximum
+// S is above that bound (or the band is the whole matrix, or neither S nor the bound is positive) the result is ksw2's.
+template <int NP> struct ThAdxState { uint32_t E1[NP], F1[NP], Tp[NP], Qp[NP], NT[NP], NQ[NP], POS[NP], BH[NP], BR[NP]; };
+
+template <int NP, bool HASN, int C, int PH>
+__device__ __forceinline__ void th_adx_step(ThAdxState<NP> &S, uint32_t (&Hd)[NP], const uint8_t *s_t, const uint8_t *s_q,
+                                           int rp, int ib, int jb, int qlen, int tlen, int uhb)
+{
+    const int lane = TH_LANE();
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int u0 = 2 * (NP * lane + k);
+        if (C) { S.Tp[k] = th_ad_pair(s_t + 128 * NP + ib + u0); if (HASN) S.NT[k] = th_ad_is4(S.Tp[k]); }
+        else { S.Qp[k] = th_ad_pair(s_q + qlen + 128 * NP - jb + u0); if (HASN) S.NQ[k] = th_ad_is4(S.Qp[k]); }
+    }
+    uint32_t up[NP], lf[NP];
+    if (C == 0) {
+        const uint32_t pe = (uint32_t)th_shr1((int)S.E1[NP - 1], (int)TH_PK_NEG);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { up[k] = th_alignbit16(S.E1[k], k ? S.E1[k - 1] : pe); lf[k] = S.F1[k]; }
+    } else {
+        const uint32_t nf = (uint32_t)th_shl1((int)S.F1[0], (int)TH_PK_NEG);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { lf[k] = th_alignbit16(k + 1 < NP ? S.F1[k + 1] : nf, S.F1[k]); up[k] = S.E1[k]; }
+    }
+    uint32_t ULO = 0, UHI = 0, BT = 0, BL = 0, HBd = 0, EBd = 0;
+    if (PH != 1) {
+        const int ulo = max(0, max(-ib, jb - qlen)), uhi = min(min(tlen - ib, jb), uhb);
+        ULO = TH_PK_DUP(ulo); UHI = TH_PK_DUP(uhi);
+    }
+    if (PH == 0) {
+        const int ut = -ib >= 0 ? -ib : 0x7fff, ul = jb >= 0 ? jb : 0x7fff;
+        BT = TH_PK_DUP(ut); BL = TH_PK_DUP(ul);
+        const int hb = rp == 0 ? 0 : -(TH_KQ + rp * TH_KE);
+        HBd = TH_PK_DUP(hb); EBd = TH_PK_DUP(hb - TH_KQ - TH_KE);
+    }
+    const uint32_t RP = TH_PK_DUP(rp);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const uint32_t EM = th_pk_negmask_op(th_pk_sub(S.Tp[k] ^ S.Qp[k], TH_AD_ONE));
+        uint32_t sc = th_sel(EM, TH_AD_ONE, 0xfffefffeu);
+        if (HASN) sc = th_sel(S.NT[k] | S.NQ[k], 0xffffffffu, sc);
+        uint32_t h = th_pk_max(th_pk_max(th_pk_add(Hd[k], sc), up[k]), lf[k]);
+        const uint32_t hq = th_pk_sub(h, TH_PK_DUP(TH_KQ));
+        uint32_t nE = th_pk_sub(th_pk_max(up[k], hq), TH_PK_DUP(TH_KE)), nF = th_pk_sub(th_pk_max(lf[k], hq), TH_PK_DUP(TH_KE));
+        if (PH == 0) {
+            const uint32_t BM = th_pk_negmask_op(th_pk_sub(S.POS[k] ^ BT, TH_AD_ONE)) | th_pk_negmask_op(th_pk_sub(S.POS[k] ^ BL, TH_AD_ONE));
+            h = th_sel(BM, HBd, h); nE = th_sel(BM, EBd, nE); nF = th_sel(BM, EBd, nF);
+        }
+        if (PH != 1) {
+            const uint32_t IM = th_pk_negmask_op(th_pk_sub(S.POS[k], ULO) | th_pk_sub(UHI, S.POS[k]));
+            h = th_sel(IM, TH_PK_NEG, h); nE = th_sel(IM, TH_PK_NEG, nE); nF = th_sel(IM, TH_PK_NEG, nF);
+        }
+        // border cells are <= 0 and cells outside the matrix or the band are minus infinity: neither can beat a best that starts at 0
+        const uint32_t upd = th_pk_negmask_op(th_pk_sub(S.BH[k], h));
+        S.BH[k] = th_pk_max(S.BH[k], h); S.BR[k] = th_sel(upd, RP, S.BR[k]);
+        Hd[k] = h; S.E1[k] = nE; S.F1[k] = nF;
+    }
+}
+
+template <int NP, bool HASN, int PH>
+__device__ __forceinline__ void th_adx_pair_steps(ThAdxState<NP> &S, uint32_t (&HA)[NP], uint32_t (&HB)[NP], const uint8_t *s_t, const uint8_t *s_q,
+                                                 int rp, int lo2, int qlen, int tlen, int uhb0, int uhb1)
+{
+    const int m = rp >> 1;
+    th_adx_step<NP, HASN, 0, PH>(S, HA, s_t, s_q, rp, m + lo2, m - lo2, qlen, tlen, uhb0);
+    th_adx_step<NP, HASN, 1, PH>(S, HB, s_t, s_q, rp + 1, m + 1 + lo2, m - lo2, qlen, tlen, uhb1);
+}
+
+__device__ __forceinline__ int th_ext_rank(int r, int t, int qlen, int tlen);
+
+// returns true when the result is certified; (max_q, max_t) as th_ksw_ext_wave
+template <int NP, bool HASN>
+__device__ __forceinline__ bool th_ksw_ext_ad_wave(const uint8_t *s_t, const uint8_t *s_q, int qlen, int tlen, int *max_q, int *max_t)
+{
+    const int lane = TH_LANE();
+    const int lo = -128 * NP, hi = 128 * NP - 1, lo2 = lo / 2, R = tlen + qlen;
+    const int uhb0 = (hi - lo) >> 1, uhb1 = (hi - lo - 1) >> 1;
+    ThAdxState<NP> S;
+    uint32_t HA[NP], HB[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int u0 = 2 * (NP * lane + k);
+        HA[k] = HB[k] = TH_PK_NEG; S.E1[k] = S.F1[k] = TH_PK_NEG; S.BH[k] = 0; S.BR[k] = 0;
+        S.POS[k] = TH_PK(u0, u0 + 1);
+        S.Tp[k] = th_ad_pair(s_t + 128 * NP + lo2 + u0); S.Qp[k] = 0x00040004u;
+        S.NT[k] = HASN ? th_ad_is4(S.Tp[k]) : 0u; S.NQ[k] = 0u;
+    }
+    const int endA = max(hi, -lo);
+    const int limB = min(min(2 * tlen - hi, 2 * qlen + lo), R);
+    int rp = 0;
+    for (; rp <= endA && rp <= R; rp += 2) th_adx_pair_steps<NP, HASN, 0>(S, HA, HB, s_t, s_q, rp, lo2, qlen, tlen, uhb0, uhb1);
+    for (; rp + 1 <= limB; rp += 2) th_adx_pair_steps<NP, HASN, 1>(S, HA, HB, s_t, s_q, rp, lo2, qlen, tlen, uhb0, uhb1);
+    for (; rp <= R; rp += 2) th_adx_pair_steps<NP, HASN, 2>(S, HA, HB, s_t, s_q, rp, lo2, qlen, tlen, uhb0, uhb1);
+    // this lane's best candidate, then the wave's: (H desc, anti-diagonal asc, SSE visiting rank asc)
+    int bestH = 0, bestR = 0x7fffffff, bestT = -1, bestRank = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int H = hh ? TH_PK_HI(S.BH[k]) : TH_PK_LO(S.BH[k]);
+            const int rq = hh ? TH_PK_HI(S.BR[k]) : TH_PK_LO(S.BR[k]);       // r' = i' + j' of the best cell of this position
+            if (H > 0) {
+                const int u = 2 * (NP * lane + k) + hh;
+                const int ibr = (rq & 1) ? (rq >> 1) + 1 + lo2 : (rq >> 1) + lo2;
+                const int t = ibr + u - 1, r = rq - 2;                         // 0-based row and ksw2's anti-diagonal
+                const int rk = th_ext_rank(r, t, qlen, tlen);
+                const bool take = H > bestH || (H == bestH && (r < bestR || (r == bestR && rk < bestRank)));
+                if (take) { bestH = H; bestR = r; bestT = t; bestRank = rk; }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int oH2 = __shfl_xor(bestH, d), oR = __shfl_xor(bestR, d), oK = __shfl_xor(bestRank, d), oT = __shfl_xor(bestT, d);
+        const bool take = oH2 > bestH || (oH2 == bestH && (oR < bestR || (oR == bestR && oK < bestRank)));
+        if (take) { bestH = oH2; bestR = oR; bestRank = oK; bestT = oT; }
+    }
+    if (bestH > 0) { *max_t = bestT; *max_q = bestR - bestT; } else { *max_t = -1; *max_q = -1; }
+    const int bound = min(qlen, tlen) - 3 - min(hi, -lo);
+    return (lo <= -qlen && hi >= tlen) || bestH > bound || (bestH <= 0 && bound <= 0);
 }
 
 // Extension, score only: returns (max_q, max_t) of the first strictly greater H over anti-diagonals

@@ -62,6 +62,7 @@ struct th_gpu {
     std::vector<th_job_t> jobs;
     double ms_kernels = 0, ms_dominant = 0, ms_k[8] = { 0 };
     int aln_wdiv = 10, aln_wadd = 24;     // first certified band of the unit alignments: half-width cons_len / wdiv + wadd
+    int aln_xpct = 36;                    // flank extensions: band half-width requested from the anti-diagonal engine, percent of min(consensus, flank) (+ 8)
     int aln_wtol = 16, aln_mode = 1;      // anti-diagonal engine: accepted shortfall of its band against that half-width; 0 = strip engine only, 2 = verify against the full matrix
     int waves_part = 8192, waves_poa = 6144, waves_aln = 8192, waves_xw = 2048;   // persistent grids: 256 CUs x 4 SIMDs x resident waves
 };
@@ -89,7 +90,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
     g->waves_aln = env_int("TH_WAVES_ALN", g->waves_aln);
     g->waves_xw = env_int("TH_WAVES_XW", g->waves_xw);
     g->aln_wdiv = std::max(1, env_int("TH_ALN_WDIV", g->aln_wdiv)); g->aln_wadd = std::max(0, env_int("TH_ALN_WADD", g->aln_wadd));
-    g->aln_wtol = std::max(0, env_int("TH_ALN_WTOL", g->aln_wtol)); g->aln_mode = env_int("TH_ALN_MODE", g->aln_mode);
+    g->aln_wtol = std::max(0, env_int("TH_ALN_WTOL", g->aln_wtol)); g->aln_mode = env_int("TH_ALN_MODE", g->aln_mode); g->aln_xpct = std::max(0, env_int("TH_ALN_XPCT", g->aln_xpct));
     return g;
 }
 
@@ -445,7 +446,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         {
 #define TH_ALN_ARGS(first, n, q) (const ThAlnItem *)g->d_items.p + (first), (n), (const ThTask *)g->d_tasks.p, (const int *)g->d_parc.p, \
                   (const uint32_t *)g->d_roff.p, (const uint8_t *)g->d_bseq.p, (const uint8_t *)g->d_cons.p, (const int *)g->d_cons_len.p, \
-                  g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, g->d_cnt.p + 1, g->d_cnt.p + (q), g->aln_wdiv, g->aln_wadd, g->aln_wtol, g->aln_mode
+                  g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, g->d_cnt.p + 1, g->d_cnt.p + (q), g->aln_wdiv, g->aln_wadd, g->aln_wtol, g->aln_mode, g->aln_xpct
             if (ns) TH_LAUNCH((th_k_align<ALN_SMALL, 2>), std::min(ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(0, ns, 4));
             if (ni > ns) TH_LAUNCH((th_k_align<ALN_BIG, 6>), std::min(ni - ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(ns, ni - ns, 7));
 #undef TH_ALN_ARGS
