@@ -218,5 +218,56 @@ __device__ __forceinline__ uint32_t th_wave_incl_pkmax(uint32_t v)
     return x;
 }
 #endif
+// ---- workgroup bitonic sort of N = 2^k words in LDS (or HBM), ascending or descending; ends with a barrier ----
+// A compare-exchange stage costs a round trip through the buffer and a barrier, so stages are grouped: a thread loads 32
+// words into registers, runs up to five consecutive stages there and stores them.  The grouped pass with unit u takes the words
+// base + x u (x = 0..31; consecutive lanes take consecutive bases, so the strided LDS accesses do not collide) and covers
+// the strides 16 u .. u that are <= the current one: u = 32 for the strides 512 .. 32, u = 1 for 16 .. 1.  A merge of size
+// 2^k thus costs max(k - 10, 0) single passes + 2 grouped ones instead of k (33 passes instead of 105 at 16384 words).
+template <typename W, bool DESC, int BLOCK>
+__device__ __forceinline__ void th_bitonic_sort(W *buf, int N, int tid)
+{
+    auto reg_pass = [&](int u, int size, int stride) {
+        for (int w = tid; w < (N >> 5); w += BLOCK) {
+            W v[32];
+            const int base = (w / u) * 32 * u + (w & (u - 1));
+#pragma unroll
+            for (int x = 0; x < 32; ++x) v[x] = buf[base + x * u];
+#pragma unroll
+            for (int st = 16; st > 0; st >>= 1) {
+                if (st * u <= stride) {
+#pragma unroll
+                    for (int x = 0; x < 32; ++x) {
+                        if ((x & st) == 0) {
+                            const bool first = (((base + x * u) & size) == 0) != DESC;      // the smaller word goes first
+                            const W a = v[x], c = v[x + st];
+                            const W mn = a < c ? a : c, mx = a < c ? c : a;
+                            v[x] = first ? mn : mx; v[x + st] = first ? mx : mn;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < 32; ++x) buf[base + x * u] = v[x];
+        }
+        __syncthreads();
+    };
+    const int top = N >= 1024 ? 512 : N >= 32 ? 16 : 0;      // largest stride the grouped passes take
+    for (int size = 2; size <= N; size <<= 1) {
+        int stride = size >> 1;
+        for (; stride > top; stride >>= 1) {
+            for (int t = tid; t < (N >> 1); t += BLOCK) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool first = ((lo & size) == 0) != DESC;
+                const W a = buf[lo], c = buf[hi];
+                if ((a > c) == first) { buf[lo] = c; buf[hi] = a; }
+            }
+            __syncthreads();
+        }
+        if (N >= 1024 && stride >= 32) { reg_pass(32, size, stride); stride = 16; }
+        if (N >= 32 && stride >= 1) reg_pass(1, size, stride);
+    }
+}
+
 // (a & m) | (b & ~m): v_bfi_b32
 __device__ __forceinline__ uint32_t th_sel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }

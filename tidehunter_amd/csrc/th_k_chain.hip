@@ -263,16 +263,7 @@ th_k_chain_sort(const uint32_t *__restrict__ roff, ThDevPara P,
     int N = 1; while (N < n) N <<= 1;
     for (int i = tid; i < N; i += TH_XS_BLOCK) s_key[i] = i < n ? ((uint32_t)S[i] << 13 | (uint32_t)i) : 0u;
     __syncthreads();
-    for (int size = 2; size <= N; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < (N >> 1); t += TH_XS_BLOCK) {
-                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
-                const bool desc = (lo & size) == 0;
-                const uint32_t a = s_key[lo], c = s_key[hi];
-                if ((a < c) == desc) { s_key[lo] = c; s_key[hi] = a; }
-            }
-            __syncthreads();
-        }
+    th_bitonic_sort<uint32_t, true, TH_XS_BLOCK>(s_key, N, tid);      // descending: best score first, ties keep the larger index first
     for (int x = tid; x < n; x += TH_XS_BLOCK) {
         const int cand = (int)(s_key[x] & 0x1fff);
         const int e = E[cand];

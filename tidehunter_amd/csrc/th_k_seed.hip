@@ -154,51 +154,7 @@ th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, T
     __syncthreads();
 
     // 2. bitonic sort, ascending on the full 64-bit word (key major, pos minor); sentinels sink to the end
-    // A compare-exchange stage costs a round trip through the buffer and a barrier, so stages are grouped: a thread loads 32
-    // words into registers, runs up to five consecutive stages there and stores them.  reg_pass(u) takes the words
-    // base + x u (x = 0..31; consecutive lanes take consecutive bases, so the strided LDS accesses do not collide) and covers
-    // the strides 16 u .. u that are <= the current one: u = 32 for the strides 512 .. 32, u = 1 for 16 .. 1.  A merge of size
-    // 2^k thus costs max(k - 10, 0) single passes + 2 grouped ones instead of k (33 passes instead of 105 at 16384 words).
-    auto reg_pass = [&](int u, int size, int stride) {
-        for (int w = tid; w < (N >> 5); w += TH_SEED_BLOCK) {
-            W v[32];
-            const int base = (w / u) * 32 * u + (w & (u - 1));
-#pragma unroll
-            for (int x = 0; x < 32; ++x) v[x] = buf[base + x * u];
-#pragma unroll
-            for (int st = 16; st > 0; st >>= 1) {
-                if (st * u <= stride) {
-#pragma unroll
-                    for (int x = 0; x < 32; ++x) {
-                        if ((x & st) == 0) {
-                            const bool asc = ((base + x * u) & size) == 0;
-                            const W a = v[x], c = v[x + st];
-                            const W mn = a < c ? a : c, mx = a < c ? c : a;
-                            v[x] = asc ? mn : mx; v[x + st] = asc ? mx : mn;
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int x = 0; x < 32; ++x) buf[base + x * u] = v[x];
-        }
-        __syncthreads();
-    };
-    const int top = N >= 1024 ? 512 : N >= 32 ? 16 : 0;      // largest stride the grouped passes take
-    for (int size = 2; size <= N; size <<= 1) {
-        int stride = size >> 1;
-        for (; stride > top; stride >>= 1) {
-            for (int t = tid; t < (N >> 1); t += TH_SEED_BLOCK) {
-                int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
-                bool asc = (lo & size) == 0;
-                W a = buf[lo], c = buf[hi];
-                if ((a > c) == asc) { buf[lo] = c; buf[hi] = a; }
-            }
-            __syncthreads();
-        }
-        if (N >= 1024 && stride >= 32) { reg_pass(32, size, stride); stride = 16; }
-        if (N >= 32 && stride >= 1) reg_pass(1, size, stride);
-    }
+    th_bitonic_sort<W, false, TH_SEED_BLOCK>(buf, N, tid);
 
     // 3. nearest earlier occurrence at distance >= min_p (src/tandem_hit.c:192-196)
     for (int x = tid; x < ne; x += TH_SEED_BLOCK) {
