@@ -181,16 +181,13 @@ th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, T
     const int p0 = min(L, tid * chunk), p1 = min(L, p0 + chunk);
     int c = 0;
     for (int p = p0; p < p1; ++p) c += tmp[off + p] != 0;
-    s_cnt[tid] = c;
+    // exclusive prefix over the threads' counts: DPP scan inside each wave, then the (few) wave totals
+    const int inc = th_wave_incl_sum(c);
+    if ((tid & 63) == 63) s_cnt[tid >> 6] = inc;
     __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int t = 0; t < TH_SEED_BLOCK; ++t) { int x = s_cnt[t]; s_cnt[t] = acc; acc += x; }
-        s_cnt[TH_SEED_BLOCK] = acc;
-        hit_n[r] = acc;
-    }
-    __syncthreads();
-    int o = s_cnt[tid];
+    int o = inc - c, tot = 0;
+    for (int wv = 0; wv < TH_SEED_BLOCK / TH_WAVE; ++wv) { const int x = s_cnt[wv]; if (wv < (tid >> 6)) o += x; tot += x; }
+    if (tid == 0) hit_n[r] = tot;
     for (int p = p0; p < p1; ++p) {
         uint32_t per = tmp[off + p];
         if (per) { hit_end[off + o] = p; hit_per[off + o] = (int)per; ++o; }
