@@ -42,7 +42,7 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
     const int r = blockIdx.x * (TH_CHAIN_BLOCK / TH_WAVE) + (threadIdx.x >> 6);
     const bool live = r < n_reads;
     const uint32_t off = live ? roff[r] : 0;
-    const int n = live ? hit_n[r] : 0, k = P.k;
+    const int n = TH_UNI(live ? hit_n[r] : 0), k = P.k;
     const int *E = hit_end + off, *Pd = hit_per + off;
     int *S = score + off, *F = from + off;
     unsigned long long *R = eps + off;
@@ -54,16 +54,19 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
     }
     TH_WAVE_FENCE();
     for (int cur = 1; cur < n; ++cur) {
-        const int ce = E[cur], cp = Pd[cur], cs = ce - cp;
+        const int ce = TH_UNI(E[cur]), cp = TH_UNI(Pd[cur]), cs = ce - cp;       // the same in every lane: scalar registers
         const int init = k + min(k, cp);
         int best = init, bi = -1, iter = 0;
         const int max_h = cp;
+        // the two period-ratio tests below as one range test on the predecessor's period: 5 cp >= 9 pp <=> pp <= (5 cp) / 9 and
+        // 5 pp >= 9 cp <=> pp >= ceil(9 cp / 5), so a connection needs plo < pp < phi
+        const uint32_t plo = (5u * (uint32_t)cp) / 9u, phi = (9u * (uint32_t)cp + 4u) / 5u;
         for (int base = cur - 1; base >= 0; base -= TH_WAVE) {
             const int idx = base - lane;
             const bool valid = idx >= 0;
             int pe, pp, psc;
             if (PK) {
-                const unsigned long long rec = valid ? R[idx] : 1ull;
+                const unsigned long long rec = R[max(idx, 0)];       // lanes before the first hit read record 0 and are discarded by `valid`
                 pe = (int)((uint32_t)rec >> 16); pp = (int)((uint32_t)rec & 0xffffu); psc = (int)(rec >> 32);
             } else { pe = valid ? E[idx] : 0; pp = valid ? Pd[idx] : 1; psc = valid ? S[idx] : 0; }
             const int ps = pe - pp;
@@ -72,7 +75,7 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             // :154 compares cp >= pp * 1.8 in double.  fl(1.8) exceeds 1.8 by a relative 2.5e-17, less than half an ulp,
             // so pp * fl(1.8) rounds to exactly 1.8 pp whenever that is an integer and stays > 0.19 away from every
             // integer otherwise: the comparison equals 5 cp >= 9 pp for all periods below 2^28 (th_gpu_upload checks).
-            if (!dstop && !(cs <= ps || 5u * (uint32_t)cp >= 9u * (uint32_t)pp || 5u * (uint32_t)pp >= 9u * (uint32_t)cp)) {
+            if (!dstop && cs > ps && (uint32_t)pp - plo - 1u < phi - plo - 1u) {
                 // hits are sorted by end, so pe <= ce, and cs > ps was just tested: both distances are plain differences and
                 // their sum is positive (ilog2 needs no guard)
                 const int dis1 = ce - pe, dis2 = cs - ps;
