@@ -71,27 +71,25 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             } else { pe = valid ? E[idx] : 0; pp = valid ? Pd[idx] : 1; psc = valid ? S[idx] : 0; }
             const int ps = pe - pp;
             const bool dstop = !valid || pe < cs;                  // :331  predecessor ends before cur starts
-            int type = TH_NO_CON, con = 0;
             // :154 compares cp >= pp * 1.8 in double.  fl(1.8) exceeds 1.8 by a relative 2.5e-17, less than half an ulp,
             // so pp * fl(1.8) rounds to exactly 1.8 pp whenever that is an integer and stays > 0.19 away from every
             // integer otherwise: the comparison equals 5 cp >= 9 pp for all periods below 2^28 (th_gpu_upload checks).
-            if (!dstop && cs > ps && (uint32_t)pp - plo - 1u < phi - plo - 1u) {
-                // hits are sorted by end, so pe <= ce, and cs > ps was just tested: both distances are plain differences and
-                // their sum is positive (ilog2 needs no guard)
-                const int dis1 = ce - pe, dis2 = cs - ps;
-                const int matched = min(dis1, k) + min(dis2, k);
-                const int dp = abs(cp - pp);
-                const int gap = (int)((uint32_t)(dp * dp) >> 1) + ((31 - __clz(dis1 + dis2)) >> 1);   // :128-142
-                con = matched - gap;
-                type = dp == 0 ? (matched < 2 * k ? TH_OVL_CON : TH_SAME_CON) : TH_REG_CON;
-            }
-            const int s = type != TH_NO_CON ? psc + con : -0x40000000;
+            const bool is_con = !dstop && cs > ps && (uint32_t)pp - plo - 1u < phi - plo - 1u;     // anything but NO_CON
+            // Every lane scores (a skipped lane costs the same issue slot as a computing one); lanes without a connection
+            // produce garbage that the selects below discard.  Hits are sorted by end, so pe <= ce, and cs > ps holds where it
+            // matters: both distances are plain differences and their sum is positive there (ilog2 needs no guard).
+            const int dis1 = ce - pe, dis2 = cs - ps;
+            const int matched = min(dis1, k) + min(dis2, k);
+            const int dq = cp - pp;
+            const int gap = (int)((uint32_t)(dq * dq) >> 1) + ((31 - __clz(dis1 + dis2)) >> 1);   // :128-142
+            const bool same0 = cp == pp, ovl = same0 && matched < 2 * k;       // SAME or OVL / OVL (where is_con)
+            const int s = is_con ? psc + matched - gap : -0x40000000;
             const int rb = th_wave_excl_max(s, best);              // best as seen just before this lane
-            const bool imp = type != TH_NO_CON && s > rb;
+            const bool imp = is_con && s > rb;
             const unsigned long long impm = __ballot(imp);
             // stop rules in scan order: :331 (dstop); :342 improving SAME/OVL and :344-346 non-improving OVL, so OVL
             // always stops; :349 max_h consecutive non-improving predecessors (only evaluated when reachable)
-            bool stop = dstop || type == TH_OVL_CON || (imp && type == TH_SAME_CON);
+            bool stop = dstop || (is_con && (ovl || (imp && same0)));
             if (iter + TH_WAVE >= max_h) {
                 const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1);
                 const unsigned long long below = impm & upto;
