@@ -93,15 +93,17 @@ __device__ __forceinline__ int th_shr1(int v, int fill) { return TH_DPP(fill, v,
 __device__ __forceinline__ int th_shl1(int v, int fill) { return TH_DPP(fill, v, 0x130, 0xf, 0xf); }   // wave_shl:1
 __device__ __forceinline__ int th_shr1_inject(int v, int inj) { return TH_DPP(inj, v, 0x138, 0xf, 0xf); }  // lane 0 keeps inj[0]
 __device__ __forceinline__ int th_rol1(int v) { return TH_DPP(v, v, 0x134, 0xf, 0xf); }                   // wave_rol:1
+// Inclusive scans: four dependent steps inside each row of 16 lanes (row_shr 1, 2, 4, 8: a lane without a source keeps its
+// value), then the two row broadcasts -- six vector instructions.  (A variant that shortens the dependency chain with three
+// independent shifts and a max3 needs nine plus identity fills; these kernels are bound by instruction issue, not by the chain.)
 __device__ __forceinline__ int th_wave_incl_max(int v)
 {
     const int id = -0x7fffffff - 1;
     int x = v;
-    x = max(x, TH_DPP(id, v, 0x111, 0xf, 0xf));     // row_shr:1
-    x = max(x, TH_DPP(id, v, 0x112, 0xf, 0xf));     // row_shr:2
-    x = max(x, TH_DPP(id, v, 0x113, 0xf, 0xf));     // row_shr:3
-    x = max(x, TH_DPP(id, x, 0x114, 0xf, 0xe));     // row_shr:4, banks 1-3
-    x = max(x, TH_DPP(id, x, 0x118, 0xf, 0xc));     // row_shr:8, banks 2-3
+    x = max(x, TH_DPP(id, x, 0x111, 0xf, 0xf));     // row_shr:1
+    x = max(x, TH_DPP(id, x, 0x112, 0xf, 0xf));     // row_shr:2
+    x = max(x, TH_DPP(id, x, 0x114, 0xf, 0xf));     // row_shr:4
+    x = max(x, TH_DPP(id, x, 0x118, 0xf, 0xf));     // row_shr:8
     x = max(x, TH_DPP(id, x, 0x142, 0xa, 0xf));     // row_bcast:15 into rows 1,3
     x = max(x, TH_DPP(id, x, 0x143, 0xc, 0xf));     // row_bcast:31 into rows 2,3
     return x;
@@ -109,11 +111,10 @@ __device__ __forceinline__ int th_wave_incl_max(int v)
 __device__ __forceinline__ int th_wave_incl_sum(int v)
 {
     int x = v;
-    x += TH_DPP(0, v, 0x111, 0xf, 0xf);
-    x += TH_DPP(0, v, 0x112, 0xf, 0xf);
-    x += TH_DPP(0, v, 0x113, 0xf, 0xf);
-    x += TH_DPP(0, x, 0x114, 0xf, 0xe);
-    x += TH_DPP(0, x, 0x118, 0xf, 0xc);
+    x += TH_DPP(0, x, 0x111, 0xf, 0xf);
+    x += TH_DPP(0, x, 0x112, 0xf, 0xf);
+    x += TH_DPP(0, x, 0x114, 0xf, 0xf);
+    x += TH_DPP(0, x, 0x118, 0xf, 0xf);
     x += TH_DPP(0, x, 0x142, 0xa, 0xf);
     x += TH_DPP(0, x, 0x143, 0xc, 0xf);
     return x;
