@@ -26,7 +26,12 @@
 
 #define TH_POA_BLOCK 64
 #define TH_POA_WB 10
+#ifndef TH_POA_QCAP
 #define TH_POA_QCAP 3072        // query bases staged in LDS by the int16-ring variant
+#endif
+#ifndef TH_POA_OCC
+#define TH_POA_OCC 6            // waves per SIMD the POA kernels are compiled for
+#endif
 #define TH_POA_QCAP_WIDE 8192   // ... by the 32-bit-ring variant (longer units read the query from HBM: QCAP = 0)
 
 #define TH_D_SRC(d)  ((d) & 7)
@@ -748,7 +753,7 @@ __device__ __forceinline__ int *th_carve(int *&p, long long cnt) { int *r = p; p
 template <int QCAP, typename RT>
 // 6 waves per SIMD: 80 VGPRs (21 dwords of scratch) and 6.5 KB of LDS per wave (query codes packed two per byte); measured per
 // 65536 reads: 4 waves 588 ms, 5 waves 557 ms
-__global__ void __launch_bounds__(TH_POA_BLOCK) TH_WAVES_PER_SIMD(6)
+__global__ void __launch_bounds__(TH_POA_BLOCK) TH_WAVES_PER_SIMD(TH_POA_OCC)
 th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict__ units, const uint32_t *__restrict__ roff,
          const uint8_t *__restrict__ bseq, ThDevPara P, int *__restrict__ scratch, long long scratch_ints,
          uint8_t *__restrict__ cons, int *__restrict__ cov, int *__restrict__ cons_len, int *__restrict__ status, int *__restrict__ queue)
