@@ -102,6 +102,11 @@ int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *d
 /* deterministic synthetic tandem-repeat reads; returns read length, writes at most cap bases */
 int th_synth_read(uint64_t seed, uint64_t read_index, int period, int copies, double err, char *dst, int cap);
 
+/* config 5 of SURVEY.md 8(d): adapter-bounded units of mixed periods (200..5000 by read_index mod 5), both strands; -1 if the
+ * adapters do not fit the shortest period.  th_synth_adapter writes len bases + NUL (which: 0 = 5' adapter, 1 = 3' adapter). */
+void th_synth_adapter(uint64_t seed, int which, char *dst, int len);
+int th_synth_read_c5(uint64_t seed, uint64_t read_index, const char *five, int five_len, const char *three, int three_len, double err, char *dst, int cap);
+
 const char *th_last_error(void);
 const char *th_version(void);
 

@@ -102,6 +102,14 @@ int tho_edlib_hw(const char *q, int qlen, const char *t, int tlen, int *start, i
 /* aligns seqs[1..n) progressively onto a graph seeded with seqs[0]; returns cons_len;
  * cons (codes 0..4) and cov must hold sum(lens) entries */
 int tho_poa_consensus(int n_seqs, const uint8_t *const *seqs, const int *lens, const tho_para_t *p, uint8_t *cons, int *cov);
+/* named switches of the restated POA (process-wide; tests only) */
+#define THO_POA_GAP_WINS_TIE 0     /* default of THO_POA_OPT_GAP_TIE: a base that is as frequent as the gap stays in the consensus */
+#define THO_POA_OPT_GAP_TIE 1
+#define THO_POA_OPT_BAND 2         /* 1 = adaptive band (default), 0 = full rows */
+void tho_poa_set_opt(int what, int value);
+/* independent exact POA (tho_poa_exact.c): full matrix, Kahn order recomputed per sequence; flags bit 0: rank consensus
+ * columns breadth-first instead of depth-first, bit 1: gap wins column ties */
+int tho_poa_exact(int n_seqs, const uint8_t *const *seqs, const int *lens, const tho_para_t *p, int flags, uint8_t *cons, int *cov);
 
 /* ---- stage 4: consensus records (src/gen_cons.c, src/abpoa_cons.c) ---- */
 typedef struct {

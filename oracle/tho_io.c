@@ -156,19 +156,30 @@ void tho_output(FILE *fp, const tho_read_t *rd, const tho_read_res_t *res, const
     }
 }
 
-/* ---- whole-file driver: chunks of reads, one ticket per read (src/main.c:273-291,402-425) ---- */
-#define CHUNK 4096
-typedef struct { const tho_para_t *p; tho_read_t *rd; tho_read_res_t *res; int n; int *next; pthread_mutex_t *mu; } work_t;
+/* ---- whole-file driver: chunks of reads, one ticket per read (src/main.c:273-291,402-425) ----
+ * Same work-queue design as the reference (a shared ticket counter, one read per ticket), made to scale to the
+ * hundreds of cores of a GPU host: the workers are created once and meet the main thread at two barriers per chunk
+ * instead of being created and joined per chunk, the ticket is an atomic increment instead of a lock, and the big
+ * per-alignment buffers are per-thread (tho_poa.c, tho_ksw2.c). */
+#define CHUNK 16384
+typedef struct { const tho_para_t *p; tho_read_t *rd; tho_read_res_t *res; volatile int n; int next; volatile int quit; pthread_barrier_t start, done; } work_t;
 
+static void work_chunk(work_t *w)
+{
+    for (;;) {
+        int i = __atomic_fetch_add(&w->next, 1, __ATOMIC_RELAXED);
+        if (i >= w->n) break;
+        tho_core(w->rd[i].seq, w->rd[i].len, w->p, &w->res[i]);
+    }
+}
 static void *worker(void *a)
 {
     work_t *w = (work_t *)a;
     for (;;) {
-        pthread_mutex_lock(w->mu);
-        int i = (*w->next)++;
-        pthread_mutex_unlock(w->mu);
-        if (i >= w->n) break;
-        tho_core(w->rd[i].seq, w->rd[i].len, w->p, &w->res[i]);
+        pthread_barrier_wait(&w->start);
+        if (w->quit) break;
+        work_chunk(w);
+        pthread_barrier_wait(&w->done);
     }
     return NULL;
 }
@@ -180,25 +191,31 @@ int tho_run_file(const char *fn, const tho_para_t *p, FILE *out)
     tho_read_t *rd = (tho_read_t *)calloc(CHUNK, sizeof(tho_read_t));
     tho_read_res_t *res = (tho_read_res_t *)calloc(CHUNK, sizeof(tho_read_res_t));
     int nt = p->n_thread < 1 ? 1 : p->n_thread, total = 0;
-    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    work_t w; memset(&w, 0, sizeof(w));
+    w.p = p; w.rd = rd; w.res = res;
+    pthread_t *tid = NULL;
+    if (nt > 1) {
+        pthread_barrier_init(&w.start, NULL, (unsigned)nt + 1); pthread_barrier_init(&w.done, NULL, (unsigned)nt + 1);
+        tid = (pthread_t *)calloc((size_t)nt, sizeof(pthread_t));
+        for (int t = 0; t < nt; ++t) pthread_create(&tid[t], NULL, worker, &w);
+    }
     for (;;) {
         int n = 0;
         while (n < CHUNK && tho_reader_next(r, &rd[n])) ++n;
         if (n == 0) break;
-        int next = 0;
-        work_t w = { p, rd, res, n, &next, &mu };
-        if (nt == 1) worker(&w);
-        else {
-            pthread_t *tid = (pthread_t *)calloc(nt, sizeof(pthread_t));
-            for (int t = 0; t < nt; ++t) pthread_create(&tid[t], NULL, worker, &w);
-            for (int t = 0; t < nt; ++t) pthread_join(tid[t], NULL);
-            free(tid);
-        }
+        w.n = n; w.next = 0;
+        if (nt == 1) work_chunk(&w);
+        else { pthread_barrier_wait(&w.start); pthread_barrier_wait(&w.done); }
         for (int i = 0; i < n; ++i) {
             if (out) tho_output(out, &rd[i], &res[i], p);
             tho_read_res_clear(&res[i]); tho_read_free(&rd[i]);
         }
         total += n;
+    }
+    if (nt > 1) {
+        w.quit = 1; pthread_barrier_wait(&w.start);
+        for (int t = 0; t < nt; ++t) pthread_join(tid[t], NULL);
+        pthread_barrier_destroy(&w.start); pthread_barrier_destroy(&w.done); free(tid);
     }
     for (int i = 0; i < CHUNK; ++i) tho_read_res_free(&res[i]);
     free(rd); free(res);

@@ -45,7 +45,10 @@ int tho_ksw2_global_cigar(const uint8_t *q, int qlen, const uint8_t *t, int tlen
 {
     *n_cigar = 0; *cigar = NULL; if (score) *score = NEG_INF;
     if (qlen <= 0 || tlen <= 0) return 0; /* ksw2_extz2_sse.c:57; ksw2_get_xid of an empty cigar = 0 */
-    uint8_t *p = (uint8_t *)malloc((size_t)qlen * tlen);
+    /* the traceback matrix (1 MB at 1000 x 1000, 25 MB at 5000 x 5000) is per-thread and grow-only: see tho_poa.c */
+    static __thread uint8_t *tl_p; static __thread size_t tl_cap;
+    if ((size_t)qlen * tlen > tl_cap) { tl_cap = (size_t)qlen * tlen + ((size_t)qlen * tlen >> 2); free(tl_p); tl_p = (uint8_t *)malloc(tl_cap); }
+    uint8_t *p = tl_p;
     int *H = (int *)malloc(sizeof(int) * qlen), *E = (int *)malloc(sizeof(int) * qlen);
     for (int j = 0; j < qlen; ++j) {
         H[j] = -(GAPO + (j + 1) * GAPE);            /* H(-1,j) */
@@ -87,7 +90,7 @@ int tho_ksw2_global_cigar(const uint8_t *q, int qlen, const uint8_t *t, int tlen
     if (i >= 0) cg = push_cigar(cg, &n, &m, 2, i + 1);
     if (j >= 0) cg = push_cigar(cg, &n, &m, 1, j + 1);
     for (int a = 0; a < n >> 1; ++a) { uint32_t x = cg[a]; cg[a] = cg[n - 1 - a]; cg[n - 1 - a] = x; }
-    free(p); free(H); free(E);
+    free(H); free(E);
     /* src/ksw2_align.c:62-86: count M columns with equal codes (N vs N counts) */
     int iden = 0, qi = 0, ti = 0;
     for (int a = 0; a < n; ++a) {

@@ -10,6 +10,7 @@
 #include <getopt.h>
 #include <sys/time.h>
 #include <sys/resource.h>
+#include <malloc.h>
 #include "tho.h"
 
 static const struct option lopt[] = {
@@ -72,10 +73,17 @@ int main(int argc, char **argv)
     if (p.only_full_length && (!five || !three)) { fprintf(stderr, "\n[main] Error: 5' and 3' adapter sequence need to be provided.\n"); return 0; }
     if (p.w < 1 || p.w > 256) { fprintf(stderr, "[tho_oracle] -w must be in 1..256 (the reference's window array has 256 slots)\n"); return 2; }
     tho_para_load_adapters(&p, five, three);
+    /* many worker threads: keep freed memory in the per-thread malloc arenas instead of returning it to the kernel (every
+     * mmap/munmap/trim takes the process-wide mm lock, which is what limited the scaling of this program on a 256-core host) */
+    mallopt(M_MMAP_THRESHOLD, 32 << 20); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_TOP_PAD, 16 << 20);
+    const double t_run = now();
     int n = tho_run_file(argv[optind], &p, out);
+    const double wall = now() - t_run;
     struct rusage ru; getrusage(RUSAGE_SELF, &ru);
-    fprintf(stderr, "[tho_oracle] reads: %d; Real time: %.3f sec; CPU: %.3f sec; Peak RSS: %.3f GB\n", n, now() - t0,
-            ru.ru_utime.tv_sec + ru.ru_stime.tv_sec + 1e-6 * (ru.ru_utime.tv_usec + ru.ru_stime.tv_usec), ru.ru_maxrss / 1024.0 / 1024.0);
+    const double cpu = ru.ru_utime.tv_sec + ru.ru_stime.tv_sec + 1e-6 * (ru.ru_utime.tv_usec + ru.ru_stime.tv_usec);
+    fprintf(stderr, "[tho_oracle] reads: %d; Real time: %.3f sec; CPU: %.3f sec; Peak RSS: %.3f GB\n", n, now() - t0, cpu, ru.ru_maxrss / 1024.0 / 1024.0);
+    if (n > 0) fprintf(stderr, "[tho_oracle] threads: %d; %.1f reads/s; %.2f ms per read per core (CPU time / reads); %.2f ms per read x threads (wall x threads / reads)\n",
+                       p.n_thread < 1 ? 1 : p.n_thread, n / wall, 1000.0 * cpu / n, 1000.0 * wall * (p.n_thread < 1 ? 1 : p.n_thread) / n);
     tho_para_free_adapters(&p);
     if (out != stdout) fclose(out);
     return 0;

@@ -13,16 +13,18 @@
  *   graph    : nodes 0 = source, 1 = sink, >=2 bases in creation order; weighted edges kept in
  *              insertion order; nodes that carry different bases of one MSA column form an
  *              "aligned ring".
- *   order    : a topological order kept incrementally ("insertion order"): the first unit is a
- *              chain source, bases, sink; when an alignment is merged, a new ring member is
- *              placed right after the last member of its ring, and a run of inserted bases
- *              right before the ring of the next aligned node of the path (before the sink
- *              if there is none).  Rings stay adjacent, every edge points forward (the
- *              path visits rows in increasing order).  The DP values of a row depend only on
- *              its predecessors' rows, so they do not depend on which topological order is
- *              used; only the left-to-right order of parallel insertion branches in the
- *              consensus does.  (abPOA re-sorts with a BFS after every sequence; this order
- *              is kept instead because it can be updated with prefix sums on the GPU.)
+ *   order    : the rows of the DP follow a topological order of the graph in which the members of an aligned ring
+ *              are adjacent.  Which such order is used cannot change the alignment: a row's values depend only on
+ *              its predecessors' rows, predecessor ties are broken by edge-insertion order (not by row order), and
+ *              the band of a row is derived from its predecessors' bands and row maxima.  abPOA obtains its order
+ *              with a breadth-first (Kahn) sort after every sequence; this file maintains one incrementally instead
+ *              (the first unit is the chain source, bases, sink; a new ring member goes right after the last member
+ *              of its ring; a run of inserted bases right before the ring of the next aligned node of the path, or
+ *              before the sink).  The only place an order could show is the left-to-right order of two parallel
+ *              insertion branches in the consensus; oracle/tho_poa_exact.c re-sorts with the Kahn sort the paper
+ *              describes (rows breadth-first, consensus columns depth- or breadth-first) and the tests compare:
+ *              no consensus differs on any job of tests/test_poa_exact.py or of the at-scale GPU-box run
+ *              (tests/test_gpu_scale.py, >= 2000 jobs per config shape).
  *              max_remain[v] = longest node count from v to the sink (sink = -1).
  *   DP       : global alignment of the query (columns 0..qlen) against the ordered nodes,
  *              convex gap = two affine pieces, 32-bit scores, score(a,b) = 0 if either is N(4),
@@ -54,6 +56,18 @@
 
 #define NEG (-0x20000000)
 #define WB 10
+
+/* Named switches (tho.h).  THO_POA_GAP_WINS_TIE: what a consensus column does when the gap is exactly as frequent as
+ * the best base -- 0: the base is kept (default; the scan order A,C,G,T,N,gap with a strict comparison), 1: the column
+ * is dropped.  libabpoa's own rule cannot be read here (absent submodule); when its source is available this default is
+ * the ONE line to pin (the HIP kernel has the same constant, TH_POA_GAP_WINS_TIE in th_k_poa.hip).
+ * THO_POA_OPT_BAND = 0 disables the adaptive band (every row spans 0..qlen): used by the cross-check tests only. */
+static int g_gap_wins_tie = THO_POA_GAP_WINS_TIE, g_band = 1;
+void tho_poa_set_opt(int what, int value)
+{
+    if (what == THO_POA_OPT_GAP_TIE) g_gap_wins_tie = value ? 1 : 0;
+    else if (what == THO_POA_OPT_BAND) g_band = value ? 1 : 0;
+}
 
 typedef struct {
     uint8_t base; int n_read;
@@ -124,15 +138,25 @@ typedef struct { int op, node, qpos; } aop_t;   /* op: 0 match/mismatch, 1 inser
 static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline int imin(int a, int b) { return a < b ? a : b; }
 
-static int align_to_graph(graph_t *g, const uint8_t *q, int qlen, const tho_para_t *p, aop_t **ops_out)
+/* returns the op count, -1 if the adaptive band came out empty or lost the global path, -2 if a node has more than 255 predecessors */
+static int align_to_graph(graph_t *g, const uint8_t *q, int qlen, const tho_para_t *p, aop_t **ops_out, int band)
 {
     const int M = p->match, X = p->mismatch, O1 = p->gap_open1, E1 = p->gap_ext1, O2 = p->gap_open2, E2 = p->gap_ext2;
     int n = g->n_node, w = WB + qlen / 100;
     int *beg = (int *)malloc(sizeof(int) * n * 4), *end = beg + n, *mpl = end + n, *mpr = mpl + n;
-    size_t *roff = (size_t *)malloc(sizeof(size_t) * n), ncell = 0, mcell = (size_t)n * (2 * w + 64);
-    /* band-only storage: row i holds columns beg[i]..end[i] at roff[i] */
-    int *H = (int *)malloc(sizeof(int) * mcell), *N1 = (int *)malloc(sizeof(int) * mcell), *N2 = (int *)malloc(sizeof(int) * mcell);
-    uint32_t *D = (uint32_t *)malloc(sizeof(uint32_t) * mcell);
+    size_t *roff = (size_t *)malloc(sizeof(size_t) * n), ncell = 0;
+    /* band-only storage: row i holds columns beg[i]..end[i] at roff[i].  The four cell arrays (a few MB each) are per-thread
+     * and grow-only: allocating and freeing them per alignment made hundreds of worker threads contend in the kernel's
+     * mmap/munmap path (the CPU baseline of bench.py runs this with one thread per core). */
+    static __thread int *tl_H, *tl_N1, *tl_N2; static __thread uint32_t *tl_D; static __thread size_t tl_mcell;
+    size_t mcell = (size_t)n * (2 * w + 64);
+    if (mcell > tl_mcell) {
+        tl_mcell = mcell + mcell / 4;
+        tl_H = (int *)realloc(tl_H, sizeof(int) * tl_mcell); tl_N1 = (int *)realloc(tl_N1, sizeof(int) * tl_mcell);
+        tl_N2 = (int *)realloc(tl_N2, sizeof(int) * tl_mcell); tl_D = (uint32_t *)realloc(tl_D, sizeof(uint32_t) * tl_mcell);
+    }
+    mcell = tl_mcell;
+    int *H = tl_H, *N1 = tl_N1, *N2 = tl_N2; uint32_t *D = tl_D;
     for (int i = 0; i < n; ++i) { mpl[i] = 0x7fffffff; mpr[i] = 0; }
 #define AT(A, i, j) ((A)[roff[i] + (size_t)((j) - beg[i])])
 #define RD(A, i, j) (((j) < beg[i] || (j) > end[i]) ? NEG : AT(A, i, j))
@@ -147,12 +171,14 @@ static int align_to_graph(graph_t *g, const uint8_t *q, int qlen, const tho_para
             if (b < mb) b = mb;
         }
         e = imin(qlen, imax(mpr[v], qlen - g->remain[v]) + w);
-        if (b > e) { fprintf(stderr, "[tho_poa] empty band at row %d\n", i); exit(1); }
+        if (!band) { b = 0; e = qlen; }
+        if (b > e) { free(beg); free(roff); return -1; }
         beg[i] = b; end[i] = e; roff[i] = ncell; ncell += (size_t)(e - b + 1);
         if (ncell > mcell) {
             while (ncell > mcell) mcell *= 2;
-            H = (int *)realloc(H, sizeof(int) * mcell); N1 = (int *)realloc(N1, sizeof(int) * mcell);
-            N2 = (int *)realloc(N2, sizeof(int) * mcell); D = (uint32_t *)realloc(D, sizeof(uint32_t) * mcell);
+            H = tl_H = (int *)realloc(H, sizeof(int) * mcell); N1 = tl_N1 = (int *)realloc(N1, sizeof(int) * mcell);
+            N2 = tl_N2 = (int *)realloc(N2, sizeof(int) * mcell); D = tl_D = (uint32_t *)realloc(D, sizeof(uint32_t) * mcell);
+            tl_mcell = mcell;
         }
         int f1 = NEG, f2 = NEG, rmax = NEG - 0x10000000, left = b, right = b;
         for (int j = b; j <= e; ++j) {
@@ -174,7 +200,7 @@ static int align_to_graph(graph_t *g, const uint8_t *q, int qlen, const tho_para
                     if (ord == 0 || c1 > e1v) { e1v = c1; pe1 = ord; }
                     if (ord == 0 || c2 > e2v) { e2v = c2; pe2 = ord; }
                 }
-                if (ord > 256) { fprintf(stderr, "[tho_poa] in-degree %d > 256\n", ord); exit(1); }
+                if (ord > 255) { free(beg); free(roff); return -2; }
                 h = m; src = 0;
                 if (e1v > h) { h = e1v; src = 1; }
                 if (e2v > h) { h = e2v; src = 2; }
@@ -206,7 +232,7 @@ static int align_to_graph(graph_t *g, const uint8_t *q, int qlen, const tho_para
         int pi = g->index[g->edge[ed].from], c = RD(H, pi, qlen);
         if (ord == 0 || c > bs) { bs = c; bi = pi; }
     }
-    if (bs <= NEG / 2) { fprintf(stderr, "[tho_poa] band lost the global path (score %d)\n", bs); exit(1); }
+    if (bs <= NEG / 2) { free(beg); free(roff); return -1; }
     /* traceback */
     aop_t *ops = (aop_t *)malloc(sizeof(aop_t) * (size_t)(n + qlen + 2));
     int no = 0, i = bi, j = qlen, st = 0;
@@ -234,7 +260,7 @@ static int align_to_graph(graph_t *g, const uint8_t *q, int qlen, const tho_para
     for (int a = 0, b2 = no - 1; a < b2; ++a, --b2) { aop_t t = ops[a]; ops[a] = ops[b2]; ops[b2] = t; }
 #undef AT
 #undef RD
-    free(beg); free(roff); free(H); free(N1); free(N2); free(D);
+    free(beg); free(roff);
     *ops_out = ops;
     return no;
 }
@@ -296,22 +322,35 @@ static void add_alignment(graph_t *g, const uint8_t *q, int qlen, const aop_t *o
     free(ins_head); free(pend);
 }
 
+/* abPOA has no failure mode; the restated band could in principle come out empty or lose the global path on a pathological
+ * graph.  Such a job is redone from scratch with full rows (the HIP pipeline does the same: status 3 / 4 -> rerun without a
+ * band); a node with more than 255 predecessors (the direction word keeps 8 bits per predecessor index) leaves the job
+ * without a consensus on both sides, with a warning -- never a dead process. */
 int tho_poa_consensus(int n_seqs, const uint8_t *const *seqs, const int *lens, const tho_para_t *p, uint8_t *cons, int *cov)
 {
-    graph_t g; memset(&g, 0, sizeof(g));
+    graph_t g; uint8_t *buf = NULL; int mbuf = 0, band = g_band, failed = 0;
+RESTART:
+    memset(&g, 0, sizeof(g));
     new_node(&g, 4); new_node(&g, 4);        /* source, sink */
-    uint8_t *buf = NULL; int mbuf = 0;
     for (int s = 0; s < n_seqs; ++s) {
         if (lens[s] > mbuf) { mbuf = lens[s]; buf = (uint8_t *)realloc(buf, mbuf); }
         for (int j = 0; j < lens[s]; ++j) buf[j] = seqs[s][j] > 4 ? 4 : seqs[s][j];
         if (s == 0) add_alignment(&g, buf, lens[s], NULL, 0);
         else {
             set_remain(&g);
-            aop_t *ops; int n_ops = align_to_graph(&g, buf, lens[s], p, &ops);
+            aop_t *ops; int n_ops = align_to_graph(&g, buf, lens[s], p, &ops, band);
+            if (n_ops < 0) {
+                free(g.node); free(g.edge); free(g.order); free(g.index); free(g.remain);
+                if (n_ops == -1 && band) { band = 0; goto RESTART; }
+                fprintf(stderr, "[tho_poa] warning: a consensus job could not be aligned (%s); reported without a consensus\n", n_ops == -2 ? "in-degree > 255" : "no global path");
+                failed = 1; memset(&g, 0, sizeof(g));
+                break;
+            }
             add_alignment(&g, buf, lens[s], ops, n_ops);
             free(ops);
         }
     }
+    if (failed) { free(buf); return 0; }
     int cl = 0;
     for (int i = 1; i + 1 < g.n_node;) {
         int v = g.order[i], cnt[5] = { 0, 0, 0, 0, 0 }, tot = 0, k = i;
@@ -321,7 +360,7 @@ int tho_poa_consensus(int n_seqs, const uint8_t *const *seqs, const int *lens, c
         for (k = i; k < i + members; ++k) { int u = g.order[k]; cnt[g.node[u].base] += g.node[u].n_read; tot += g.node[u].n_read; }
         int gap = n_seqs - tot, best = 0, bb = -1;
         for (int b = 0; b < 5; ++b) if (cnt[b] > best) { best = cnt[b]; bb = b; }
-        if (gap > best) bb = -1;
+        if (g_gap_wins_tie ? gap >= best : gap > best) bb = -1;
         if (bb >= 0) { cons[cl] = (uint8_t)bb; if (cov) cov[cl] = best; ++cl; }
         i += members;
     }

@@ -81,6 +81,8 @@ def load():
     lib.tho_ksw2_left_ext.argtypes = [u8p, C.c_int, u8p, C.c_int, ip, ip]
     lib.tho_edlib_hw.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, ip, ip, C.c_int]
     lib.tho_poa_consensus.argtypes = [C.c_int, C.POINTER(u8p), ip, C.POINTER(Para), u8p, ip]
+    lib.tho_poa_exact.argtypes = [C.c_int, C.POINTER(u8p), ip, C.POINTER(Para), C.c_int, u8p, ip]
+    lib.tho_poa_set_opt.argtypes = [C.c_int, C.c_int]
     lib.tho_core.argtypes = [C.c_char_p, C.c_int, C.POINTER(Para), C.POINTER(ReadRes)]
     lib.tho_read_res_free.argtypes = [C.POINTER(ReadRes)]
     lib.tho_para_load_adapters.argtypes = [C.POINTER(Para), C.c_char_p, C.c_char_p]
@@ -208,3 +210,39 @@ def stages(seq: bytes, para):
     if hn:
         lib.free(hp)
     return dict(bseq=b, hits=hits, score=score, frm=frm, chains=chains)
+
+
+POA_OPT_GAP_TIE, POA_OPT_BAND = 1, 2
+
+
+def units_of(seq: bytes, sub_pos):
+    """the units abpoa_gen_cons() slices out of a read for one run of boundaries (src/abpoa_cons.c:41-48), as code arrays"""
+    b = encode(seq)
+    L = len(seq)
+    out = []
+    for s, e in zip(sub_pos[:-1], sub_pos[1:]):
+        if s < 0 or e < 0 or s >= L - 1 or e + 1 > L:
+            continue
+        out.append(b[s + 1:e + 1])
+    return out
+
+
+def _poa_call(fn, units, para, *extra):
+    n = len(units)
+    arrs = [np.ascontiguousarray(u, dtype=np.uint8) for u in units]
+    ptrs = (C.POINTER(C.c_uint8) * n)(*[a.ctypes.data_as(C.POINTER(C.c_uint8)) for a in arrs])
+    lens = (C.c_int * n)(*[len(a) for a in arrs])
+    tot = sum(len(a) for a in arrs) + 1
+    cons = np.zeros(tot, dtype=np.uint8); cov = np.zeros(tot, dtype=np.int32)
+    cl = fn(n, ptrs, lens, C.byref(para), *extra, cons.ctypes.data_as(C.POINTER(C.c_uint8)), cov.ctypes.data_as(C.POINTER(C.c_int)))
+    return bytes(b"ACGTN"[c] for c in cons[:cl]), cov[:cl].copy()
+
+
+def poa_banded(units, para):
+    """oracle/tho_poa.c (the restatement the HIP kernel is held to)"""
+    return _poa_call(load().tho_poa_consensus, units, para)
+
+
+def poa_exact(units, para, flags=0):
+    """oracle/tho_poa_exact.c: full matrix, Kahn order; flags bit 0 = breadth-first column ranks, bit 1 = gap wins ties"""
+    return _poa_call(load().tho_poa_exact, units, para, flags)

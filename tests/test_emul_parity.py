@@ -208,3 +208,14 @@ def test_emul_strip_engine_still_matches(emu, monkeypatch):
     seqs = [TH.synth_read(th.lib, 5, 0, 500, 4, 0.10), TH.synth_read(th.lib, 5, 2, 520, 3, 0.16)]
     assert U.assert_records_equal(seqs, th.process(seqs), O.default_para(), "strip") >= 1
     th.close()
+
+
+def test_emul_poa_band_failure_is_rerun_without_a_band(emu, monkeypatch):
+    """TH_POA_TEST_FAIL makes every job report "band lost the path" on the banded pass: the pipeline must rerun those jobs with
+    full rows instead of failing the batch, and (the band never matters at these error rates) reach the same records"""
+    monkeypatch.setenv("TH_POA_TEST_FAIL", "1")
+    th = TH.TideHunter(lib_path=emu)
+    seqs = _reads(th.lib, [(60, 8, 0.10), (120, 5, 0.08), (35, 12, 0.12)])
+    got = th.process(seqs)
+    assert U.assert_records_equal(seqs, got, O.default_para(), "noband rerun") >= 3
+    th.close()

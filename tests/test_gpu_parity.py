@@ -53,9 +53,9 @@ def test_gpu_test_fq_real_reads(th):
 
 
 @pytest.mark.parametrize("period,copies,err,n,seed", [
-    (200, 20, 0.10, 40, 2),      # config 2 shape: short period, chain-dominated
-    (1000, 10, 0.10, 24, 1),     # config 3 shape (headline)
-    (5000, 4, 0.15, 4, 3),       # config 4 shape: long period, wide POA band, 5000^2 alignments
+    (200, 20, 0.10, 256, 2),     # config 2 shape: short period, chain-dominated
+    (1000, 10, 0.10, 256, 1),    # config 3 shape (headline)
+    (5000, 4, 0.15, 32, 3),      # config 4 shape: long period, wide POA band, 5000^2 alignments
     (50, 30, 0.05, 16, 9),
 ])
 def test_gpu_synthetic_configs(th, period, copies, err, n, seed):

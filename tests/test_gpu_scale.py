@@ -1,0 +1,148 @@
+"""GPU parity at scale, reproduced by the driver (`pytest -m gpu`): what tools/parity_scale.sh did by hand in round 1.
+
+  * byte identity of the command line (reader -> batch seam -> writer) against the CPU oracle's command line on thousands
+    of synthetic reads per BASELINE.json config shape and several option sets;
+  * config 5 AT SPEC: periods {200, 500, 1000, 2000, 5000}, copies max(3, 10000 // period), both strands,
+    5'/3' adapters, gzipped (multi-line) FASTQ input through the command line, with and without -F / -s;
+  * the HIP POA kernel against the INDEPENDENT exact POA (oracle/tho_poa_exact.c: full matrix, Kahn order) on >= 2000 jobs
+    per config shape when the host has the cores for it.
+Sample sizes scale with the host's core count (the oracle costs ~70 ms per headline read per core); on the 256-core GPU box
+they reach the sizes quoted above.  Everything POA touches is "GPU == oracle", not "== reference" (abPOA is absent).
+"""
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+import oracle_lib as O
+import th_util as U
+import tidehunter_amd as TH
+
+pytestmark = pytest.mark.gpu
+
+CORES = os.cpu_count() or 8
+EXE = os.path.join(U.ROOT, "tidehunter_amd", "TideHunter-amd")
+ORACLE = os.path.join(O.ODIR, "tho_oracle")
+
+
+def _n(full, per_core):
+    return int(min(full, max(48, per_core * CORES)))
+
+
+def _run(cmd):
+    return subprocess.run(cmd, check=True, capture_output=True).stdout
+
+
+def _both(tmp_path, opts, infile):
+    O.load()
+    gpu = _run([EXE, *opts, str(infile)])
+    cpu = _run([ORACLE, "-t", str(CORES), *opts, str(infile)])
+    return gpu, cpu
+
+
+@pytest.fixture(scope="module")
+def shape_files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("scale")
+    lib = TH.load_library()
+    files = {}
+    for name, (n, period, copies, err, seed) in dict(C3=(_n(4096, 16), 1000, 10, 0.10, 1), C2=(_n(4096, 32), 200, 20, 0.10, 2),
+                                                    C4=(_n(512, 2), 5000, 4, 0.15, 3)).items():
+        fn = d / (name + ".fa")
+        U.write_fasta(fn, [TH.synth_read(lib, seed, i, period, copies, err) for i in range(n)], prefix="syn_%s_" % name)
+        files[name] = (fn, n)
+    return files
+
+
+@pytest.mark.parametrize("shape,opts", [
+    ("C3", []), ("C3", ["-f", "2"]), ("C3", ["-f", "4", "-c", "3"]),
+    ("C2", []), ("C2", ["-u", "-f", "2"]), ("C2", ["-k", "10", "-w", "5"]), ("C2", ["-H"]),
+    ("C4", []), ("C4", ["-f", "2", "-l"]),
+])
+def test_gpu_cli_byte_identity_at_scale(tmp_path, shape_files, shape, opts):
+    fn, n = shape_files[shape]
+    gpu, cpu = _both(tmp_path, opts, fn)
+    assert gpu == cpu, "%s %r: command-line output differs from the oracle's" % (shape, opts)
+    assert gpu.count(b"\n") >= n // 2
+
+
+def test_gpu_config5_at_spec_gz_fastq(tmp_path):
+    """config 5 at its SURVEY 8(d) definition, >= 200 reads, gz FASTQ through the command line; all five period classes with
+    adapters (the 2000 / 5000 classes are the ones that reach th_k_poa<8192,int> and th_k_align<24576,6>)"""
+    n = max(200, _n(1000, 4))
+    n -= n % 10
+    seqs, ad = U.config5_spec(tmp_path, n)
+    assert {len(s) // 4000 for s in seqs} >= {2, 3}                      # ~10 kb reads and the ~15 kb reads of the 5000 class
+    fq = tmp_path / "c5.fq.gz"
+    U.write_fastq_gz(fq, seqs, prefix="c5_", line=0)
+    fq_wrapped = tmp_path / "c5_wrapped.fq.gz"
+    U.write_fastq_gz(fq_wrapped, seqs[:40], prefix="c5_", line=70)      # multi-line FASTQ records
+    adopt = ["-5", ad[0], "-3", ad[1]]
+    for opts in (adopt, adopt + ["-F", "-f", "2"], adopt + ["-F", "-s", "-f", "4"]):
+        gpu, cpu = _both(tmp_path, opts, fq)
+        assert gpu == cpu, "config 5 %r: output differs from the oracle's" % (opts[4:],)
+    gpu, cpu = _both(tmp_path, adopt, fq_wrapped)
+    assert gpu == cpu and gpu.count(b">") >= 30
+    # the records themselves, through the batch seam: every period class yields full-length consensuses on both strands
+    para = O.default_para()
+    O.load().tho_para_load_adapters(para, ad[0].encode(), ad[1].encode())
+    t = TH.TideHunter(device=0, adapters=ad)
+    got = t.process(seqs)
+    assert U.assert_records_equal(seqs, got, para, "config 5 at spec") >= n * 9 // 10
+    by_class = {}
+    for i, rr in enumerate(got):
+        for r in rr:
+            if r["full_length"] > 0:
+                by_class.setdefault(i % 5, set()).add(r["full_length"])
+    assert all(by_class.get(c) == {1, 2} for c in range(5)), by_class
+    t.close()
+
+
+def test_gpu_config5_sharded_blocks_match_whole(tmp_path):
+    """config 5 says "sharded across 8 GPUs": contiguous blocks balanced by bases (bench.py / th_run_file_multi use the same
+    rule) give the same records as the whole set in one batch"""
+    import bench
+    n = 80
+    seqs, ad = U.config5_spec(tmp_path, n)
+    t = TH.TideHunter(device=0, adapters=ad)
+    whole = t.process(seqs)
+    cuts = bench.partition_by_bases([len(s) for s in seqs], 8)
+    assert cuts[0] == 0 and cuts[-1] == n and all(a < b for a, b in zip(cuts, cuts[1:]))
+    parts = []
+    for a, b in zip(cuts, cuts[1:]):
+        parts += t.process(seqs[a:b])
+    assert parts == whole
+    t.close()
+
+
+@pytest.mark.parametrize("period,copies,err,seed,full,per_core", [
+    (1000, 10, 0.10, 1, 2048, 10),     # config 3
+    (200, 20, 0.10, 2, 2048, 40),      # config 2
+    (5000, 4, 0.15, 3, 256, 1),        # config 4 (a job costs ~10 s and ~0.5 GB on the CPU)
+])
+def test_gpu_poa_equals_independent_exact_poa(period, copies, err, seed, full, per_core):
+    """HIP POA kernel == full-matrix Kahn-order POA on every job: neither the adaptive band, nor the int16 / packed rows,
+    nor the incremental node order of the kernel changes a consensus at the configs' error rates"""
+    n = _n(full, per_core)
+    lib = TH.load_library()
+    seqs = [TH.synth_read(lib, seed + 100, i, period, copies, err) for i in range(n)]
+    t = TH.TideHunter(device=0)
+    got = t.process(seqs)
+    t.close()
+    para = O.default_para()
+    jobs = []
+    for s, rr in zip(seqs, got):
+        for r in rr:
+            u = O.units_of(s, r["sub_pos"])
+            if len(u) > 2:
+                jobs.append((u, r["seq"]))
+    assert len(jobs) >= n * 3 // 4
+
+    def one(job):
+        u, rec = job
+        d, _ = O.poa_exact(u, para, 0)
+        return d == rec
+
+    with ThreadPoolExecutor(min(CORES, 64 if period >= 5000 else 256)) as ex:
+        ok = list(ex.map(one, jobs))
+    assert all(ok), "%d of %d POA jobs differ from the exact POA" % (ok.count(False), len(ok))

@@ -11,6 +11,17 @@ DATA = os.path.join(ROOT, "tests", "golden", "data")
 EMUL_SO = os.path.join(ROOT, "tests", "cpu_emul", "libth_emul.so")
 
 
+def synth_lib():
+    """the product library, for its deterministic read generator only (th_synth_read needs no GPU)"""
+    import tidehunter_amd as TH
+    return TH.load_library()
+
+
+def synth_read(lib, seed, index, period, copies, err):
+    import tidehunter_amd as TH
+    return TH.synth_read(lib, seed, index, period, copies, err)
+
+
 def emul_lib_path():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpu_emul")], check=True, stdout=subprocess.DEVNULL)
     return EMUL_SO
@@ -41,11 +52,21 @@ def read_fastx(path):
     return out
 
 
+def oracle_records(seqs, para):
+    """tho_core() on every read; the calls release the GIL, so the host cores of the box work in parallel"""
+    from concurrent.futures import ThreadPoolExecutor
+    if len(seqs) < 8:
+        return [O.core(s, para) for s in seqs]
+    with ThreadPoolExecutor(min(64, os.cpu_count() or 8)) as ex:
+        return list(ex.map(lambda s: O.core(s, para), seqs))
+
+
 def assert_records_equal(seqs, got, para, label=""):
     """got: TideHunter.process() output; compared field by field with the oracle's tho_core()."""
     n = 0
+    want = oracle_records(seqs, para)
     for idx, (s, recs) in enumerate(zip(seqs, got)):
-        exp = O.core(s, para)
+        exp = want[idx]
         assert len(exp) == len(recs), "%s read %d: %d records, oracle %d" % (label, idx, len(recs), len(exp))
         for a, b in zip(exp, recs):
             assert a["sub_pos"] == b["sub_pos"], (label, idx)
@@ -72,8 +93,11 @@ def stage_compare(th, seqs, para):
     cells = th.debug_stage(7, 4 * T, np.int32)
     parc = th.debug_stage(9, 8 * T + 1024, np.int32)
     bseq = th.debug_stage(0, T, np.uint8)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(min(64, os.cpu_count() or 8)) as ex:
+        all_st = list(ex.map(lambda s: O.stages(s, para), seqs))
     for r, s in enumerate(seqs):
-        st = O.stages(s, para)
+        st = all_st[r]
         o, n = int(roff[r]), int(hn[r])
         assert np.array_equal(bseq[o:o + len(s)], st["bseq"]), r
         hits = (he[o:o + n].astype(np.uint64) << np.uint64(32)) | hp[o:o + n].astype(np.uint64)
@@ -120,3 +144,34 @@ def config5_reads(tmpdir, n, seed=5, err=0.10, periods=(200, 500, 1000)):
         s = bytes(out)
         reads.append(rc(s) if r & 1 else s)
     return reads, fns
+
+
+def write_fasta(path, seqs, prefix="r"):
+    with open(path, "wb") as f:
+        for i, s in enumerate(seqs):
+            f.write(b">%s%d\n" % (prefix.encode(), i) + s + b"\n")
+
+
+def write_fastq_gz(path, seqs, prefix="r", line=0):
+    """gzipped FASTQ; line > 0 wraps sequence and quality lines (multi-line FASTQ, which the kseq grammar allows)"""
+    import gzip
+    with gzip.open(path, "wb", compresslevel=1) as f:
+        for i, s in enumerate(seqs):
+            q = bytes(33 + (j * 7 + i) % 40 for j in range(len(s)))
+            if line > 0:
+                wrap = lambda b: b"\n".join(b[k:k + line] for k in range(0, len(b), line)) if b else b""
+                f.write(b"@%s%d some comment\n" % (prefix.encode(), i) + wrap(s) + b"\n+\n" + wrap(q) + b"\n")
+            else:
+                f.write(b"@%s%d\n" % (prefix.encode(), i) + s + b"\n+\n" + q + b"\n")
+
+
+def config5_spec(tmpdir, n, seed=5):
+    """SURVEY.md 8(d) config 5 AT SPEC: periods {200, 500, 1000, 2000, 5000} by read index, copies max(3, 10000 // period),
+    10 % error, both strands, 84-nt 5' / 25-nt 3' adapters from seed 55 written to 5p.fa / 3p.fa."""
+    import tidehunter_amd as TH
+    lib = synth_lib()
+    ad = TH.synth_adapters(lib)
+    fns = (os.path.join(str(tmpdir), "5p.fa"), os.path.join(str(tmpdir), "3p.fa"))
+    open(fns[0], "wb").write(b">5p\n" + ad[0] + b"\n")
+    open(fns[1], "wb").write(b">3p\n" + ad[1] + b"\n")
+    return [TH.synth_read_c5(lib, seed, i, ad) for i in range(n)], fns

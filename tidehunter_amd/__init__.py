@@ -60,6 +60,8 @@ def load_library(path=None):
     lib.th_batch_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     lib.th_run_file.argtypes = [C.c_char_p, C.POINTER(Para), C.c_void_p, C.c_int, C.c_int]
     lib.th_synth_read.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_char_p, C.c_int]
+    lib.th_synth_adapter.argtypes = [C.c_uint64, C.c_int, C.c_char_p, C.c_int]
+    lib.th_synth_read_c5.argtypes = [C.c_uint64, C.c_uint64, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_double, C.c_char_p, C.c_int]
     lib.th_last_error.restype = C.c_char_p
     lib.th_version.restype = C.c_char_p
     lib.th_debug_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]
@@ -185,4 +187,26 @@ def synth_read(lib, seed, index, period, copies, err):
     buf = C.create_string_buffer(cap)
     n = lib.th_synth_read(seed, index, period, copies, err, buf, cap)
     assert n <= cap
+    return buf.raw[:n]
+
+
+C5_ADAPTER_SEED, C5_FIVE_LEN, C5_THREE_LEN = 55, 84, 25
+
+
+def synth_adapters(lib, seed=C5_ADAPTER_SEED):
+    """(5' adapter, 3' adapter) of config 5"""
+    out = []
+    for which, n in ((0, C5_FIVE_LEN), (1, C5_THREE_LEN)):
+        buf = C.create_string_buffer(n + 1)
+        lib.th_synth_adapter(seed, which, buf, n)
+        out.append(buf.raw[:n])
+    return tuple(out)
+
+
+def synth_read_c5(lib, seed, index, adapters, err=0.10):
+    """config 5 read `index`: period {200,500,1000,2000,5000}[index % 5], copies max(3, 10000 // period), both strands"""
+    cap = 20000
+    buf = C.create_string_buffer(cap)
+    n = lib.th_synth_read_c5(seed, index, adapters[0], len(adapters[0]), adapters[1], len(adapters[1]), err, buf, cap)
+    assert 0 < n <= cap
     return buf.raw[:n]

@@ -24,7 +24,7 @@
 #include "tidehunter_amd.h"
 #include "th_internal.h"
 
-static char g_err[512];
+static __thread char g_err[512];   /* per thread, like the device layer's message */
 const char *th_last_error(void) { return g_err[0] ? g_err : th_gpu_error(); }
 const char *th_version(void) { return "1.5.5-mi355x.r1"; }
 static int host_fail(const char *m) { snprintf(g_err, sizeof(g_err), "%s", m); fprintf(stderr, "[tidehunter_amd] %s\n", m); return -1; }
@@ -744,5 +744,44 @@ int th_synth_read(uint64_t seed, uint64_t read_index, int period, int copies, do
             } else { if (n < cap) dst[n] = b; ++n; }
         }
     free(unit);
+    return n;
+}
+
+/* read r has period {200, 500, 1000, 2000, 5000}[r mod 5], copies = max(3, 10000 / period); the unit
+ * is 5' adapter + random insert + reverse complement of the 3' adapter, copied with the same per-base edit model as
+ * th_synth_read(); every second group of five reads is reverse-complemented (both strands).  Adapters come from
+ * th_synth_adapter(seed 55, ...) in the configs' definition; any pair can be passed. */
+void th_synth_adapter(uint64_t seed, int which, char *dst, int len)
+{
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + (uint64_t)(which + 1) * 0xA24BAED4963EE407ull;
+    for (int i = 0; i < len; ++i) dst[i] = "ACGT"[sm64(&s) >> 62];
+    dst[len] = 0;
+}
+int th_synth_read_c5(uint64_t seed, uint64_t read_index, const char *five, int five_len, const char *three, int three_len, double err, char *dst, int cap)
+{
+    static const int periods[5] = { 200, 500, 1000, 2000, 5000 };
+    const int period = periods[read_index % 5], copies = 10000 / period > 3 ? 10000 / period : 3;
+    if (five_len + three_len >= period) return -1;
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + read_index * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull;
+    char *unit = (char *)malloc((size_t)period), *trc = rc_seq(three, three_len);
+    memcpy(unit, five, (size_t)five_len);
+    for (int i = five_len; i < period - three_len; ++i) unit[i] = "ACGT"[sm64(&s) >> 62];
+    memcpy(unit + period - three_len, trc, (size_t)three_len);
+    free(trc);
+    int n = 0;
+    for (int c = 0; c < copies; ++c)
+        for (int i = 0; i < period; ++i) {
+            char b = unit[i];
+            if (sm_u(&s) < err) {
+                int kind = (int)(sm_u(&s) * 3);
+                if (kind == 0) { int bi = (int)(strchr("ACGT", b) - "ACGT"); b = "ACGT"[(bi + 1 + (int)(sm_u(&s) * 3)) & 3]; if (n < cap) dst[n] = b; ++n; }
+                else if (kind == 1) { if (n < cap) dst[n] = b; ++n; char x = "ACGT"[(int)(sm_u(&s) * 4) & 3]; if (n < cap) dst[n] = x; ++n; }
+            } else { if (n < cap) dst[n] = b; ++n; }
+        }
+    free(unit);
+    if (((read_index / 5) & 1) && n <= cap) {     /* antisense strand */
+        char *r = rc_seq(dst, n);
+        memcpy(dst, r, (size_t)n); free(r);
+    }
     return n;
 }

@@ -43,6 +43,10 @@
 #define TH_D_XF1 (1u << 29)
 #define TH_D_XF2 (1u << 30)
 
+// Consensus column rule when the gap is exactly as frequent as the best base: 0 = the base stays (a later symbol of the scan
+// A,C,G,T,N,gap must be strictly more frequent), 1 = the column is dropped.  libabpoa's rule is unverifiable here (absent
+// submodule); this constant and THO_POA_GAP_WINS_TIE (oracle/tho.h) are the one line each to change when it can be read.
+#define TH_POA_GAP_WINS_TIE 0
 #define TH_POA_INL 4
 #define TH_POA_RING 4      // recent rows kept in LDS (a row can read the three before it)
 #define TH_POA_RW 192      // widest cached band
@@ -246,7 +250,7 @@ __device__ unsigned long long th_poa_prof[18];
 // QCAP > 0: the query is staged in LDS (s_qs); RT = short: int16 ring with packed rows, RT = int: 32-bit ring (exact for any
 // score range, one column per lane).  The int16 variant returns -5 when the alignment's scores may not fit.
 template <int QCAP, typename RT>
-__device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t *s_qs, RT (*s_ring)[3][TH_POA_RS], int (*s_rmeta)[8], int qlen, const ThDevPara &P)
+__device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t *s_qs, RT (*s_ring)[3][TH_POA_RS], int (*s_rmeta)[8], int qlen, const ThDevPara &P, const bool noband)
 {
     constexpr bool LQ = QCAP > 0, WIDE = sizeof(RT) == 4;
     const int lane = TH_LANE();
@@ -332,6 +336,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             if (i > 0) { b = max(0, min(mpl, qlen - rm) - w); b = max(b, mb); }
             e = min(qlen, max(mpr, qlen - rm) + w);
         }
+        if (noband) { b = 0; e = qlen; }          // retry of a job whose adaptive band failed (status 3 / 4): full rows
         b = TH_UNI(b); e = TH_UNI(e);
         if (b > e) return -2;
         // a row owns the cells of columns (b & ~1) .. (e | 1): packed rows store column pairs
@@ -731,7 +736,7 @@ __device__ int th_poa_consensus(ThPoaG &g, int n_seqs, uint8_t *__restrict__ con
                     if (c_g > best) { best = c_g; bb = 2; }
                     if (c_t > best) { best = c_t; bb = 3; }
                     if (c_n > best) { best = c_n; bb = 4; }
-                    if (n_seqs - tot > best) bb = -1;
+                    if (TH_POA_GAP_WINS_TIE ? n_seqs - tot >= best : n_seqs - tot > best) bb = -1;
                 }
             }
         }
@@ -747,7 +752,7 @@ __device__ int th_poa_consensus(ThPoaG &g, int n_seqs, uint8_t *__restrict__ con
 
 __device__ __forceinline__ int *th_carve(int *&p, long long cnt) { int *r = p; p += (cnt + 3) & ~3LL; return r; }
 
-// status: 0 ok, 1 scratch too small for the graph, 2 band cells overflow, 3 internal order error, 4 band lost the path,
+// status: 0 ok, 1 scratch too small for the graph, 2 band cells overflow, 3 empty band, 4 band lost the path,
 //         5 in-degree > 255, 6 consensus longer than cons_cap, 7 scores may not fit the int16 ring (rerun on the 32-bit variant)
 // QCAP: query bases staged in LDS (0: read from HBM); RT: element type of the LDS ring of recent rows (see th_poa_dp)
 template <int QCAP, typename RT>
@@ -756,9 +761,12 @@ template <int QCAP, typename RT>
 __global__ void __launch_bounds__(TH_POA_BLOCK) TH_WAVES_PER_SIMD(TH_POA_OCC)
 th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict__ units, const uint32_t *__restrict__ roff,
          const uint8_t *__restrict__ bseq, ThDevPara P, int *__restrict__ scratch, long long scratch_ints,
-         uint8_t *__restrict__ cons, int *__restrict__ cov, int *__restrict__ cons_len, int *__restrict__ status, int *__restrict__ queue)
+         uint8_t *__restrict__ cons, int *__restrict__ cov, int *__restrict__ cons_len, int *__restrict__ status, int *__restrict__ queue, int flags)
 {
+    // flags: bit 0 = no adaptive band (the rerun of a job whose band failed); bits 8.. = test knob TH_POA_TEST_FAIL: jobs whose
+    // index is a multiple of it report status 4 on the banded pass, so the tests can drive the rerun path
     constexpr bool LQ = QCAP > 0;
+    const bool noband = flags & 1; const int test_fail = flags >> 8;
     __shared__ __attribute__((aligned(4))) uint8_t s_qs[QCAP / 2 + 4]; // column j's query code (0..4, code of q[j-1]; 4 for j = 0 and j > qlen) in nibble j & 1 of byte j >> 1
     __shared__ __attribute__((aligned(4))) RT s_ring[TH_POA_RING][3][TH_POA_RS];
     __shared__ int s_rmeta[TH_POA_RING][8];
@@ -810,9 +818,10 @@ th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict
             const int deg = th_poa_rows(g);
             TH_PROF(0);
             if (deg > 255) { st = 5; break; }
-            const int bi = th_poa_dp<QCAP, RT>(g, q, s_qs, s_ring, s_rmeta, qlen, P);
+            int bi = th_poa_dp<QCAP, RT>(g, q, s_qs, s_ring, s_rmeta, qlen, P, noband);
+            if (test_fail && !noband && t % test_fail == 0 && bi >= 0) bi = -4;
             TH_PROF(1);
-            if (bi < 0) { st = bi == -3 ? 2 : bi == -5 ? 7 : 4; break; }
+            if (bi < 0) { st = bi == -3 ? 2 : bi == -5 ? 7 : bi == -2 ? 3 : 4; break; }
             const int no = th_poa_traceback(g, bi, qlen);
             TH_PROF(2);
             th_poa_merge(g, q, no);

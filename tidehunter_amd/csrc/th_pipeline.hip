@@ -11,16 +11,19 @@
 #include <algorithm>
 #include <chrono>
 #include "th_internal.h"
+
+// one message per thread: th_run_file_multi drives one handle per device from its own thread
+static thread_local std::string g_th_err;
+extern "C" const char *th_gpu_error(void) { return g_th_err.c_str(); }
+static int th_fail(const std::string &m) { g_th_err = m; fprintf(stderr, "[tidehunter_amd] %s\n", m.c_str()); return -1; }
+static int th_launch_failed(const char *kernel, const char *why) { return th_fail(std::string("kernel launch failed: ") + kernel + ": " + why); }
+
 #include "th_dev.h"
 #include "th_k_seed.hip"
 #include "th_k_chain.hip"
 #include "th_k_partition.hip"
 #include "th_k_poa.hip"
 #include "th_k_align.hip"
-
-static std::string g_th_err;
-extern "C" const char *th_gpu_error(void) { return g_th_err.c_str(); }
-static int th_fail(const std::string &m) { g_th_err = m; fprintf(stderr, "[tidehunter_amd] %s\n", m.c_str()); return -1; }
 
 static double th_wall_s() { using namespace std::chrono; return duration<double>(steady_clock::now().time_since_epoch()).count(); }
 
@@ -97,6 +100,9 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
 extern "C" void th_gpu_destroy(th_gpu_t *g)
 {
     if (!g) return;
+#ifndef TH_CPU_EMUL
+    (void)hipSetDevice(g->device);
+#endif
     g->d_seq.release(); g->d_bseq.release(); g->d_tracked.release(); g->d_sub.release(); g->d_scl.release(); g->d_sst.release(); g->d_cons_c.release(); g->d_cov_c.release(); g->d_cc_len.release(); g->d_cc_off.release(); g->d_eps.release(); g->d_xovf.release(); g->d_xorder.release(); g->d_xstart.release(); g->d_xend.release(); g->d_cons.release(); g->d_roff.release(); g->d_tmp.release();
     g->d_hit_end.release(); g->d_hit_per.release(); g->d_hit_n.release(); g->d_score.release(); g->d_from.release(); g->d_cells.release();
     g->d_cnt.release(); g->d_read_ch_base.release(); g->d_read_ch_n.release(); g->d_gsort.release(); g->d_gsort_off.release(); g->d_rec.release();
@@ -112,8 +118,20 @@ extern "C" void th_gpu_destroy(th_gpu_t *g)
 
 #define TRY(x) do { if ((x) != 0) return th_fail(std::string("device runtime call failed: ") + #x); } while (0)
 
+// A handle belongs to one device, but the calling thread's current HIP device may have changed since th_gpu_create
+// (torch.cuda.set_device, a second handle for another GPU, a call from another thread): every entry point re-selects it,
+// otherwise allocations and launches would land on the wrong GPU.
+static int th_select_device(const th_gpu *g)
+{
+#ifndef TH_CPU_EMUL
+    if (hipSetDevice(g->device) != hipSuccess) return th_fail("hipSetDevice(" + std::to_string(g->device) + ") failed");
+#endif
+    (void)g; return 0;
+}
+
 extern "C" int th_gpu_upload(th_gpu_t *g, const char *const *seqs, const int *lens, int n)
 {
+    TRY(th_select_device(g));
     g->n = n; g->h_roff.assign((size_t)n + 1, 0);
     long long T = 0; int mx = 0;
     for (int i = 0; i < n; ++i) { g->h_roff[i] = (uint32_t)T; T += lens[i]; mx = std::max(mx, lens[i]); }
@@ -181,7 +199,7 @@ static void build_jobs(th_gpu *g)
     }
 }
 
-static long long poa_need_ints(const ThTask &t, double cell_factor)
+static long long poa_need_ints(const ThTask &t, double cell_factor, bool noband = false)
 {
     if (t.n_units <= 2) return 0;
     // mirrors the carve in th_k_poa: 39 node/row arrays of `cap`, the overflow pool, the alignment-op arrays
@@ -190,6 +208,7 @@ static long long poa_need_ints(const ThTask &t, double cell_factor)
     const long long w = TH_POA_WB + t.max_len / 100;
     long long rows = std::min<long long>(cap, (long long)(2.2 * t.max_len) + 64);
     long long cells = (long long)(rows * (2 * w + 1 + 48) * cell_factor);
+    if (noband) cells = (long long)(cap * ((long long)t.max_len + 4) * (cell_factor > 1.5 ? 1.25 : 1.0));   // full rows over every node
     return (graph + 5 * cells + 63) & ~63LL;
 }
 
@@ -207,6 +226,8 @@ struct KTimer {
             ev[k].clear();
         }
     }
+    // a run that returns early (arena overflow, a failed launch, ...) never reaches collect(): release its events here
+    ~KTimer() { for (int k = 0; k < TK_N; ++k) for (Ev &e : ev[k]) { hipEventDestroy(e.a); hipEventDestroy(e.b); } }
 };
 #define KT_BEGIN(k) kt.begin(k)
 #define KT_END(k) kt.end(k)
@@ -219,6 +240,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
 {
     const int n = g->n; const long long T = g->T; const size_t padT = (size_t)((T + 15) & ~15LL);
     const double t_run0 = th_wall_s(); (void)t_run0;
+    TRY(th_select_device(g));
     g->jobs.clear(); g->ms_kernels = g->ms_dominant = 0; g->n_rec = 0;
     g->h_tasks.clear(); g->h_parc.clear();
     if (n == 0) return 0;
@@ -361,10 +383,13 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         std::vector<int> todo_n, todo_w;
         for (int t : todo) (g->h_tasks[t].max_len <= TH_POA_QCAP ? todo_n : todo_w).push_back(t);
         double factor = 1.5; bool patched = false;   // patched: some results live in subset arrays
+        const int poa_test_fail = std::max(0, env_int("TH_POA_TEST_FAIL", 0));   // test knob, see th_k_poa
+        bool noband = false;                          // set for the rerun of jobs whose adaptive band failed
         auto run_group = [&](const std::vector<int> &grp, bool wide, std::vector<int> &again, std::vector<int> &to_wide) -> int {
             if (grp.empty()) return 0;
             long long need = 1024; int max_unit = 0;
-            for (int t : grp) { need = std::max(need, poa_need_ints(g->h_tasks[t], factor)); max_unit = std::max(max_unit, g->h_tasks[t].max_len); }
+            for (int t : grp) { need = std::max(need, poa_need_ints(g->h_tasks[t], factor, noband)); max_unit = std::max(max_unit, g->h_tasks[t].max_len); }
+            const int poa_flags = (noband ? 1 : 0) | poa_test_fail << 8;
             const int wv = (int)std::min<long long>(std::min<long long>((long long)grp.size(), g->waves_poa), std::max<long long>(1, (64LL << 30) / (need * 4)));
             TRY(g->d_scratch.ensure((size_t)(need * wv)));
             const ThTask *dt = g->d_tasks.p; int *dcl = g->d_cons_len.p, *dst = g->d_status.p;
@@ -382,7 +407,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
             TRY(th_rt_memset(g->d_cnt.p + 2, 0, 2 * sizeof(int), g->stream));      // job queue head
             KT_BEGIN(TK_POA);
 #define POA_LAUNCH(QC, RT) TH_LAUNCH((th_k_poa<QC, RT>), wv, TH_POA_BLOCK, g->stream, dt, (int)grp.size(), (const ThUnit *)g->d_units.p, (const uint32_t *)g->d_roff.p, \
-                          (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, dcl, dst, g->d_cnt.p + 2)
+                          (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, dcl, dst, g->d_cnt.p + 2, poa_flags)
             if (!wide) POA_LAUNCH(TH_POA_QCAP, short);
             else if (max_unit <= TH_POA_QCAP_WIDE) POA_LAUNCH(TH_POA_QCAP_WIDE, int);
             else POA_LAUNCH(0, int);
@@ -397,7 +422,9 @@ extern "C" int th_gpu_run(th_gpu_t *g)
                 g->h_cons_len[t] = cl[x]; g->h_status[t] = st[x];
                 if (st[x] == 1 || st[x] == 2) again.push_back(t);
                 else if (st[x] == 7 && !wide) to_wide.push_back(t);
-                else if (st[x] != 0) return th_fail("POA kernel failed with status " + std::to_string(st[x]));
+                // 3 / 4 (the adaptive band came out empty or lost the global path) are rerun without a band below; 5 / 6 (in-degree
+                // above 255, consensus longer than its slot) stay failed.  None of them may fail the batch: abPOA has no such
+                // failure mode, and one pathological read must not stop a multi-million-read run.
             }
             return 0;
         };
@@ -410,6 +437,22 @@ extern "C" int th_gpu_run(th_gpu_t *g)
             todo_n.swap(again_n); todo_w.swap(again_w);
         }
         todo.clear(); todo.insert(todo.end(), todo_n.begin(), todo_n.end()); todo.insert(todo.end(), todo_w.begin(), todo_w.end());
+        if (todo.empty()) {
+            // jobs whose adaptive band failed: once more with full rows on the 32-bit variant (oracle/tho_poa.c does the same)
+            std::vector<int> nb;
+            for (int t = 0; t < nt; ++t) if (g->h_status[t] == 3 || g->h_status[t] == 4) nb.push_back(t);
+            noband = true; factor = 1.0;
+            for (int attempt = 0; attempt < 3 && !nb.empty(); ++attempt, factor *= 2) {
+                std::vector<int> again, none;
+                TRY(run_group(nb, true, again, none));
+                nb.swap(again);
+            }
+            noband = false;
+            todo = nb;
+        }
+        int n_failed = 0;
+        for (int t = 0; t < nt; ++t) if (g->h_status[t] != 0 && g->h_status[t] != 1 && g->h_status[t] != 2) { g->h_cons_len[t] = 0; ++n_failed; patched = true; }
+        if (n_failed) fprintf(stderr, "[tidehunter_amd] warning: %d consensus job(s) could not be aligned (POA status 3-6) and are reported without a consensus\n", n_failed);
         if (patched) {   // some results live in subset arrays: the alignment kernel reads the main one
             TRY(th_rt_h2d(g->d_cons_len.p, g->h_cons_len.data(), (size_t)nt * 4, g->stream));
             TRY(th_rt_sync(g->stream));
@@ -499,6 +542,7 @@ extern "C" long long th_gpu_debug(th_gpu_t *g, int what, void *dst, long long ca
 {
     const void *src = nullptr; long long bytes = 0;
     std::vector<int> tmp;
+    if (th_select_device(g)) return -1;
     switch (what) {
     case 0: src = g->d_bseq.p; bytes = g->T; break;
     case 1: src = g->d_hit_n.p; bytes = 4LL * g->n; break;

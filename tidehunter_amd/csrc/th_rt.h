@@ -36,6 +36,9 @@ static inline int th_rt_memset(void *d, int v, size_t n, th_stream_t s) { if (n)
 static inline int th_rt_sync(th_stream_t s) { TH_CHECK(hipStreamSynchronize(s)); return 0; }
 static inline int th_rt_host_alloc(void **p, size_t n) { TH_CHECK(hipHostMalloc(p, n ? n : 1, hipHostMallocDefault)); return 0; }
 static inline int th_rt_host_free(void *p) { if (p) TH_CHECK(hipHostFree(p)); return 0; }
-#define TH_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+// a launch the runtime rejects (resource limits, wrong device, ...) must not pass silently: the enclosing function returns
+// th_launch_failed(...) (an int, defined by the pipeline before its first launch)
+#define TH_LAUNCH(kernel, grid, block, stream, ...) do { hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__); \
+        const hipError_t le_ = hipGetLastError(); if (le_ != hipSuccess) return th_launch_failed(#kernel, hipGetErrorString(le_)); } while (0)
 #define TH_LANE() ((int)(threadIdx.x & 63))
 #endif
