@@ -2,22 +2,29 @@
 """bench.py -- reads/s of the TideHunter hot path on MI355X (BASELINE.json metric).
 
 One "step" = one pass of the whole hot path (encode -> self-hits -> chain -> partition -> POA ->
-unit/consensus alignments -> host record arithmetic) over one batch of synthetic reads of the
-headline configuration (BASELINE.json configs[2]: period 1000 x 10 copies, 10 % error, ~10 kb reads).
-The batch is uploaded to HBM before the timed region (inputs resident), every step processes a
-different batch (read index = (rank_offset + step * batch + i) mod 100000); the default batch is the whole 100k-read set.
+unit/consensus alignments -> host record arithmetic) over one batch of synthetic reads.  Default
+workload: BASELINE.json configs[2], the headline (period 1000 x 10 copies, 10 % error, ~10 kb reads,
+100 000 reads per step per GPU); --config c2 / c4 / c5 select the other shapes of SURVEY.md 8(d).
+The batch is uploaded to HBM before the timed region (inputs resident); every step processes a different batch.
 
   python bench.py --gpus N --steps K --warmup W
-For N > 1 the driver launches one rank per GPU with torch.distributed.run; reads shard across ranks
-(no data-path collective; RCCL is used for the barrier and the max-over-ranks of the time only).
+For N > 1 the driver launches one rank per GPU with torch.distributed.run (started from here as a child process when
+WORLD_SIZE is not set).  The step's global read set (N x batch reads) is cut into N contiguous blocks balanced by
+CUMULATIVE BASES; the data path has no collective -- RCCL carries the read-length exchange that the
+partition needs, the barrier and the max-over-ranks of the time.  --steal K cuts the set into N*K blocks that ranks
+take from a shared ticket counter (th_ticket_*, POSIX shared memory; the reference's THREAD_READ_I, src/main.c:277-281):
+then uploads happen inside the timed region and the line says so.
 
-Prints ONE JSON line (rank 0) with `roofline` (the kernel with the largest device time -- th_k_poa --, HIP-event
-timed on the kernel's own stream inside the library) and `cpu_baseline` (the CPU oracle, a scalar C port of the
-reference's algorithm, timed on the host cores on a bounded sample of the same workload; N=1 only).
+Prints ONE JSON line (rank 0) with `roofline` (the kernel with the largest device time, HIP-event timed on the
+kernel's own stream inside the library), `cpu_baseline` (the CPU oracle -- a scalar C port of the reference's algorithm,
+NOT the reference binary -- on the host cores, N=1 only) and `value_e2e` (the command line on the same workload, first byte
+parsed to last byte written, N=1 only).
 """
 import argparse
+import hashlib
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -25,28 +32,135 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PERIOD, COPIES, ERR, SEED = 1000, 10, 0.10, 1
-HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0          # measured copy ceiling quoted in SURVEY.md 8(d)
+
+# name -> (period, copies, err, seed, reads in the config's set, default reads per step per GPU)
+CONFIGS = {
+    "c2": dict(period=200, copies=20, err=0.10, seed=2, set_size=10000, batch=65536,
+               label="C2: period 200 x 20 copies, 10 percent error, ~4 kb reads (chain-dominated)"),
+    "c3": dict(period=1000, copies=10, err=0.10, seed=1, set_size=100000, batch=100000,
+               label="C3 headline: synthetic tandem-repeat reads, period 1000 x 10 copies, 10 percent error (sub/ins/del), ~10 kb"),
+    "c4": dict(period=5000, copies=4, err=0.15, seed=3, set_size=20000, batch=8192,
+               label="C4: period 5000 x 4 copies, 15 percent error, ~20 kb reads (long period)"),
+    "c5": dict(period=None, copies=None, err=0.10, seed=5, set_size=100000, batch=50000,
+               label="C5: periods {200,500,1000,2000,5000} by read index, copies max(3, 10000 // period), 10 percent error, both strands, "
+                     "5'/3' adapters (-5/-3: full-length path + adapter search)"),
+    # rehearsal shape for the CPU-emulation tests of the multi-rank path (never a bench line)
+    "tiny": dict(period=60, copies=6, err=0.08, seed=3, set_size=64, batch=4, label="tiny rehearsal shape (tests only)"),
+}
 
 
-def cpu_baseline(lib, TH, n_reads):
-    """CPU oracle (oracle/tho_oracle, kind 'port') on the first n_reads of the same read set."""
-    import multiprocessing
-    cores = multiprocessing.cpu_count()
+def effective_cpus():
+    """CPUs this process can actually use: the affinity mask capped by the cgroup CPU quota (the GPU boxes show 256 logical CPUs
+    to nproc but schedule the container on a 16-CPU quota; threads beyond the quota only add throttling)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        try:                                                                   # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def partition_by_bases(lens, parts):
+    """cuts[0..parts]: contiguous blocks of the read list balanced by cumulative bases (cost is ~ bases); block b
+    is reads cuts[b]:cuts[b+1].  Every block is non-empty when there are at least `parts` reads."""
+    import numpy as np
+    n = len(lens)
+    if parts <= 1 or n == 0:
+        return [0, n]
+    cum = np.cumsum(np.asarray(lens, dtype=np.int64))
+    total = int(cum[-1])
+    cuts = [0]
+    for b in range(1, parts):
+        c = int(np.searchsorted(cum, total * b / parts, side="left")) + 1      # first prefix holding at least b/parts of the bases
+        c = max(c, cuts[-1] + 1) if n >= parts else max(c, cuts[-1])
+        cuts.append(min(c, n - (parts - b) if n >= parts else n))
+    cuts.append(n)
+    return cuts
+
+
+def cpu_baseline(lib, make_read, n_reads, cfg):
+    """CPU oracle (oracle/tho_oracle, kind 'port') on the first n_reads of the same read set, with one thread and with one
+    thread per core; reports the per-core cost both ways so that the thread scaling is visible."""
+    cores = effective_cpus()
     exe = os.path.join(ROOT, "oracle", "tho_oracle")
     if not os.path.exists(exe):
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "tho_oracle"], check=True)
     path = "/tmp/th_bench_cpu_sample_%d.fa" % os.getpid()
+    n1 = max(8, min(48, n_reads // 16))
     with open(path, "wb") as f:
         for i in range(n_reads):
-            f.write(b">syn_p%d_c%d_e%.2f_s%d_%d\n" % (PERIOD, COPIES, ERR, SEED, i) + TH.synth_read(lib, SEED, i, PERIOD, COPIES, ERR) + b"\n")
-    t0 = time.time()
-    subprocess.run([exe, "-t", str(cores), "-o", "/dev/null", path], check=True, stderr=subprocess.DEVNULL)
-    dt = time.time() - t0
-    os.unlink(path)
-    return {"value": n_reads / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "%d reads of the same set (period %d x %d, %.0f%% err), oracle/tho_oracle -t %d, %.1f s"
-                      % (n_reads, PERIOD, COPIES, ERR * 100, cores, dt)}
+            f.write(b">syn_%d\n" % i + make_read(i) + b"\n")
+    with open(path + ".1", "wb") as f:
+        for i in range(n1):
+            f.write(b">syn_%d\n" % i + make_read(i) + b"\n")
+    extra = cfg.get("cli_opts", [])
+
+    def run(threads, fn):
+        t0 = time.time()
+        err = subprocess.run([exe, "-t", str(threads), *extra, "-o", "/dev/null", fn], check=True, capture_output=True, text=True).stderr
+        m = re.search(r"threads: (\d+); ([0-9.]+) reads/s; ([0-9.]+) ms per read per core", err)
+        return float(m.group(2)), float(m.group(3)), time.time() - t0
+
+    r1, ms1, _ = run(1, path + ".1")
+    rn, msn, dt = run(cores, path)
+    os.unlink(path); os.unlink(path + ".1")
+    return {"value": rn, "unit": "reads/s", "cores": cores, "kind": "port", "logical_cpus_visible": os.cpu_count(),
+            "cores_note": "cores = CPUs this container may use (affinity mask capped by the cgroup CPU quota), one oracle thread each",
+            "single_thread": {"reads_per_s": r1, "ms_per_read_per_core": ms1, "reads": n1},
+            "all_threads": {"reads_per_s": rn, "ms_per_read_per_core_cpu_time": msn, "ms_per_read_x_threads_wall": 1000.0 * cores / rn, "threads": cores},
+            "thread_scaling_efficiency": rn / (r1 * cores) if r1 > 0 else None,
+            "sample": "%d reads of the same set, oracle/tho_oracle -t %d, %.1f s (and %d reads at -t 1)" % (n_reads, cores, dt, n1),
+            "note": "scalar C restatement of the reference's algorithm (oracle/; no SIMD, its POA is a restatement because abPOA is absent), "
+                    "NOT the reference binary: a GPU/port ratio says nothing about the reference.  Reference-derived context (SURVEY.md "
+                    "section 6, measured on the reference's own code, 2.1 GHz Xeon): stages 1-3 + all ksw2 work cost 20 ms per read per "
+                    "core at this shape WITHOUT abPOA, so an ideal %d-core host runs at most %.0f reads/s before any abPOA time." % (cores, cores * 50.0)}
+
+
+def cli_e2e(lib, make_read, n_reads, cfg, batch_opt):
+    """value_e2e: the command line on one step's reads, wall-clock from the first byte parsed to the last byte written
+    (th_run_file's own clock; process start and HIP initialisation are reported separately as `wall_with_startup_s`)."""
+    exe = os.path.join(ROOT, "tidehunter_amd", "TideHunter-amd")
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    path, outp = os.path.join(d, "th_bench_e2e_%d.fa" % os.getpid()), os.path.join(d, "th_bench_e2e_%d.out" % os.getpid())
+    nbytes = 0
+    try:
+        with open(path, "wb") as f:
+            for i in range(n_reads):
+                s = make_read(i)
+                nbytes += len(s)
+                f.write(b">syn_%d\n" % i + s + b"\n")
+        t0 = time.time()
+        err = subprocess.run([exe, *cfg.get("cli_opts", []), "-b", str(batch_opt), "-o", outp, path], check=True, capture_output=True, text=True,
+                             env=dict(os.environ, TH_TRACE="1")).stderr
+        wall = time.time() - t0
+        m = re.search(r"\[th_run_file\] (\d+) reads on \d+ device\(s\): wall ([0-9.]+) s; busy: reader ([0-9.]+) s, device batches ([0-9.]+) s \(summed\), writer ([0-9.]+) s", err)
+        inner = float(m.group(2))
+        md5 = hashlib.md5(open(outp, "rb").read()).hexdigest()
+        return {"value": n_reads / inner, "unit": "reads/s", "reads": n_reads, "seconds_first_byte_to_last_byte": inner, "wall_with_startup_s": wall,
+                "mbases_per_s": nbytes / inner / 1e6, "reader_busy_s": float(m.group(3)), "device_busy_s": float(m.group(4)), "writer_busy_s": float(m.group(5)),
+                "batch_reads": batch_opt, "output_md5": md5,
+                "what": "TideHunter-amd (reader -> H2D -> kernels -> record arithmetic -> writer) on a FASTA of the same reads in %s" % d}
+    finally:
+        for p in (path, outp):
+            if os.path.exists(p):
+                os.unlink(p)
+
+
+def spawn_ranks(a):
+    """--gpus N without a launcher: start torch.distributed.run as a child BEFORE anything touches the GPU and pass its exit code on"""
+    port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd).returncode)
 
 
 def main():
@@ -54,106 +168,238 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=2)   # two: device buffers reach their steady size (a batch that grows one is first-touched inside a kernel)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("TH_BENCH_BATCH", "100000")), help="reads per step per GPU")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("TH_BENCH_BATCH", "0")), help="reads per step per GPU (0: the config's default)")
+    ap.add_argument("--steal", type=int, default=0, help="blocks per rank per step taken from a shared ticket counter (0: static partition by bases)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1: auto, 0: skip)")
+    ap.add_argument("--e2e", type=int, default=-1, help="reads for the end-to-end command-line run (-1: one step's batch, 0: skip)")
+    ap.add_argument("--digest", action="store_true", help="add an md5 over all records of the timed steps in read order (tests)")
     a = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
+    if a.gpus != world:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d; launch with `python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                 "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...`" % (a.gpus, world, a.gpus, a.gpus))
+    rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    cfg = dict(CONFIGS[a.config])
+    B = a.batch if a.batch > 0 else cfg["batch"]
+
     import torch
     dist = None
-    # TH_BENCH_BACKEND / TH_BENCH_DEVICE exist to rehearse the multi-rank path on a one-GPU box (gloo, every rank on device 0)
+    # TH_BENCH_BACKEND / TH_BENCH_DEVICE / TH_BENCH_LIB rehearse the multi-rank path without N GPUs (gloo; every rank on one
+    # device, or the CPU-emulation build of the kernels in tests/): tests/test_bench_multirank.py
     backend = os.environ.get("TH_BENCH_BACKEND", "nccl")
+    on_gpu = backend == "nccl" or "TH_BENCH_LIB" not in os.environ
     if "TH_BENCH_DEVICE" in os.environ:
         local = int(os.environ["TH_BENCH_DEVICE"])
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
+        if on_gpu:
+            torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
     import tidehunter_amd as TH
-    lib = TH.load_library()
-    th = TH.TideHunter(device=local)
+    lib = TH.load_library(os.environ.get("TH_BENCH_LIB"))
+    adapters, kw = None, {}
+    if a.config == "c5":
+        adapters = TH.synth_adapters(lib)
+        d = "/tmp/th_bench_c5_%d" % os.getpid()
+        os.makedirs(d, exist_ok=True)
+        fns = (os.path.join(d, "5p.fa"), os.path.join(d, "3p.fa"))
+        open(fns[0], "wb").write(b">5p\n" + adapters[0] + b"\n"); open(fns[1], "wb").write(b">3p\n" + adapters[1] + b"\n")
+        kw["adapters"] = fns
+        cfg["cli_opts"] = ["-5", fns[0], "-3", fns[1]]
+    th = TH.TideHunter(device=local, lib_path=os.environ.get("TH_BENCH_LIB"), **kw)
 
-    B = a.batch
-    n_batches = a.warmup + a.steps
-
-    def make_batch(b):
-        base = (rank * n_batches + b) * B
-        return [TH.synth_read(lib, SEED, (base + i) % 100000, PERIOD, COPIES, ERR) for i in range(B)]
+    def make_read(i):
+        i %= cfg["set_size"]
+        if a.config == "c5":
+            return TH.synth_read_c5(lib, cfg["seed"], i, adapters, cfg["err"])
+        return TH.synth_read(lib, cfg["seed"], i, cfg["period"], cfg["copies"], cfg["err"])
 
     def sync_all():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
-    batches = [make_batch(b) for b in range(n_batches)]
-    bases = sum(len(s) for bt in batches[a.warmup:] for s in bt)
+    n_batches = a.warmup + a.steps
+    G = B * world                                   # reads of one step's global set (weak scaling: B per GPU)
+    n_blocks = world * max(1, a.steal)
+
+    def step_blocks(b):
+        """block boundaries of step b's global set [b*G, (b+1)*G), balanced by cumulative bases; every rank generates its
+        nominal share, the lengths are exchanged (control-plane metadata only), and each rank fills in what its blocks need"""
+        base = b * G
+        mine = {base + rank * B + i: make_read(base + rank * B + i) for i in range(B)}
+        if world == 1 and n_blocks == 1:
+            return [0, G], mine, base
+        lens = torch.tensor([len(mine[base + rank * B + i]) for i in range(B)], dtype=torch.int32)
+        if dist is not None:
+            if backend == "nccl":
+                lens = lens.cuda()
+            allv = [torch.empty_like(lens) for _ in range(world)]
+            dist.all_gather(allv, lens)
+            lens = torch.cat(allv).cpu()
+        return partition_by_bases(lens.tolist(), n_blocks), mine, base
+
+    def block_reads(cuts, mine, base, k):
+        return [mine[base + i] if base + i in mine else make_read(base + i) for i in range(cuts[k], cuts[k + 1])]
+
+    plans = [step_blocks(b) for b in range(n_batches)]
+    ticket = None
+    if a.steal > 0:
+        name = ("/th_bench_%s" % os.environ.get("MASTER_PORT", str(os.getppid()))).encode()
+        if rank == 0:
+            ticket = lib.th_ticket_open(name, 1)
+        if dist is not None:
+            dist.barrier()
+        if rank != 0:
+            ticket = lib.th_ticket_open(name, 0)
+        assert ticket, "th_ticket_open failed"
+        if a.steps + a.warmup > 512:
+            sys.exit("bench.py: --steal supports at most 512 steps")
+    static_reads = [None if a.steal > 0 else block_reads(*plans[b], rank) for b in range(n_batches)]
+
     for b in range(a.warmup):
-        th.upload(batches[b]); th.run(); th.collect()
-    # timed region: inputs are made resident first (upload outside), then run + collect are timed
-    t_total, n_cons, alg_bytes, kms = 0.0, 0, 0, {}
-    for b in range(a.warmup, n_batches):
-        th.upload(batches[b])
-        sync_all()
-        t0 = time.perf_counter()
-        th.run()                 # all kernels + the small D2H of result records
-        th.collect_native()      # host-side record arithmetic in C (src/gen_cons.c:208-301)
-        torch.cuda.synchronize()
-        t_total += time.perf_counter() - t0
-        recs = th.records()      # Python dict view for the byte accounting below: not part of the path
+        if a.steal > 0:
+            while True:
+                k = lib.th_ticket_next(ticket, b)
+                if k >= n_blocks:
+                    break
+                th.upload(block_reads(*plans[b], k)); th.run(); th.collect()
+        else:
+            th.upload(static_reads[b]); th.run(); th.collect()
+    t_total, n_cons, alg_bytes, kms, n_reads_mine, bases_mine, digests, blocks_mine = 0.0, 0, 0, {}, 0, 0, {}, 0
+
+    def account(batch, recs, first_index):
+        nonlocal n_cons, alg_bytes, n_reads_mine, bases_mine
         for kname, v in th.timing().items():
             kms[kname] = kms.get(kname, 0.0) + v
-        for s, rr in zip(batches[b], recs):
+        for j, (s, rr) in enumerate(zip(batch, recs)):
             alg_bytes += len(s)                                     # SURVEY 8(d): B_alg = L + sum(cons_len + 4*pos_n + 40)
             for r in rr:
                 alg_bytes += r["cons_len"] + 4 * len(r["sub_pos"]) + 40
                 n_cons += 1
+            if a.digest:
+                digests[first_index + j] = hashlib.md5(repr([(r["seq"], r["start"], r["end"], r["cons_len"], "%.6f" % r["copy_num"], "%.6f" % r["ave_match"],
+                                                               r["full_length"], r["sub_pos"]) for r in rr]).encode()).hexdigest()
+        n_reads_mine += len(batch)
+        bases_mine += sum(len(s) for s in batch)
+
+    for b in range(a.warmup, n_batches):
+        cuts, mine, base = plans[b]
+        if a.steal > 0:
+            # dynamic: blocks from the shared ticket counter; the upload of a block cannot precede the timed region
+            sync_all()
+            t0 = time.perf_counter()
+            done = []
+            while True:
+                k = lib.th_ticket_next(ticket, b)
+                if k >= n_blocks:
+                    break
+                batch = block_reads(cuts, mine, base, k)
+                th.upload(batch); th.run(); th.collect_native()
+                done.append((k, batch, th.records()))
+                blocks_mine += 1
+            if on_gpu:
+                torch.cuda.synchronize()
+            t_total += time.perf_counter() - t0
+            for k, batch, recs in done:
+                account(batch, recs, base + cuts[k])
+        else:
+            # static: this rank's block is made resident first (upload outside), then run + collect are timed
+            batch = static_reads[b]
+            th.upload(batch)
+            sync_all()
+            t0 = time.perf_counter()
+            th.run()                 # all kernels + the small D2H of result records
+            th.collect_native()      # host-side record arithmetic in C (src/gen_cons.c:208-301)
+            if on_gpu:
+                torch.cuda.synchronize()
+            t_total += time.perf_counter() - t0
+            account(batch, th.records(), base + cuts[rank])     # Python dict view for the byte accounting: not part of the path
+            blocks_mine += 1
     sync_all()
+    tot = torch.tensor([float(n_reads_mine), float(bases_mine), float(n_cons), float(alg_bytes)], dtype=torch.float64)
     if dist is not None:
-        t = torch.tensor([t_total], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+        dev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([t_total], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_total = float(t.item())
-    reads = B * a.steps * world
+        tot = tot.to(dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        tot = tot.cpu()
+        if a.digest:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, digests)
+            digests = {k: v for g in gathered for k, v in g.items()}
+    reads, bases, n_cons_all = int(tot[0].item()), tot[1].item(), tot[2].item()
+    assert reads == G * a.steps, (reads, G, a.steps)
     value = reads / t_total
     out = {
-        "metric": "reads/sec on 10 kb period-1000x10 reads (TideHunter hot path)", "value": value, "unit": "reads/s",
+        "metric": "reads/sec on 10 kb period-1000x10 reads (TideHunter hot path)" if a.config == "c3" else "reads/sec (TideHunter hot path, %s)" % a.config,
+        "value": value, "unit": "reads/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000.0 * t_total / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "mbases_per_s": bases * world / t_total / 1e6,
-        "config": {"workload": "C3 headline: synthetic tandem-repeat reads, period 1000 x 10 copies, 10 percent error (sub/ins/del), ~10 kb; "
-                               + "%d reads per step per GPU drawn from the 100k-read set (seed 1)" % B,
-                   "reads_per_step_per_gpu": B, "sharding": "contiguous read blocks per rank, no data-path collective"},
-        "consensus_per_read": n_cons / float(B * a.steps),
+        "dtype_note": "integer DP throughout: chain DP and POA fallback rows in int32, packed POA rows and banded alignments in int16 pairs (exact by range proofs)",
+        "mbases_per_s": bases / t_total / 1e6,
+        "config": {"workload": cfg["label"] + "; %d reads per step per GPU drawn from the %d-read set (seed %d)" % (B, cfg["set_size"], cfg["seed"]),
+                   "name": a.config, "reads_per_step_per_gpu": B,
+                   "sharding": ("contiguous read blocks per rank balanced by cumulative bases, no data-path collective" if a.steal == 0 else
+                                "%d blocks per step (balanced by cumulative bases) taken by the ranks from a shared ticket counter; uploads inside the timed region" % n_blocks),
+                   "inputs_resident_before_timing": a.steal == 0},
+        "consensus_per_read": n_cons_all / float(reads),
     }
+    if a.digest:
+        h = hashlib.md5()
+        for k in sorted(digests):
+            h.update(digests[k].encode())
+        out["records_digest"] = h.hexdigest()
+        out["records_digest_reads"] = len(digests)
     if rank == 0:
-        dom = max(kms, key=kms.get)                      # dominant kernel = largest device time
-        launch_s = kms[dom] / 1000.0 / a.steps             # one launch of it per step
-        per_launch_bytes = alg_bytes / float(a.steps)
+        dom = max(kms, key=kms.get)                      # dominant kernel = largest device time (this rank's launches)
+        launches = max(1, blocks_mine)
+        launch_s = kms[dom] / 1000.0 / launches            # one launch of it per block
+        per_launch_bytes = alg_bytes / float(launches)
         ach = per_launch_bytes / launch_s / 1e9 if launch_s > 0 else 0.0
         # traffic: HBM bytes of one launch of the dominant kernel from the PMC passes of this same command
-        # (tools/prof_round.sh -> profiles/r01_hbm_traffic.json); counters cannot be read from inside the process, so
-        # the committed profile is quoted when it was taken at the same batch size, else null
+        # (tools/prof_round.sh -> profiles/rNN_hbm_traffic.json); counters cannot be read from inside the process, so
+        # the committed profile is quoted when it was taken at the same workload and batch size, else null
         traffic, traffic_src = None, None
-        try:
-            prof = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")))
-            if prof.get("reads_per_launch") == B:
-                for kname, v in prof["kernels"].items():
-                    if kname.replace("void ", "").split("<")[0] == dom:
-                        traffic, traffic_src = v["hbm_bytes_per_launch_corrected"], "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-        except (OSError, ValueError, KeyError):
-            pass
+        for pf in ("r02_hbm_traffic.json",):
+            try:
+                prof = json.load(open(os.path.join(ROOT, "profiles", pf)))
+                if prof.get("reads_per_launch") == B and prof.get("config", "c3") == a.config and a.steal == 0:
+                    for kname, v in prof["kernels"].items():
+                        if kname.replace("void ", "").split("<")[0] == dom:
+                            traffic, traffic_src = v["hbm_bytes_per_launch_corrected"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % pf
+            except (OSError, ValueError, KeyError):
+                pass
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "frac_of_measured_copy_peak": ach / HBM_COPY_GBS, "measured_copy_peak": HBM_COPY_GBS,
                            "traffic": traffic, "traffic_source": traffic_src, "launch_ms": launch_s * 1000.0,
-                           "kernel_ms_per_step": {k: v / a.steps for k, v in kms.items()},
-                           "algorithmic_bytes_per_launch": per_launch_bytes}
-        if world == 1 and a.cpu_sample != 0:
-            n_cpu = a.cpu_sample if a.cpu_sample > 0 else min(4096, max(64, 16 * (os.cpu_count() or 8)))
-            out["cpu_baseline"] = cpu_baseline(lib, TH, n_cpu)
-        print(json.dumps(out))
+                           "kernel_ms_per_launch": {k: v / launches for k, v in kms.items()},
+                           "algorithmic_bytes_per_launch": per_launch_bytes,
+                           "note": "this path is instruction-issue bound, not bandwidth bound (DESIGN.md section 4): the HBM fraction is reported because "
+                                   "north_star names that roofline; profiles/r02_pmc_instr.json holds the VALU issue fractions"}
     th.close()
+    if ticket:
+        lib.th_ticket_close(ticket, 1 if rank == 0 else 0)
+    if rank == 0:
+        if world == 1 and a.e2e != 0 and "TH_BENCH_LIB" not in os.environ:
+            n_e2e = a.e2e if a.e2e > 0 else B
+            out["value_e2e"] = cli_e2e(lib, make_read, n_e2e, cfg, min(65536, max(1024, n_e2e // 2)))
+        if world == 1 and a.cpu_sample != 0:
+            n_cpu = a.cpu_sample if a.cpu_sample > 0 else min(4096, max(64, 24 * effective_cpus()))
+            out["cpu_baseline"] = cpu_baseline(lib, make_read, n_cpu, cfg)
+        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -29,8 +29,9 @@ extern "C" {
 #define TH_FASTQ_FMT 3
 #define TH_TAB_QUAL_FMT 4
 
-/* mini_tandem_para, src/tidehunter.h:47-61 (same field names and meaning; cons_out/detail_fp, which
- * are FILE* owned by main(), are left to the caller) */
+/* mini_tandem_para, src/tidehunter.h:47-61: SAME fields in the SAME order and types, so the layouts are identical and a
+ * maintainer may pass a mini_tandem_para* where a th_para_t* is expected (tests/test_boundary.py checks the field lists against
+ * the reference header).  cons_out / detail_fp are carried but not used by the library: the caller owns the output stream. */
 typedef struct {
     int64_t k, w; int hpc;
     int min_copy, min_cov; double max_div, div_exp, min_frac;
@@ -41,15 +42,19 @@ typedef struct {
     char *five_fn, *five_seq, *five_rc_seq; int five_len;
     char *three_fn, *three_seq, *three_rc_seq; int three_len;
     int out_fmt, min_len, only_unit, only_longest, only_full_length, single_copy;
+    FILE *cons_out, *detail_fp;
     int n_thread;
 } th_para_t;
 
-/* tandem_seq_t, src/tidehunter.h:63-72.  cons_seq/cons_qual replace the kseq seq_t: the consensus
- * strings of one read are concatenated and split by cons_len[], exactly as in the reference
- * (src/main.c:253-263). */
+/* kstring_t (src/kseq.h:84-87) and seq_t (src/seq.h:6-8), same layouts */
+typedef struct { size_t l, m; char *s; } th_kstring_t;
+typedef struct { th_kstring_t name, seq, comment, qual; } th_seq_t;
+
+/* tandem_seq_t, src/tidehunter.h:63-72: identical layout.  The consensus strings of one read are concatenated in
+ * cons_seq->seq.s (qualities in cons_seq->qual.s) and split by cons_len[], exactly as in the reference (src/main.c:253-263),
+ * so the reference's own mini_tandem_output() can print slots filled by th_process_batch(). */
 typedef struct {
-    char *cons_seq; size_t cons_seq_l, cons_seq_m;
-    char *cons_qual; size_t cons_qual_l, cons_qual_m;
+    th_seq_t *cons_seq;
     int cons_n, cons_m;
     int *cons_start, *cons_end, *cons_len; double *copy_num, *ave_match;
     int8_t *full_length;
@@ -95,8 +100,9 @@ void th_output(FILE *fp, int n, const char *const *names, const char *const *seq
 
 /* mini_tandem(), src/main.c:375-436: whole-file driver (FASTA/FASTQ, optionally gzipped) */
 int th_run_file(const char *read_fn, th_para_t *p, FILE *out, int device, int batch_reads);
-/* the same over several devices of one node: batch i runs on devices[i % n_dev] (reads are independent, src/tidehunter.c:23-60,
- * so the shards exchange nothing); output order = input order.  1 <= n_dev <= 16. */
+/* the same over several devices of one node: one worker per device takes the next batch from a shared ticket counter -- the
+ * reference's THREAD_READ_I (src/main.c:273-291) at batch granularity, so a device that finishes early takes more batches
+ * (reads are independent, src/tidehunter.c:23-60: the shards exchange nothing); output order = input order.  1 <= n_dev <= 16. */
 int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *devices, int n_dev, int batch_reads);
 
 /* deterministic synthetic tandem-repeat reads; returns read length, writes at most cap bases */
@@ -106,6 +112,14 @@ int th_synth_read(uint64_t seed, uint64_t read_index, int period, int copies, do
  * adapters do not fit the shortest period.  th_synth_adapter writes len bases + NUL (which: 0 = 5' adapter, 1 = 3' adapter). */
 void th_synth_adapter(uint64_t seed, int which, char *dst, int len);
 int th_synth_read_c5(uint64_t seed, uint64_t read_index, const char *five, int five_len, const char *three, int three_len, double err, char *dst, int cap);
+
+/* Shared ticket counters for one-process-per-GPU launches (bench.py --steal): the multi-process form of the reference's ticket
+ * counter, src/main.c:208-210,277-281.  `name` is a POSIX shared-memory name ("/th_job_1234"); one rank creates, all open;
+ * th_ticket_next returns the previous value of counter `counter` (0..511) and advances it atomically. */
+typedef struct th_ticket th_ticket_t;
+th_ticket_t *th_ticket_open(const char *name, int create);
+long long th_ticket_next(th_ticket_t *t, int counter);
+void th_ticket_close(th_ticket_t *t, int unlink_it);
 
 const char *th_last_error(void);
 const char *th_version(void);

@@ -6,8 +6,8 @@
     5'/3' adapters, gzipped (multi-line) FASTQ input through the command line, with and without -F / -s;
   * the HIP POA kernel against the INDEPENDENT exact POA (oracle/tho_poa_exact.c: full matrix, Kahn order) on >= 2000 jobs
     per config shape when the host has the cores for it.
-Sample sizes scale with the host's core count (the oracle costs ~70 ms per headline read per core); on the 256-core GPU box
-they reach the sizes quoted above.  Everything POA touches is "GPU == oracle", not "== reference" (abPOA is absent).
+Sample sizes scale with the CPUs the container may use (the oracle costs ~35-70 ms per headline read per core); with the 16-CPU
+quota of the GPU boxes they reach the sizes quoted above (4096 / 4096 / 512 reads, 2048 / 2048 / 256 POA jobs).  Everything POA touches is "GPU == oracle", not "== reference" (abPOA is absent).
 """
 import os
 import subprocess
@@ -21,7 +21,7 @@ import tidehunter_amd as TH
 
 pytestmark = pytest.mark.gpu
 
-CORES = os.cpu_count() or 8
+CORES = U.effective_cpus()
 EXE = os.path.join(U.ROOT, "tidehunter_amd", "TideHunter-amd")
 ORACLE = os.path.join(O.ODIR, "tho_oracle")
 
@@ -46,8 +46,8 @@ def shape_files(tmp_path_factory):
     d = tmp_path_factory.mktemp("scale")
     lib = TH.load_library()
     files = {}
-    for name, (n, period, copies, err, seed) in dict(C3=(_n(4096, 16), 1000, 10, 0.10, 1), C2=(_n(4096, 32), 200, 20, 0.10, 2),
-                                                    C4=(_n(512, 2), 5000, 4, 0.15, 3)).items():
+    for name, (n, period, copies, err, seed) in dict(C3=(_n(4096, 256), 1000, 10, 0.10, 1), C2=(_n(4096, 256), 200, 20, 0.10, 2),
+                                                    C4=(_n(512, 32), 5000, 4, 0.15, 3)).items():
         fn = d / (name + ".fa")
         U.write_fasta(fn, [TH.synth_read(lib, seed, i, period, copies, err) for i in range(n)], prefix="syn_%s_" % name)
         files[name] = (fn, n)
@@ -69,7 +69,7 @@ def test_gpu_cli_byte_identity_at_scale(tmp_path, shape_files, shape, opts):
 def test_gpu_config5_at_spec_gz_fastq(tmp_path):
     """config 5 at its SURVEY 8(d) definition, >= 200 reads, gz FASTQ through the command line; all five period classes with
     adapters (the 2000 / 5000 classes are the ones that reach th_k_poa<8192,int> and th_k_align<24576,6>)"""
-    n = max(200, _n(1000, 4))
+    n = max(200, _n(1000, 20))
     n -= n % 10
     seqs, ad = U.config5_spec(tmp_path, n)
     assert {len(s) // 4000 for s in seqs} >= {2, 3}                      # ~10 kb reads and the ~15 kb reads of the 5000 class
@@ -116,9 +116,9 @@ def test_gpu_config5_sharded_blocks_match_whole(tmp_path):
 
 
 @pytest.mark.parametrize("period,copies,err,seed,full,per_core", [
-    (1000, 10, 0.10, 1, 2048, 10),     # config 3
-    (200, 20, 0.10, 2, 2048, 40),      # config 2
-    (5000, 4, 0.15, 3, 256, 1),        # config 4 (a job costs ~10 s and ~0.5 GB on the CPU)
+    (1000, 10, 0.10, 1, 2048, 128),    # config 3
+    (200, 20, 0.10, 2, 2048, 128),     # config 2
+    (5000, 4, 0.15, 3, 256, 16),       # config 4 (a job costs ~5-10 s and ~0.5 GB on the CPU)
 ])
 def test_gpu_poa_equals_independent_exact_poa(period, copies, err, seed, full, per_core):
     """HIP POA kernel == full-matrix Kahn-order POA on every job: neither the adaptive band, nor the int16 / packed rows,

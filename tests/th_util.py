@@ -11,6 +11,12 @@ DATA = os.path.join(ROOT, "tests", "golden", "data")
 EMUL_SO = os.path.join(ROOT, "tests", "cpu_emul", "libth_emul.so")
 
 
+def effective_cpus():
+    """usable CPUs (affinity capped by the cgroup quota): see bench.effective_cpus"""
+    import bench
+    return bench.effective_cpus()
+
+
 def synth_lib():
     """the product library, for its deterministic read generator only (th_synth_read needs no GPU)"""
     import tidehunter_amd as TH
@@ -57,7 +63,7 @@ def oracle_records(seqs, para):
     from concurrent.futures import ThreadPoolExecutor
     if len(seqs) < 8:
         return [O.core(s, para) for s in seqs]
-    with ThreadPoolExecutor(min(64, os.cpu_count() or 8)) as ex:
+    with ThreadPoolExecutor(min(64, effective_cpus())) as ex:
         return list(ex.map(lambda s: O.core(s, para), seqs))
 
 
@@ -94,7 +100,7 @@ def stage_compare(th, seqs, para):
     parc = th.debug_stage(9, 8 * T + 1024, np.int32)
     bseq = th.debug_stage(0, T, np.uint8)
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(min(64, os.cpu_count() or 8)) as ex:
+    with ThreadPoolExecutor(min(64, effective_cpus())) as ex:
         all_st = list(ex.map(lambda s: O.stages(s, para), seqs))
     for r, s in enumerate(seqs):
         st = all_st[r]

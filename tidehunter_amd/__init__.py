@@ -22,13 +22,23 @@ class Para(C.Structure):
                 ("five_fn", C.c_void_p), ("five_seq", C.c_void_p), ("five_rc_seq", C.c_void_p), ("five_len", C.c_int),
                 ("three_fn", C.c_void_p), ("three_seq", C.c_void_p), ("three_rc_seq", C.c_void_p), ("three_len", C.c_int),
                 ("out_fmt", C.c_int), ("min_len", C.c_int), ("only_unit", C.c_int), ("only_longest", C.c_int),
-                ("only_full_length", C.c_int), ("single_copy", C.c_int), ("n_thread", C.c_int)]
+                ("only_full_length", C.c_int), ("single_copy", C.c_int), ("cons_out", C.c_void_p), ("detail_fp", C.c_void_p),
+                ("n_thread", C.c_int)]
+
+
+class KString(C.Structure):
+    """th_kstring_t == kstring_t (src/kseq.h:84-87)"""
+    _fields_ = [("l", C.c_size_t), ("m", C.c_size_t), ("s", C.POINTER(C.c_char))]
+
+
+class Seq(C.Structure):
+    """th_seq_t == seq_t (src/seq.h:6-8)"""
+    _fields_ = [("name", KString), ("seq", KString), ("comment", KString), ("qual", KString)]
 
 
 class TandemSeq(C.Structure):
-    """th_tandem_seq_t == tandem_seq_t (src/tidehunter.h:63-72)"""
-    _fields_ = [("cons_seq", C.POINTER(C.c_char)), ("cons_seq_l", C.c_size_t), ("cons_seq_m", C.c_size_t),
-                ("cons_qual", C.POINTER(C.c_char)), ("cons_qual_l", C.c_size_t), ("cons_qual_m", C.c_size_t),
+    """th_tandem_seq_t == tandem_seq_t (src/tidehunter.h:63-72), identical layout"""
+    _fields_ = [("cons_seq", C.POINTER(Seq)),
                 ("cons_n", C.c_int), ("cons_m", C.c_int),
                 ("cons_start", C.POINTER(C.c_int)), ("cons_end", C.POINTER(C.c_int)), ("cons_len", C.POINTER(C.c_int)),
                 ("copy_num", C.POINTER(C.c_double)), ("ave_match", C.POINTER(C.c_double)),
@@ -62,6 +72,11 @@ def load_library(path=None):
     lib.th_synth_read.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_char_p, C.c_int]
     lib.th_synth_adapter.argtypes = [C.c_uint64, C.c_int, C.c_char_p, C.c_int]
     lib.th_synth_read_c5.argtypes = [C.c_uint64, C.c_uint64, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_double, C.c_char_p, C.c_int]
+    lib.th_ticket_open.argtypes = [C.c_char_p, C.c_int]
+    lib.th_ticket_open.restype = C.c_void_p
+    lib.th_ticket_next.argtypes = [C.c_void_p, C.c_int]
+    lib.th_ticket_next.restype = C.c_longlong
+    lib.th_ticket_close.argtypes = [C.c_void_p, C.c_int]
     lib.th_last_error.restype = C.c_char_p
     lib.th_version.restype = C.c_char_p
     lib.th_debug_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]
@@ -166,8 +181,9 @@ class TideHunter:
                 out.append(dict(sub_pos=sub))
                 continue
             L = t.cons_len[c]
-            seq = C.string_at(C.addressof(t.cons_seq.contents) + cs, L)
-            qual = C.string_at(C.addressof(t.cons_qual.contents) + cs, L) if t.cons_qual and t.cons_qual_l >= cs + L else None
+            ks, kq = t.cons_seq.contents.seq, t.cons_seq.contents.qual
+            seq = C.string_at(C.addressof(ks.s.contents) + cs, L)
+            qual = C.string_at(C.addressof(kq.s.contents) + cs, L) if kq.s and kq.l >= cs + L else None
             out.append(dict(seq=seq, qual=qual, cons_len=L, start=t.cons_start[c], end=t.cons_end[c], copy_num=t.copy_num[c],
                             ave_match=t.ave_match[c], full_length=int(t.full_length[c]), sub_pos=sub))
             cs += L

@@ -21,6 +21,9 @@
 #include <pthread.h>
 #include <unistd.h>
 #include <time.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include "tidehunter_amd.h"
 #include "th_internal.h"
 
@@ -191,6 +194,7 @@ th_tandem_seq_t *th_alloc_tandem_seq(int n)
 {
     th_tandem_seq_t *t = (th_tandem_seq_t *)calloc((size_t)n, sizeof(th_tandem_seq_t));
     for (int i = 0; i < n; ++i) {
+        t[i].cons_seq = (th_seq_t *)calloc(1, sizeof(th_seq_t));
         t[i].cons_m = 1;
         t[i].cons_start = (int *)malloc(sizeof(int)); t[i].cons_end = (int *)malloc(sizeof(int)); t[i].cons_len = (int *)malloc(sizeof(int));
         t[i].copy_num = (double *)malloc(sizeof(double)); t[i].ave_match = (double *)malloc(sizeof(double));
@@ -203,7 +207,8 @@ void th_free_tandem_seq(th_tandem_seq_t *t, int n)
 {
     if (!t) return;
     for (int i = 0; i < n; ++i) {
-        free(t[i].cons_seq); free(t[i].cons_qual); free(t[i].cons_start); free(t[i].cons_end); free(t[i].cons_len);
+        free(t[i].cons_seq->name.s); free(t[i].cons_seq->comment.s); free(t[i].cons_seq->seq.s); free(t[i].cons_seq->qual.s); free(t[i].cons_seq);
+        free(t[i].cons_start); free(t[i].cons_end); free(t[i].cons_len);
         free(t[i].copy_num); free(t[i].ave_match); free(t[i].full_length); free(t[i].cons_score); free(t[i].pos_n); free(t[i].pos_m);
         for (int j = 0; j < t[i].cons_m; ++j) free(t[i].sub_pos[j]);
         free(t[i].sub_pos);
@@ -235,14 +240,15 @@ static void write_cons(th_tandem_seq_t *t, const char *seq, const uint8_t *qual,
 {
     if (cons_len < p->min_len || cons_len > p->max_p) return;
     if (p->only_longest && t->cons_n == 1) {
-        if (end - start > t->cons_end[0] - t->cons_start[0]) { t->cons_n = 0; t->cons_seq_l = 0; t->cons_qual_l = 0; }
+        if (end - start > t->cons_end[0] - t->cons_start[0]) { t->cons_n = 0; t->cons_seq->seq.l = 0; t->cons_seq->qual.l = 0; }
         else return;
     }
-    if (t->cons_seq_l + cons_len >= t->cons_seq_m) { t->cons_seq_m = t->cons_seq_l + cons_len + 1; t->cons_seq = (char *)realloc(t->cons_seq, t->cons_seq_m); }
-    memcpy(t->cons_seq + t->cons_seq_l, seq, cons_len); t->cons_seq_l += cons_len;
+    th_kstring_t *cs = &t->cons_seq->seq, *cq = &t->cons_seq->qual;
+    if (cs->l + cons_len >= cs->m) { cs->m = cs->l + cons_len + 1; cs->s = (char *)realloc(cs->s, cs->m); }
+    memcpy(cs->s + cs->l, seq, cons_len); cs->l += cons_len;
     if (qual) {
-        if (t->cons_qual_l + cons_len >= t->cons_qual_m) { t->cons_qual_m = t->cons_qual_l + cons_len + 1; t->cons_qual = (char *)realloc(t->cons_qual, t->cons_qual_m); }
-        memcpy(t->cons_qual + t->cons_qual_l, qual, cons_len); t->cons_qual_l += cons_len;
+        if (cq->l + cons_len >= cq->m) { cq->m = cq->l + cons_len + 1; cq->s = (char *)realloc(cq->s, cq->m); }
+        memcpy(cq->s + cq->l, qual, cons_len); cq->l += cons_len;
     }
     tseq_grow(t);
     int c = t->cons_n;
@@ -505,7 +511,7 @@ static void *collect_range(void *arg)
     int ji = lo;
     for (int r = a->r0; r < a->r1; ++r) {
         th_tandem_seq_t *t = &a->out[r];
-        t->cons_n = 0; t->cons_seq_l = 0; t->cons_qual_l = 0;
+        t->cons_n = 0; t->cons_seq->seq.l = 0; t->cons_seq->qual.l = 0;
         while (ji < o->n_jobs && o->jobs[ji].read == r) { finish_job(h, o, &o->jobs[ji], t); ++ji; }
         if (h->lens[r] >= p->k && p->single_copy == 1 && p->only_full_length && p->five_seq != NULL && p->three_seq != NULL)
             single_copy(h->lens[r], h->seqs[r], t, p);   /* src/tidehunter.c:24,49-51 */
@@ -587,13 +593,13 @@ void th_output(FILE *fp, int n, const char *const *names, const char *const *seq
                         t->cons_start[ci] + 1, t->cons_end[ci] + 1, t->cons_len[ci], t->ave_match[ci], t->full_length[ci]);
                 put_subpos(fp, t->sub_pos[ci], t->pos_n[ci], '\t');
             }
-            fwrite(t->cons_seq + cs, 1, (size_t)t->cons_len[ci], fp);
+            fwrite(t->cons_seq->seq.s + cs, 1, (size_t)t->cons_len[ci], fp);
             if (p->out_fmt == TH_FASTQ_FMT) fputs("\n+\n", fp); else if (p->out_fmt == TH_TAB_QUAL_FMT) fputc('\t', fp);
-            if (p->out_fmt == TH_FASTQ_FMT || p->out_fmt == TH_TAB_QUAL_FMT) fwrite(t->cons_qual + cs, 1, (size_t)t->cons_len[ci], fp);
+            if (p->out_fmt == TH_FASTQ_FMT || p->out_fmt == TH_TAB_QUAL_FMT) fwrite(t->cons_seq->qual.s + cs, 1, (size_t)t->cons_len[ci], fp);
             fputc('\n', fp);
             cs += (size_t)t->cons_len[ci];
         }
-        t->cons_n = 0; t->cons_seq_l = 0; t->cons_qual_l = 0;
+        t->cons_n = 0; t->cons_seq->seq.l = 0; t->cons_seq->qual.l = 0;
     }
 }
 
@@ -610,9 +616,10 @@ typedef struct {
     pthread_mutex_t mu; pthread_cond_t cv;
     th_reader_t *rd; FILE *out; th_para_t *p; int batch_reads; volatile int stop;
     int eof_batch;               /* index of the empty batch that ends the input (-1 until the reader meets it) */
+    int next_batch;              /* ticket counter of the device workers (the reference's THREAD_READ_I, src/main.c:277-281, at batch granularity) */
     double t_read, t_write;      /* busy seconds of the two side threads (TH_TRACE=1 prints them) */
 } th_pipe_t;
-typedef struct { th_pipe_t *q; int dev_index, device; int rc, total; double busy; } th_dev_worker_t;
+typedef struct { th_pipe_t *q; int dev_index, device; int rc, total, batches; double busy; } th_dev_worker_t;
 
 /* waits until the slot holds batch `batch` in state `state` (batch < 0: any occupant -- the reader waiting for a free slot);
  * returns 0 if that batch lies beyond the end of the input instead */
@@ -665,14 +672,18 @@ static void *pipe_writer(void *arg)
         if (n == 0) return NULL;
     }
 }
-/* one worker per device: batches dev_index, dev_index + n_dev, ... (reads are independent, so the shards need no exchange;
- * the writer restores input order) */
+/* one worker per device.  Workers take the next batch from a shared ticket counter, as the reference's threads take reads
+ * (src/main.c:273-291): a device that finishes early (shorter reads, shorter periods) simply takes more batches -- stealing
+ * with no extra mechanism.  Reads are independent, so the shards exchange nothing; the writer restores input order.  At most
+ * n_dev tickets are outstanding and the ring has 2 n_dev + 1 slots, so a ticket's slot is never still owned by the writer's
+ * backlog of an earlier lap for long. */
 static void *pipe_device(void *arg)
 {
     th_dev_worker_t *w = (th_dev_worker_t *)arg; th_pipe_t *q = w->q;
     th_handle_t *h = th_init(q->p, w->device);
     if (!h) { w->rc = -1; q->stop = 1; }
-    for (int i = w->dev_index;; i += q->n_dev) {
+    for (;;) {
+        const int i = __atomic_fetch_add(&q->next_batch, 1, __ATOMIC_RELAXED);
         th_slot_t *s = &q->slot[i % q->n_slot];
         if (!slot_wait(q, s, SLOT_FILLED, i)) break;
         if (s->n > 0 && h && !q->stop) {
@@ -682,6 +693,7 @@ static void *pipe_device(void *arg)
             if (rc) { w->rc = -1; q->stop = 1; } else w->total += s->n;   /* never partial output: a failed batch and everything after it are dropped */
         }
         const int last = s->n == 0;
+        ++w->batches;
         slot_set(q, s, SLOT_DONE);
         if (last) break;
     }
@@ -711,9 +723,11 @@ int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *d
     int total = 0, rc = 0; double busy = 0;
     for (int d = 0; d < n_dev; ++d) { pthread_join(t_dev[d], NULL); total += w[d].total; rc |= w[d].rc; busy += w[d].busy; }
     pthread_join(t_rd, NULL); pthread_join(t_wr, NULL);
-    if (getenv("TH_TRACE"))
+    if (getenv("TH_TRACE")) {
         fprintf(stderr, "[th_run_file] %d reads on %d device(s): wall %.3f s; busy: reader %.3f s, device batches %.3f s (summed), writer %.3f s\n",
                 total, n_dev, now_s() - t_start, q->t_read, busy, q->t_write);
+        if (n_dev > 1) for (int d = 0; d < n_dev; ++d) fprintf(stderr, "[th_run_file]   worker %d (device %d): %d batches, %d reads, busy %.3f s\n", d, devices[d], w[d].batches, w[d].total, w[d].busy);
+    }
     for (int i = 0; i < q->n_slot; ++i) { th_free_tandem_seq(q->slot[i].ts, batch_reads); free(q->slot[i].names); free(q->slot[i].seqs); free(q->slot[i].lens); free(q->slot[i].noff); free(q->slot[i].soff); free(q->slot[i].arena.s); }
     pthread_mutex_destroy(&q->mu); pthread_cond_destroy(&q->cv);
     free(q); rd_close(r);
@@ -784,4 +798,35 @@ int th_synth_read_c5(uint64_t seed, uint64_t read_index, const char *five, int f
         memcpy(dst, r, (size_t)n); free(r);
     }
     return n;
+}
+
+/* ---------------------------------------------------------------- shared ticket counters (multi-process work stealing) */
+/* The reference balances its threads with one shared counter (THREAD_READ_I under a write lock, src/main.c:208-210,277-281).
+ * With one process per GPU the counter has to live in memory all ranks of the node can reach: a page of POSIX shared memory,
+ * 512 independent 64-bit counters, advanced with an atomic fetch-add (no lock, no collective). */
+#define TH_TICKET_N 512
+struct th_ticket { long long *c; char name[128]; };
+th_ticket_t *th_ticket_open(const char *name, int create)
+{
+    int fd = shm_open(name, create ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
+    if (fd < 0) { host_fail("shm_open failed for the ticket counters"); return NULL; }
+    if (create && ftruncate(fd, TH_TICKET_N * (off_t)sizeof(long long)) != 0) { close(fd); host_fail("ftruncate failed for the ticket counters"); return NULL; }
+    void *m = mmap(NULL, TH_TICKET_N * sizeof(long long), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { host_fail("mmap failed for the ticket counters"); return NULL; }
+    th_ticket_t *t = (th_ticket_t *)calloc(1, sizeof(*t));
+    t->c = (long long *)m; snprintf(t->name, sizeof(t->name), "%s", name);
+    return t;
+}
+long long th_ticket_next(th_ticket_t *t, int counter)
+{
+    if (!t || counter < 0 || counter >= TH_TICKET_N) return -1;
+    return __atomic_fetch_add(&t->c[counter], 1LL, __ATOMIC_RELAXED);
+}
+void th_ticket_close(th_ticket_t *t, int unlink_it)
+{
+    if (!t) return;
+    munmap(t->c, TH_TICKET_N * sizeof(long long));
+    if (unlink_it) shm_unlink(t->name);
+    free(t);
 }

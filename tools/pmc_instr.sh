@@ -2,7 +2,7 @@
 # Instruction counters of one bench step (own rocprofv3 pass, kernel trace only): VALU / SALU wave-instructions per launch
 # and the share of VALU issue slots they fill (1024 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz).
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/pmc_instr; mkdir -p $O; cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $O -o run -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $O -o run -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --e2e 0 > $O/log 2>&1
 python3 - <<'PY'
 import csv, glob, json, os, collections
 O = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out/pmc_instr")
@@ -22,7 +22,7 @@ for k in acc:
     valu, salu, s = acc[k].get("SQ_INSTS_VALU", 0.0), acc[k].get("SQ_INSTS_SALU", 0.0), dur.get(k, 0.0)
     out[k] = {"launches": len(n[k]), "valu_wave_instr": valu, "salu_wave_instr": salu, "seconds_under_counters": s,
               "valu_issue_fraction": (valu * 4 / (1024 * 2.4e9 * s)) if s > 0 else None}
-json.dump({"note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU, one pass of `bench.py --steps 1 --warmup 0` (65536 reads of config 3); "
+json.dump({"note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU, one pass of `bench.py --steps 1 --warmup 0` (%d reads of config 3 per launch); " % int(os.environ.get("TH_BENCH_BATCH", "100000")) +
                    "valu_issue_fraction = VALU wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel seconds in this pass)", "kernels": out},
           open(os.path.join(O, "pmc_instr.json"), "w"), indent=1)
 for k, v in out.items(): print("%-40s valu %.3e salu %.3e  %.3f s  issue %.2f" % (k[:40], v["valu_wave_instr"], v["salu_wave_instr"], v["seconds_under_counters"], v["valu_issue_fraction"] or 0))

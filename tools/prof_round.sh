@@ -4,9 +4,9 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/round; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $O/stats.log 2>&1
-timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/pmc_fetch.log 2>&1
-timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --e2e 0 > $O/stats.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --e2e 0 > $O/pmc_fetch.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --e2e 0 > $O/pmc_write.log 2>&1
 # reduce the per-dispatch counter rows on the box (the raw csv is large)
 python3 - <<'PY'
 import csv, glob, json, os, collections
@@ -26,7 +26,7 @@ for k, v in res.items():
     v["hbm_bytes_per_launch_corrected"] = (2 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 1 --warmup 0` (config 3); "
                    "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per the gfx950 correction in MI355X_MICROARCH.md",
-           "reads_per_launch": int(os.environ.get("TH_BENCH_BATCH", "100000")), "kernels": res},
+           "reads_per_launch": int(os.environ.get("TH_BENCH_BATCH", "100000")), "config": "c3", "kernels": res},
           open(os.path.join(O, "hbm_traffic.json"), "w"), indent=1)
 PY
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
