@@ -121,8 +121,8 @@ def test_gpu_config5_sharded_blocks_match_whole(tmp_path):
     (5000, 4, 0.15, 3, 256, 16),       # config 4 (a job costs ~5-10 s and ~0.5 GB on the CPU)
 ])
 def test_gpu_poa_equals_independent_exact_poa(period, copies, err, seed, full, per_core):
-    """HIP POA kernel == full-matrix Kahn-order POA on every job: neither the adaptive band, nor the int16 / packed rows,
-    nor the incremental node order of the kernel changes a consensus at the configs' error rates"""
+    """HIP POA kernel vs full-matrix Kahn-order POA on every job: the int16 / packed rows and the incremental node order of the
+    kernel never change a consensus, and the adaptive band (part of the algorithm) does so on at most 0.5 % of the jobs"""
     n = _n(full, per_core)
     lib = TH.load_library()
     seqs = [TH.synth_read(lib, seed + 100, i, period, copies, err) for i in range(n)]
@@ -145,4 +145,22 @@ def test_gpu_poa_equals_independent_exact_poa(period, copies, err, seed, full, p
 
     with ThreadPoolExecutor(min(CORES, 64 if period >= 5000 else 256)) as ex:
         ok = list(ex.map(one, jobs))
-    assert all(ok), "%d of %d POA jobs differ from the exact POA" % (ok.count(False), len(ok))
+    # A job may differ from the exact POA only through the adaptive band, which is part of the published algorithm (first seen
+    # on the GPU box: 1 of 2053 config-2 jobs, a 3-unit run of period ~300): then the kernel must equal the banded restatement,
+    # and the restatement WITHOUT its band must equal the exact POA (i.e. the node order is never the cause).
+    lib = O.load()
+    band_only = 0
+    for (u, rec), good in zip(jobs, ok):
+        if good:
+            continue
+        b, _ = O.poa_banded(u, para)
+        try:
+            lib.tho_poa_set_opt(O.POA_OPT_BAND, 0)
+            ub, _ = O.poa_banded(u, para)
+        finally:
+            lib.tho_poa_set_opt(O.POA_OPT_BAND, 1)
+        d, _ = O.poa_exact(u, para, 0)
+        assert rec == b, "HIP kernel differs from the banded restatement"
+        assert ub == d, "the node order changed a consensus (unbanded restatement != exact POA)"
+        band_only += 1
+    assert band_only * 200 <= len(jobs), "%d of %d POA jobs are changed by the adaptive band" % (band_only, len(jobs))

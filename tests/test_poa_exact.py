@@ -4,8 +4,8 @@ abPOA is an empty submodule of the reference (.gitmodules:1-4), so oracle/tho_po
 is held to -- has no reference output to be pinned against.  These tests tie it down from the other side instead:
 
   * oracle/tho_poa_exact.c is a second, independent POA (full matrix, Kahn order recomputed per sequence, different data
-    structures).  On the shapes of BASELINE.json's configs the adaptive band and the incremental node order of
-    tho_poa.c never change a consensus: banded == exact, with consensus columns ranked depth-first or breadth-first.
+    structures).  On samples of the shapes of BASELINE.json's configs the adaptive band and the incremental node order of
+    tho_poa.c do not change a consensus: banded == exact, with consensus columns ranked depth-first or breadth-first.
   * At error rates far above the configs' (20-30 %) the adaptive band -- which is part of the published algorithm --
     does lose the optimum now and then; the ORDER still never matters (tho_poa.c unbanded == exact).
   * README.md:232 is an ANCHOR, NOT A PIN: the consensus it prints (203 bases) belongs to an older partition of the same
@@ -72,6 +72,7 @@ def test_band_and_order_never_change_the_consensus_on_config_shapes(period, copi
 
     with ThreadPoolExecutor(8) as ex:
         ok = list(ex.map(one, jobs))
+    # (on these samples the band is harmless too; at scale it is not always: tests/test_gpu_scale.py found 1 of 2053 config-2 jobs)
     assert all(ok), "%d of %d jobs differ between tho_poa.c and the exact POA" % (ok.count(False), len(ok))
 
 
