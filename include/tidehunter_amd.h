@@ -88,6 +88,8 @@ int th_process_batch(th_handle_t *h, const char *const *seqs, const int *lens, i
  * the device path alone:  upload (H2D) -> run (all kernels + small D2H) -> collect (host-side
  * double arithmetic, adapter search, filters; src/gen_cons.c:208-301, src/abpoa_cons.c:92-108). */
 int th_batch_upload(th_handle_t *h, const char *const *seqs, const int *lens, int n);
+/* optional: sizes the device buffers for batches of up to max_reads reads / max_bases bases, so that growing batches do not re-allocate */
+int th_batch_reserve(th_handle_t *h, int max_reads, long long max_bases);
 int th_batch_run(th_handle_t *h);
 int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out);
 /* device milliseconds of the last th_batch_run() per kernel, measured with HIP events on the library's own

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <mutex>
 #include <algorithm>
 #include <functional>
 
@@ -76,8 +77,12 @@ inline void block_barrier()
     while (s.block_arrive[b] < need) yield();
     ++f.n_block_ops;
 }
+// the emulation keeps one global scheduler state (and `__shared__` is a plain static): launches from several host threads
+// (two device workers of the file driver) are serialised here
+inline std::mutex &launch_mutex() { static std::mutex m; return m; }
 template <class F> void launch(dim3 grid, dim3 block, F body)
 {
+    std::lock_guard<std::mutex> lock(launch_mutex());
     State &s = S();
     int nt = (int)(block.x * block.y * block.z);
     const size_t STK = 256 * 1024;

@@ -219,3 +219,33 @@ def test_emul_poa_band_failure_is_rerun_without_a_band(emu, monkeypatch):
     got = th.process(seqs)
     assert U.assert_records_equal(seqs, got, O.default_para(), "noband rerun") >= 3
     th.close()
+
+
+def test_emul_file_driver_pipeline(emu, tmp_path):
+    """th_run_file_multi on the emulation library: reader -> device workers (two per device, batches taken from the shared ticket
+    counter, ramped batch sizes) -> writer; several batches, output order = input order, bytes equal to the oracle's command line"""
+    import ctypes as C
+    import subprocess
+    th = TH.TideHunter(lib_path=emu, out_fmt=2)
+    seqs = _reads(th.lib, [(60, 8, 0.10), (120, 5, 0.08), (35, 12, 0.12), (80, 6, 0.05), (50, 9, 0.1), (70, 7, 0.1), (64, 6, 0.08)])
+    fa = tmp_path / "in.fa"
+    U.write_fasta(fa, seqs)
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p; libc.fopen.argtypes = [C.c_char_p, C.c_char_p]; libc.fclose.argtypes = [C.c_void_p]
+    th.lib.th_run_file_multi.argtypes = [C.c_char_p, C.POINTER(TH.Para), C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int]
+    want = subprocess.run([os.path.join(O.ODIR, "tho_oracle"), "-t", "2", "-f", "2", str(fa)], check=True, capture_output=True).stdout
+    for devs, batch, env in (([0], 2, {}), ([0, 0], 3, {}), ([0], 100, {"TH_RAMP0": "1"}), ([0], 2, {"TH_WORKERS_PER_DEV": "1"})):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            out = tmp_path / "out.txt"
+            fp = libc.fopen(str(out).encode(), b"w")
+            arr = (C.c_int * len(devs))(*devs)
+            n = th.lib.th_run_file_multi(str(fa).encode(), th.para, fp, arr, len(devs), batch)
+            libc.fclose(fp)
+        finally:
+            for k in env:
+                del os.environ[k]
+        assert n == len(seqs), (devs, batch, env)
+        assert out.read_bytes() == want, (devs, batch, env)
+    th.close()

@@ -187,6 +187,7 @@ static inline uint32_t th_pk_max(uint32_t a, uint32_t b) { return TH_PK(TH_PK_LO
 static inline uint32_t th_pk_negmask(uint32_t a) { return (TH_PK_LO(a) < 0 ? 0xffffu : 0u) | (TH_PK_HI(a) < 0 ? 0xffff0000u : 0u); }
 static inline uint32_t th_alignbit16(uint32_t hi, uint32_t lo) { return (lo >> 16) | (hi << 16); }   // (lo.hi, hi.lo)
 static inline uint32_t th_pk_negmask_op(uint32_t a) { return th_pk_negmask(a); }
+static inline uint32_t th_pk_sign(uint32_t a) { return (TH_PK_LO(a) < 0 ? 1u : 0u) | (TH_PK_HI(a) < 0 ? 0x10000u : 0u); }
 static inline uint32_t th_ubfe(uint32_t v, uint32_t off, uint32_t w) { return (v >> (off & 31)) & ((1u << w) - 1); }
 __device__ __forceinline__ uint32_t th_wave_incl_pkmax(uint32_t v)
 {
@@ -204,6 +205,8 @@ __device__ __forceinline__ uint32_t th_alignbit16(uint32_t hi, uint32_t lo) { re
 // the same as th_pk_negmask, but opaque to the optimiser: hipcc turns ashr(sub_sat(a, b), 15) feeding a bit-select into
 // two 16-bit compares, two v_cndmask and a v_perm; written as one instruction it stays v_pk_sub / v_pk_ashrrev / v_bfi
 __device__ __forceinline__ uint32_t th_pk_negmask_op(uint32_t a) { uint32_t r; asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }
+// sign bits of the two halves as 0 / 1 in bits 0 and 16: one v_pk_lshrrev_b16 (kept opaque for the same reason)
+__device__ __forceinline__ uint32_t th_pk_sign(uint32_t a) { uint32_t r; asm("v_pk_lshrrev_b16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }
 __device__ __forceinline__ uint32_t th_ubfe(uint32_t v, uint32_t off, uint32_t w) { return __builtin_amdgcn_ubfe(v, off, w); }
 __device__ __forceinline__ uint32_t th_wave_incl_pkmax(uint32_t v)
 {

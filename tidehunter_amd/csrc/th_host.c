@@ -355,6 +355,7 @@ int th_batch_upload(th_handle_t *h, const char *const *seqs, const int *lens, in
     h->n = n; h->seqs = seqs; h->lens = lens;
     return th_gpu_upload(h->gpu, seqs, lens, n);
 }
+int th_batch_reserve(th_handle_t *h, int max_reads, long long max_bases) { return th_gpu_reserve(h->gpu, max_reads, max_bases); }
 int th_batch_run(th_handle_t *h) { return th_gpu_run(h->gpu); }
 int th_batch_timing(th_handle_t *h, double *ms_kernel, int n)
 {
@@ -609,12 +610,13 @@ void th_output(FILE *fp, int n, const char *const *names, const char *const *seq
  * work on batch i.  Output order = input order (src/main.c:217). */
 enum { SLOT_EMPTY = 0, SLOT_FILLED = 1, SLOT_DONE = 2 };
 #define TH_MAX_DEV 16
-#define TH_MAX_SLOT (2 * TH_MAX_DEV + 1)
+#define TH_MAX_WORKER (2 * TH_MAX_DEV)          /* up to two workers (handles, streams) per device */
+#define TH_MAX_SLOT (2 * TH_MAX_WORKER + 1)
 typedef struct { char **names, **seqs; int *lens; int n, state, batch; th_tandem_seq_t *ts; th_str_t arena; size_t *noff, *soff; } th_slot_t;   /* batch: index of the batch the slot holds */
 typedef struct {
     th_slot_t slot[TH_MAX_SLOT]; int n_slot, n_dev;
     pthread_mutex_t mu; pthread_cond_t cv;
-    th_reader_t *rd; FILE *out; th_para_t *p; int batch_reads; volatile int stop;
+    th_reader_t *rd; FILE *out; th_para_t *p; int batch_reads, ramp0; volatile int stop;
     int eof_batch;               /* index of the empty batch that ends the input (-1 until the reader meets it) */
     int next_batch;              /* ticket counter of the device workers (the reference's THREAD_READ_I, src/main.c:277-281, at batch granularity) */
     double t_read, t_write;      /* busy seconds of the two side threads (TH_TRACE=1 prints them) */
@@ -648,8 +650,11 @@ static void *pipe_reader(void *arg)
         int n = 0; long long bases = 0;
         const double t0 = now_s();
         s->arena.l = 0;
+        /* the first batches are small and grow fourfold (ramp0, 4 ramp0, ... up to batch_reads): the device starts after a few
+         * milliseconds of parsing instead of after a whole batch, and the pipeline fills while the batches grow */
+        const long long target = i < 10 && ((long long)q->ramp0 << (2 * i)) < q->batch_reads ? ((long long)q->ramp0 << (2 * i)) : q->batch_reads;
         if (!q->stop)
-            while (n < q->batch_reads && bases < max_bases && rd_next_into(q->rd, &s->arena, &s->noff[n], &s->soff[n], &s->lens[n])) { bases += s->lens[n]; ++n; }
+            while (n < target && bases < max_bases && rd_next_into(q->rd, &s->arena, &s->noff[n], &s->soff[n], &s->lens[n])) { bases += s->lens[n]; ++n; }
         for (int k = 0; k < n; ++k) { s->names[k] = s->arena.s + s->noff[k]; s->seqs[k] = s->arena.s + s->soff[k]; }
         q->t_read += now_s() - t0;
         s->n = n; s->batch = i;
@@ -688,6 +693,10 @@ static void *pipe_device(void *arg)
         if (!slot_wait(q, s, SLOT_FILLED, i)) break;
         if (s->n > 0 && h && !q->stop) {
             const double t0 = now_s();
+            if (w->batches == 0 && s->n < q->batch_reads) {      /* first (small) batch of this worker: size the device buffers for full batches */
+                long long bases = 0; for (int k = 0; k < s->n; ++k) bases += s->lens[k];
+                th_batch_reserve(h, q->batch_reads, (long long)((double)bases / s->n * q->batch_reads * 1.1) + 65536);
+            }
             const int rc = th_process_batch(h, (const char *const *)s->seqs, s->lens, s->n, s->ts);
             w->busy += now_s() - t0;
             if (rc) { w->rc = -1; q->stop = 1; } else w->total += s->n;   /* never partial output: a failed batch and everything after it are dropped */
@@ -701,22 +710,31 @@ static void *pipe_device(void *arg)
     return NULL;
 }
 
-int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *devices, int n_dev, int batch_reads)
+int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *devices_in, int n_dev_in, int batch_reads)
 {
-    if (n_dev < 1 || n_dev > TH_MAX_DEV) return host_fail("between 1 and 16 devices");
+    if (n_dev_in < 1 || n_dev_in > TH_MAX_DEV) return host_fail("between 1 and 16 devices");
     if (batch_reads <= 0) batch_reads = 65536;
+    /* Two workers (handle + stream each) per listed device by default: while one batch's kernels run, the other worker uploads
+     * its next batch (pinned staging + H2D) and does the host-side record arithmetic of its previous one, so the device does
+     * not idle between batches.  TH_WORKERS_PER_DEV=1 restores one worker per device. */
+    int wpd = 2;
+    { const char *e = getenv("TH_WORKERS_PER_DEV"); if (e && atoi(e) >= 1 && atoi(e) <= 2) wpd = atoi(e); }
+    int devices[TH_MAX_WORKER], n_dev = 0;
+    for (int r = 0; r < wpd; ++r) for (int d = 0; d < n_dev_in; ++d) devices[n_dev++] = devices_in[d];
     if (p->five_fn && p->three_fn && !p->five_seq) if (th_load_adapters(p)) return -1;
     th_reader_t *r = rd_open(read_fn);
     if (!r) { char m[300]; snprintf(m, sizeof(m), "fail to open file '%s'", read_fn); return host_fail(m); }
     th_pipe_t *q = (th_pipe_t *)calloc(1, sizeof(th_pipe_t));
     pthread_mutex_init(&q->mu, NULL); pthread_cond_init(&q->cv, NULL);
     q->rd = r; q->out = out; q->p = p; q->batch_reads = batch_reads; q->n_dev = n_dev; q->n_slot = 2 * n_dev + 1; q->eof_batch = -1;
+    q->ramp0 = batch_reads / 8 > 2048 ? batch_reads / 8 : 2048;
+    { const char *e = getenv("TH_RAMP0"); if (e && atoi(e) > 0) q->ramp0 = atoi(e); }
     for (int i = 0; i < q->n_slot; ++i) {
         q->slot[i].names = (char **)calloc(batch_reads, sizeof(char *)); q->slot[i].seqs = (char **)calloc(batch_reads, sizeof(char *));
         q->slot[i].lens = (int *)calloc(batch_reads, sizeof(int)); q->slot[i].ts = th_alloc_tandem_seq(batch_reads);
         q->slot[i].noff = (size_t *)calloc(batch_reads, sizeof(size_t)); q->slot[i].soff = (size_t *)calloc(batch_reads, sizeof(size_t));
     }
-    pthread_t t_rd, t_wr, t_dev[TH_MAX_DEV]; th_dev_worker_t w[TH_MAX_DEV];
+    pthread_t t_rd, t_wr, t_dev[TH_MAX_WORKER]; th_dev_worker_t w[TH_MAX_WORKER];
     const double t_start = now_s();
     pthread_create(&t_rd, NULL, pipe_reader, q); pthread_create(&t_wr, NULL, pipe_writer, q);
     for (int d = 0; d < n_dev; ++d) { memset(&w[d], 0, sizeof(w[d])); w[d].q = q; w[d].dev_index = d; w[d].device = devices[d]; pthread_create(&t_dev[d], NULL, pipe_device, &w[d]); }

@@ -39,6 +39,8 @@ typedef struct th_gpu th_gpu_t;
 
 th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device);
 void th_gpu_destroy(th_gpu_t *g);
+/* sizes the per-read / per-base buffers for batches of up to n reads and T bases (optional; avoids re-allocation when batches grow) */
+int th_gpu_reserve(th_gpu_t *g, int n, long long T);
 /* copies the reads into pinned memory and on to HBM; the batch stays resident until the next upload */
 int th_gpu_upload(th_gpu_t *g, const char *const *seqs, const int *lens, int n);
 /* runs the whole device path on the resident batch and brings the small result records back */

@@ -34,6 +34,21 @@
 #endif
 #define TH_POA_QCAP_WIDE 8192   // ... by the 32-bit-ring variant (longer units read the query from HBM: QCAP = 0)
 
+// Direction words.  In registers (traceback) a word has the layout of the TH_D_* macros below.  In HBM a cell of a row with at
+// most four predecessors -- every packed row, nearly every other row -- is a 16-bit word made of raw comparison results:
+//   bits 7..4  "strictly better than everything before it" for E1, E2, F1, F2 in that order (the source is the last one set)
+//   bits 3..0  XE1, XE2, XF1, XF2: the gap was extended rather than opened
+//   bits 9..8 / 11..10 / 13..12  edge index of the predecessor that gave the diagonal / the E1 / the E2 value
+// so the packed row stores the sign bits of eight saturating differences as they come (two instructions per bit) instead of
+// assembling a 32-bit word per cell, and the traffic of the direction matrix halves.  Rows with more than four predecessors
+// store whole cells (int4, the 32-bit word in .w); th_poa_dir() returns the register layout for either kind.
+#define TH_D16_WIDE_DEG 4
+__device__ __forceinline__ uint32_t th_d16_expand(uint32_t w)
+{
+    const uint32_t src = (w & 0x10u) ? 4u : (w & 0x20u) ? 3u : (w & 0x40u) ? 2u : (w & 0x80u) ? 1u : 0u;
+    return src | ((w >> 8) & 3u) << 3 | ((w >> 10) & 3u) << 11 | ((w >> 12) & 3u) << 19
+         | ((w >> 3) & 1u) << 27 | ((w >> 2) & 1u) << 28 | ((w >> 1) & 1u) << 29 | (w & 1u) << 30;
+}
 #define TH_D_SRC(d)  ((d) & 7)
 #define TH_D_PM(d)   (((d) >> 3) & 0xff)
 #define TH_D_PE1(d)  (((d) >> 11) & 0xff)
@@ -62,10 +77,10 @@ struct ThPoaG {
     int *order, *order2;
     // by row (order index)
     int *r_meta, *r_p, *r_s, *r_rem, *r_beg, *r_end, *r_mpl, *r_mpr;
-    long long *r_off;
+    int *r_off, *r_foff;       // offset of a row's band start among the direction words / among the full cells (rows that store them)
     int *cntB, *headB, *aft;
     int *ops, *pv, *glo, *pth;
-    int4 *cell; int *dcell; long long cell_cap;     // full cells (rows some far row will read) / direction words (all rows)
+    int4 *cell; uint16_t *dcell; long long cell_cap, full_cap;     // full cells (rows some far row will read, rows of in-degree > 4) / 16-bit direction words (all other rows)
 };
 
 __device__ __forceinline__ int th_poa_in(const ThPoaG &g, int v, int ord)
@@ -257,7 +272,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     const int M = P.match, X = P.mismatch, O1 = P.go1, E1 = P.ge1, O2 = P.go2, E2 = P.ge2;
     qlen = TH_UNI(qlen);
     const int n = TH_UNI(g.n_node), w = TH_POA_WB + qlen / 100;
-    long long ncell = 0;
+    long long ncell = 0, nfull = 0;
     // Every real score lies within +-real_b: a path to (i, j) has at most i + j unit steps, the dearest of which is a
     // mismatch (X for two units) or a one-base gap (open + extend for one unit); E'/F carry one more open + extend.
     // Rows are cached as int16 (and packed rows are used) only if that, the upward drift of unreachable cells (M per
@@ -284,7 +299,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     // band, row-maximum columns and cell offset of the rows of the current 64-row chunk: lane (row & 63) of these registers
     // (one v_writelane each per row); they go to the row tables in HBM 64 rows at a time, so the common row issues no
     // metadata store at all.  A predecessor inside the chunk is read back with v_readlane, an older one from the tables.
-    int m_beg = 0, m_end = 0, m_left = 0, m_right = 0, m_offlo = 0, m_offhi = 0;
+    int m_beg = 0, m_end = 0, m_left = 0, m_right = 0, m_off = 0, m_foff = 0;
     for (int x = lane; x < TH_POA_RING * 3 * TH_POA_PAD; x += TH_WAVE) s_ring[x / (3 * TH_POA_PAD)][(x / TH_POA_PAD) % 3][x % TH_POA_PAD] = (RT)(WIDE ? TH_NEG : -32768);
     TH_WAVE_FENCE();
 #if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
@@ -341,13 +356,16 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         if (b > e) return -2;
         // a row owns the cells of columns (b & ~1) .. (e | 1): packed rows store column pairs
         const int B0 = b & ~1, span = (e | 1) - B0 + 1;
-        if (ncell + span > g.cell_cap) return -3;
-        const long long my_off = ncell + (b - B0);               // offset of column b, as every reader expects
-        int4 *row = g.cell + my_off; int *drow = g.dcell + my_off;
-        ncell += span;
         const int myslot = i & 3, lslot = (i - 1) & 3;
         const bool cache_me = cache16_ok && e - b < TH_POA_RW;
-        const bool store_full = needfull || !cache_me;     // otherwise only the direction word leaves the CU
+        const bool store_full = needfull || !cache_me || inn > TH_D16_WIDE_DEG;     // otherwise only the 16-bit direction word leaves the CU
+        // direction words (2 bytes per cell, every row) and full cells (16 bytes, only the rows that store them) live in separate
+        // regions with their own running offsets: the scratch of a wave shrinks from ~18 to ~3 bytes per band cell
+        if (ncell + span > g.cell_cap || (store_full && nfull + span > g.full_cap)) return -3;
+        const int my_off = (int)ncell + (b - B0);                // offset of column b, as every reader expects
+        const int my_foff = store_full ? (int)nfull + (b - B0) : 0;
+        int4 *row = g.cell + my_foff; uint16_t *drow = g.dcell + my_off;
+        ncell += span; if (store_full) nfull += span;
         int rmax = TH_NEG - 0x10000000, left = b, right = b;
         const bool pk = !WIDE && LQ && ring_all && cache_me && !needfull;    // rows some far row will read take the 32-bit path (they store whole cells)
         const int npk = fast ? 1 : inn;
@@ -371,7 +389,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 // predecessor rows (all in the ring): diagonal pair (j0-1, j0) and vertical pairs (j0, j0+1) of each; anything outside
                 // a row's band reads -inf (its slot is clean, indices beyond either end are sent to the padding).  The first
                 // predecessor in edge order wins ties, as in the one-column-per-lane path; PMV / PE1V / PE2V hold the winners' edge
-                // indices, already shifted to their place in the direction word (PE2V 16 bits lower)
+                // indices, already shifted to their place in the 16-bit direction word
                 uint32_t m = 0, e1v = 0, e2v = 0, PMV = 0, PE1V = 0, PE2V = 0;
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
@@ -387,12 +405,12 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                         else {
                             const uint32_t gm = th_pk_negmask_op(th_pk_sub(m, mo)), ge1 = th_pk_negmask_op(th_pk_sub(e1v, c1)), ge2 = th_pk_negmask_op(th_pk_sub(e2v, c2));
                             m = th_pk_max(m, mo); e1v = th_pk_max(e1v, c1); e2v = th_pk_max(e2v, c2);
-                            PMV = th_sel(gm, TH_PK_DUP(o << 3), PMV); PE1V = th_sel(ge1, TH_PK_DUP(o << 11), PE1V); PE2V = th_sel(ge2, TH_PK_DUP(o << 3), PE2V);
+                            PMV = th_sel(gm, TH_PK_DUP(o << 8), PMV); PE1V = th_sel(ge1, TH_PK_DUP(o << 10), PE1V); PE2V = th_sel(ge2, TH_PK_DUP(o << 12), PE2V);
                         }
                     }
                 }
-                const uint32_t hnf1 = th_pk_max(m, e1v), g1 = th_pk_negmask(th_pk_sub(m, e1v));
-                const uint32_t hnf = th_pk_max(hnf1, e2v), g2 = th_pk_negmask(th_pk_sub(hnf1, e2v));
+                const uint32_t hnf1 = th_pk_max(m, e1v), dg1 = th_pk_sub(m, e1v);           // sign of dg1: E1 strictly better
+                const uint32_t hnf = th_pk_max(hnf1, e2v), dg2 = th_pk_sub(hnf1, e2v);
                 // F1 / F2: max-plus prefix over the row in the domain value + column * extension
                 const uint32_t JR = TH_PK(jr, jr + 1);
                 const uint32_t JE1 = TH_PK(TH_PK_LO(JR) * E1, TH_PK_HI(JR) * E1), JE2 = TH_PK(TH_PK_LO(JR) * E2, TH_PK_HI(JR) * E2);
@@ -406,25 +424,21 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 carry1 = max(carry1, TH_READLANE(i1, 63)); carry2 = max(carry2, TH_READLANE(i2, 63));
                 const uint32_t x1 = TH_PK(b1, max(b1, a1l)), x2 = TH_PK(b2, max(b2, a2l));                 // (before lo, before hi)
                 const uint32_t f1 = th_pk_sub(x1, JE1), f2 = th_pk_sub(x2, JE2);
-                const uint32_t h3 = th_pk_max(hnf, f1), g3 = th_pk_negmask(th_pk_sub(hnf, f1));
-                const uint32_t h = th_pk_max(h3, f2), g4 = th_pk_negmask(th_pk_sub(h3, f2));
-                // direction codes (src | flags << 3 per half) and the next row's E1', E2'
+                const uint32_t h3 = th_pk_max(hnf, f1), dg3 = th_pk_sub(hnf, f1);
+                const uint32_t h = th_pk_max(h3, f2), dg4 = th_pk_sub(h3, f2);
+                // direction word of the two columns: the sign bits of eight saturating differences, the first one ending in bit 7
                 const uint32_t hO1 = th_pk_sub(h, O1P), hO2 = th_pk_sub(h, O2P);
-                uint32_t code = g1 & 0x00010001u;
-                code = th_sel(g2, 0x00020002u, code); code = th_sel(g3, 0x00030003u, code); code = th_sel(g4, 0x00040004u, code);
-                code |= th_pk_negmask(th_pk_sub(hO1, e1v)) & 0x00080008u;
-                code |= th_pk_negmask(th_pk_sub(hO2, e2v)) & 0x00100010u;
-                code |= th_pk_negmask(th_pk_sub(hO1, f1)) & 0x00200020u;
-                code |= th_pk_negmask(th_pk_sub(hO2, f2)) & 0x00400040u;
+                uint32_t code = th_pk_sign(dg1);
+                code = (code << 1) | th_pk_sign(dg2);
+                code = (code << 1) | th_pk_sign(dg3);
+                code = (code << 1) | th_pk_sign(dg4);
+                code = (code << 1) | th_pk_sign(th_pk_sub(hO1, e1v));
+                code = (code << 1) | th_pk_sign(th_pk_sub(hO2, e2v));
+                code = (code << 1) | th_pk_sign(th_pk_sub(hO1, f1));
+                code = (code << 1) | th_pk_sign(th_pk_sub(hO2, f2));
+                if (npk > 1) code |= PMV | PE1V | PE2V;
                 const uint32_t n1 = th_pk_sub(th_pk_max(hO1, e1v), E1P), n2 = th_pk_sub(th_pk_max(hO2, e2v), E2P);
-                uint32_t d_lo = (code & 7u) | ((code << 24) & 0x78000000u), d_hi = ((code >> 16) & 7u) | ((code << 8) & 0x78000000u);
-                if (npk > 1) {
-                    const uint32_t X = PMV | PE1V;
-                    d_lo |= (X & 0xffffu) | (PE2V << 16); d_hi |= (X >> 16) | (PE2V & 0xffff0000u);
-                }
-                if (j0 <= e) {
-                    *(unsigned long long *)(drow + (j0 - b)) = (unsigned long long)d_hi << 32 | d_lo;   // column b-1 / e+1 of an odd edge land in the row's own padding
-                }
+                if (j0 <= e) *(uint32_t *)(drow + (j0 - b)) = code;      // column b-1 / e+1 of an odd edge land in the row's own padding
                 if (wi < TH_POA_RS / 2) { wH[wi] = th_sel(IM, h, TH_PK_NEG); wE1[wi] = th_sel(IM, n1, TH_PK_NEG); wE2[wi] = th_sel(IM, n2, TH_PK_NEG); }
                 // row maximum and its first / last column: the maximum of H is a maximum of hnf (an F value is always
                 // below the hnf it came from), and H == max only where hnf == max
@@ -462,11 +476,9 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                     const int s = pi & 3;
                     int hp = TH_NEG, c1 = TH_NEG, c2 = TH_NEG;
                     // the predecessor row's band and cell offset: chunk registers or row tables
-                    int pb, pe; long long po;
-                    if (pi >= (i & ~63)) {
-                        pb = TH_READLANE(m_beg, pi & 63); pe = TH_READLANE(m_end, pi & 63);
-                        po = ((long long)TH_READLANE(m_offhi, pi & 63) << 32) | (uint32_t)TH_READLANE(m_offlo, pi & 63);
-                    } else { pb = g.r_beg[pi]; pe = g.r_end[pi]; po = g.r_off[pi]; }
+                    int pb, pe, po;       // po: the predecessor's full cells (only read when it is not in the ring: such rows store them)
+                    if (pi >= (i & ~63)) { pb = TH_READLANE(m_beg, pi & 63); pe = TH_READLANE(m_end, pi & 63); po = TH_READLANE(m_foff, pi & 63); }
+                    else { pb = g.r_beg[pi]; pe = g.r_end[pi]; po = g.r_foff[pi]; }
                     // the three rows before this one are still in the LDS ring if their band fitted it (every cached slot is clean)
                     if (i - pi < TH_POA_RING && cache16_ok && pe - pb < TH_POA_RW) {           // LDS ring: no HBM round trip
                         if (in) {
@@ -511,7 +523,9 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                     if (f2 > h - O2) d |= TH_D_XF2;
                 }
                 const int n1 = max(h - O1, e1v) - E1, n2 = max(h - O2, e2v) - E2;
-                drow[j - b] = (int)d;
+                if (inn <= TH_D16_WIDE_DEG)
+                    drow[j - b] = (uint16_t)((src ? 0x100u >> src : 0u) | (d >> 27 & 1u) << 3 | (d >> 28 & 1u) << 2 | (d >> 29 & 1u) << 1 | (d >> 30 & 1u)
+                                             | (uint32_t)pm << 8 | (uint32_t)pe1 << 10 | (uint32_t)pe2 << 12);
                 if (store_full) { int4 cv; cv.x = h; cv.y = n1; cv.z = n2; cv.w = (int)d; row[j - b] = cv; }
                 if (cache_me) { s_ring[myslot][0][TH_RIDX(j, b)] = TH_RING_ST(h); s_ring[myslot][1][TH_RIDX(j, b)] = TH_RING_ST(n1); s_ring[myslot][2][TH_RIDX(j, b)] = TH_RING_ST(n2); }
             }
@@ -529,10 +543,10 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
           pf_n[cat] += 1; pf_t[cat] += dt; }
 #endif
         m_beg = TH_WRITELANE(m_beg, b, sl); m_end = TH_WRITELANE(m_end, e, sl); m_left = TH_WRITELANE(m_left, L_l, sl); m_right = TH_WRITELANE(m_right, L_r, sl);
-        m_offlo = TH_WRITELANE(m_offlo, (int)(uint32_t)my_off, sl); m_offhi = TH_WRITELANE(m_offhi, (int)(my_off >> 32), sl);
+        m_off = TH_WRITELANE(m_off, my_off, sl); m_foff = TH_WRITELANE(m_foff, my_foff, sl);
         if (sl == 63 || i + 2 >= n) {          // chunk complete (or last row): its rows' metadata to the tables, coalesced
             const int r = (i & ~63) + lane;
-            if (r <= i) { g.r_beg[r] = m_beg; g.r_end[r] = m_end; g.r_off[r] = ((long long)m_offhi << 32) | (uint32_t)m_offlo; g.r_mpl[r] = m_left; g.r_mpr[r] = m_right; }
+            if (r <= i) { g.r_beg[r] = m_beg; g.r_end[r] = m_end; g.r_off[r] = m_off; g.r_foff[r] = m_foff; g.r_mpl[r] = m_left; g.r_mpr[r] = m_right; }
         }
         TH_WAVE_FENCE();
     }
@@ -546,12 +560,19 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         for (int o = 0; o < sinn; ++o) {
             const int pi = g.pos[th_poa_in(g, 1, o)];
             const int pb = g.r_beg[pi], pe = g.r_end[pi];
-            const int c = (qlen >= pb && qlen <= pe) ? g.cell[g.r_off[pi] + (qlen - pb)].x : TH_NEG;
+            const int c = (qlen >= pb && qlen <= pe) ? g.cell[g.r_foff[pi] + (qlen - pb)].x : TH_NEG;
             if (o == 0 || c > bs) { bs = c; bi = pi; }
         }
     }
     if (bs <= TH_NEG / 2) return -4;
     return bi;
+}
+
+// direction word of cell (row, column offset `o` from the row's band start) in the register layout of the TH_D_* macros
+__device__ __forceinline__ uint32_t th_poa_dir(const ThPoaG &g, int row, int o)
+{
+    const int deg = (g.r_meta[row] >> 8) & 0xff;
+    return deg > TH_D16_WIDE_DEG ? (uint32_t)g.cell[g.r_foff[row] + o].w : th_d16_expand(g.dcell[g.r_off[row] + o]);
 }
 
 // ---- traceback: wave-uniform walk; direction words come from tiles of 16 rows x 4 diagonals ----
@@ -573,7 +594,7 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
             if (row >= 1) {
                 const int rb = g.r_beg[row], re = g.r_end[row];
                 t_p0 = g.r_p[row * 4]; t_p1 = g.r_p[row * 4 + 1]; t_p2 = g.r_p[row * 4 + 2]; t_p3 = g.r_p[row * 4 + 3];
-                if (col >= rb && col <= re) { t_d = g.dcell[g.r_off[row] + (col - rb)]; t_ok = 1; }
+                if (col >= rb && col <= re) { t_d = (int)th_poa_dir(g, row, col - rb); t_ok = 1; }
             }
             {
                 const int want = (int)TH_D_PM((uint32_t)t_d);
@@ -616,7 +637,7 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
                 else {
                     uint32_t pd;
                     if (hit && okv) pd = (uint32_t)dv;
-                    else pd = (uint32_t)g.dcell[g.r_off[ci] + (cj - g.r_beg[ci])];
+                    else pd = th_poa_dir(g, ci, cj - g.r_beg[ci]);
                     const uint32_t bit = st == 1 ? TH_D_XE1 : st == 2 ? TH_D_XE2 : st == 3 ? TH_D_XF1 : TH_D_XF2;
                     if (!(pd & bit)) st = 0;
                 }
@@ -798,11 +819,18 @@ th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict
         g.order = th_carve(p, cap); g.order2 = th_carve(p, cap);
         g.r_meta = th_carve(p, cap); g.r_p = th_carve(p, cap * 4); g.r_s = th_carve(p, cap * 4); g.r_rem = th_carve(p, cap);
         g.r_beg = th_carve(p, cap); g.r_end = th_carve(p, cap); g.r_mpl = th_carve(p, cap); g.r_mpr = th_carve(p, cap);
-        g.r_off = (long long *)th_carve(p, 2 * cap);
+        g.r_off = th_carve(p, cap); g.r_foff = th_carve(p, cap);
         g.cntB = th_carve(p, cap); g.headB = th_carve(p, cap); g.aft = th_carve(p, cap);
         g.ops = th_carve(p, 2 * opn); g.pv = th_carve(p, opn); g.glo = th_carve(p, opn); g.pth = th_carve(p, opn + 2);
-        g.cell_cap = (scratch_ints - (p - my)) / 5 & ~3LL;
-        g.cell = (int4 *)p; g.dcell = p + 4 * g.cell_cap;
+        // what is left: half for the direction words (2 bytes per cell), half for the full cells (16 bytes; normally a few per cent of
+        // the rows store them, so one cell in eight is plenty -- a job that needs more comes back with status 2 and is retried with
+        // more scratch); the rerun without a band stores every row in full: one share in nine for the direction words
+        {
+            const long long avail = scratch_ints - (p - my);
+            const long long dints = (noband ? avail / 9 : avail / 2) & ~3LL;
+            g.cell_cap = dints * 2; g.full_cap = (avail - dints) / 4;
+            g.dcell = (uint16_t *)p; g.cell = (int4 *)(p + dints);
+        }
         int st = 0;
         if (p - my > scratch_ints || g.cell_cap < 64) st = 1;
         if (!st) th_poa_seed(g, rb + U[0].start, U[0].len);

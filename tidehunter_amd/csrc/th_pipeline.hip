@@ -12,6 +12,8 @@
 #include <chrono>
 #include "th_internal.h"
 
+static double th_wall_s() { using namespace std::chrono; return duration<double>(steady_clock::now().time_since_epoch()).count(); }
+
 // one message per thread: th_run_file_multi drives one handle per device from its own thread
 static thread_local std::string g_th_err;
 extern "C" const char *th_gpu_error(void) { return g_th_err.c_str(); }
@@ -25,16 +27,21 @@ static int th_launch_failed(const char *kernel, const char *why) { return th_fai
 #include "th_k_poa.hip"
 #include "th_k_align.hip"
 
-static double th_wall_s() { using namespace std::chrono; return duration<double>(steady_clock::now().time_since_epoch()).count(); }
-
+#define TH_STAGE_BYTES (16u << 20)
+// seconds this thread spent in device malloc / free and the bytes it asked for (TH_TRACE prints them per run)
+static thread_local double g_alloc_s = 0, g_free_s = 0; static thread_local long long g_alloc_bytes = 0; static thread_local int g_alloc_n = 0;
 template <class T> struct DBuf {
     T *p = nullptr; size_t cap = 0;
     int ensure(size_t n) {
         if (n <= cap) return 0;
+        double t0 = th_wall_s();
         if (p) th_rt_free(p);
+        g_free_s += th_wall_s() - t0;
         p = nullptr; cap = 0;
         size_t want = n + n / 8 + 64;
+        t0 = th_wall_s();
         if (th_rt_malloc((void **)&p, want * sizeof(T))) return -1;
+        g_alloc_s += th_wall_s() - t0; g_alloc_bytes += (long long)(want * sizeof(T)); ++g_alloc_n;
         cap = want; return 0;
     }
     void release() { if (p) th_rt_free(p); p = nullptr; cap = 0; }
@@ -47,7 +54,7 @@ struct Ev { hipEvent_t a, b; };
 struct th_gpu {
     th_gpu_para_t para; ThDevPara dp; int device; th_stream_t stream;
     int n = 0; long long T = 0; int max_len = 0;
-    uint8_t *h_seq = nullptr; size_t h_seq_cap = 0;
+    uint8_t *h_stage[2] = { nullptr, nullptr }; th_event_t stage_ev[2]; bool stage_ok = false;   // pinned staging for the upload (2 x TH_STAGE_BYTES)
     std::vector<uint32_t> h_roff; std::vector<long long> h_gsort_off; long long gsort_total = 0;
     DBuf<uint8_t> d_seq, d_bseq, d_tracked, d_cons;
     DBuf<uint32_t> d_roff, d_tmp;
@@ -58,7 +65,7 @@ struct th_gpu {
     DBuf<ThChainRec> d_rec;
     DBuf<int> d_par, d_par_off, d_par_n, d_par_dst, d_parc, d_bnd, d_scratch, d_cov, d_cons_len, d_status, d_iden, d_ext;
     DBuf<ThTask> d_tasks, d_sub; DBuf<ThUnit> d_units; DBuf<ThAlnItem> d_items; DBuf<int> d_scl, d_sst;   // d_sub/d_scl/d_sst: task subsets of POA relaunches
-    int n_rec = 0;
+    int n_rec = 0, reserve_n = 0;
     std::vector<ThChainRec> h_rec; std::vector<int> h_par_n, h_par_dst, h_parc, h_read_ch_base, h_read_ch_n;
     std::vector<ThTask> h_tasks; std::vector<ThUnit> h_units; std::vector<ThAlnItem> h_items;
     std::vector<int> h_cons_len, h_status, h_iden, h_ext, h_cov; std::vector<uint8_t> h_cons;
@@ -109,7 +116,7 @@ extern "C" void th_gpu_destroy(th_gpu_t *g)
     g->d_par.release(); g->d_par_off.release(); g->d_par_n.release(); g->d_par_dst.release(); g->d_parc.release(); g->d_bnd.release(); g->d_scratch.release();
     g->d_cov.release(); g->d_cons_len.release(); g->d_status.release(); g->d_iden.release(); g->d_ext.release();
     g->d_tasks.release(); g->d_units.release(); g->d_items.release();
-    if (g->h_seq) th_rt_host_free(g->h_seq);
+    if (g->stage_ok) for (int b = 0; b < 2; ++b) { th_rt_host_free(g->h_stage[b]); th_rt_event_destroy(g->stage_ev[b]); }
 #ifndef TH_CPU_EMUL
     hipStreamDestroy(g->stream);
 #endif
@@ -129,6 +136,24 @@ static int th_select_device(const th_gpu *g)
     (void)g; return 0;
 }
 
+// Sizes every per-read / per-base buffer for batches of up to n reads and T bases, so that a run of growing batches (the file
+// driver starts with small ones) does not free and re-allocate gigabytes at every step.  Buffers whose size depends on the
+// stage results (chain records, consensus jobs, POA scratch) still grow on demand.
+extern "C" int th_gpu_reserve(th_gpu_t *g, int n, long long T)
+{
+    TRY(th_select_device(g));
+    if (n <= 0 || T <= 0) return 0;
+    if (T >= (1LL << 31)) T = (1LL << 31) - 64;
+    const size_t padT = (size_t)((T + 15) & ~15LL);
+    TRY(g->d_seq.ensure(padT)); TRY(g->d_bseq.ensure(padT)); TRY(g->d_roff.ensure((size_t)n + 1)); TRY(g->d_gsort_off.ensure((size_t)n));
+    TRY(g->d_tmp.ensure(padT)); TRY(g->d_hit_end.ensure(padT)); TRY(g->d_hit_per.ensure(padT)); TRY(g->d_hit_n.ensure(n));
+    TRY(g->d_score.ensure(padT)); TRY(g->d_from.ensure(padT)); TRY(g->d_cells.ensure(padT)); TRY(g->d_tracked.ensure(padT));
+    TRY(g->d_xorder.ensure(padT)); TRY(g->d_xstart.ensure(padT)); TRY(g->d_xend.ensure(padT)); TRY(g->d_eps.ensure(padT));
+    TRY(g->d_read_ch_base.ensure(n)); TRY(g->d_read_ch_n.ensure(n)); TRY(g->d_rec.ensure((size_t)n * 8 + 4096));
+    g->reserve_n = n;
+    return 0;
+}
+
 extern "C" int th_gpu_upload(th_gpu_t *g, const char *const *seqs, const int *lens, int n)
 {
     TRY(th_select_device(g));
@@ -139,13 +164,6 @@ extern "C" int th_gpu_upload(th_gpu_t *g, const char *const *seqs, const int *le
     if (mx >= (1 << 28)) return th_fail("a read of 2^28 bases or more is not supported (32-bit period arithmetic in th_k_chain_dp)");
     g->h_roff[n] = (uint32_t)T; g->T = T; g->max_len = mx;
     size_t padT = (size_t)((T + 15) & ~15LL);
-    if (padT + 16 > g->h_seq_cap) {
-        if (g->h_seq) th_rt_host_free(g->h_seq);
-        g->h_seq = nullptr; g->h_seq_cap = padT + padT / 8 + 4096;
-        TRY(th_rt_host_alloc((void **)&g->h_seq, g->h_seq_cap));
-    }
-    for (int i = 0; i < n; ++i) memcpy(g->h_seq + g->h_roff[i], seqs[i], (size_t)lens[i]);
-    memset(g->h_seq + T, 'N', padT - (size_t)T);
     // reads whose sort does not fit the LDS buffers get a segment of HBM scratch
     g->h_gsort_off.assign((size_t)n, -1); long long gs = 0;
     for (int i = 0; i < n; ++i) {
@@ -156,7 +174,34 @@ extern "C" int th_gpu_upload(th_gpu_t *g, const char *const *seqs, const int *le
     g->gsort_total = gs;
     TRY(g->d_seq.ensure(padT)); TRY(g->d_bseq.ensure(padT)); TRY(g->d_roff.ensure((size_t)n + 1));
     TRY(g->d_gsort_off.ensure((size_t)n)); TRY(g->d_gsort.ensure((size_t)gs));
-    TRY(th_rt_h2d(g->d_seq.p, g->h_seq, padT, g->stream));
+    // The reads go to HBM through two small pinned staging buffers: while one is on its way (async H2D) the host concatenates
+    // the next reads into the other.  (One pinned buffer for the whole batch meant pinning ~1 GB before the first byte moved:
+    // 0.13-0.19 s per handle, and the copy could not overlap the concatenation.)
+    if (!g->stage_ok) {
+        for (int b = 0; b < 2; ++b) { TRY(th_rt_host_alloc((void **)&g->h_stage[b], TH_STAGE_BYTES)); TRY(th_rt_event_create(&g->stage_ev[b])); }
+        g->stage_ok = true;
+    }
+    {
+        size_t done = 0, fill = 0; int cur = 0, used[2] = { 0, 0 };
+        auto flush = [&]() -> int {
+            if (!fill) return 0;
+            TRY(th_rt_h2d(g->d_seq.p + done, g->h_stage[cur], fill, g->stream));
+            TRY(th_rt_event_record(g->stage_ev[cur], g->stream));
+            used[cur] = 1; done += fill; fill = 0; cur ^= 1;
+            if (used[cur]) TRY(th_rt_event_wait(g->stage_ev[cur]));      // the buffer we are about to refill must have left
+            return 0;
+        };
+        for (int i = 0; i <= n; ++i) {
+            const char *src = i < n ? seqs[i] : nullptr; size_t left = i < n ? (size_t)lens[i] : padT - (size_t)T;   // the tail is padded with 'N'
+            while (left) {
+                const size_t c = std::min(left, (size_t)TH_STAGE_BYTES - fill);
+                if (src) { memcpy(g->h_stage[cur] + fill, src, c); src += c; } else memset(g->h_stage[cur] + fill, 'N', c);
+                fill += c; left -= c;
+                if (fill == TH_STAGE_BYTES) TRY(flush());
+            }
+        }
+        TRY(flush());
+    }
     TRY(th_rt_h2d(g->d_roff.p, g->h_roff.data(), ((size_t)n + 1) * 4, g->stream));
     TRY(th_rt_h2d(g->d_gsort_off.p, g->h_gsort_off.data(), (size_t)n * 8, g->stream));
     TRY(th_rt_sync(g->stream));
@@ -208,8 +253,10 @@ static long long poa_need_ints(const ThTask &t, double cell_factor, bool noband 
     const long long w = TH_POA_WB + t.max_len / 100;
     long long rows = std::min<long long>(cap, (long long)(2.2 * t.max_len) + 64);
     long long cells = (long long)(rows * (2 * w + 1 + 48) * cell_factor);
-    if (noband) cells = (long long)(cap * ((long long)t.max_len + 4) * (cell_factor > 1.5 ? 1.25 : 1.0));   // full rows over every node
-    return (graph + 5 * cells + 63) & ~63LL;
+    // per band cell: 2 bytes of direction word, and room for one cell in eight to be stored in full (16 bytes) -- th_k_poa splits the
+    // rest of the scratch half and half; without a band every row is stored in full (4.5 ints per cell)
+    if (noband) { cells = (long long)(cap * ((long long)t.max_len + 4) * (cell_factor > 1.5 ? 1.25 : 1.0)); return (graph + 5 * cells + 63) & ~63LL; }
+    return (graph + cells + 63) & ~63LL;
 }
 
 // per-kernel device time: HIP events recorded on the pipeline's own stream around each launch
@@ -248,7 +295,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
 #ifndef TH_CPU_EMUL
     KTimer kt; kt.s = g->stream;
 #endif
-    int rec_cap = n * 8 + 4096;
+    int rec_cap = std::max(n, g->reserve_n) * 8 + 4096;
     if (getenv("TH_REC_CAP")) rec_cap = std::max(1, atoi(getenv("TH_REC_CAP")));      // test knob: forces the arena-growth path
     TRY(g->d_tmp.ensure(padT)); TRY(g->d_hit_end.ensure(padT)); TRY(g->d_hit_per.ensure(padT)); TRY(g->d_hit_n.ensure(n));
     TRY(g->d_score.ensure(padT)); TRY(g->d_from.ensure(padT)); TRY(g->d_cells.ensure(padT)); TRY(g->d_tracked.ensure(padT));
@@ -357,7 +404,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         TRY(th_rt_sync(g->stream));
     } else TRY(th_rt_sync(g->stream));
 
-    if (getenv("TH_TRACE")) fprintf(stderr, "[th] %.3f s: stages 1-3 done, %d chains\n", th_wall_s() - t_run0, n_rec);
+    if (getenv("TH_TRACE")) fprintf(stderr, "[th] %.3f s: stages 1-3 done, %d chains (device malloc %.3f s for %.2f GB in %d calls, free %.3f s so far)\n", th_wall_s() - t_run0, n_rec, g_alloc_s, g_alloc_bytes / 1e9, g_alloc_n, g_free_s);
     build_jobs(g);
     const int nt = (int)g->h_tasks.size();
     g->jobs.resize(nt);
@@ -391,7 +438,9 @@ extern "C" int th_gpu_run(th_gpu_t *g)
             for (int t : grp) { need = std::max(need, poa_need_ints(g->h_tasks[t], factor, noband)); max_unit = std::max(max_unit, g->h_tasks[t].max_len); }
             const int poa_flags = (noband ? 1 : 0) | poa_test_fail << 8;
             const int wv = (int)std::min<long long>(std::min<long long>((long long)grp.size(), g->waves_poa), std::max<long long>(1, (64LL << 30) / (need * 4)));
-            TRY(g->d_scratch.ensure((size_t)(need * wv)));
+            // a handle reserved for larger batches takes the scratch of the full persistent grid at once (with slack for longer units)
+            const long long wv_alloc = (g->reserve_n > g->n && !noband) ? std::min<long long>(std::min<long long>(g->reserve_n, g->waves_poa), std::max<long long>(1, (64LL << 30) / (need * 4))) : wv;
+            TRY(g->d_scratch.ensure((size_t)(need * std::max<long long>(wv, wv_alloc))));
             const ThTask *dt = g->d_tasks.p; int *dcl = g->d_cons_len.p, *dst = g->d_status.p;
             DBuf<ThTask> &d_sub = g->d_sub; DBuf<int> &d_scl = g->d_scl, &d_sst = g->d_sst;
             const bool whole = (int)grp.size() == nt;            // every task in its original order: the main arrays serve
@@ -521,6 +570,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
             j.max_q_l = g->h_ext[4 * t]; j.max_t_l = g->h_ext[4 * t + 1]; j.max_q_r = g->h_ext[4 * t + 2]; j.max_t_r = g->h_ext[4 * t + 3];
         }
     }
+    if (getenv("TH_TRACE")) fprintf(stderr, "[th] %.3f s: run done (this thread so far: device malloc %.3f s for %.2f GB in %d calls, free %.3f s)\n", th_wall_s() - t_run0, g_alloc_s, g_alloc_bytes / 1e9, g_alloc_n, g_free_s);
 #ifndef TH_CPU_EMUL
     kt.collect(g->ms_k);
 #endif

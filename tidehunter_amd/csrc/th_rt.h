@@ -22,6 +22,11 @@ static inline int th_rt_memset(void *d, int v, size_t n, th_stream_t) { memset(d
 static inline int th_rt_sync(th_stream_t) { return 0; }
 static inline int th_rt_host_alloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : -1; }
 static inline int th_rt_host_free(void *p) { free(p); return 0; }
+typedef int th_event_t;
+static inline int th_rt_event_create(th_event_t *e) { *e = 0; return 0; }
+static inline int th_rt_event_record(th_event_t, th_stream_t) { return 0; }
+static inline int th_rt_event_wait(th_event_t) { return 0; }
+static inline int th_rt_event_destroy(th_event_t) { return 0; }
 #define TH_LAUNCH(kernel, grid, block, stream, ...) hipemul::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
 #define TH_LANE() ((int)(threadIdx.x & 63))
 #else
@@ -36,6 +41,11 @@ static inline int th_rt_memset(void *d, int v, size_t n, th_stream_t s) { if (n)
 static inline int th_rt_sync(th_stream_t s) { TH_CHECK(hipStreamSynchronize(s)); return 0; }
 static inline int th_rt_host_alloc(void **p, size_t n) { TH_CHECK(hipHostMalloc(p, n ? n : 1, hipHostMallocDefault)); return 0; }
 static inline int th_rt_host_free(void *p) { if (p) TH_CHECK(hipHostFree(p)); return 0; }
+typedef hipEvent_t th_event_t;
+static inline int th_rt_event_create(th_event_t *e) { TH_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming)); return 0; }
+static inline int th_rt_event_record(th_event_t e, th_stream_t s) { TH_CHECK(hipEventRecord(e, s)); return 0; }
+static inline int th_rt_event_wait(th_event_t e) { TH_CHECK(hipEventSynchronize(e)); return 0; }
+static inline int th_rt_event_destroy(th_event_t e) { TH_CHECK(hipEventDestroy(e)); return 0; }
 // a launch the runtime rejects (resource limits, wrong device, ...) must not pass silently: the enclosing function returns
 // th_launch_failed(...) (an int, defined by the pipeline before its first launch)
 #define TH_LAUNCH(kernel, grid, block, stream, ...) do { hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__); \
