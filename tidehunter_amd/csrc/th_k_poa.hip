@@ -80,7 +80,7 @@ struct ThPoaG {
     int *r_off, *r_foff;       // offset of a row's band start among the direction words / among the full cells (rows that store them)
     int *cntB, *headB, *aft;
     int *ops, *pv, *glo, *pth;
-    int4 *cell; uint16_t *dcell; long long cell_cap, full_cap;     // full cells (rows some far row will read, rows of in-degree > 4) / 16-bit direction words (all other rows)
+    int4 *cell; uint16_t *dcell; long long cell_bytes;     // full cells (rows some far row will read, rows of in-degree > 4) / 16-bit direction words (all other rows)
 };
 
 __device__ __forceinline__ int th_poa_in(const ThPoaG &g, int v, int ord)
@@ -359,13 +359,15 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         const int myslot = i & 3, lslot = (i - 1) & 3;
         const bool cache_me = cache16_ok && e - b < TH_POA_RW;
         const bool store_full = needfull || !cache_me || inn > TH_D16_WIDE_DEG;     // otherwise only the 16-bit direction word leaves the CU
-        // direction words (2 bytes per cell, every row) and full cells (16 bytes, only the rows that store them) live in separate
-        // regions with their own running offsets: the scratch of a wave shrinks from ~18 to ~3 bytes per band cell
-        if (ncell + span > g.cell_cap || (store_full && nfull + span > g.full_cap)) return -3;
+        // direction words (2 bytes per cell, every row) grow upwards from the start of the cell region; full cells (16 bytes, only the
+        // rows that store them: g.cell points at the END of the region and their offsets are negative) grow downwards from its end.
+        // A wave's scratch shrinks from ~18 to ~3-6 bytes per band cell, whatever the share of rows stored in full.
+        if (store_full) nfull += span;
+        if ((ncell + span) * 2 + nfull * 16 > g.cell_bytes) return -3;
         const int my_off = (int)ncell + (b - B0);                // offset of column b, as every reader expects
-        const int my_foff = store_full ? (int)nfull + (b - B0) : 0;
+        const int my_foff = store_full ? -(int)nfull + (b - B0) : 0;
         int4 *row = g.cell + my_foff; uint16_t *drow = g.dcell + my_off;
-        ncell += span; if (store_full) nfull += span;
+        ncell += span;
         int rmax = TH_NEG - 0x10000000, left = b, right = b;
         const bool pk = !WIDE && LQ && ring_all && cache_me && !needfull;    // rows some far row will read take the 32-bit path (they store whole cells)
         const int npk = fast ? 1 : inn;
@@ -822,17 +824,12 @@ th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict
         g.r_off = th_carve(p, cap); g.r_foff = th_carve(p, cap);
         g.cntB = th_carve(p, cap); g.headB = th_carve(p, cap); g.aft = th_carve(p, cap);
         g.ops = th_carve(p, 2 * opn); g.pv = th_carve(p, opn); g.glo = th_carve(p, opn); g.pth = th_carve(p, opn + 2);
-        // what is left: half for the direction words (2 bytes per cell), half for the full cells (16 bytes; normally a few per cent of
-        // the rows store them, so one cell in eight is plenty -- a job that needs more comes back with status 2 and is retried with
-        // more scratch); the rerun without a band stores every row in full: one share in nine for the direction words
         {
-            const long long avail = scratch_ints - (p - my);
-            const long long dints = (noband ? avail / 9 : avail / 2) & ~3LL;
-            g.cell_cap = dints * 2; g.full_cap = (avail - dints) / 4;
-            g.dcell = (uint16_t *)p; g.cell = (int4 *)(p + dints);
+            const long long avail = (scratch_ints - (p - my)) & ~3LL;
+            g.cell_bytes = avail * 4; g.dcell = (uint16_t *)p; g.cell = (int4 *)(p + avail);
         }
         int st = 0;
-        if (p - my > scratch_ints || g.cell_cap < 64) st = 1;
+        if (p - my > scratch_ints || g.cell_bytes < 4096) st = 1;
         if (!st) th_poa_seed(g, rb + U[0].start, U[0].len);
         for (int s = 1; s < T.n_units && !st; ++s) {
             const uint8_t *q = rb + U[s].start; const int qlen = U[s].len;

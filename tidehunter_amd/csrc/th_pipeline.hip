@@ -253,10 +253,11 @@ static long long poa_need_ints(const ThTask &t, double cell_factor, bool noband 
     const long long w = TH_POA_WB + t.max_len / 100;
     long long rows = std::min<long long>(cap, (long long)(2.2 * t.max_len) + 64);
     long long cells = (long long)(rows * (2 * w + 1 + 48) * cell_factor);
-    // per band cell: 2 bytes of direction word, and room for one cell in eight to be stored in full (16 bytes) -- th_k_poa splits the
-    // rest of the scratch half and half; without a band every row is stored in full (4.5 ints per cell)
+    // per band cell: 2 bytes of direction word, plus 16 bytes for the rows that store full cells (measured share: well under a
+    // quarter); the two kinds grow towards each other inside one region, so only their sum matters.  `cells` already carries the
+    // attempt's factor (1.5 at first): 8 bytes per estimated cell (4 sent 2.5 % of the headline jobs into a second pass).  Without a band every row is stored in full (18 bytes per cell).
     if (noband) { cells = (long long)(cap * ((long long)t.max_len + 4) * (cell_factor > 1.5 ? 1.25 : 1.0)); return (graph + 5 * cells + 63) & ~63LL; }
-    return (graph + cells + 63) & ~63LL;
+    return (graph + 2 * cells + 63) & ~63LL;
 }
 
 // per-kernel device time: HIP events recorded on the pipeline's own stream around each launch
