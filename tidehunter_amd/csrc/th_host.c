@@ -713,7 +713,7 @@ static void *pipe_device(void *arg)
 int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *devices_in, int n_dev_in, int batch_reads)
 {
     if (n_dev_in < 1 || n_dev_in > TH_MAX_DEV) return host_fail("between 1 and 16 devices");
-    if (batch_reads <= 0) batch_reads = 65536;
+    if (batch_reads <= 0) batch_reads = 32768;      /* two workers x (per-position arrays + POA scratch) stay under ~100 GB of HBM */
     /* Two workers (handle + stream each) per listed device by default: while one batch's kernels run, the other worker uploads
      * its next batch (pinned staging + H2D) and does the host-side record arithmetic of its previous one, so the device does
      * not idle between batches.  TH_WORKERS_PER_DEV=1 restores one worker per device. */

@@ -28,23 +28,35 @@ static int th_launch_failed(const char *kernel, const char *why) { return th_fai
 #include "th_k_align.hip"
 
 #define TH_STAGE_BYTES (16u << 20)
+#define TH_POA_SCRATCH_BYTES (96LL << 30)       // upper limit of the POA scratch of one handle (HBM: 288 GB; two handles may share a device)
 // seconds this thread spent in device malloc / free and the bytes it asked for (TH_TRACE prints them per run)
 static thread_local double g_alloc_s = 0, g_free_s = 0; static thread_local long long g_alloc_bytes = 0; static thread_local int g_alloc_n = 0;
+// One device allocation per handle, made when the handle first learns its batch size (th_gpu_reserve / the first upload), from
+// which the buffers below are carved.  hipMalloc while ANOTHER stream of the process is running kernels waits for a kernel
+// boundary each time (measured with two workers on one device: 28 calls took 5.9 s next to persistent kernels of 0.1-0.6 s each,
+// 0.009 s on an idle device), so a worker must not allocate piecemeal while its neighbour computes.  A buffer that outgrows the
+// arena falls back to its own hipMalloc.
+struct Arena { char *base = nullptr; size_t cap = 0, top = 0; };
+static thread_local Arena *g_arena = nullptr;
 template <class T> struct DBuf {
-    T *p = nullptr; size_t cap = 0;
+    T *p = nullptr; size_t cap = 0; bool in_arena = false;
     int ensure(size_t n) {
         if (n <= cap) return 0;
         double t0 = th_wall_s();
-        if (p) th_rt_free(p);
+        if (p && !in_arena) th_rt_free(p);          // (an arena region that is outgrown is simply abandoned)
         g_free_s += th_wall_s() - t0;
-        p = nullptr; cap = 0;
+        p = nullptr; cap = 0; in_arena = false;
         size_t want = n + n / 8 + 64;
+        const size_t bytes = (want * sizeof(T) + 255) & ~(size_t)255;
+        if (g_arena && g_arena->base && g_arena->top + bytes <= g_arena->cap) {
+            p = (T *)(g_arena->base + g_arena->top); g_arena->top += bytes; in_arena = true; cap = want; return 0;
+        }
         t0 = th_wall_s();
         if (th_rt_malloc((void **)&p, want * sizeof(T))) return -1;
         g_alloc_s += th_wall_s() - t0; g_alloc_bytes += (long long)(want * sizeof(T)); ++g_alloc_n;
         cap = want; return 0;
     }
-    void release() { if (p) th_rt_free(p); p = nullptr; cap = 0; }
+    void release() { if (p && !in_arena) th_rt_free(p); p = nullptr; cap = 0; in_arena = false; }
 };
 
 #ifndef TH_CPU_EMUL
@@ -65,7 +77,7 @@ struct th_gpu {
     DBuf<ThChainRec> d_rec;
     DBuf<int> d_par, d_par_off, d_par_n, d_par_dst, d_parc, d_bnd, d_scratch, d_cov, d_cons_len, d_status, d_iden, d_ext;
     DBuf<ThTask> d_tasks, d_sub; DBuf<ThUnit> d_units; DBuf<ThAlnItem> d_items; DBuf<int> d_scl, d_sst;   // d_sub/d_scl/d_sst: task subsets of POA relaunches
-    int n_rec = 0, reserve_n = 0;
+    int n_rec = 0, reserve_n = 0; Arena arena;
     std::vector<ThChainRec> h_rec; std::vector<int> h_par_n, h_par_dst, h_parc, h_read_ch_base, h_read_ch_n;
     std::vector<ThTask> h_tasks; std::vector<ThUnit> h_units; std::vector<ThAlnItem> h_items;
     std::vector<int> h_cons_len, h_status, h_iden, h_ext, h_cov; std::vector<uint8_t> h_cons;
@@ -110,6 +122,7 @@ extern "C" void th_gpu_destroy(th_gpu_t *g)
 #ifndef TH_CPU_EMUL
     (void)hipSetDevice(g->device);
 #endif
+    g_arena = nullptr;
     g->d_seq.release(); g->d_bseq.release(); g->d_tracked.release(); g->d_sub.release(); g->d_scl.release(); g->d_sst.release(); g->d_cons_c.release(); g->d_cov_c.release(); g->d_cc_len.release(); g->d_cc_off.release(); g->d_eps.release(); g->d_xovf.release(); g->d_xorder.release(); g->d_xstart.release(); g->d_xend.release(); g->d_cons.release(); g->d_roff.release(); g->d_tmp.release();
     g->d_hit_end.release(); g->d_hit_per.release(); g->d_hit_n.release(); g->d_score.release(); g->d_from.release(); g->d_cells.release();
     g->d_cnt.release(); g->d_read_ch_base.release(); g->d_read_ch_n.release(); g->d_gsort.release(); g->d_gsort_off.release(); g->d_rec.release();
@@ -117,6 +130,7 @@ extern "C" void th_gpu_destroy(th_gpu_t *g)
     g->d_cov.release(); g->d_cons_len.release(); g->d_status.release(); g->d_iden.release(); g->d_ext.release();
     g->d_tasks.release(); g->d_units.release(); g->d_items.release();
     if (g->stage_ok) for (int b = 0; b < 2; ++b) { th_rt_host_free(g->h_stage[b]); th_rt_event_destroy(g->stage_ev[b]); }
+    if (g->arena.base) th_rt_free(g->arena.base);
 #ifndef TH_CPU_EMUL
     hipStreamDestroy(g->stream);
 #endif
@@ -133,7 +147,32 @@ static int th_select_device(const th_gpu *g)
 #ifndef TH_CPU_EMUL
     if (hipSetDevice(g->device) != hipSuccess) return th_fail("hipSetDevice(" + std::to_string(g->device) + ") failed");
 #endif
-    (void)g; return 0;
+    g_arena = const_cast<Arena *>(&g->arena);
+    return 0;
+}
+
+// The handle's arena, sized for batches of up to n reads / T bases: ~48 bytes per base of per-position arrays, the POA scratch of
+// the full persistent grid at ~100 ints per base of the average read (3.7 MB per wave at the headline shape; long-period batches
+// need more and take their scratch from hipMalloc), and room for the per-job arrays.
+static int th_arena_create(th_gpu *g, int n, long long T)
+{
+    if (g->arena.base || n <= 0 || T <= 0) return 0;
+    const double avg = (double)T / n;
+    const size_t poa = (size_t)std::min<double>((double)TH_POA_SCRATCH_BYTES / 2, 100.0 * avg * 4.0 * std::min(n, g->waves_poa) * 1.15);
+    size_t want = (size_t)(50.0 * (double)T) + (size_t)n * 256 + poa + (64u << 20);
+#ifndef TH_CPU_EMUL
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && want > fr / 2) want = fr / 2;     // never more than half of what is free
+#endif
+#ifndef TH_CPU_EMUL
+    if (want < (96u << 20)) return 0;                     // tiny batches (tests): plain allocations
+#endif
+    const double t0 = th_wall_s();
+    void *p = nullptr;
+    if (th_rt_malloc(&p, want)) return 0;                 // no arena: every buffer allocates for itself
+    g_alloc_s += th_wall_s() - t0; g_alloc_bytes += (long long)want; ++g_alloc_n;
+    g->arena.base = (char *)p; g->arena.cap = want; g->arena.top = 0;
+    return 0;
 }
 
 // Sizes every per-read / per-base buffer for batches of up to n reads and T bases, so that a run of growing batches (the file
@@ -144,6 +183,7 @@ extern "C" int th_gpu_reserve(th_gpu_t *g, int n, long long T)
     TRY(th_select_device(g));
     if (n <= 0 || T <= 0) return 0;
     if (T >= (1LL << 31)) T = (1LL << 31) - 64;
+    TRY(th_arena_create(g, n, T));
     const size_t padT = (size_t)((T + 15) & ~15LL);
     TRY(g->d_seq.ensure(padT)); TRY(g->d_bseq.ensure(padT)); TRY(g->d_roff.ensure((size_t)n + 1)); TRY(g->d_gsort_off.ensure((size_t)n));
     TRY(g->d_tmp.ensure(padT)); TRY(g->d_hit_end.ensure(padT)); TRY(g->d_hit_per.ensure(padT)); TRY(g->d_hit_n.ensure(n));
@@ -172,6 +212,7 @@ extern "C" int th_gpu_upload(th_gpu_t *g, const char *const *seqs, const int *le
         if (N > TH_XSORT_LDS) { g->h_gsort_off[i] = gs; gs += N; }
     }
     g->gsort_total = gs;
+    TRY(th_arena_create(g, n, T));                        // (no-op once the handle has one)
     TRY(g->d_seq.ensure(padT)); TRY(g->d_bseq.ensure(padT)); TRY(g->d_roff.ensure((size_t)n + 1));
     TRY(g->d_gsort_off.ensure((size_t)n)); TRY(g->d_gsort.ensure((size_t)gs));
     // The reads go to HBM through two small pinned staging buffers: while one is on its way (async H2D) the host concatenates
@@ -244,20 +285,23 @@ static void build_jobs(th_gpu *g)
     }
 }
 
-static long long poa_need_ints(const ThTask &t, double cell_factor, bool noband = false)
+// Scratch of one POA wave for task t, in ints.  Mirrors the carve in th_k_poa: 39 node / row arrays of `cap`, the overflow pool,
+// the alignment-op arrays, then the cell region.  Cell region: every band cell has a 2-byte direction word; rows that store full
+// cells add 16 bytes per cell -- a few per cent of the rows when the band fits the LDS ring, EVERY row when it does not (the 32-bit
+// variant on long units: measured band ~ 2w + 1 + len / 30 at 15 % error).  Graph rows grow by ~9 % of the unit length per unit
+// (measured: 1.27 x at 4 units of 5000, ~1.5 x at 9 units of 1000, ~2.6 x at 20 units of 200).  cell_factor is the attempt's
+// safety factor (1.5 at first, doubled for the jobs that come back with "scratch too small").
+static long long poa_need_ints(const ThTask &t, double cell_factor, bool noband = false, bool wide = false)
 {
     if (t.n_units <= 2) return 0;
-    // mirrors the carve in th_k_poa: 39 node/row arrays of `cap`, the overflow pool, the alignment-op arrays
     const long long cap = t.sum_len + 2, ocap = 2LL * (t.sum_len + t.n_units + 8), opn = cap + t.max_len + 2;
-    long long graph = 39 * cap + 2 * ocap + 5 * opn + 512;
+    const long long graph = 39 * cap + 2 * ocap + 5 * opn + 512;
+    if (noband) return (graph + (long long)(cap * ((long long)t.max_len + 4) * (cell_factor > 1.5 ? 1.25 : 1.0) * 4.5) + 63) & ~63LL;   // full rows, all stored in full
     const long long w = TH_POA_WB + t.max_len / 100;
-    long long rows = std::min<long long>(cap, (long long)(2.2 * t.max_len) + 64);
-    long long cells = (long long)(rows * (2 * w + 1 + 48) * cell_factor);
-    // per band cell: 2 bytes of direction word, plus 16 bytes for the rows that store full cells (measured share: well under a
-    // quarter); the two kinds grow towards each other inside one region, so only their sum matters.  `cells` already carries the
-    // attempt's factor (1.5 at first): 8 bytes per estimated cell (4 sent 2.5 % of the headline jobs into a second pass).  Without a band every row is stored in full (18 bytes per cell).
-    if (noband) { cells = (long long)(cap * ((long long)t.max_len + 4) * (cell_factor > 1.5 ? 1.25 : 1.0)); return (graph + 5 * cells + 63) & ~63LL; }
-    return (graph + 2 * cells + 63) & ~63LL;
+    const long long span = 2 * w + 1 + 48 + t.max_len / 30;
+    const long long rows = std::min<long long>(cap, (long long)(t.max_len * (1.0 + 0.09 * (t.n_units - 1))) + 64);
+    const bool all_full = wide && span + 16 >= TH_POA_RW;
+    return (graph + (long long)(rows * span * cell_factor * (all_full ? 4.5 : 1.5)) + 63) & ~63LL;
 }
 
 // per-kernel device time: HIP events recorded on the pipeline's own stream around each launch
@@ -436,11 +480,11 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         auto run_group = [&](const std::vector<int> &grp, bool wide, std::vector<int> &again, std::vector<int> &to_wide) -> int {
             if (grp.empty()) return 0;
             long long need = 1024; int max_unit = 0;
-            for (int t : grp) { need = std::max(need, poa_need_ints(g->h_tasks[t], factor, noband)); max_unit = std::max(max_unit, g->h_tasks[t].max_len); }
+            for (int t : grp) { need = std::max(need, poa_need_ints(g->h_tasks[t], factor, noband, wide)); max_unit = std::max(max_unit, g->h_tasks[t].max_len); }
             const int poa_flags = (noband ? 1 : 0) | poa_test_fail << 8;
-            const int wv = (int)std::min<long long>(std::min<long long>((long long)grp.size(), g->waves_poa), std::max<long long>(1, (64LL << 30) / (need * 4)));
+            const int wv = (int)std::min<long long>(std::min<long long>((long long)grp.size(), g->waves_poa), std::max<long long>(1, (TH_POA_SCRATCH_BYTES) / (need * 4)));
             // a handle reserved for larger batches takes the scratch of the full persistent grid at once (with slack for longer units)
-            const long long wv_alloc = (g->reserve_n > g->n && !noband) ? std::min<long long>(std::min<long long>(g->reserve_n, g->waves_poa), std::max<long long>(1, (64LL << 30) / (need * 4))) : wv;
+            const long long wv_alloc = (g->reserve_n > g->n && !noband) ? std::min<long long>(std::min<long long>(g->reserve_n, g->waves_poa), std::max<long long>(1, (TH_POA_SCRATCH_BYTES) / (need * 4))) : wv;
             TRY(g->d_scratch.ensure((size_t)(need * std::max<long long>(wv, wv_alloc))));
             const ThTask *dt = g->d_tasks.p; int *dcl = g->d_cons_len.p, *dst = g->d_status.p;
             DBuf<ThTask> &d_sub = g->d_sub; DBuf<int> &d_scl = g->d_scl, &d_sst = g->d_sst;
@@ -478,7 +522,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
             }
             return 0;
         };
-        for (int attempt = 0; attempt < 6 && (!todo_n.empty() || !todo_w.empty()); ++attempt, factor *= 4) {
+        for (int attempt = 0; attempt < 8 && (!todo_n.empty() || !todo_w.empty()); ++attempt, factor *= 2) {
             std::vector<int> again_n, again_w, to_wide;
             TRY(run_group(todo_n, false, again_n, to_wide));
             todo_w.insert(todo_w.end(), to_wide.begin(), to_wide.end());     // same scratch factor: they have not run yet
@@ -507,7 +551,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
             TRY(th_rt_h2d(g->d_cons_len.p, g->h_cons_len.data(), (size_t)nt * 4, g->stream));
             TRY(th_rt_sync(g->stream));
         }
-        if (!todo.empty()) return th_fail("POA scratch still too small after 6 attempts");
+        if (!todo.empty()) return th_fail("POA scratch still too small after 8 attempts");
 #if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
         { unsigned long long pr[18]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(th_poa_prof), sizeof(pr));
           fprintf(stderr, "[poa_prof] rows %llu dp %llu traceback %llu merge %llu (cycles summed over waves)\n", pr[0], pr[1], pr[2], pr[3]);
