@@ -107,6 +107,12 @@ int th_run_file(const char *read_fn, th_para_t *p, FILE *out, int device, int ba
  * (reads are independent, src/tidehunter.c:23-60: the shards exchange nothing); output order = input order.  1 <= n_dev <= 16. */
 int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *devices, int n_dev, int batch_reads);
 
+/* The FASTA/FASTQ reader alone (kseq grammar, src/kseq.h:176-215; the reader of mini_tandem_read_seq, src/main.c:173-182), no device
+ * involved: an uncompressed file is mmap'ed and parsed in place (single-line sequences are never copied), a bgzip file is inflated by
+ * a pool of threads, plain gzip / stdin stream through zlib on a producer thread.  Returns the number of records, -1 if the file
+ * cannot be opened; *n_bases and *digest (FNV-1a over names and sequences) are optional. */
+long long th_parse_file(const char *read_fn, long long *n_bases, unsigned long long *digest);
+
 /* deterministic synthetic tandem-repeat reads; returns read length, writes at most cap bases */
 int th_synth_read(uint64_t seed, uint64_t read_index, int period, int copies, double err, char *dst, int cap);
 

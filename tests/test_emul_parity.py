@@ -234,14 +234,20 @@ def test_emul_file_driver_pipeline(emu, tmp_path):
     libc.fopen.restype = C.c_void_p; libc.fopen.argtypes = [C.c_char_p, C.c_char_p]; libc.fclose.argtypes = [C.c_void_p]
     th.lib.th_run_file_multi.argtypes = [C.c_char_p, C.POINTER(TH.Para), C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int]
     want = subprocess.run([os.path.join(O.ODIR, "tho_oracle"), "-t", "2", "-f", "2", str(fa)], check=True, capture_output=True).stdout
-    for devs, batch, env in (([0], 2, {}), ([0, 0], 3, {}), ([0], 100, {"TH_RAMP0": "1"}), ([0], 2, {"TH_WORKERS_PER_DEV": "1"})):
+    import gzip
+    gz, bgz = tmp_path / "in.fa.gz", tmp_path / "in.fa.bgz"
+    with gzip.open(gz, "wb") as f:
+        f.write(fa.read_bytes())
+    U.write_bgzf(bgz, fa.read_bytes(), block=300)
+    for devs, batch, env, src in (([0], 2, {}, fa), ([0, 0], 3, {}, fa), ([0], 100, {"TH_RAMP0": "1"}, fa), ([0], 2, {"TH_WORKERS_PER_DEV": "1"}, fa),
+                                  ([0], 3, {}, gz), ([0], 3, {}, bgz)):
         for k, v in env.items():
             os.environ[k] = v
         try:
             out = tmp_path / "out.txt"
             fp = libc.fopen(str(out).encode(), b"w")
             arr = (C.c_int * len(devs))(*devs)
-            n = th.lib.th_run_file_multi(str(fa).encode(), th.para, fp, arr, len(devs), batch)
+            n = th.lib.th_run_file_multi(str(src).encode(), th.para, fp, arr, len(devs), batch)
             libc.fclose(fp)
         finally:
             for k in env:

@@ -181,3 +181,17 @@ def config5_spec(tmpdir, n, seed=5):
     open(fns[0], "wb").write(b">5p\n" + ad[0] + b"\n")
     open(fns[1], "wb").write(b">3p\n" + ad[1] + b"\n")
     return [TH.synth_read_c5(lib, seed, i, ad) for i in range(n)], fns
+
+
+def write_bgzf(path, data: bytes, block=0xff00, level=1):
+    """block-gzipped file (bgzip / BGZF: gzip members <= 64 KiB with their size in a 'BC' extra subfield, then the empty EOF member)"""
+    import struct
+    import zlib
+    with open(path, "wb") as f:
+        for off in list(range(0, len(data), block)) + [None]:
+            chunk = b"" if off is None else data[off:off + block]
+            c = zlib.compressobj(level, zlib.DEFLATED, -15)
+            comp = c.compress(chunk) + c.flush()
+            bsize = 12 + 6 + len(comp) + 8
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1))
+            f.write(comp + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))

@@ -72,6 +72,8 @@ def load_library(path=None):
     lib.th_synth_read.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_char_p, C.c_int]
     lib.th_synth_adapter.argtypes = [C.c_uint64, C.c_int, C.c_char_p, C.c_int]
     lib.th_synth_read_c5.argtypes = [C.c_uint64, C.c_uint64, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_double, C.c_char_p, C.c_int]
+    lib.th_parse_file.argtypes = [C.c_char_p, C.POINTER(C.c_longlong), C.POINTER(C.c_ulonglong)]
+    lib.th_parse_file.restype = C.c_longlong
     lib.th_ticket_open.argtypes = [C.c_char_p, C.c_int]
     lib.th_ticket_open.restype = C.c_void_p
     lib.th_ticket_next.argtypes = [C.c_void_p, C.c_int]

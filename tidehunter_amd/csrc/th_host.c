@@ -59,59 +59,254 @@ void th_free_para(th_para_t *p)
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 /* ---------------------------------------------------------------- FASTA/FASTQ(.gz) reader (kseq grammar, src/kseq.h:176-215) */
-typedef struct { gzFile fp; unsigned char *buf; int beg, end, eof, last; } th_reader_t;
+/* Three sources behind one record grammar (the reference reads everything through one gzread loop, src/kseq.h:52-72):
+ *   MEM     an uncompressed regular file is mmap'ed and parsed in place: a sequence that sits on one line is handed on as a
+ *           pointer into the mapping (no copy at all -- the only copy left is the one into the pinned upload staging area, made
+ *           by each device worker), only names and multi-line sequences are copied.  ~10 GB/s on one thread.
+ *   BGZF    a block-gzipped file (bgzip: gzip members of <= 64 KiB whose compressed size sits in a 'BC' extra field) is mmap'ed,
+ *           its members are inflated by a pool of threads straight to their final offsets, a group of members at a time, one
+ *           group ahead of the parser.
+ *   STREAM  anything else (plain gzip, stdin): zlib on a producer thread, double-buffered, so that inflation overlaps parsing
+ *           (a single deflate stream cannot be inflated in parallel; ~0.4 GB/s). */
 typedef struct { char *s; size_t l, m; } th_str_t;
 static void str_putc(th_str_t *s, int c)
 {
     if (s->l + 2 > s->m) { s->m = s->m ? s->m * 2 : 256; s->s = (char *)realloc(s->s, s->m); }
     s->s[s->l++] = (char)c; s->s[s->l] = 0;
 }
+static void str_append(th_str_t *s, const char *p, size_t n)
+{
+    if (s->l + n + 2 > s->m) { while (s->l + n + 2 > s->m) s->m = s->m ? s->m * 2 : 256; s->s = (char *)realloc(s->s, s->m); }
+    memcpy(s->s + s->l, p, n); s->l += n; s->s[s->l] = 0;
+}
+
+enum { RD_STREAM = 0, RD_MEM = 1, RD_BGZF = 2 };
+#define RD_CHUNK (4u << 20)
+#define BGZF_GROUP 512                    /* members per group: <= 32 MiB of text */
+typedef struct { const unsigned char *src; uint32_t clen, isize; size_t out_off; } bgzf_blk_t;
+typedef struct th_reader {
+    int mode, last, eof;
+    /* the window the grammar reads from */
+    const unsigned char *buf; size_t beg, end;
+    /* STREAM: zlib on a producer thread, two buffers */
+    gzFile fp; unsigned char *sbuf[2]; long slen[2]; int sfull[2], scur, sdone, squit; pthread_t sthr; pthread_mutex_t smu; pthread_cond_t scv; int sthr_on;
+    /* MEM / BGZF: the mapping */
+    const unsigned char *map; size_t map_len;
+    /* BGZF: groups of members, inflated by a pool */
+    size_t zpos; unsigned char *gbuf[2]; size_t gcap[2], glen[2]; int gcur, gpending, zbusy, zfinished; bgzf_blk_t *blk; int nblk; volatile int next_blk; int zerr;
+    pthread_t zthr[16]; int nz; pthread_mutex_t zmu; pthread_cond_t zcv; int zgo, zdone, zquit;
+} th_reader_t;
+
+static void *stream_producer(void *arg)
+{
+    th_reader_t *r = (th_reader_t *)arg;
+    for (int b = 0;; b ^= 1) {
+        pthread_mutex_lock(&r->smu);
+        while (r->sfull[b] && !r->squit) pthread_cond_wait(&r->scv, &r->smu);
+        const int quit = r->squit;
+        pthread_mutex_unlock(&r->smu);
+        if (quit) return NULL;
+        const long n = gzread(r->fp, r->sbuf[b], RD_CHUNK);
+        pthread_mutex_lock(&r->smu);
+        r->slen[b] = n > 0 ? n : 0; r->sfull[b] = 1; if (n <= 0) r->sdone = 1;
+        pthread_cond_broadcast(&r->scv); pthread_mutex_unlock(&r->smu);
+        if (n <= 0) return NULL;
+    }
+}
+/* BGZF member at p: returns its total size and the sizes of its deflate data / text, 0 if p is not a BGZF member */
+static size_t bgzf_member(const unsigned char *p, size_t avail, uint32_t *clen, uint32_t *isize, const unsigned char **cdata)
+{
+    if (avail < 28 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+    const unsigned xlen = p[10] | p[11] << 8;
+    if (12 + (size_t)xlen > avail) return 0;
+    unsigned bsize = 0, off = 12;
+    while (off + 4 <= 12 + xlen) {
+        const unsigned slen = p[off + 2] | p[off + 3] << 8;
+        if (p[off] == 'B' && p[off + 1] == 'C' && slen == 2) bsize = (p[off + 4] | p[off + 5] << 8) + 1u;
+        off += 4 + slen;
+    }
+    if (!bsize || bsize > avail || bsize < 12 + xlen + 8) return 0;
+    *cdata = p + 12 + xlen; *clen = bsize - 12 - xlen - 8;
+    *isize = p[bsize - 4] | p[bsize - 3] << 8 | p[bsize - 2] << 16 | (uint32_t)p[bsize - 1] << 24;
+    return bsize;
+}
+static void *bgzf_worker(void *arg)
+{
+    th_reader_t *r = (th_reader_t *)arg;
+    z_stream z; int gen = 0;
+    for (;;) {
+        pthread_mutex_lock(&r->zmu);
+        while (r->zgo == gen && !r->zquit) pthread_cond_wait(&r->zcv, &r->zmu);
+        gen = r->zgo;
+        const int quit = r->zquit;
+        pthread_mutex_unlock(&r->zmu);
+        if (quit) return NULL;
+        unsigned char *out = r->gbuf[r->gpending];
+        for (;;) {
+            const int i = __atomic_fetch_add(&r->next_blk, 1, __ATOMIC_RELAXED);
+            if (i >= r->nblk) break;
+            const bgzf_blk_t *b = &r->blk[i];
+            memset(&z, 0, sizeof(z));
+            if (inflateInit2(&z, -15) != Z_OK) { r->zerr = 1; continue; }
+            z.next_in = (unsigned char *)b->src; z.avail_in = b->clen; z.next_out = out + b->out_off; z.avail_out = b->isize;
+            const int rc = inflate(&z, Z_FINISH);
+            if (rc != Z_STREAM_END || z.total_out != b->isize) r->zerr = 1;
+            inflateEnd(&z);
+        }
+        pthread_mutex_lock(&r->zmu);
+        if (++r->zdone == r->nz) pthread_cond_broadcast(&r->zcv);
+        pthread_mutex_unlock(&r->zmu);
+    }
+}
+/* indexes the next group of members and starts its inflation into gbuf[which]; returns 0 at the end of the file */
+static int bgzf_start_group(th_reader_t *r, int which)
+{
+    size_t out = 0; int n = 0;
+    while (n < BGZF_GROUP && r->zpos < r->map_len) {
+        uint32_t clen, isize; const unsigned char *cd;
+        const size_t sz = bgzf_member(r->map + r->zpos, r->map_len - r->zpos, &clen, &isize, &cd);
+        if (!sz) { r->zerr = 1; break; }
+        r->blk[n].src = cd; r->blk[n].clen = clen; r->blk[n].isize = isize; r->blk[n].out_off = out;
+        out += isize; r->zpos += sz; ++n;
+    }
+    if (n == 0) return 0;
+    if (out > r->gcap[which]) { free(r->gbuf[which]); r->gcap[which] = out + (out >> 3) + 65536; r->gbuf[which] = (unsigned char *)malloc(r->gcap[which]); }
+    r->glen[which] = out; r->nblk = n; r->next_blk = 0; r->gpending = which; r->zbusy = 1;
+    pthread_mutex_lock(&r->zmu); r->zdone = 0; ++r->zgo; pthread_cond_broadcast(&r->zcv); pthread_mutex_unlock(&r->zmu);
+    return 1;
+}
+static void bgzf_wait_group(th_reader_t *r)
+{
+    if (!r->zbusy) return;
+    pthread_mutex_lock(&r->zmu);
+    while (r->zdone < r->nz) pthread_cond_wait(&r->zcv, &r->zmu);
+    pthread_mutex_unlock(&r->zmu);
+    r->zbusy = 0;
+}
+/* next window of text; 0 at the end of the input */
+static int rd_fill(th_reader_t *r)
+{
+    if (r->eof) return 0;
+    if (r->mode == RD_MEM) { r->eof = 1; return 0; }                   /* the mapping was the only window */
+    if (r->mode == RD_STREAM) {
+        if (r->scur >= 0) {                                             /* hand the consumed buffer back */
+            pthread_mutex_lock(&r->smu); r->sfull[r->scur] = 0; pthread_cond_broadcast(&r->scv); pthread_mutex_unlock(&r->smu);
+        }
+        const int b = r->scur < 0 ? 0 : r->scur ^ 1;
+        pthread_mutex_lock(&r->smu);
+        while (!r->sfull[b]) pthread_cond_wait(&r->scv, &r->smu);
+        pthread_mutex_unlock(&r->smu);
+        r->scur = b;
+        if (r->slen[b] <= 0) { r->eof = 1; return 0; }
+        r->buf = r->sbuf[b]; r->beg = 0; r->end = (size_t)r->slen[b];
+        return 1;
+    }
+    /* BGZF: the group started earlier is (being) inflated; wait for it, expose it, start the one after it */
+    for (;;) {
+        if (r->zfinished) { r->eof = 1; return 0; }
+        if (!r->zbusy && !bgzf_start_group(r, 0)) { r->eof = 1; return 0; }
+        bgzf_wait_group(r);
+        if (r->zerr) { fprintf(stderr, "[tidehunter_amd] corrupt BGZF input\n"); r->eof = 1; return 0; }
+        const int ready = r->gpending;
+        r->buf = r->gbuf[ready]; r->beg = 0; r->end = r->glen[ready]; r->gcur = ready;
+        if (!bgzf_start_group(r, ready ^ 1)) r->zfinished = 1;
+        if (r->end > 0) return 1;
+    }
+}
 static int rd_getc(th_reader_t *r)
 {
-    if (r->beg >= r->end) {
-        if (r->eof) return -1;
-        r->beg = 0; r->end = gzread(r->fp, r->buf, 1 << 18);
-        if (r->end <= 0) { r->eof = 1; r->end = 0; return -1; }
-    }
+    if (r->beg >= r->end && !rd_fill(r)) return -1;
     return r->buf[r->beg++];
 }
-/* appends the rest of the current line to s (s may be NULL), consumes the '\n'; returns the byte count, -1 at end of file */
-static long rd_line(th_reader_t *r, th_str_t *s)
+/* Consumes the rest of the current line.  Appends it to s when s is not NULL; when zc is not NULL and the line lies in one
+ * window, *zc / *zn receive a pointer into the window instead (MEM mode: it stays valid for the whole run).  Returns the byte
+ * count (without the newline), -1 at the end of the input. */
+static long rd_line(th_reader_t *r, th_str_t *s, const char **zc, size_t *zn)
 {
     long got = 0;
+    if (zc) *zc = NULL;
     for (;;) {
-        if (r->beg >= r->end) {
-            if (r->eof) return got ? got : -1;
-            r->beg = 0; r->end = gzread(r->fp, r->buf, 1 << 18);
-            if (r->end <= 0) { r->eof = 1; r->end = 0; return got ? got : -1; }
-        }
+        if (r->beg >= r->end && !rd_fill(r)) return got ? got : -1;
         const unsigned char *p = r->buf + r->beg;
-        const int avail = r->end - r->beg;
-        const unsigned char *nl = (const unsigned char *)memchr(p, '\n', (size_t)avail);
-        const int n = nl ? (int)(nl - p) : avail;
-        if (s && n) {
-            if (s->l + (size_t)n + 2 > s->m) { while (s->l + (size_t)n + 2 > s->m) s->m = s->m ? s->m * 2 : 256; s->s = (char *)realloc(s->s, s->m); }
-            memcpy(s->s + s->l, p, (size_t)n); s->l += (size_t)n; s->s[s->l] = 0;
-        }
-        got += n; r->beg += n + (nl ? 1 : 0);
+        const size_t avail = r->end - r->beg;
+        const unsigned char *nl = (const unsigned char *)memchr(p, '\n', avail);
+        const size_t n = nl ? (size_t)(nl - p) : avail;
+        if (zc && got == 0 && r->mode == RD_MEM) { *zc = (const char *)p; *zn = n; }        /* one window: a line never spans two */
+        else if (s && n) str_append(s, (const char *)p, n);
+        got += (long)n; r->beg += n + (nl ? 1 : 0);
         if (nl) return got;
     }
 }
 static th_reader_t *rd_open(const char *fn)
 {
-    gzFile fp = strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(0, "r");
-    if (!fp) return NULL;
     th_reader_t *r = (th_reader_t *)calloc(1, sizeof(*r));
-    r->fp = fp; r->buf = (unsigned char *)malloc(1 << 18);
+    r->scur = -1; r->gcur = -1;
+    int fd = strcmp(fn, "-") ? open(fn, O_RDONLY) : -1;
+    struct stat st;
+    if (strcmp(fn, "-") && fd < 0) { free(r); return NULL; }
+    if (fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && !getenv("TH_READER_STREAM")) {
+        void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+            const unsigned char *p = (const unsigned char *)m;
+            uint32_t cl, is; const unsigned char *cd;
+            if (st.st_size >= 2 && p[0] == 0x1f && p[1] == 0x8b) {
+                if (bgzf_member(p, (size_t)st.st_size, &cl, &is, &cd)) {
+                    r->mode = RD_BGZF; r->map = p; r->map_len = (size_t)st.st_size;
+                    r->blk = (bgzf_blk_t *)malloc(sizeof(bgzf_blk_t) * BGZF_GROUP);
+                    pthread_mutex_init(&r->zmu, NULL); pthread_cond_init(&r->zcv, NULL);
+                    long nc = sysconf(_SC_NPROCESSORS_ONLN); r->nz = nc >= 32 ? 12 : nc >= 8 ? 6 : 2;
+                    { const char *e = getenv("TH_READER_THREADS"); if (e && atoi(e) >= 1 && atoi(e) <= 16) r->nz = atoi(e); }
+                    for (int t = 0; t < r->nz; ++t) pthread_create(&r->zthr[t], NULL, bgzf_worker, r);
+                    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                    close(fd);
+                    return r;
+                }
+                munmap(m, (size_t)st.st_size);           /* plain gzip: stream it */
+            } else {
+                r->mode = RD_MEM; r->map = p; r->map_len = (size_t)st.st_size; r->buf = p; r->beg = 0; r->end = (size_t)st.st_size;
+                madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                close(fd);
+                return r;
+            }
+        }
+    }
+    r->mode = RD_STREAM;
+    r->fp = fd >= 0 ? gzdopen(fd, "r") : gzdopen(0, "r");
+    if (!r->fp) { if (fd >= 0) close(fd); free(r); return NULL; }
+    gzbuffer(r->fp, 1 << 20);
+    r->sbuf[0] = (unsigned char *)malloc(RD_CHUNK); r->sbuf[1] = (unsigned char *)malloc(RD_CHUNK);
+    pthread_mutex_init(&r->smu, NULL); pthread_cond_init(&r->scv, NULL);
+    pthread_create(&r->sthr, NULL, stream_producer, r); r->sthr_on = 1;
     return r;
 }
-static void rd_close(th_reader_t *r) { if (r) { gzclose(r->fp); free(r->buf); free(r); } }
-/* Appends one record to the arena `a` as name\0sequence\0 and returns its offsets (the arena may move while it grows, so
- * callers turn offsets into pointers when the batch is complete).  1 = record read, 0 = end of file.  One arena per batch
+static void rd_close(th_reader_t *r)
+{
+    if (!r) return;
+    if (r->mode == RD_STREAM) {
+        if (r->sthr_on) {          /* the producer finishes the read it is in, sees the flag and stops */
+            pthread_mutex_lock(&r->smu); r->squit = 1; pthread_cond_broadcast(&r->scv); pthread_mutex_unlock(&r->smu);
+            pthread_join(r->sthr, NULL);
+        }
+        gzclose(r->fp); free(r->sbuf[0]); free(r->sbuf[1]);
+    } else {
+        if (r->mode == RD_BGZF) {
+            bgzf_wait_group(r);
+            pthread_mutex_lock(&r->zmu); r->zquit = 1; pthread_cond_broadcast(&r->zcv); pthread_mutex_unlock(&r->zmu);
+            for (int t = 0; t < r->nz; ++t) pthread_join(r->zthr[t], NULL);
+            free(r->gbuf[0]); free(r->gbuf[1]); free(r->blk);
+        }
+        munmap((void *)r->map, r->map_len);
+    }
+    free(r);
+}
+/* Appends one record to the arena `a` as name\0[sequence\0] and returns its offsets (the arena may move while it grows, so
+ * callers turn offsets into pointers when the batch is complete).  A sequence that sits on one line of a mapped file is not
+ * copied: *zc_seq points into the mapping and *seq_off is (size_t)-1.  1 = record read, 0 = end of file.  One arena per batch
  * slot, reused from batch to batch: no per-read malloc/free, and no page-fault storm next to the device allocations. */
-static int rd_next_into(th_reader_t *r, th_str_t *a, size_t *name_off, size_t *seq_off, int *len)
+static int rd_next_into(th_reader_t *r, th_str_t *a, size_t *name_off, size_t *seq_off, const char **zc_seq, int *len)
 {
     int c;
+    if (zc_seq) *zc_seq = NULL;
     if (r->last == 0) {
         while ((c = rd_getc(r)) != -1 && c != '>' && c != '@') {}
         if (c == -1) return 0;
@@ -122,19 +317,26 @@ static int rd_next_into(th_reader_t *r, th_str_t *a, size_t *name_off, size_t *s
     str_putc(a, 0);
     if (c != '\n' && c != -1) while ((c = rd_getc(r)) != -1 && c != '\n') {}
     *seq_off = a->l;
+    const char *zc = NULL; size_t zn = 0, sl = 0; int n_lines = 0;
+    const int want_zc = zc_seq != NULL && r->mode == RD_MEM;
     while ((c = rd_getc(r)) != -1 && c != '>' && c != '+' && c != '@') {
         if (c == '\n') continue;
-        str_putc(a, c);
-        rd_line(r, a);
-        if (a->l - *seq_off > 1 && a->s[a->l - 1] == '\r') a->s[--a->l] = 0;
+        --r->beg;                                         /* the line starts with c: take it whole */
+        if (n_lines == 1 && zc) { str_append(a, zc, zn); zc = NULL; }      /* a second line: the sequence has to be assembled */
+        const char *lz = NULL; size_t ln = 0;
+        const size_t before = a->l;
+        rd_line(r, a, (want_zc && n_lines == 0) ? &lz : NULL, &ln);
+        if (lz) { zc = lz; zn = ln; sl = ln; if (sl > 1 && zc[zn - 1] == '\r') { --zn; --sl; } }
+        else { sl += a->l - before; if (sl > 1 && a->s[a->l - 1] == '\r') { a->s[--a->l] = 0; --sl; } }
+        ++n_lines;
     }
-    const size_t sl = a->l - *seq_off;
-    str_putc(a, 0);
+    if (zc) { *zc_seq = zc; *seq_off = (size_t)-1; }
+    else str_putc(a, 0);
     r->last = (c == '>' || c == '@') ? c : 0;
     if (c == '+') {
         while ((c = rd_getc(r)) != -1 && c != '\n') {}
         size_t ql = 0; long n;
-        while (ql < sl && (n = rd_line(r, NULL)) >= 0) ql += (size_t)n;   /* quality lines until as long as the sequence */
+        while (ql < sl && (n = rd_line(r, NULL, NULL, NULL)) >= 0) ql += (size_t)n;   /* quality lines until as long as the sequence */
         r->last = 0;
     }
     *len = (int)sl;
@@ -144,8 +346,8 @@ static int rd_next_into(th_reader_t *r, th_str_t *a, size_t *name_off, size_t *s
 static int rd_next(th_reader_t *r, char **name, char **seq, int *len)
 {
     th_str_t a = { 0, 0, 0 }; size_t no, so;
-    if (!rd_next_into(r, &a, &no, &so, len)) { free(a.s); return 0; }
-    *name = strdup(a.s + no); *seq = (char *)malloc((size_t)*len + 1); memcpy(*seq, a.s + so, (size_t)*len + 1);
+    if (!rd_next_into(r, &a, &no, &so, NULL, len)) { free(a.s); return 0; }
+    *name = strdup(a.s + no); *seq = (char *)malloc((size_t)*len + 1); memcpy(*seq, a.s + so, (size_t)*len); (*seq)[*len] = 0;
     free(a.s);
     return 1;
 }
@@ -654,8 +856,8 @@ static void *pipe_reader(void *arg)
          * milliseconds of parsing instead of after a whole batch, and the pipeline fills while the batches grow */
         const long long target = i < 10 && ((long long)q->ramp0 << (2 * i)) < q->batch_reads ? ((long long)q->ramp0 << (2 * i)) : q->batch_reads;
         if (!q->stop)
-            while (n < target && bases < max_bases && rd_next_into(q->rd, &s->arena, &s->noff[n], &s->soff[n], &s->lens[n])) { bases += s->lens[n]; ++n; }
-        for (int k = 0; k < n; ++k) { s->names[k] = s->arena.s + s->noff[k]; s->seqs[k] = s->arena.s + s->soff[k]; }
+            while (n < target && bases < max_bases && rd_next_into(q->rd, &s->arena, &s->noff[n], &s->soff[n], (const char **)&s->seqs[n], &s->lens[n])) { bases += s->lens[n]; ++n; }
+        for (int k = 0; k < n; ++k) { s->names[k] = s->arena.s + s->noff[k]; if (s->soff[k] != (size_t)-1) s->seqs[k] = s->arena.s + s->soff[k]; }
         q->t_read += now_s() - t0;
         s->n = n; s->batch = i;
         if (n == 0) { pthread_mutex_lock(&q->mu); q->eof_batch = i; pthread_mutex_unlock(&q->mu); }
@@ -754,6 +956,39 @@ int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *d
 int th_run_file(const char *read_fn, th_para_t *p, FILE *out, int device, int batch_reads)
 {
     return th_run_file_multi(read_fn, p, out, &device, 1, batch_reads);
+}
+
+/* ---------------------------------------------------------------- the reader alone */
+/* Parses read_fn with the reader th_run_file uses, batch slot and all, without touching a device: the record count is returned,
+ * *n_bases receives the bases, *digest (optional: it costs about as much as the parsing) an FNV-1a hash over every name and
+ * sequence in order, so that the mmap / BGZF / stream paths can be compared.  -1 if the file cannot be opened. */
+long long th_parse_file(const char *read_fn, long long *n_bases, unsigned long long *digest)
+{
+    th_reader_t *r = rd_open(read_fn);
+    if (!r) return -1;
+    th_str_t a = { 0, 0, 0 };
+    long long n = 0, bases = 0; unsigned long long h = 1469598103934665603ull;
+    for (;;) {
+        a.l = 0;
+        int k = 0, len; size_t no, so; const char *zc;
+        while (k < 4096 && rd_next_into(r, &a, &no, &so, &zc, &len)) {
+            if (digest) {
+                const unsigned char *nm = (const unsigned char *)a.s + no;
+                for (; *nm; ++nm) h = (h ^ *nm) * 1099511628211ull;
+                const unsigned char *sq = (const unsigned char *)(so == (size_t)-1 ? zc : a.s + so);
+                unsigned long long h2 = h;
+                for (int i = 0; i < len; ++i) h2 = (h2 ^ sq[i]) * 1099511628211ull;
+                h = h2 ^ (unsigned long long)len;
+            }
+            bases += len; ++k;
+        }
+        n += k;
+        if (k < 4096) break;
+    }
+    free(a.s); rd_close(r);
+    if (n_bases) *n_bases = bases;
+    if (digest) *digest = h;
+    return n;
 }
 
 /* ---------------------------------------------------------------- synthetic reads */
