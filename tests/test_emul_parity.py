@@ -255,3 +255,26 @@ def test_emul_file_driver_pipeline(emu, tmp_path):
         assert n == len(seqs), (devs, batch, env)
         assert out.read_bytes() == want, (devs, batch, env)
     th.close()
+
+
+def test_emul_parallel_minimizer_rules(emu, monkeypatch):
+    """-w > 1: the wave-parallel selection (per-position rules) against the oracle's restatement of src/tandem_hit.c:97-157 and
+    against the sequential replay kept in the kernel (TH_MINIMIZER_SEQ=1); TH_MINIMIZER_STRICT fails the run if any read had to
+    fall back to the replay.  Inputs with N runs, runs shorter than a window, low-complexity stretches, w up to 256."""
+    rng = np.random.default_rng(7)
+    rnd = lambda n, alpha=b"ACGT": bytes(alpha[i] for i in rng.integers(0, len(alpha), n))
+    lib = TH.load_library()
+    seqs = [TH.synth_read(lib, 5, i, 80 + 7 * i, 5, 0.08) for i in range(4)]
+    seqs += [rnd(300, b"AC"), rnd(400, b"ACGTN"), b"ACGT" * 60, b"A" * 150 + rnd(100), rnd(40), rnd(12), b"ACGTNACGTNNNACGTACGTACGTTTGACAAC" * 9,
+             rnd(150) + b"N" + rnd(9) + b"N" + rnd(200), rnd(3), b""]
+    monkeypatch.setenv("TH_MINIMIZER_STRICT", "1")
+    for kw in (dict(w=5), dict(w=2, k=8), dict(w=40, k=6), dict(w=256, k=3), dict(w=7, k=16)):
+        para = O.default_para(**kw)
+        for seq_only in (False, True):
+            if seq_only:
+                monkeypatch.setenv("TH_MINIMIZER_SEQ", "1")
+            th = TH.TideHunter(lib_path=emu, **kw)
+            monkeypatch.delenv("TH_MINIMIZER_SEQ", raising=False)
+            th.process(seqs)
+            U.stage_compare(th, seqs, para)
+            th.close()

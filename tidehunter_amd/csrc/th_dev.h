@@ -9,6 +9,7 @@
 struct ThDevPara {
     int k;                       // k-mer length (-k)
     int w;                       // -w: minimizer window (1 = every k-mer)
+    int w_seq;                   // TH_MINIMIZER_SEQ=1: minimizer selection by the sequential replay only (the tests' cross-check)
     int hpc;                     // -H: homopolymer-compressed k-mers (src/tandem_hit.c:46)
     uint32_t min_p, max_p;       // period limits, cast as at src/tandem_hit.c:235
     double one_minus_div;        // 1 - max_div (src/partition.c:202,252: the one double product on the path)

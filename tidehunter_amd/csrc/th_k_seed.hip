@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(TH_SEED_BLOCK)
 th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, ThDevPara P,
           int *__restrict__ hit_end, int *__restrict__ hit_per, int *__restrict__ hit_n,
           uint32_t *__restrict__ tmp, W *__restrict__ gsort, const long long *__restrict__ gsort_off,
-          int *__restrict__ err)
+          int *__restrict__ err, int *__restrict__ n_seq_fallback)
 {
     __shared__ W lds[CAP];
     const W NONE_W = (W)~(W)0;
@@ -77,12 +77,61 @@ th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, T
     W *buf = N <= CAP ? lds : gsort + gsort_off[r];
 
     if (P.w > 1) {
-        // 1m. minimizer words (src/tandem_hit.c:97-157).  The reference's selection is a sequential state machine
-        // whose first-window and post-N gating does not reduce to "minimum of every window", so lane 0 replays it
-        // exactly over an LDS window; the other lanes pre-fill the sort buffer.  Off by default (-w 1).
+        // 1m. minimizer words (src/tandem_hit.c:97-157).  The reference's selection is a sequential state machine (one step per
+        // base: a w-slot ring of (key, position), a tracked minimum, emissions gated by the length l of the current A/C/G/T run).
+        // Without -H it is replayed in parallel from three per-position facts: the tracked minimum after step t is always the
+        // smallest key of the last w slots, newest slot on ties (the `<=` of the replacement and the `>=` of the rescan); a word is
+        // written only when the minimum is replaced (l >= w+k), leaves the ring (l >= w+k-1; then also the ties of its successor),
+        // when the first window of a run completes (l == w+k-1: the ties of the minimum), and once at the end of the read.  Every
+        // thread evaluates those rules for its steps and marks the slots whose words the reference writes.  The sequential replay
+        // stays below: it serves -H, any read on which a slot would be marked twice (the reference would then write a word twice;
+        // not seen on any test input), and TH_MINIMIZER_SEQ=1 (P.w < 0 on entry), the tests' cross-check of the parallel rules.
         for (int e = tid; e < N; e += TH_SEED_BLOCK) buf[e] = NONE_W;
+        const bool seq_only = P.hpc || P.w_seq;
+        __shared__ int s_n, s_dup;
+        if (tid == 0) { s_n = 0; s_dup = seq_only ? 1 : 0; }
         __syncthreads();
-        if (tid == 0) {
+        if (!seq_only) {
+            const int w = P.w, wk = w + k;
+            const uint32_t NONE = 0xffffffffu;
+            uint32_t *KEY = (uint32_t *)hit_end + off; int *LEN = hit_per + off; uint32_t *MARK = tmp + off;   // scratch until the sort: all three are rewritten below
+            for (int t = tid; t < L; t += TH_SEED_BLOCK) {
+                int l = 0; while (l < wk && t - l >= 0 && b[t - l] < 4) ++l;        // run length ending at t, capped at w + k
+                uint32_t key = NONE;
+                if (l >= k) { key = 0; for (int x = k - 1; x >= 0; --x) key = key << 2 | b[t - x]; }
+                KEY[t] = key; LEN[t] = l; MARK[t] = 0;
+            }
+            __syncthreads();
+            for (int t = tid; t < L; t += TH_SEED_BLOCK) {
+                // minimum of the ring before this step (slots t-w .. t-1) and after it (t-w+1 .. t), newest slot on ties
+                uint32_t pk = NONE, ck = NONE; int ps = -1, cs = -1;
+                for (int x = max(0, t - w); x <= t; ++x) {
+                    const uint32_t kx = KEY[x];
+                    if (x < t && kx <= pk) { pk = kx; ps = x; }
+                    if (x > t - w && kx <= ck) { ck = kx; cs = x; }
+                }
+                const int l = LEN[t]; const uint32_t kt = KEY[t];
+                if (t >= 1) {
+                    if (l == wk - 1 && pk != NONE)                                  // the run's first full window: ties of the minimum (:126-131)
+                        for (int x = max(0, t - w + 1); x < t; ++x) if (KEY[x] == pk && x != ps) atomicAdd(&MARK[x], 1u);
+                    if (kt <= pk) { if (l >= wk && pk != NONE) atomicAdd(&MARK[ps], 1u); }          // replaced (:133-135)
+                    else if (ps == t - w) {                                                          // left the ring (:136-148)
+                        if (l >= wk - 1 && pk != NONE) atomicAdd(&MARK[ps], 1u);
+                        if (l >= wk - 1 && ck != NONE) for (int x = t - w + 1; x <= t; ++x) if (KEY[x] == ck && x != cs) atomicAdd(&MARK[x], 1u);
+                    }
+                }
+                if (t == L - 1 && ck != NONE) atomicAdd(&MARK[cs], 1u);            // :151
+            }
+            __syncthreads();
+            for (int t = tid; t < L; t += TH_SEED_BLOCK) {
+                const uint32_t m = TH_LOAD_L2(&MARK[t]);
+                if (m) { const int n = atomicAdd(&s_n, 1); if (n < N) buf[n] = (W)((W)KEY[t] << PB | (uint32_t)t); if (m > 1) s_dup = 1; }
+            }
+            __syncthreads();
+            if (s_dup) { for (int e = tid; e < N; e += TH_SEED_BLOCK) buf[e] = NONE_W; if (tid == 0) atomicAdd(n_seq_fallback, 1); }
+            __syncthreads();
+        }
+        if (tid == 0 && s_dup) {
             const int w = P.w;
             const uint32_t mask = k >= 16 ? 0xffffffffu : (1u << (2 * k)) - 1u, NONE = 0xffffffffu;
             uint32_t key = 0, sel_key = NONE, sel_pos = NONE;

@@ -95,7 +95,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
 {
     th_gpu *g = new th_gpu();
     g->para = *p;
-    g->dp.k = p->k; g->dp.w = p->w; g->dp.hpc = p->hpc; g->dp.min_p = p->min_p; g->dp.max_p = p->max_p; g->dp.one_minus_div = p->one_minus_div; g->dp.min_copy = p->min_copy;
+    g->dp.k = p->k; g->dp.w = p->w; g->dp.w_seq = env_int("TH_MINIMIZER_SEQ", 0) ? 1 : 0; g->dp.hpc = p->hpc; g->dp.min_p = p->min_p; g->dp.max_p = p->max_p; g->dp.one_minus_div = p->one_minus_div; g->dp.min_copy = p->min_copy;
     g->dp.match = p->match; g->dp.mismatch = p->mismatch; g->dp.go1 = p->go1; g->dp.ge1 = p->ge1; g->dp.go2 = p->go2; g->dp.ge2 = p->ge2;
     g->device = device;
 #ifdef TH_CPU_EMUL
@@ -346,14 +346,14 @@ extern "C" int th_gpu_run(th_gpu_t *g)
     TRY(g->d_score.ensure(padT)); TRY(g->d_from.ensure(padT)); TRY(g->d_cells.ensure(padT)); TRY(g->d_tracked.ensure(padT));
     TRY(g->d_xorder.ensure(padT)); TRY(g->d_xstart.ensure(padT)); TRY(g->d_xend.ensure(padT));
     TRY(g->d_xovf.ensure((size_t)std::min(n, g->waves_xw) * 7 * (TH_TOPN - TH_TOPL)));
-    TRY(g->d_cnt.ensure(8)); TRY(g->d_read_ch_base.ensure(n)); TRY(g->d_read_ch_n.ensure(n)); TRY(g->d_rec.ensure(rec_cap));
-    TRY(th_rt_memset(g->d_cnt.p, 0, 8 * sizeof(int), g->stream));
+    TRY(g->d_cnt.ensure(16)); TRY(g->d_read_ch_base.ensure(n)); TRY(g->d_read_ch_n.ensure(n)); TRY(g->d_rec.ensure(rec_cap));
+    TRY(th_rt_memset(g->d_cnt.p, 0, 16 * sizeof(int), g->stream));
 
     const int enc_blocks = (int)std::min<long long>(2048, (T / 16 + 255) / 256 + 1);
     KT_BEGIN(TK_SEED);
     TH_LAUNCH(th_k_encode, enc_blocks, 256, g->stream, (const uint8_t *)g->d_seq.p, g->d_bseq.p, (long long)T);
 #define HITS_LAUNCH(W, PB, CAP, GS) TH_LAUNCH((th_k_hits<W, PB, CAP>), n, TH_SEED_BLOCK, g->stream, (const uint8_t *)g->d_bseq.p, (const uint32_t *)g->d_roff.p, g->dp, \
-                  g->d_hit_end.p, g->d_hit_per.p, g->d_hit_n.p, g->d_tmp.p, GS, (const long long *)g->d_gsort_off.p, g->d_cnt.p + 1)
+                  g->d_hit_end.p, g->d_hit_per.p, g->d_hit_n.p, g->d_tmp.p, GS, (const long long *)g->d_gsort_off.p, g->d_cnt.p + 1, g->d_cnt.p + 8)
     // 32-bit sort words when key << PB | pos stays below the all-ones sentinel and every read sorts in LDS
     if (g->dp.k <= 9 && g->max_len < 16384) HITS_LAUNCH(uint32_t, 14, 16384, (uint32_t *)nullptr);
     else if (g->dp.k <= 8 && g->max_len < 32768) HITS_LAUNCH(uint32_t, 15, 32768, (uint32_t *)nullptr);
@@ -371,7 +371,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
               (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, (const int *)g->d_score.p,
               g->d_xorder.p, g->d_xstart.p, g->d_xend.p);
     KT_END(TK_CHAIN_X);
-    int cnt[8];
+    int cnt[16];      // 0 chain records, 1 error flags, 2-7 work-queue heads / arena tops, 8 reads whose minimizer selection fell back to the sequential replay
     // chain extraction fills an arena of chain records with one atomic per read; a batch with more chains than the arena
     // holds (8 per read on average) reruns the extraction with a larger one -- the kernels only read stage 1-2 results
     for (int attempt = 0;; ++attempt) {
@@ -399,6 +399,10 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         TRY(th_rt_h2d(g->d_cnt.p + 1, &keep, sizeof(int), g->stream));
     }
     if (cnt[1] & 8) return th_fail("minimizer selection repeated a word or overflowed its buffer");
+    if (cnt[8] && g->dp.w > 1 && !g->dp.hpc && !g->dp.w_seq) {
+        if (getenv("TH_MINIMIZER_STRICT")) return th_fail("the parallel minimizer rules marked a slot twice on " + std::to_string(cnt[8]) + " read(s) (sequential replay used)");
+        if (getenv("TH_TRACE")) fprintf(stderr, "[th] minimizer selection: %d read(s) took the sequential replay\n", cnt[8]);
+    }
     if (cnt[1]) return th_fail("stage 1-2 kernels reported error flags " + std::to_string(cnt[1]));
     const int n_rec = cnt[0]; g->n_rec = n_rec;
     g->h_read_ch_base.resize(n); g->h_read_ch_n.resize(n);
