@@ -544,6 +544,11 @@ th_handle_t *th_init(const th_para_t *p, int device)
     gp.match = p->match; gp.mismatch = p->mismatch; gp.go1 = p->gap_open1; gp.ge1 = p->gap_ext1; gp.go2 = p->gap_open2; gp.ge2 = p->gap_ext2;
     gp.only_unit = p->only_unit;
     gp.want_cov = (p->min_cov > 0 || p->min_frac > 0.0 || p->out_fmt == TH_FASTQ_FMT || p->out_fmt == TH_TAB_QUAL_FMT) ? 1 : 0;
+    if (p->five_seq != NULL && p->three_seq != NULL && p->five_rc_seq != NULL && p->three_rc_seq != NULL) {   /* src/gen_cons.c:226,238-263 */
+        gp.ad_seq[0] = p->five_seq; gp.ad_seq[1] = p->three_rc_seq; gp.ad_seq[2] = p->five_rc_seq; gp.ad_seq[3] = p->three_seq;
+        gp.ad_len[0] = gp.ad_len[2] = p->five_len; gp.ad_len[1] = gp.ad_len[3] = p->three_len;
+        gp.ad_k[0] = gp.ad_k[2] = (int)(p->five_len * (1 - p->ada_match_rat)); gp.ad_k[1] = gp.ad_k[3] = (int)(p->three_len * (1 - p->ada_match_rat));
+    }
     th_gpu_t *g = th_gpu_create(&gp, device);
     if (!g) return NULL;
     th_handle_t *h = (th_handle_t *)calloc(1, sizeof(*h));
@@ -671,19 +676,23 @@ static void finish_job(const th_handle_t *h, const th_gpu_out_t *o, const th_job
         if (qual) { qual2 = (uint8_t *)malloc((size_t)cons_len << 1); memcpy(qual2, qual, cons_len); memcpy(qual2 + cons_len, qual, cons_len); }
         int tar_start = -1, tar_end = -1, tot_ed = INT_MAX, e5, e3, s5 = -1, n5 = -1, s3 = -1, n3 = -1;
         int k5 = (int)(p->five_len * (1 - p->ada_match_rat)), k3 = (int)(p->three_len * (1 - p->ada_match_rat));
-        e5 = edlib_hw(p->five_seq, p->five_len, cons2, cons_len << 1, &s5, &n5, k5);
+        /* the four searches ran on the device (th_k_adapter) when o->adapt is set: (ed, start, end) of 5', rc(3'), rc(5'), 3' */
+        const int *ad = o->adapt ? o->adapt + 12 * (int)(j - o->jobs) : NULL;
+#define AD_HW(sr, q, ql, kk, st, en) (ad ? (*(st) = ad[3 * (sr) + 1], *(en) = ad[3 * (sr) + 2], ad[3 * (sr)]) : edlib_hw((q), (ql), cons2, cons_len << 1, (st), (en), (kk)))
+        e5 = AD_HW(0, p->five_seq, p->five_len, k5, &s5, &n5);
         if (e5 == -1) goto REV;
-        e3 = edlib_hw(p->three_rc_seq, p->three_len, cons2, cons_len << 1, &s3, &n3, k3);
+        e3 = AD_HW(1, p->three_rc_seq, p->three_len, k3, &s3, &n3);
         if (e3 == -1) goto REV;
         if (s3 <= n5) {
             if (n3 + cons_len < cons_len << 1 && s3 + cons_len > n5) { tar_start = n5 + 1; tar_end = s3 + cons_len - 1; full_length = 1; tot_ed = e5 + e3; }
         } else { tar_start = n5 + 1; tar_end = s3 - 1; tot_ed = e5 + e3; full_length = 1; }
         if (tot_ed == 0) goto WRITE;
 REV:
-        e5 = edlib_hw(p->five_rc_seq, p->five_len, cons2, cons_len << 1, &s5, &n5, k5);
+        e5 = AD_HW(2, p->five_rc_seq, p->five_len, k5, &s5, &n5);
         if (e5 == -1) goto WRITE;
-        e3 = edlib_hw(p->three_seq, p->three_len, cons2, cons_len << 1, &s3, &n3, k3);
+        e3 = AD_HW(3, p->three_seq, p->three_len, k3, &s3, &n3);
         if (e3 == -1) goto WRITE;
+#undef AD_HW
         if (e5 + e3 < tot_ed) {
             if (s5 <= n3) {
                 if (n5 + cons_len < cons_len << 1 && s5 + cons_len > n3) { tar_start = n3 + 1; tar_end = s5 + cons_len - 1; full_length = 2; }

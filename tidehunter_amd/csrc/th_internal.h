@@ -13,6 +13,9 @@ typedef struct {
     int match, mismatch, go1, ge1, go2, ge2;
     int only_unit;          /* -u: stop after partition (no POA, no alignment) */
     int want_cov;           /* per-base coverage is needed on the host (-r / -c filters, FASTQ / -f 4 qualities) */
+    /* adapter search on the device (src/gen_cons.c:226-291): the four queries in the order 5', rc(3'), rc(5'), 3' with their
+     * lengths and edlib thresholds k = (int)(len * (1 - ada_match_rat)) (float arithmetic, done by the host); NULL = no adapters */
+    const char *ad_seq[4]; int ad_len[4], ad_k[4];
 } th_gpu_para_t;
 
 /* one consensus job as the host sees it after the device run */
@@ -30,6 +33,8 @@ typedef struct {
     int n_jobs; const th_job_t *jobs;
     const int *par;         /* compact par_pos values */
     const uint8_t *cons; const int *cov; const int *iden;   /* cov is NULL unless want_cov */
+    const int *adapt;       /* 12 ints per job: (ed, start, end) of the four adapter searches on consensus + consensus; NULL when the
+                             * device did not run them (no adapters, or an adapter longer than 256 symbols: the host searches) */
     double ms_kernels;      /* device time of the last run (HIP events), all kernels */
     double ms_dominant;     /* device time of the slowest kernel of the last run */
     double ms_kernel[8];    /* per kernel: 0 encode+hits, 1 chain_dp, 2 chain_extract, 3 partition, 4 poa, 5 align */

@@ -26,6 +26,7 @@ static int th_launch_failed(const char *kernel, const char *why) { return th_fai
 #include "th_k_partition.hip"
 #include "th_k_poa.hip"
 #include "th_k_align.hip"
+#include "th_k_adapter.hip"
 
 #define TH_STAGE_BYTES (16u << 20)
 #define TH_POA_SCRATCH_BYTES (96LL << 30)       // upper limit of the POA scratch of one handle (HBM: 288 GB; two handles may share a device)
@@ -78,6 +79,7 @@ struct th_gpu {
     DBuf<int> d_par, d_par_off, d_par_n, d_par_dst, d_parc, d_bnd, d_scratch, d_cov, d_cons_len, d_status, d_iden, d_ext;
     DBuf<ThTask> d_tasks, d_sub; DBuf<ThUnit> d_units; DBuf<ThAlnItem> d_items; DBuf<int> d_scl, d_sst;   // d_sub/d_scl/d_sst: task subsets of POA relaunches
     int n_rec = 0, reserve_n = 0; Arena arena;
+    bool ad_on = false; int ad_min_cons = 0; ThAdPara h_ad; DBuf<ThAdPara> d_adp; DBuf<int> d_ad; std::vector<int> h_ad_out; bool ad_valid = false;
     std::vector<ThChainRec> h_rec; std::vector<int> h_par_n, h_par_dst, h_parc, h_read_ch_base, h_read_ch_n;
     std::vector<ThTask> h_tasks; std::vector<ThUnit> h_units; std::vector<ThAlnItem> h_items;
     std::vector<int> h_cons_len, h_status, h_iden, h_ext, h_cov; std::vector<uint8_t> h_cons;
@@ -98,6 +100,23 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
     g->dp.k = p->k; g->dp.w = p->w; g->dp.w_seq = env_int("TH_MINIMIZER_SEQ", 0) ? 1 : 0; g->dp.hpc = p->hpc; g->dp.min_p = p->min_p; g->dp.max_p = p->max_p; g->dp.one_minus_div = p->one_minus_div; g->dp.min_copy = p->min_copy;
     g->dp.match = p->match; g->dp.mismatch = p->mismatch; g->dp.go1 = p->go1; g->dp.ge1 = p->ge1; g->dp.go2 = p->go2; g->dp.ge2 = p->ge2;
     g->device = device;
+    // adapter search tables (th_k_adapter.hip): per consensus letter the query positions it matches, forward and reversed query
+    if (p->ad_seq[0] && p->ad_seq[1] && p->ad_seq[2] && p->ad_seq[3]) {
+        g->ad_on = true; memset(&g->h_ad, 0, sizeof(g->h_ad));
+        auto eq = [](char a, char b) { if (a == b) return true; if ((a ^ b) != 0x20) return false; const char x = a | 0x20; return x == 'a' || x == 'c' || x == 'g' || x == 't' || x == 'n'; };
+        for (int sr = 0; sr < 4; ++sr) {
+            const int m = p->ad_len[sr];
+            if (m > 64 * TH_AD_MAXB) { g->ad_on = false; break; }
+            g->h_ad.len[sr] = m; g->h_ad.k[sr] = p->ad_k[sr]; g->h_ad.nb[sr] = (m + 63) / 64;
+            for (int c = 0; c < 5; ++c)
+                for (int i = 0; i < m; ++i) {
+                    if (eq(p->ad_seq[sr][i], "ACGTN"[c])) g->h_ad.peq[sr][0][c][i / 64] |= 1ull << (i & 63);
+                    if (eq(p->ad_seq[sr][m - 1 - i], "ACGTN"[c])) g->h_ad.peq[sr][1][c][i / 64] |= 1ull << (i & 63);
+                }
+        }
+        g->ad_min_cons = p->ad_len[0] + p->ad_len[3];
+    }
+    g->para.ad_seq[0] = g->para.ad_seq[1] = g->para.ad_seq[2] = g->para.ad_seq[3] = nullptr;     // (borrowed strings: not kept)
 #ifdef TH_CPU_EMUL
     g->stream = 0;
     g->waves_part = 2; g->waves_poa = 2; g->waves_aln = 3; g->waves_xw = 2;
@@ -128,7 +147,7 @@ extern "C" void th_gpu_destroy(th_gpu_t *g)
     g->d_cnt.release(); g->d_read_ch_base.release(); g->d_read_ch_n.release(); g->d_gsort.release(); g->d_gsort_off.release(); g->d_rec.release();
     g->d_par.release(); g->d_par_off.release(); g->d_par_n.release(); g->d_par_dst.release(); g->d_parc.release(); g->d_bnd.release(); g->d_scratch.release();
     g->d_cov.release(); g->d_cons_len.release(); g->d_status.release(); g->d_iden.release(); g->d_ext.release();
-    g->d_tasks.release(); g->d_units.release(); g->d_items.release();
+    g->d_tasks.release(); g->d_units.release(); g->d_items.release(); g->d_adp.release(); g->d_ad.release();
     if (g->stage_ok) for (int b = 0; b < 2; ++b) { th_rt_host_free(g->h_stage[b]); th_rt_event_destroy(g->stage_ev[b]); }
     if (g->arena.base) th_rt_free(g->arena.base);
 #ifndef TH_CPU_EMUL
@@ -333,7 +352,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
     const int n = g->n; const long long T = g->T; const size_t padT = (size_t)((T + 15) & ~15LL);
     const double t_run0 = th_wall_s(); (void)t_run0;
     TRY(th_select_device(g));
-    g->jobs.clear(); g->ms_kernels = g->ms_dominant = 0; g->n_rec = 0;
+    g->jobs.clear(); g->ms_kernels = g->ms_dominant = 0; g->n_rec = 0; g->ad_valid = false;
     g->h_tasks.clear(); g->h_parc.clear();
     if (n == 0) return 0;
     for (int k = 0; k < TK_N; ++k) g->ms_k[k] = 0;
@@ -594,6 +613,18 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         }
         KT_END(TK_ALIGN);
         if (getenv("TH_TRACE")) { th_rt_sync(g->stream); fprintf(stderr, "[th] %.3f s: align done (%d items)\n", th_wall_s() - t_run0, ni); }
+        // ---- adapter searches on the doubled consensus (src/gen_cons.c:226-291), four per job, one per lane ----
+        if (g->ad_on) {
+            TRY(g->d_adp.ensure(1)); TRY(g->d_ad.ensure((size_t)nt * 12));
+            TRY(th_rt_h2d(g->d_adp.p, &g->h_ad, sizeof(ThAdPara), g->stream));
+            KT_BEGIN(TK_ALIGN);
+            TH_LAUNCH(th_k_adapter, (nt * 4 + 63) / 64, 64, g->stream, (const ThTask *)g->d_tasks.p, nt, (const uint8_t *)g->d_cons.p, (const int *)g->d_cons_len.p,
+                      (const ThAdPara *)g->d_adp.p, g->ad_min_cons, g->d_ad.p);
+            KT_END(TK_ALIGN);
+            g->h_ad_out.resize((size_t)nt * 12);
+            TRY(th_rt_d2h(g->h_ad_out.data(), g->d_ad.p, (size_t)nt * 48, g->stream));
+            g->ad_valid = true;
+        }
         // results: consensus strings compacted to their lengths (the slots are sized for the worst case), coverage only on request
         std::vector<int> cc_off(nt); long long cc_total = 0;
         for (int t = 0; t < nt; ++t) { cc_off[t] = (int)cc_total; cc_total += (g->h_cons_len[t] + 3) & ~3; }
@@ -632,6 +663,7 @@ extern "C" int th_gpu_get(th_gpu_t *g, th_gpu_out_t *out)
 {
     out->n_jobs = (int)g->jobs.size(); out->jobs = g->jobs.data(); out->par = g->h_parc.data();
     out->cons = g->h_cons.data(); out->cov = g->para.want_cov ? g->h_cov.data() : nullptr; out->iden = g->h_iden.data();
+    out->adapt = g->ad_valid ? g->h_ad_out.data() : nullptr;
     out->ms_kernels = g->ms_kernels; out->ms_dominant = g->ms_dominant;
     for (int k = 0; k < TK_N; ++k) out->ms_kernel[k] = g->ms_k[k];
     return 0;
