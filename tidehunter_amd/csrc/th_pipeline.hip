@@ -380,10 +380,14 @@ extern "C" int th_gpu_run(th_gpu_t *g)
     KT_END(TK_SEED); KT_BEGIN(TK_CHAIN_DP);
     if (g->max_len < 65536 && !getenv("TH_CHAIN_UNPACKED")) {      // (the environment knob exists for the CPU tests)
         TRY(g->d_eps.ensure(padT));
-        TH_LAUNCH((th_k_chain_dp<true>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
+        if (env_int("TH_CHAIN_RING", 1))
+        TH_LAUNCH((th_k_chain_dp<true, true>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
+                  (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p, g->d_eps.p);
+        else
+        TH_LAUNCH((th_k_chain_dp<true, false>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
                   (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p, g->d_eps.p);
     } else
-        TH_LAUNCH((th_k_chain_dp<false>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
+        TH_LAUNCH((th_k_chain_dp<false, false>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
                   (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p, (unsigned long long *)nullptr);
     KT_END(TK_CHAIN_DP); KT_BEGIN(TK_CHAIN_X);
     TH_LAUNCH(th_k_chain_sort, n, TH_XS_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, g->dp,
