@@ -7,7 +7,7 @@ cd $R
 timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 bash tools/prof_round.sh > $O/prof_round.log 2>&1
-cp $O/hbm_traffic.json $R/profiles/r01_hbm_traffic.json
+cp $O/hbm_traffic.json $R/profiles/r02_hbm_traffic.json
 timeout 600 python3 bench.py > $O/bench_final.json 2> $O/bench_final.err
 bash tools/pmc_instr.sh > $R/gpurun_out/pmc_instr/summary.txt 2>&1
 ( timeout 300 python tools/step_times.py 65536 200 20 0.10 | tail -1; timeout 300 python tools/step_times.py 8192 5000 4 0.15 | tail -1 ) > $O/other_shapes.txt 2>&1
