@@ -25,14 +25,13 @@ enum { TH_NO_CON = 0, TH_REG_CON = 1, TH_SAME_CON = 2, TH_OVL_CON = 3 };
 // ---------------------------------------------------------------------------------------------
 // PK: every read of the batch is shorter than 65536 bases, so a hit's (end, period) fit one 32-bit word; the window
 // scan then reads one 8-byte {end<<16|period, score} record per predecessor instead of three 4-byte words.
-// RING: the packed records of the most recent TH_CHAIN_RING hits of each wave's read are staged in LDS (4 KiB per wave, 16 KiB per
+// RING: the packed records of the most recent RING hits of each wave's read are staged in LDS (4 KiB per wave, 16 KiB per
 // workgroup: still 8 waves per SIMD).  A record enters the ring once, 64 at a time and coalesced, when `cur` reaches its chunk;
 // its score is patched in place when the hit is finalised; the window scan then reads LDS instead of re-reading every hit ~250
 // times through L2 (the in-flight working set of 8192 waves x 34 KB does not fit L2, so those re-reads were fabric traffic:
 // 888 GB per 100 000 reads, profiles/r01_hbm_traffic.json).  Trips that reach further back than the ring (rare: more than
 // ~450 hits within one period) read HBM as before.
-#define TH_CHAIN_RING 512
-template <bool PK, bool RING>
+template <bool PK, int RING>      // RING: entries of the LDS ring (0 = none, 512, 1024)
 __global__ void __launch_bounds__(TH_CHAIN_BLOCK)
 th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
               const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ hit_n,
@@ -53,7 +52,7 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
     const int *E = hit_end + off, *Pd = hit_per + off;
     int *S = score + off, *F = from + off;
     unsigned long long *R = eps + off;
-    __shared__ unsigned long long s_ring[RING ? TH_CHAIN_BLOCK / TH_WAVE : 1][RING ? TH_CHAIN_RING : 1];
+    __shared__ unsigned long long s_ring[RING ? TH_CHAIN_BLOCK / TH_WAVE : 1][RING ? RING : 1];
     unsigned long long *ring = s_ring[RING ? (threadIdx.x >> 6) : 0];
     // init_dp (src/tandem_chain.c:113-126): score = k + min(k, period), no predecessor
     for (int i = lane; i < n; i += TH_WAVE) {
@@ -65,10 +64,10 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
     if (RING && lane < n) ring[lane] = R[lane];                      // chunk 0
     for (int cur = 1; cur < n; ++cur) {
         if (RING && (cur & 63) == 0) {                               // the chunk cur .. cur+63 enters the ring (its scores are still the initial ones)
-            if (cur + lane < n) ring[(cur + lane) & (TH_CHAIN_RING - 1)] = R[cur + lane];
+            if (cur + lane < n) ring[(cur + lane) & (RING - 1)] = R[cur + lane];
             TH_WAVE_FENCE();
         }
-        const int ring_lo = RING ? (cur | 63) + 1 - TH_CHAIN_RING : 0;      // oldest hit index the ring still holds
+        const int ring_lo = RING ? (cur | 63) + 1 - RING : 0;      // oldest hit index the ring still holds
         const int ce = TH_UNI(E[cur]), cp = TH_UNI(Pd[cur]), cs = ce - cp;       // the same in every lane: scalar registers
         const int init = k + min(k, cp);
         int best = init, bi = -1, iter = 0;
@@ -82,7 +81,7 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             int pe, pp, psc;
             if (PK) {
                 // lanes before the first hit read some record and are discarded by `valid`
-                const unsigned long long rec = (RING && base - (TH_WAVE - 1) >= ring_lo) ? ring[idx & (TH_CHAIN_RING - 1)] : R[max(idx, 0)];
+                const unsigned long long rec = (RING && base - (TH_WAVE - 1) >= ring_lo) ? ring[idx & (RING - 1)] : R[max(idx, 0)];
                 pe = (int)((uint32_t)rec >> 16); pp = (int)((uint32_t)rec & 0xffffu); psc = (int)(rec >> 32);
             } else { pe = valid ? E[idx] : 0; pp = valid ? Pd[idx] : 1; psc = valid ? S[idx] : 0; }
             const int ps = pe - pp;
@@ -123,7 +122,7 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
         if (lane == 0 && best > init) {                                                                 // :352-354
             S[cur] = best; F[cur] = bi;
             if (PK) ((int *)(R + cur))[1] = best;
-            if (RING) ((int *)(ring + (cur & (TH_CHAIN_RING - 1))))[1] = best;
+            if (RING) ((int *)(ring + (cur & (RING - 1))))[1] = best;
         }
         TH_WAVE_FENCE();
     }

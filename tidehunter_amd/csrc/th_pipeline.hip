@@ -380,14 +380,13 @@ extern "C" int th_gpu_run(th_gpu_t *g)
     KT_END(TK_SEED); KT_BEGIN(TK_CHAIN_DP);
     if (g->max_len < 65536 && !getenv("TH_CHAIN_UNPACKED")) {      // (the environment knob exists for the CPU tests)
         TRY(g->d_eps.ensure(padT));
-        if (env_int("TH_CHAIN_RING", 1))
-        TH_LAUNCH((th_k_chain_dp<true, true>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
-                  (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p, g->d_eps.p);
-        else
-        TH_LAUNCH((th_k_chain_dp<true, false>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
-                  (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p, g->d_eps.p);
+#define CHAIN_LAUNCH(RG) TH_LAUNCH((th_k_chain_dp<true, RG>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp, \
+                  (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p, g->d_eps.p)
+        const int ring = env_int("TH_CHAIN_RING", 512);
+        if (ring >= 1024) CHAIN_LAUNCH(1024); else if (ring >= 512) CHAIN_LAUNCH(512); else CHAIN_LAUNCH(0);
+#undef CHAIN_LAUNCH
     } else
-        TH_LAUNCH((th_k_chain_dp<false, false>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
+        TH_LAUNCH((th_k_chain_dp<false, 0>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
                   (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p, (unsigned long long *)nullptr);
     KT_END(TK_CHAIN_DP); KT_BEGIN(TK_CHAIN_X);
     TH_LAUNCH(th_k_chain_sort, n, TH_XS_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, g->dp,
@@ -587,32 +586,40 @@ extern "C" int th_gpu_run(th_gpu_t *g)
           unsigned long long z[18] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(th_poa_prof), z, sizeof(z)); }
 #endif
         // ---- unit-vs-consensus alignments and flank extensions ----
-        // Items whose two sequences fit the small staging area of the anti-diagonal engine (4 KB: 5 waves per SIMD) go first;
-        // tasks with longer units / consensus form a second list for the kernel variant with a 24 KB area and up to 6 registers per lane.
+        // Items whose two sequences fit the small staging area of the anti-diagonal engine (4 KB: 5 waves per SIMD) go first; tasks
+        // whose unit + consensus fit 7 KB with at most two registers per lane (periods up to ~2500) form a second list for the same
+        // register budget with a larger area; the rest a third one for the variant with a 24 KB area and up to 6 registers per lane
+        // (two waves per SIMD) -- before this split the 2000-base units of config 5 ran on that variant although they need two.
         int max_cl = 0;
-        const int ALN_SMALL = 4096, ALN_BIG = 24576;
-        std::vector<ThAlnItem> big_items;
+        const int ALN_SMALL = 4096, ALN_MID = 7168, ALN_BIG = 24576;
+        std::vector<ThAlnItem> mid_items, big_items;
         for (int t = 0; t < nt; ++t) {
             max_cl = std::max(max_cl, g->h_cons_len[t]);
-            const bool big = (long long)g->h_tasks[t].max_len + g->h_cons_len[t] + 512 * 2 + 16 > ALN_SMALL;
-            for (int u = 0; u < g->h_tasks[t].pos_n - 1; ++u) { ThAlnItem it = { t, u }; (big ? big_items : g->h_items).push_back(it); }
+            const long long need2 = (long long)g->h_tasks[t].max_len + g->h_cons_len[t] + 512 * 2 + 16;
+            const bool two_regs = 2 * (g->h_cons_len[t] / g->aln_wdiv + g->aln_wadd - g->aln_wtol) + 2 + 64 <= 512;     // th_ad_pick would settle for NP <= 2
+            std::vector<ThAlnItem> &dst = need2 <= ALN_SMALL ? g->h_items : (need2 <= ALN_MID && two_regs) ? mid_items : big_items;
+            for (int u = 0; u < g->h_tasks[t].pos_n - 1; ++u) { ThAlnItem it = { t, u }; dst.push_back(it); }
             ThAlnItem l = { t, -1 }, r = { t, -2 }; g->h_items.push_back(l); g->h_items.push_back(r);
         }
         const int ns = (int)g->h_items.size();
+        g->h_items.insert(g->h_items.end(), mid_items.begin(), mid_items.end());
+        const int nm = (int)g->h_items.size();
         g->h_items.insert(g->h_items.end(), big_items.begin(), big_items.end());
         const int ni = (int)g->h_items.size();
         const long long bnd_aln = (std::max<long long>(((long long)max_cl + 128) * 4, ((long long)g->max_len + 128) * 2) + 3) & ~3LL;
         const int wa = std::min(ni, g->waves_aln);
         TRY(g->d_items.ensure(ni)); TRY(g->d_bnd.ensure((size_t)(bnd_aln * wa)));
         TRY(th_rt_h2d(g->d_items.p, g->h_items.data(), (size_t)ni * sizeof(ThAlnItem), g->stream));
-        TRY(th_rt_memset(g->d_cnt.p + 7, 0, sizeof(int), g->stream));      // queue head of the second list (d_cnt[4], the first one's, was zeroed at the start of the run)
+        TRY(th_rt_memset(g->d_cnt.p + 7, 0, sizeof(int), g->stream));      // queue heads of the second and third list (d_cnt[4], the first one's, was zeroed at the start of the run)
+        TRY(th_rt_memset(g->d_cnt.p + 9, 0, sizeof(int), g->stream));
         KT_BEGIN(TK_ALIGN);
         {
 #define TH_ALN_ARGS(first, n, q) (const ThAlnItem *)g->d_items.p + (first), (n), (const ThTask *)g->d_tasks.p, (const int *)g->d_parc.p, \
                   (const uint32_t *)g->d_roff.p, (const uint8_t *)g->d_bseq.p, (const uint8_t *)g->d_cons.p, (const int *)g->d_cons_len.p, \
                   g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, g->d_cnt.p + 1, g->d_cnt.p + (q), g->aln_wdiv, g->aln_wadd, g->aln_wtol, g->aln_mode, g->aln_xpct
             if (ns) TH_LAUNCH((th_k_align<ALN_SMALL, 2>), std::min(ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(0, ns, 4));
-            if (ni > ns) TH_LAUNCH((th_k_align<ALN_BIG, 6>), std::min(ni - ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(ns, ni - ns, 7));
+            if (nm > ns) TH_LAUNCH((th_k_align<ALN_MID, 2>), std::min(nm - ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(ns, nm - ns, 9));
+            if (ni > nm) TH_LAUNCH((th_k_align<ALN_BIG, 6>), std::min(ni - nm, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(nm, ni - nm, 7));
 #undef TH_ALN_ARGS
         }
         KT_END(TK_ALIGN);
