@@ -938,7 +938,7 @@ int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *d
     th_pipe_t *q = (th_pipe_t *)calloc(1, sizeof(th_pipe_t));
     pthread_mutex_init(&q->mu, NULL); pthread_cond_init(&q->cv, NULL);
     q->rd = r; q->out = out; q->p = p; q->batch_reads = batch_reads; q->n_dev = n_dev; q->n_slot = 2 * n_dev + 1; q->eof_batch = -1;
-    q->ramp0 = batch_reads / 8 > 2048 ? batch_reads / 8 : 2048;
+    q->ramp0 = batch_reads / 4 > 2048 ? batch_reads / 4 : 2048;       /* one small batch, then full ones: a mapped file parses at ~10 GB/s, so only the first launch has to wait */
     { const char *e = getenv("TH_RAMP0"); if (e && atoi(e) > 0) q->ramp0 = atoi(e); }
     for (int i = 0; i < q->n_slot; ++i) {
         q->slot[i].names = (char **)calloc(batch_reads, sizeof(char *)); q->slot[i].seqs = (char **)calloc(batch_reads, sizeof(char *));
