@@ -177,8 +177,8 @@ static int th_arena_create(th_gpu *g, int n, long long T)
 {
     if (g->arena.base || n <= 0 || T <= 0) return 0;
     const double avg = (double)T / n;
-    const size_t poa = (size_t)std::min<double>((double)TH_POA_SCRATCH_BYTES / 2, 100.0 * avg * 4.0 * std::min(n, g->waves_poa) * 1.15);
-    size_t want = (size_t)(50.0 * (double)T) + (size_t)n * 256 + poa + (64u << 20);
+    const size_t poa = (size_t)std::min<double>((double)TH_POA_SCRATCH_BYTES / 2, 100.0 * avg * 4.0 * std::min(n, g->waves_poa) * 1.3);
+    size_t want = (size_t)(64.0 * (double)T) + (size_t)n * 1024 + poa + (256u << 20);      // (buffers carry 12.5 % slack; consensus jobs, items, par_pos: ~10 bytes per base)
 #ifndef TH_CPU_EMUL
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) == hipSuccess && want > fr / 2) want = fr / 2;     // never more than half of what is free
