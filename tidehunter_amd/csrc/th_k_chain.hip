@@ -31,7 +31,7 @@ enum { TH_NO_CON = 0, TH_REG_CON = 1, TH_SAME_CON = 2, TH_OVL_CON = 3 };
 // times through L2 (the in-flight working set of 8192 waves x 34 KB does not fit L2, so those re-reads were fabric traffic:
 // 888 GB per 100 000 reads, profiles/r01_hbm_traffic.json).  Trips that reach further back than the ring (rare: more than
 // ~450 hits within one period) read HBM as before.
-template <bool PK, int RING>      // RING: entries of the LDS ring (0 = none, 512, 1024)
+template <bool PK, int RING>      // RING: entries of the LDS ring (0 = none, 512, 768, 1024); slot of hit x = x mod RING
 __global__ void __launch_bounds__(TH_CHAIN_BLOCK)
 th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
               const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ hit_n,
@@ -54,6 +54,8 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
     unsigned long long *R = eps + off;
     __shared__ unsigned long long s_ring[RING ? TH_CHAIN_BLOCK / TH_WAVE : 1][RING ? RING : 1];
     unsigned long long *ring = s_ring[RING ? (threadIdx.x >> 6) : 0];
+    constexpr bool RP2 = RING == 0 || (RING & (RING - 1)) == 0;         // power of two: the slot is a mask; else the wave keeps cur mod RING in a scalar
+    int cur_slot = RP2 ? 0 : 1 % (RING ? RING : 1);                     // cur mod RING (cur starts at 1)
     // init_dp (src/tandem_chain.c:113-126): score = k + min(k, period), no predecessor
     for (int i = lane; i < n; i += TH_WAVE) {
         const int e = E[i], p = Pd[i], s0 = k + min(k, p);
@@ -64,7 +66,7 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
     if (RING && lane < n) ring[lane] = R[lane];                      // chunk 0
     for (int cur = 1; cur < n; ++cur) {
         if (RING && (cur & 63) == 0) {                               // the chunk cur .. cur+63 enters the ring (its scores are still the initial ones)
-            if (cur + lane < n) ring[(cur + lane) & (RING - 1)] = R[cur + lane];
+            if (cur + lane < n) ring[RP2 ? ((cur + lane) & (RING - 1)) : (int)min((uint32_t)(cur_slot + lane), (uint32_t)(cur_slot + lane - RING))] = R[cur + lane];
             TH_WAVE_FENCE();
         }
         const int ring_lo = RING ? (cur | 63) + 1 - RING : 0;      // oldest hit index the ring still holds
@@ -75,13 +77,16 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
         // the two period-ratio tests below as one range test on the predecessor's period: 5 cp >= 9 pp <=> pp <= (5 cp) / 9 and
         // 5 pp >= 9 cp <=> pp >= ceil(9 cp / 5), so a connection needs plo < pp < phi
         const uint32_t plo = (5u * (uint32_t)cp) / 9u, phi = (9u * (uint32_t)cp + 4u) / 5u;
-        for (int base = cur - 1; base >= 0; base -= TH_WAVE) {
+        int bslot = RP2 ? 0 : (cur_slot == 0 ? RING - 1 : cur_slot - 1);      // (cur - 1) mod RING
+        for (int base = cur - 1; base >= 0; base -= TH_WAVE, bslot = RP2 ? 0 : (bslot >= TH_WAVE ? bslot - TH_WAVE : bslot - TH_WAVE + RING)) {
             const int idx = base - lane;
             const bool valid = idx >= 0;
             int pe, pp, psc;
             if (PK) {
                 // lanes before the first hit read some record and are discarded by `valid`
-                const unsigned long long rec = (RING && base - (TH_WAVE - 1) >= ring_lo) ? ring[idx & (RING - 1)] : R[max(idx, 0)];
+                // slot of idx = base - lane: (cur_slot - (cur - base) - lane) mod RING, the wave-uniform part reduced on the scalar unit
+                const unsigned long long rec = (RING && base - (TH_WAVE - 1) >= ring_lo)
+                    ? ring[RP2 ? (idx & (RING - 1)) : (int)min((uint32_t)(bslot - lane), (uint32_t)(bslot - lane + RING))] : R[max(idx, 0)];
                 pe = (int)((uint32_t)rec >> 16); pp = (int)((uint32_t)rec & 0xffffu); psc = (int)(rec >> 32);
             } else { pe = valid ? E[idx] : 0; pp = valid ? Pd[idx] : 1; psc = valid ? S[idx] : 0; }
             const int ps = pe - pp;
@@ -122,8 +127,9 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
         if (lane == 0 && best > init) {                                                                 // :352-354
             S[cur] = best; F[cur] = bi;
             if (PK) ((int *)(R + cur))[1] = best;
-            if (RING) ((int *)(ring + (cur & (RING - 1))))[1] = best;
+            if (RING) ((int *)(ring + (RP2 ? (cur & (RING - 1)) : cur_slot)))[1] = best;
         }
+        if (!RP2 && ++cur_slot == RING) cur_slot = 0;
         TH_WAVE_FENCE();
     }
 }

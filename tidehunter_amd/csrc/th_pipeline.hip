@@ -383,7 +383,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
 #define CHAIN_LAUNCH(RG) TH_LAUNCH((th_k_chain_dp<true, RG>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp, \
                   (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p, g->d_eps.p)
         const int ring = env_int("TH_CHAIN_RING", 512);
-        if (ring >= 1024) CHAIN_LAUNCH(1024); else if (ring >= 512) CHAIN_LAUNCH(512); else CHAIN_LAUNCH(0);
+        if (ring >= 1024) CHAIN_LAUNCH(1024); else if (ring >= 768) CHAIN_LAUNCH(768); else if (ring >= 512) CHAIN_LAUNCH(512); else CHAIN_LAUNCH(0);
 #undef CHAIN_LAUNCH
     } else
         TH_LAUNCH((th_k_chain_dp<false, 0>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)g->d_roff.p, n, g->dp,
