@@ -12,11 +12,13 @@ import th_util as U
 ROOT = U.ROOT
 
 
-def _bench(tmp_path, nproc, port, *args):
+def _bench(tmp_path, nproc, port, *args, self_spawn=False):
     env = dict(os.environ, TH_BENCH_BACKEND="gloo", TH_BENCH_LIB=U.emul_lib_path(), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
     common = ["--config", "tiny", "--steps", "1", "--warmup", "1", "--digest", "--cpu-sample", "0", "--e2e", "0", *args]
-    if nproc == 1:
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common]
+    if nproc == 1 or self_spawn:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), *common]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), *common]
@@ -30,7 +32,9 @@ def test_bench_two_ranks_match_one_rank(tmp_path):
     one = _bench(tmp_path, 1, 29541, "--batch", "8")
     two = _bench(tmp_path, 2, 29542, "--batch", "4")
     steal = _bench(tmp_path, 2, 29543, "--batch", "4", "--steal", "2")
-    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and steal["n_gpus"] == 2
+    spawned = _bench(tmp_path, 2, 29544, "--batch", "4", self_spawn=True)      # `python bench.py --gpus 2` without a launcher starts one itself
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and steal["n_gpus"] == 2 and spawned["n_gpus"] == 2
+    assert spawned["records_digest"] == one["records_digest"]
     for j in (one, two, steal):
         assert j["unit"] == "reads/s" and j["value"] > 0 and j["scaling"] == "weak" and j["records_digest_reads"] == 8
         assert "roofline" in j and j["roofline"]["bound"] == "hbm"
