@@ -291,3 +291,38 @@ def test_emul_chain_dp_lds_ring_wraps(emu, monkeypatch):
         assert int(th.debug_stage(1, 4 * len(seqs), np.int32)[0]) > 1000
         U.stage_compare(th, seqs, O.default_para(only_unit=1))
         th.close()
+
+
+def test_emul_device_adapter_search_block_boundaries(emu, tmp_path):
+    """th_k_adapter (Myers bit-vector, 64-symbol blocks): adapter lengths on both sides of the block boundaries, lower-case and N
+    in the adapters, a looser -a, and an adapter of more than 256 symbols (kept on the host); records equal the oracle's edlib restatement"""
+    rng = np.random.default_rng(21)
+    rnd = lambda n: bytes(b"ACGT"[i] for i in rng.integers(0, 4, n))
+    comp = bytes.maketrans(b"ACGTacgtN", b"TGCAtgcaN")
+    rc = lambda s: s.translate(comp)[::-1]
+    for l5, l3, ada in ((63, 5, 0.8), (64, 65, 0.8), (129, 30, 0.7), (84, 25, 0.9), (300, 40, 0.8)):
+        five, three = rnd(l5), rnd(l3)
+        five = five[:10].lower() + b"N" + five[11:] if l5 > 20 else five
+        f5, f3 = tmp_path / ("5_%d.fa" % l5), tmp_path / ("3_%d.fa" % l3)
+        f5.write_bytes(b">five\n" + five + b"\n"); f3.write_bytes(b">three\n" + three + b"\n")
+        seqs = []
+        for i in range(4):
+            unit = five.upper().replace(b"N", b"A") + rnd(40 + 10 * i) + rc(three)
+            s = bytearray()
+            for b in unit * 4:
+                x = rng.random()
+                if x < 0.03:
+                    s.append(b"ACGT"[int(rng.integers(0, 4))])
+                elif x < 0.05:
+                    continue
+                else:
+                    s.append(b)
+            seqs.append(rc(bytes(s)) if i & 1 else bytes(s))
+        para = O.default_para(ada_match_rat=ada)
+        O.load().tho_para_load_adapters(para, str(f5).encode(), str(f3).encode())
+        th = TH.TideHunter(lib_path=emu, adapters=(str(f5), str(f3)), ada_match_rat=ada)
+        got = th.process(seqs)
+        assert U.assert_records_equal(seqs, got, para, "adapters %d/%d" % (l5, l3)) >= 3
+        if l5 <= 256:
+            assert any(r["full_length"] > 0 for rr in got for r in rr), (l5, l3)
+        th.close()
