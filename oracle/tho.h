@@ -19,8 +19,12 @@
  *     submodule of the reference (.gitmodules:1-4, pinned commit unknown);
  *     tho_poa.c restates the published abPOA algorithm (adaptive-band
  *     partial-order alignment, convex gaps, row-column consensus) and is the
- *     de-facto oracle for the HIP POA kernel.  Claims are "GPU == this CPU POA",
- *     never "== reference", whenever more than two noisy units reach POA.
+ *     de-facto oracle for the HIP POA kernel.  It is cross-checked against
+ *     tho_poa_exact.c, an independent full-matrix POA in Kahn order (the node
+ *     order never changes a consensus; the adaptive band, part of the
+ *     algorithm, rarely does: tests/test_poa_exact.py, tests/test_gpu_scale.py).
+ *     Claims are "GPU == this CPU POA", never "== reference", whenever more
+ *     than two noisy units reach POA.
  */
 #ifndef THO_H
 #define THO_H
