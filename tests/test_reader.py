@@ -47,6 +47,15 @@ def test_reader_paths_agree_on_awkward_input(tmp_path):
            _parse(lib, bgz, env={"TH_READER_THREADS": "1"}), _parse(lib, bgz, env={"TH_READER_STREAM": "1"})]
     assert all(g[:2] == want for g in got), [g[:2] for g in got]
     assert len({g[2] for g in got}) == 1
+    # "-" = standard input (the reference reads stdin through the same gzread, src/main.c:378), plain and gzipped
+    import subprocess
+    import sys
+    child = ("import sys, ctypes as C; sys.path.insert(0, %r); import tidehunter_amd as TH; lib = TH.load_library(); "
+             "nb = C.c_longlong(); d = C.c_ulonglong(); n = lib.th_parse_file(b'-', C.byref(nb), C.byref(d)); print(n, nb.value, d.value)" % U.ROOT)
+    for src in (plain, gz):
+        with open(src, "rb") as f:
+            out = subprocess.run([sys.executable, "-c", child], stdin=f, capture_output=True, text=True, check=True).stdout.split()
+        assert (int(out[0]), int(out[1]), int(out[2])) == (want[0], want[1], got[0][2])
     assert lib.th_parse_file(str(tmp_path / "missing.fa").encode(), None, None) == -1
     (tmp_path / "empty.fa").write_bytes(b"")
     assert _parse(lib, tmp_path / "empty.fa")[:2] == (0, 0)
