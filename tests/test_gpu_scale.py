@@ -83,6 +83,13 @@ def test_gpu_config5_at_spec_gz_fastq(tmp_path):
         assert gpu == cpu, "config 5 %r: output differs from the oracle's" % (opts[4:],)
     gpu, cpu = _both(tmp_path, adopt, fq_wrapped)
     assert gpu == cpu and gpu.count(b">") >= 30
+    # the same records block-gzipped (bgzip: inflated by the reader's thread pool) and uncompressed (mmap'ed, zero-copy)
+    import gzip
+    raw = gzip.open(fq).read()
+    bgz, plain = tmp_path / "c5.fq.bgz", tmp_path / "c5.fq"
+    U.write_bgzf(bgz, raw); plain.write_bytes(raw)
+    want = _run([EXE, *adopt, str(fq)])
+    assert _run([EXE, *adopt, str(bgz)]) == want and _run([EXE, *adopt, str(plain)]) == want
     # the records themselves, through the batch seam: every period class yields full-length consensuses on both strands
     para = O.default_para()
     O.load().tho_para_load_adapters(para, ad[0].encode(), ad[1].encode())
