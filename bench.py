@@ -410,6 +410,10 @@ def main():
             n_cpu = a.cpu_sample if a.cpu_sample > 0 else min(4096, max(64, 24 * effective_cpus()))
             out["cpu_baseline"] = cpu_baseline(lib, make_read, n_cpu, cfg)
         print(json.dumps(out))
+    if a.config == "c5":
+        for fn in kw["adapters"]:
+            os.unlink(fn)
+        os.rmdir(os.path.dirname(kw["adapters"][0]))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -108,6 +108,7 @@ static void *stream_producer(void *arg)
         if (quit) return NULL;
         const long n = gzread(r->fp, r->sbuf[b], RD_CHUNK);
         pthread_mutex_lock(&r->smu);
+        if (n < 0) { int en = 0; fprintf(stderr, "[tidehunter_amd] read error: %s\n", gzerror(r->fp, &en)); }
         r->slen[b] = n > 0 ? n : 0; r->sfull[b] = 1; if (n <= 0) r->sdone = 1;
         pthread_cond_broadcast(&r->scv); pthread_mutex_unlock(&r->smu);
         if (n <= 0) return NULL;
