@@ -318,7 +318,7 @@ def main():
                 batch = block_reads(cuts, mine, base, k)
                 th.upload(batch); th.run(); th.collect_native()
                 done.append((k, batch, th.records()))
-                blocks_mine += 1
+                blocks_mine += th.launches()
             if on_gpu:
                 torch.cuda.synchronize()
             t_total += time.perf_counter() - t0
@@ -336,7 +336,7 @@ def main():
                 torch.cuda.synchronize()
             t_total += time.perf_counter() - t0
             account(batch, th.records(), base + cuts[rank])     # Python dict view for the byte accounting: not part of the path
-            blocks_mine += 1
+            blocks_mine += th.launches()                        # a large batch runs as two concurrent halves: two launches of every kernel
     sync_all()
     tot = torch.tensor([float(n_reads_mine), float(bases_mine), float(n_cons), float(alg_bytes)], dtype=torch.float64)
     if dist is not None:
@@ -377,7 +377,7 @@ def main():
     if rank == 0:
         dom = max(kms, key=kms.get)                      # dominant kernel = largest device time (this rank's launches)
         launches = max(1, blocks_mine)
-        launch_s = kms[dom] / 1000.0 / launches            # one launch of it per block
+        launch_s = kms[dom] / 1000.0 / launches            # one launch of it per block (or per concurrent half of a block)
         per_launch_bytes = alg_bytes / float(launches)
         ach = per_launch_bytes / launch_s / 1e9 if launch_s > 0 else 0.0
         # traffic: HBM bytes of one launch of the dominant kernel from the PMC passes of this same command
@@ -387,7 +387,7 @@ def main():
         for pf in ("r02_hbm_traffic.json",):
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", pf)))
-                if prof.get("reads_per_launch") == B and prof.get("config", "c3") == a.config and a.steal == 0:
+                if prof.get("reads_per_launch") == B * a.steps // launches and prof.get("config", "c3") == a.config and a.steal == 0:
                     for kname, v in prof["kernels"].items():
                         if kname.replace("void ", "").split("<")[0] == dom:
                             traffic, traffic_src = v["hbm_bytes_per_launch_corrected"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % pf
@@ -397,7 +397,9 @@ def main():
                            "frac_of_measured_copy_peak": ach / HBM_COPY_GBS, "measured_copy_peak": HBM_COPY_GBS,
                            "traffic": traffic, "traffic_source": traffic_src, "launch_ms": launch_s * 1000.0,
                            "kernel_ms_per_launch": {k: v / launches for k, v in kms.items()},
-                           "algorithmic_bytes_per_launch": per_launch_bytes,
+                           "algorithmic_bytes_per_launch": per_launch_bytes, "launches_per_step": launches / float(a.steps),
+                           "concurrency_note": "a batch of >= 16384 reads runs as two concurrent halves on two streams; a launch's duration is measured with HIP events "
+                                               "on its own stream while the other half's kernels share the device, so it is longer than the same launch alone",
                            "note": "this path is instruction-issue bound, not bandwidth bound (DESIGN.md section 4): the HBM fraction is reported because "
                                    "north_star names that roofline; profiles/r02_pmc_instr.json holds the VALU issue fractions"}
     th.close()

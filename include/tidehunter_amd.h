@@ -93,8 +93,11 @@ int th_batch_reserve(th_handle_t *h, int max_reads, long long max_bases);
 int th_batch_run(th_handle_t *h);
 int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out);
 /* device milliseconds of the last th_batch_run() per kernel, measured with HIP events on the library's own
- * stream: [0] encode+hits [1] chain_dp [2] chain_extract [3] partition [4] poa [5] align; returns 6 */
+ * stream(s): [0] encode+hits [1] chain_dp [2] chain_extract [3] partition [4] poa [5] align; returns 6 */
 int th_batch_timing(th_handle_t *h, double *ms_kernel, int n);
+/* A batch of 16384 reads or more (TH_SUBBATCH_MIN) runs as two concurrent halves on two streams of the handle's device (TH_SUBBATCH=1
+ * turns that off); th_batch_timing sums the halves, th_batch_launches returns how many there were (1 or 2) in the last upload. */
+int th_batch_launches(th_handle_t *h);
 
 /* mini_tandem_output(), src/main.c:214-271 (resets the slots after printing, as the reference does) */
 void th_output(FILE *fp, int n, const char *const *names, const char *const *seqs, const int *lens,

@@ -326,3 +326,21 @@ def test_emul_device_adapter_search_block_boundaries(emu, tmp_path):
         if l5 <= 256:
             assert any(r["full_length"] > 0 for rr in got for r in rr), (l5, l3)
         th.close()
+
+
+def test_emul_batch_runs_as_two_concurrent_halves(emu, monkeypatch):
+    """a large batch is cut into two halves by bases that run on two pipelines of the handle at once (TH_SUBBATCH_MIN lowers the
+    threshold for the test): same records as the oracle, merged in read order; adapters and -s included"""
+    monkeypatch.setenv("TH_SUBBATCH_MIN", "3")
+    ad = (os.path.join(U.DATA, "5prime.fa"), os.path.join(U.DATA, "3prime.fa"))
+    seqs = _reads(TH.load_library(), [(60, 8, 0.10), (120, 5, 0.08), (35, 12, 0.12), (200, 3, 0.10), (90, 6, 0.0), (70, 7, 0.1)]) + [b"ACGT" * 3, b""]
+    for kw, adapters in ((dict(), None), (dict(out_fmt=4, min_cov=2), None), (dict(only_full_length=1, single_copy=1), ad)):
+        th = TH.TideHunter(lib_path=emu, adapters=adapters, **kw)
+        got = th.process(seqs)
+        assert th.launches() == 2
+        para = O.default_para(**kw)
+        if adapters:
+            O.load().tho_para_load_adapters(para, ad[0].encode(), ad[1].encode())
+        U.assert_records_equal(seqs, got, para, "two halves %r" % (kw,))
+        assert th.process(seqs[:2]) == got[:2] and th.launches() == 1
+        th.close()

@@ -68,6 +68,7 @@ def load_library(path=None):
     lib.th_batch_run.argtypes = [C.c_void_p]
     lib.th_batch_collect.argtypes = [C.c_void_p, C.POINTER(TandemSeq)]
     lib.th_batch_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+    lib.th_batch_launches.argtypes = [C.c_void_p]
     lib.th_run_file.argtypes = [C.c_char_p, C.POINTER(Para), C.c_void_p, C.c_int, C.c_int]
     lib.th_synth_read.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_char_p, C.c_int]
     lib.th_synth_adapter.argtypes = [C.c_uint64, C.c_int, C.c_char_p, C.c_int]
@@ -166,6 +167,10 @@ class TideHunter:
         a = (C.c_double * 8)()
         n = self.lib.th_batch_timing(self.h, a, 8)
         return {self.KERNELS[i]: a[i] for i in range(n)}
+
+    def launches(self):
+        """concurrent parts the last uploaded batch runs as (1, or 2 for batches of TH_SUBBATCH_MIN = 16384 reads and more)"""
+        return self.lib.th_batch_launches(self.h)
 
     def process(self, seqs):
         """tidehunter_core() on every read of the batch; returns a list (per read) of record dicts."""

@@ -32,9 +32,15 @@ const char *th_last_error(void) { return g_err[0] ? g_err : th_gpu_error(); }
 const char *th_version(void) { return "1.5.5-mi355x.r1"; }
 static int host_fail(const char *m) { snprintf(g_err, sizeof(g_err), "%s", m); fprintf(stderr, "[tidehunter_amd] %s\n", m); return -1; }
 
+/* A handle owns up to two device pipelines (own stream, own buffers) on its GPU.  A large batch is cut in two halves balanced by
+ * bases that run CONCURRENTLY: the three large kernels each leave vector-issue slots idle (0.75-0.96 busy) and every pipeline has host
+ * gaps between its launches, and a second stream fills both -- measured with two ranks sharing one GPU: +7 % reads/s at the headline
+ * shape, +20 % on config 5 (tools/gpu_tworank.sh).  Reads are independent, so the halves exchange nothing; results are merged by
+ * read index.  Small batches (tests, the file driver's own two workers) use one pipeline. */
+#define TH_MAX_SUB 2
 struct th_handle {
     th_para_t para;              /* snapshot (adapter strings are borrowed from the caller's th_para_t) */
-    th_gpu_t *gpu;
+    th_gpu_t *gpu[TH_MAX_SUB]; int n_sub_max, n_sub, sub_min, sub_off[TH_MAX_SUB + 1];
     int n; const char *const *seqs; const int *lens;   /* the resident batch (borrowed until collect) */
 };
 
@@ -535,7 +541,7 @@ static int edlib_hw(const char *q, int qlen, const char *t, int tlen, int *start
 }
 
 /* ---------------------------------------------------------------- batch seam */
-th_handle_t *th_init(const th_para_t *p, int device)
+static th_handle_t *th_init_sub(const th_para_t *p, int device, int n_sub_max)
 {
     g_err[0] = 0;
     if (p->w < 1 || p->w > 256) { host_fail("-w must be in 1..256 (the reference's minimizer window, src/tandem_hit.c:100, has 256 slots)"); return NULL; }
@@ -550,28 +556,70 @@ th_handle_t *th_init(const th_para_t *p, int device)
         gp.ad_len[0] = gp.ad_len[2] = p->five_len; gp.ad_len[1] = gp.ad_len[3] = p->three_len;
         gp.ad_k[0] = gp.ad_k[2] = (int)(p->five_len * (1 - p->ada_match_rat)); gp.ad_k[1] = gp.ad_k[3] = (int)(p->three_len * (1 - p->ada_match_rat));
     }
-    th_gpu_t *g = th_gpu_create(&gp, device);
-    if (!g) return NULL;
     th_handle_t *h = (th_handle_t *)calloc(1, sizeof(*h));
-    h->para = *p; h->gpu = g;
+    h->para = *p; h->n_sub_max = n_sub_max < 1 ? 1 : n_sub_max > TH_MAX_SUB ? TH_MAX_SUB : n_sub_max; h->n_sub = 1;
+    h->sub_min = 16384;
+    { const char *e = getenv("TH_SUBBATCH_MIN"); if (e && atoi(e) > 0) h->sub_min = atoi(e); }
+    for (int s = 0; s < h->n_sub_max; ++s) {
+        h->gpu[s] = th_gpu_create(&gp, device);
+        if (!h->gpu[s]) { for (int x = 0; x < s; ++x) th_gpu_destroy(h->gpu[x]); free(h); return NULL; }
+    }
     return h;
 }
-void th_destroy(th_handle_t *h) { if (!h) return; th_gpu_destroy(h->gpu); free(h); }
+th_handle_t *th_init(const th_para_t *p, int device)
+{
+    int ns = TH_MAX_SUB;
+    const char *e = getenv("TH_SUBBATCH");
+    if (e && atoi(e) >= 1) ns = atoi(e);
+    return th_init_sub(p, device, ns);
+}
+void th_destroy(th_handle_t *h) { if (!h) return; for (int s = 0; s < h->n_sub_max; ++s) th_gpu_destroy(h->gpu[s]); free(h); }
 
 int th_batch_upload(th_handle_t *h, const char *const *seqs, const int *lens, int n)
 {
     h->n = n; h->seqs = seqs; h->lens = lens;
-    return th_gpu_upload(h->gpu, seqs, lens, n);
+    h->n_sub = (h->n_sub_max >= 2 && n >= h->sub_min) ? 2 : 1;
+    h->sub_off[0] = 0; h->sub_off[h->n_sub] = n;
+    if (h->n_sub == 2) {                       /* two halves balanced by bases (cost ~ bases) */
+        long long tot = 0, acc = 0; int cut = 0;
+        for (int i = 0; i < n; ++i) tot += lens[i];
+        while (cut < n - 1 && 2 * (acc + lens[cut]) <= tot) acc += lens[cut++];
+        if (cut < 1) cut = 1;
+        h->sub_off[1] = cut;
+    }
+    for (int s = 0; s < h->n_sub; ++s)
+        if (th_gpu_upload(h->gpu[s], seqs + h->sub_off[s], lens + h->sub_off[s], h->sub_off[s + 1] - h->sub_off[s])) return -1;
+    return 0;
 }
-int th_batch_reserve(th_handle_t *h, int max_reads, long long max_bases) { return th_gpu_reserve(h->gpu, max_reads, max_bases); }
-int th_batch_run(th_handle_t *h) { return th_gpu_run(h->gpu); }
+int th_batch_reserve(th_handle_t *h, int max_reads, long long max_bases)
+{
+    const int ns = (h->n_sub_max >= 2 && max_reads >= h->sub_min) ? 2 : 1;
+    for (int s = 0; s < ns; ++s) if (th_gpu_reserve(h->gpu[s], max_reads / ns + 64, max_bases / ns + max_bases / 16)) return -1;
+    return 0;
+}
+static void *sub_run(void *arg) { return (void *)(intptr_t)th_gpu_run((th_gpu_t *)arg); }
+int th_batch_run(th_handle_t *h)
+{
+    if (h->n_sub == 1) return th_gpu_run(h->gpu[0]);
+    pthread_t tid; void *r1 = NULL;
+    if (pthread_create(&tid, NULL, sub_run, h->gpu[1]) != 0) return host_fail("pthread_create failed");
+    const int r0 = th_gpu_run(h->gpu[0]);
+    pthread_join(tid, &r1);
+    if (r1 != NULL && !g_err[0]) snprintf(g_err, sizeof(g_err), "the second half of the batch failed on the device (see stderr)");
+    return (r0 || r1 != NULL) ? -1 : 0;
+}
+/* device milliseconds of the last run per kernel, summed over the concurrent halves; th_batch_launches() says how many there were */
 int th_batch_timing(th_handle_t *h, double *ms_kernel, int n)
 {
-    th_gpu_out_t o; th_gpu_get(h->gpu, &o);
-    for (int i = 0; i < n && i < 8; ++i) ms_kernel[i] = o.ms_kernel[i];
+    for (int i = 0; i < n && i < 8; ++i) ms_kernel[i] = 0;
+    for (int s = 0; s < h->n_sub; ++s) {
+        th_gpu_out_t o; th_gpu_get(h->gpu[s], &o);
+        for (int i = 0; i < n && i < 8; ++i) ms_kernel[i] += o.ms_kernel[i];
+    }
     return 6;
 }
-long long th_debug_stage(th_handle_t *h, int what, void *dst, long long cap) { return th_gpu_debug(h->gpu, what, dst, cap); }
+int th_batch_launches(th_handle_t *h) { return h->n_sub; }
+long long th_debug_stage(th_handle_t *h, int what, void *dst, long long cap) { return h->n_sub == 1 ? th_gpu_debug(h->gpu[0], what, dst, cap) : -1; }
 
 typedef struct { int ed, start, end; } ed_res_t;
 static int collect_ed(const th_para_t *p, const char *q, int qlen, const char *seq, int seq_len, ed_res_t *r)   /* src/gen_cons.c:89-110 */
@@ -624,11 +672,11 @@ static int code_of(unsigned char c)
 }
 
 /* host half of seqs_msa()/abpoa_gen_cons() for one run, from the integer evidence the device produced */
-static void finish_job(const th_handle_t *h, const th_gpu_out_t *o, const th_job_t *j, th_tandem_seq_t *t)
+static void finish_job(const th_handle_t *h, const th_gpu_out_t *o, const th_job_t *j, th_tandem_seq_t *t, int rb)
 {
     const th_para_t *p = &h->para;
     const int *pos = o->par + j->pos_off; const int pos_n = j->pos_n;
-    const char *seq = h->seqs[j->read]; const int seq_len = h->lens[j->read];
+    const char *seq = h->seqs[rb + j->read]; const int seq_len = h->lens[rb + j->read];      /* rb: first read of the half this job belongs to */
     if (p->only_unit) { write_unit(t, pos, pos_n); return; }
     int cons_len = j->cons_len, n_seqs = j->n_seqs;
     if (cons_len <= 0) return;
@@ -714,7 +762,7 @@ WRITE:
 
 /* Record arithmetic of a batch (src/gen_cons.c:208-301 per consensus job): reads are independent and each writes only its
  * own tandem_seq_t slot, so the batch is cut into contiguous read ranges for a few worker threads. */
-typedef struct { th_handle_t *h; const th_gpu_out_t *o; th_tandem_seq_t *out; int r0, r1; } collect_arg_t;
+typedef struct { th_handle_t *h; const th_gpu_out_t *o; th_tandem_seq_t *out; int r0, r1, rb; } collect_arg_t;   /* reads rb + r0 .. rb + r1 of the batch = r0 .. r1 of the half */
 static void *collect_range(void *arg)
 {
     collect_arg_t *a = (collect_arg_t *)arg;
@@ -723,17 +771,18 @@ static void *collect_range(void *arg)
     while (lo < hi) { int mid = (lo + hi) >> 1; if (o->jobs[mid].read < a->r0) lo = mid + 1; else hi = mid; }
     int ji = lo;
     for (int r = a->r0; r < a->r1; ++r) {
-        th_tandem_seq_t *t = &a->out[r];
+        th_tandem_seq_t *t = &a->out[a->rb + r];
         t->cons_n = 0; t->cons_seq->seq.l = 0; t->cons_seq->qual.l = 0;
-        while (ji < o->n_jobs && o->jobs[ji].read == r) { finish_job(h, o, &o->jobs[ji], t); ++ji; }
-        if (h->lens[r] >= p->k && p->single_copy == 1 && p->only_full_length && p->five_seq != NULL && p->three_seq != NULL)
-            single_copy(h->lens[r], h->seqs[r], t, p);   /* src/tidehunter.c:24,49-51 */
+        while (ji < o->n_jobs && o->jobs[ji].read == r) { finish_job(h, o, &o->jobs[ji], t, a->rb); ++ji; }
+        if (h->lens[a->rb + r] >= p->k && p->single_copy == 1 && p->only_full_length && p->five_seq != NULL && p->three_seq != NULL)
+            single_copy(h->lens[a->rb + r], h->seqs[a->rb + r], t, p);   /* src/tidehunter.c:24,49-51 */
     }
     return NULL;
 }
 int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out)
 {
-    th_gpu_out_t o; th_gpu_get(h->gpu, &o);
+    th_gpu_out_t o[TH_MAX_SUB];
+    for (int s = 0; s < h->n_sub; ++s) th_gpu_get(h->gpu[s], &o[s]);
     /* worker threads for the record arithmetic (adapter searches are the heavy part): -t if given above the reference's
      * default of 4, else 16 on hosts with 32 or more cores, else 8; TH_HOST_THREADS overrides */
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
@@ -743,9 +792,13 @@ int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out)
     if (nth > 64) nth = 64;
     if (h->n < 256 * nth) nth = 1;
     collect_arg_t arg[64]; pthread_t tid[64];
-    for (int t = 0; t < nth; ++t) {
-        arg[t].h = h; arg[t].o = &o; arg[t].out = out;
-        arg[t].r0 = (int)((long long)h->n * t / nth); arg[t].r1 = (int)((long long)h->n * (t + 1) / nth);
+    if (h->n_sub == 2 && nth < 2) nth = 2;
+    for (int t = 0; t < nth; ++t) {          /* the threads are shared out over the halves in proportion to their reads */
+        const int t_split = h->n_sub == 2 ? (int)((long long)nth * h->sub_off[1] / (h->n ? h->n : 1)) : nth;
+        const int ts = h->n_sub == 2 ? (t_split < 1 ? 1 : t_split > nth - 1 ? nth - 1 : t_split) : nth;
+        const int s = t < ts ? 0 : 1, k = s ? t - ts : t, m = s ? nth - ts : ts, cnt = h->sub_off[s + 1] - h->sub_off[s];
+        arg[t].h = h; arg[t].o = &o[s]; arg[t].out = out; arg[t].rb = h->sub_off[s];
+        arg[t].r0 = (int)((long long)cnt * k / m); arg[t].r1 = (int)((long long)cnt * (k + 1) / m);
     }
     for (int t = 1; t < nth; ++t) pthread_create(&tid[t], NULL, collect_range, &arg[t]);
     collect_range(&arg[0]);
@@ -762,8 +815,9 @@ int th_process_batch(th_handle_t *h, const char *const *seqs, const int *lens, i
     const double t2 = now_s();
     const int rc = th_batch_collect(h, out);
     if (getenv("TH_TRACE")) {
-        th_gpu_out_t o; th_gpu_get(h->gpu, &o);
-        fprintf(stderr, "[th_process_batch] %d reads: upload %.3f s, device run %.3f s (kernels %.3f s), collect %.3f s\n", n, t1 - t0, t2 - t1, o.ms_kernels / 1000.0, now_s() - t2);
+        double km = 0;
+        for (int s = 0; s < h->n_sub; ++s) { th_gpu_out_t o; th_gpu_get(h->gpu[s], &o); km += o.ms_kernels; }
+        fprintf(stderr, "[th_process_batch] %d reads in %d concurrent part(s): upload %.3f s, device run %.3f s (kernels %.3f s summed), collect %.3f s\n", n, h->n_sub, t1 - t0, t2 - t1, km / 1000.0, now_s() - t2);
     }
     return rc;
 }
@@ -897,7 +951,7 @@ static void *pipe_writer(void *arg)
 static void *pipe_device(void *arg)
 {
     th_dev_worker_t *w = (th_dev_worker_t *)arg; th_pipe_t *q = w->q;
-    th_handle_t *h = th_init(q->p, w->device);
+    th_handle_t *h = th_init_sub(q->p, w->device, 1);      /* the driver's two workers per device already give the device two streams */
     if (!h) { w->rc = -1; q->stop = 1; }
     for (;;) {
         const int i = __atomic_fetch_add(&q->next_batch, 1, __ATOMIC_RELAXED);
