@@ -597,6 +597,8 @@ int th_batch_reserve(th_handle_t *h, int max_reads, long long max_bases)
     for (int s = 0; s < ns; ++s) if (th_gpu_reserve(h->gpu[s], max_reads / ns + 64, max_bases / ns + max_bases / 16)) return -1;
     return 0;
 }
+/* (Tried: starting the second half only when the first has finished stages 1-3, so that the halves sit in different stages.  Worse:
+ * the late half's first kernels queue behind the POA grid -- config 3 88.1 k against 92.0 k reads/s, config 2 171 k against 185 k.) */
 static void *sub_run(void *arg) { return (void *)(intptr_t)th_gpu_run((th_gpu_t *)arg); }
 int th_batch_run(th_handle_t *h)
 {

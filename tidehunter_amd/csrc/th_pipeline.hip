@@ -39,6 +39,10 @@ static thread_local double g_alloc_s = 0, g_free_s = 0; static thread_local long
 // arena falls back to its own hipMalloc.
 struct Arena { char *base = nullptr; size_t cap = 0, top = 0; };
 static thread_local Arena *g_arena = nullptr;
+// a pinned vector is grown with a quarter of slack: re-pinning (hipHostFree + hipHostMalloc) costs milliseconds and must not recur as
+// batches of slightly different sizes follow each other
+template <class V> static inline void th_room(V &v, size_t n) { if (v.capacity() < n) v.reserve(n + n / 4 + 64); }
+
 template <class T> struct DBuf {
     T *p = nullptr; size_t cap = 0; bool in_arena = false;
     int ensure(size_t n) {
@@ -68,7 +72,7 @@ struct th_gpu {
     th_gpu_para_t para; ThDevPara dp; int device; th_stream_t stream;
     int n = 0; long long T = 0; int max_len = 0;
     uint8_t *h_stage[2] = { nullptr, nullptr }; th_event_t stage_ev[2]; bool stage_ok = false;   // pinned staging for the upload (2 x TH_STAGE_BYTES)
-    std::vector<uint32_t> h_roff; std::vector<long long> h_gsort_off; long long gsort_total = 0;
+    th_pvec<uint32_t> h_roff; th_pvec<long long> h_gsort_off; long long gsort_total = 0;
     DBuf<uint8_t> d_seq, d_bseq, d_tracked, d_cons;
     DBuf<uint32_t> d_roff, d_tmp;
     DBuf<uint16_t> d_xorder; DBuf<int> d_xstart, d_xend, d_xovf;
@@ -79,10 +83,10 @@ struct th_gpu {
     DBuf<int> d_par, d_par_off, d_par_n, d_par_dst, d_parc, d_bnd, d_scratch, d_cov, d_cons_len, d_status, d_iden, d_ext;
     DBuf<ThTask> d_tasks, d_sub; DBuf<ThUnit> d_units; DBuf<ThAlnItem> d_items; DBuf<int> d_scl, d_sst;   // d_sub/d_scl/d_sst: task subsets of POA relaunches
     int n_rec = 0, reserve_n = 0; Arena arena;
-    bool ad_on = false; int ad_min_cons = 0; ThAdPara h_ad; DBuf<ThAdPara> d_adp; DBuf<int> d_ad; std::vector<int> h_ad_out; bool ad_valid = false;
-    std::vector<ThChainRec> h_rec; std::vector<int> h_par_n, h_par_dst, h_parc, h_read_ch_base, h_read_ch_n;
-    std::vector<ThTask> h_tasks; std::vector<ThUnit> h_units; std::vector<ThAlnItem> h_items;
-    std::vector<int> h_cons_len, h_status, h_iden, h_ext, h_cov; std::vector<uint8_t> h_cons;
+    bool ad_on = false; int ad_min_cons = 0; ThAdPara h_ad; DBuf<ThAdPara> d_adp; DBuf<int> d_ad; th_pvec<int> h_ad_out; bool ad_valid = false;
+    th_pvec<ThChainRec> h_rec; th_pvec<int> h_par_n, h_par_dst, h_parc, h_read_ch_base, h_read_ch_n;      // pinned: see th_rt.h
+    th_pvec<ThTask> h_tasks, h_sub; th_pvec<ThUnit> h_units; th_pvec<ThAlnItem> h_items;
+    th_pvec<int> h_cons_len, h_status, h_iden, h_ext, h_cov, h_cl, h_st, h_cc_off, h_cnt; th_pvec<uint8_t> h_cons;
     std::vector<th_job_t> jobs;
     double ms_kernels = 0, ms_dominant = 0, ms_k[8] = { 0 };
     int aln_wdiv = 10, aln_wadd = 24;     // first certified band of the unit alignments: half-width cons_len / wdiv + wadd
@@ -216,7 +220,7 @@ extern "C" int th_gpu_reserve(th_gpu_t *g, int n, long long T)
 extern "C" int th_gpu_upload(th_gpu_t *g, const char *const *seqs, const int *lens, int n)
 {
     TRY(th_select_device(g));
-    g->n = n; g->h_roff.assign((size_t)n + 1, 0);
+    g->n = n; th_room(g->h_roff, (size_t)n + 1); g->h_roff.assign((size_t)n + 1, 0);
     long long T = 0; int mx = 0;
     for (int i = 0; i < n; ++i) { g->h_roff[i] = (uint32_t)T; T += lens[i]; mx = std::max(mx, lens[i]); }
     if (T >= (1LL << 31)) return th_fail("batch holds 2^31 bases or more; split it");
@@ -224,7 +228,7 @@ extern "C" int th_gpu_upload(th_gpu_t *g, const char *const *seqs, const int *le
     g->h_roff[n] = (uint32_t)T; g->T = T; g->max_len = mx;
     size_t padT = (size_t)((T + 15) & ~15LL);
     // reads whose sort does not fit the LDS buffers get a segment of HBM scratch
-    g->h_gsort_off.assign((size_t)n, -1); long long gs = 0;
+    th_room(g->h_gsort_off, (size_t)n); g->h_gsort_off.assign((size_t)n, -1); long long gs = 0;
     for (int i = 0; i < n; ++i) {
         int ne = lens[i] - g->dp.k + 1; if (ne < 1) continue;
         long long N = 1; while (N < ne) N <<= 1;
@@ -272,6 +276,7 @@ extern "C" int th_gpu_upload(th_gpu_t *g, const char *const *seqs, const int *le
 static void build_jobs(th_gpu *g)
 {
     g->h_tasks.clear(); g->h_units.clear(); g->h_items.clear(); g->jobs.clear();
+    th_room(g->h_tasks, g->h_par_n.size() + 16); th_room(g->h_units, g->h_parc.size() + 16);     // at most one task per chain, one unit per boundary
     const int min_copy = g->dp.min_copy;
     long long cons_top = 0; int aln_top = 0;
     // chains grouped by read, in emission order: records of read r are rec[base .. base+cnt)
@@ -393,7 +398,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
               (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, (const int *)g->d_score.p,
               g->d_xorder.p, g->d_xstart.p, g->d_xend.p);
     KT_END(TK_CHAIN_X);
-    int cnt[16];      // 0 chain records, 1 error flags, 2-7 work-queue heads / arena tops, 8 reads whose minimizer selection fell back to the sequential replay
+    g->h_cnt.assign(16, 0); int *cnt = g->h_cnt.data();      // (pinned) 0 chain records, 1 error flags, 2-7 work-queue heads / arena tops, 8 reads whose minimizer selection fell back to the sequential replay
     // chain extraction fills an arena of chain records with one atomic per read; a batch with more chains than the arena
     // holds (8 per read on average) reruns the extraction with a larger one -- the kernels only read stage 1-2 results
     for (int attempt = 0;; ++attempt) {
@@ -409,7 +414,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
                   (const uint16_t *)g->d_xorder.p, (const int *)g->d_xstart.p, (const int *)g->d_xend.p, g->d_xovf.p, g->d_rec.p, rec_cap, g->d_cnt.p,
                   g->d_read_ch_base.p, g->d_read_ch_n.p, g->d_cnt.p + 1, g->d_cnt.p + 6);
         KT_END(TK_CHAIN_X);
-        TRY(th_rt_d2h(cnt, g->d_cnt.p, sizeof(cnt), g->stream));
+        TRY(th_rt_d2h(cnt, g->d_cnt.p, 16 * sizeof(int), g->stream));
         TRY(th_rt_sync(g->stream));
         if (!(cnt[1] & 1)) break;
         if (attempt == 4 || (long long)rec_cap * 4 > (1LL << 30)) return th_fail("chain record arena overflow");
@@ -427,9 +432,11 @@ extern "C" int th_gpu_run(th_gpu_t *g)
     }
     if (cnt[1]) return th_fail("stage 1-2 kernels reported error flags " + std::to_string(cnt[1]));
     const int n_rec = cnt[0]; g->n_rec = n_rec;
+    th_room(g->h_read_ch_base, (size_t)n); th_room(g->h_read_ch_n, (size_t)n);
     g->h_read_ch_base.resize(n); g->h_read_ch_n.resize(n);
     TRY(th_rt_d2h(g->h_read_ch_base.data(), g->d_read_ch_base.p, (size_t)n * 4, g->stream));
     TRY(th_rt_d2h(g->h_read_ch_n.data(), g->d_read_ch_n.p, (size_t)n * 4, g->stream));
+    th_room(g->h_rec, (size_t)n_rec); th_room(g->h_par_n, (size_t)n_rec); th_room(g->h_par_dst, (size_t)n_rec);
     g->h_rec.resize(n_rec); g->h_par_n.assign(n_rec, 0); g->h_par_dst.assign(n_rec, 0);
     if (n_rec) {
         // ---- partition ----
@@ -454,7 +461,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
                       (const uint8_t *)g->d_bseq.p, (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_cells.p, g->dp,
                       g->d_par.p, (int)par_cap, g->d_cnt.p + 5, g->d_par_off.p, g->d_par_n.p, g->d_bnd.p, bnd_part, g->d_cnt.p + 1, mul, g->d_cnt.p + 7);
             KT_END(TK_PART);
-            TRY(th_rt_d2h(cnt, g->d_cnt.p, sizeof(cnt), g->stream));
+            TRY(th_rt_d2h(cnt, g->d_cnt.p, 16 * sizeof(int), g->stream));
             TRY(th_rt_sync(g->stream));
             if (!cnt[1]) break;
             if (cap_mul >= 64) return th_fail("partition scratch overflow (par_pos region or boundary buffer)");
@@ -466,7 +473,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         TRY(th_rt_sync(g->stream));
         long long tot = 0;
         for (int c = 0; c < n_rec; ++c) { g->h_par_dst[c] = (int)tot; tot += g->h_par_n[c]; }
-        g->h_parc.resize((size_t)tot);
+        th_room(g->h_parc, (size_t)tot); g->h_parc.resize((size_t)tot);
         TRY(g->d_parc.ensure((size_t)tot + 1));
         TRY(th_rt_h2d(g->d_par_dst.p, g->h_par_dst.data(), (size_t)n_rec * 4, g->stream));
         TH_LAUNCH(th_k_gather_par, n_rec, 64, g->stream, n_rec, (const int *)g->d_par.p, (const int *)g->d_par_off.p, (const int *)g->d_par_n.p,
@@ -493,6 +500,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         TRY(th_rt_h2d(g->d_tasks.p, g->h_tasks.data(), (size_t)nt * sizeof(ThTask), g->stream));
         TRY(th_rt_h2d(g->d_units.p, g->h_units.data(), g->h_units.size() * sizeof(ThUnit), g->stream));
         // ---- POA: persistent waves with private scratch; tasks that outgrow it are retried with more ----
+        th_room(g->h_cons_len, (size_t)nt); th_room(g->h_status, (size_t)nt);
         g->h_cons_len.assign(nt, 0); g->h_status.assign(nt, 0);
         std::vector<int> todo(nt); for (int t = 0; t < nt; ++t) todo[t] = t;
         // Two kernel variants: the common one keeps recent rows as int16 in LDS (packed rows, 5 waves per SIMD) and gives a job
@@ -517,7 +525,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
             const bool whole = (int)grp.size() == nt;            // every task in its original order: the main arrays serve
             if (!whole) {
                 patched = true;
-                std::vector<ThTask> sub; sub.reserve(grp.size());
+                th_pvec<ThTask> &sub = g->h_sub; sub.clear(); th_room(sub, grp.size());
                 for (int t : grp) sub.push_back(g->h_tasks[t]);
                 TRY(d_sub.ensure(sub.size())); TRY(d_scl.ensure(sub.size())); TRY(d_sst.ensure(sub.size()));
                 TRY(th_rt_h2d(d_sub.p, sub.data(), sub.size() * sizeof(ThTask), g->stream));
@@ -533,7 +541,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
             else POA_LAUNCH(0, int);
             KT_END(TK_POA);
             if (getenv("TH_TRACE")) { th_rt_sync(g->stream); fprintf(stderr, "[th] %.3f s: poa done (%d jobs, %d waves, %s ring, %lld MB scratch)\n", th_wall_s() - t_run0, (int)grp.size(), wv, wide ? "32-bit" : "int16", (long long)(need * wv * 4 >> 20)); }
-            std::vector<int> cl(grp.size()), st(grp.size());
+            th_pvec<int> &cl = g->h_cl, &st = g->h_st; th_room(cl, grp.size()); th_room(st, grp.size()); cl.assign(grp.size(), 0); st.assign(grp.size(), 0);
             TRY(th_rt_d2h(cl.data(), dcl, grp.size() * 4, g->stream));
             TRY(th_rt_d2h(st.data(), dst, grp.size() * 4, g->stream));
             TRY(th_rt_sync(g->stream));
@@ -592,15 +600,17 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         // (two waves per SIMD) -- before this split the 2000-base units of config 5 ran on that variant although they need two.
         int max_cl = 0;
         const int ALN_SMALL = 4096, ALN_MID = 7168, ALN_BIG = 24576;
-        std::vector<ThAlnItem> mid_items, big_items;
+        std::vector<ThAlnItem> small_items, mid_items, big_items;
         for (int t = 0; t < nt; ++t) {
             max_cl = std::max(max_cl, g->h_cons_len[t]);
             const long long need2 = (long long)g->h_tasks[t].max_len + g->h_cons_len[t] + 512 * 2 + 16;
             const bool two_regs = 2 * (g->h_cons_len[t] / g->aln_wdiv + g->aln_wadd - g->aln_wtol) + 2 + 64 <= 512;     // th_ad_pick would settle for NP <= 2
-            std::vector<ThAlnItem> &dst = need2 <= ALN_SMALL ? g->h_items : (need2 <= ALN_MID && two_regs) ? mid_items : big_items;
+            std::vector<ThAlnItem> &dst = need2 <= ALN_SMALL ? small_items : (need2 <= ALN_MID && two_regs) ? mid_items : big_items;
             for (int u = 0; u < g->h_tasks[t].pos_n - 1; ++u) { ThAlnItem it = { t, u }; dst.push_back(it); }
-            ThAlnItem l = { t, -1 }, r = { t, -2 }; g->h_items.push_back(l); g->h_items.push_back(r);
+            ThAlnItem l = { t, -1 }, r = { t, -2 }; small_items.push_back(l); small_items.push_back(r);
         }
+        th_room(g->h_items, small_items.size() + mid_items.size() + big_items.size());
+        g->h_items.insert(g->h_items.end(), small_items.begin(), small_items.end());
         const int ns = (int)g->h_items.size();
         g->h_items.insert(g->h_items.end(), mid_items.begin(), mid_items.end());
         const int nm = (int)g->h_items.size();
@@ -632,12 +642,12 @@ extern "C" int th_gpu_run(th_gpu_t *g)
             TH_LAUNCH(th_k_adapter, (nt * 4 + 63) / 64, 64, g->stream, (const ThTask *)g->d_tasks.p, nt, (const uint8_t *)g->d_cons.p, (const int *)g->d_cons_len.p,
                       (const ThAdPara *)g->d_adp.p, g->ad_min_cons, g->d_ad.p);
             KT_END(TK_ALIGN);
-            g->h_ad_out.resize((size_t)nt * 12);
+            th_room(g->h_ad_out, (size_t)nt * 12); g->h_ad_out.resize((size_t)nt * 12);
             TRY(th_rt_d2h(g->h_ad_out.data(), g->d_ad.p, (size_t)nt * 48, g->stream));
             g->ad_valid = true;
         }
         // results: consensus strings compacted to their lengths (the slots are sized for the worst case), coverage only on request
-        std::vector<int> cc_off(nt); long long cc_total = 0;
+        th_pvec<int> &cc_off = g->h_cc_off; th_room(cc_off, (size_t)nt); cc_off.assign(nt, 0); long long cc_total = 0;
         for (int t = 0; t < nt; ++t) { cc_off[t] = (int)cc_total; cc_total += (g->h_cons_len[t] + 3) & ~3; }
         TRY(g->d_cc_len.ensure(nt)); TRY(g->d_cc_off.ensure(nt)); TRY(g->d_cons_c.ensure((size_t)cc_total + 4));
         if (g->para.want_cov) TRY(g->d_cov_c.ensure((size_t)cc_total + 4));
@@ -645,13 +655,14 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         TRY(th_rt_h2d(g->d_cc_off.p, cc_off.data(), (size_t)nt * 4, g->stream));
         TH_LAUNCH(th_k_gather_cons, nt, 128, g->stream, nt, (const ThTask *)g->d_tasks.p, (const int *)g->d_cc_len.p, (const int *)g->d_cc_off.p,
                   (const uint8_t *)g->d_cons.p, (const int *)g->d_cov.p, g->d_cons_c.p, g->para.want_cov ? g->d_cov_c.p : (int *)nullptr);
+        th_room(g->h_iden, (size_t)aln_total); th_room(g->h_ext, (size_t)nt * 4); th_room(g->h_cons, (size_t)cc_total + 4);
         g->h_iden.resize(aln_total); g->h_ext.resize((size_t)nt * 4); g->h_cons.resize((size_t)cc_total + 4);
         TRY(th_rt_d2h(g->h_iden.data(), g->d_iden.p, (size_t)aln_total * 4, g->stream));
         TRY(th_rt_d2h(g->h_ext.data(), g->d_ext.p, (size_t)nt * 16, g->stream));
         TRY(th_rt_d2h(g->h_cons.data(), g->d_cons_c.p, (size_t)cc_total, g->stream));
-        if (g->para.want_cov) { g->h_cov.resize((size_t)cc_total + 4); TRY(th_rt_d2h(g->h_cov.data(), g->d_cov_c.p, (size_t)cc_total * 4, g->stream)); }
+        if (g->para.want_cov) { th_room(g->h_cov, (size_t)cc_total + 4); g->h_cov.resize((size_t)cc_total + 4); TRY(th_rt_d2h(g->h_cov.data(), g->d_cov_c.p, (size_t)cc_total * 4, g->stream)); }
         for (int t = 0; t < nt; ++t) g->jobs[t].cons_off = cc_off[t];
-        TRY(th_rt_d2h(cnt, g->d_cnt.p, sizeof(cnt), g->stream));
+        TRY(th_rt_d2h(cnt, g->d_cnt.p, 16 * sizeof(int), g->stream));
         TRY(th_rt_sync(g->stream));
         if (cnt[1] & 64) return th_fail("TH_ALN_MODE=2: a banded alignment differs from the full matrix");
         if (cnt[1]) return th_fail("alignment boundary buffer overflow");

@@ -52,3 +52,23 @@ static inline int th_rt_event_destroy(th_event_t e) { TH_CHECK(hipEventDestroy(e
         const hipError_t le_ = hipGetLastError(); if (le_ != hipSuccess) return th_launch_failed(#kernel, hipGetErrorString(le_)); } while (0)
 #define TH_LANE() ((int)(threadIdx.x & 63))
 #endif
+
+// Host arrays that device copies read from or write to live in pinned memory: a copy between HBM and PAGEABLE host memory is staged
+// by the runtime and moved by a blit kernel, which needs a compute unit -- and next to another stream's persistent grid (the two
+// concurrent halves of a batch, the file driver's two workers) waits for one, up to a whole kernel (seen in the kernel trace: copies
+// averaging 19 ms).  Pinned buffers go through the DMA engines.  std::vector with this allocator keeps the code unchanged; growth
+// re-pins, so the vectors are members that keep their capacity from batch to batch.
+#include <vector>
+#include <new>
+template <class T> struct th_pinned_alloc {
+    typedef T value_type;
+    th_pinned_alloc() {}
+    template <class U> th_pinned_alloc(const th_pinned_alloc<U> &) {}
+    static bool pin() { static const bool on = !(getenv("TH_NOPIN") && atoi(getenv("TH_NOPIN"))); return on; }     // TH_NOPIN=1: plain malloc (A/B measurements)
+    T *allocate(size_t n) { void *p = nullptr; if (!pin()) { p = malloc(n * sizeof(T) + 1); if (!p) throw std::bad_alloc(); return (T *)p; }
+                            if (th_rt_host_alloc(&p, n * sizeof(T)) != 0 || !p) throw std::bad_alloc(); return (T *)p; }
+    void deallocate(T *p, size_t) { if (!pin()) free(p); else th_rt_host_free(p); }
+    template <class U> bool operator==(const th_pinned_alloc<U> &) const { return true; }
+    template <class U> bool operator!=(const th_pinned_alloc<U> &) const { return false; }
+};
+template <class T> using th_pvec = std::vector<T, th_pinned_alloc<T>>;
