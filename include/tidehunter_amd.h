@@ -96,7 +96,7 @@ int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out);
  * stream(s): [0] encode+hits [1] chain_dp [2] chain_extract [3] partition [4] poa [5] align; returns 6 */
 int th_batch_timing(th_handle_t *h, double *ms_kernel, int n);
 /* A batch of 16384 reads or more (TH_SUBBATCH_MIN) runs as two concurrent halves on two streams of the handle's device (TH_SUBBATCH=1
- * turns that off); th_batch_timing sums the halves, th_batch_launches returns how many there were (1 or 2) in the last upload. */
+ * turns that off, 3 or 4 make more parts); th_batch_timing sums the parts, th_batch_launches returns how many the last upload made. */
 int th_batch_launches(th_handle_t *h);
 
 /* mini_tandem_output(), src/main.c:214-271 (resets the slots after printing, as the reference does) */

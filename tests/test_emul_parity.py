@@ -332,6 +332,15 @@ def test_emul_batch_runs_as_two_concurrent_halves(emu, monkeypatch):
     """a large batch is cut into two halves by bases that run on two pipelines of the handle at once (TH_SUBBATCH_MIN lowers the
     threshold for the test): same records as the oracle, merged in read order; adapters and -s included"""
     monkeypatch.setenv("TH_SUBBATCH_MIN", "3")
+    # (three parts as well)
+    monkeypatch.setenv("TH_SUBBATCH", "3")
+    th = TH.TideHunter(lib_path=emu)
+    seqs3 = _reads(TH.load_library(), [(60, 8, 0.10), (120, 5, 0.08), (35, 12, 0.12), (200, 3, 0.10), (90, 6, 0.0)])
+    got3 = th.process(seqs3)
+    assert th.launches() == 3
+    U.assert_records_equal(seqs3, got3, O.default_para(), "three parts")
+    th.close()
+    monkeypatch.setenv("TH_SUBBATCH", "2")
     ad = (os.path.join(U.DATA, "5prime.fa"), os.path.join(U.DATA, "3prime.fa"))
     seqs = _reads(TH.load_library(), [(60, 8, 0.10), (120, 5, 0.08), (35, 12, 0.12), (200, 3, 0.10), (90, 6, 0.0), (70, 7, 0.1)]) + [b"ACGT" * 3, b""]
     for kw, adapters in ((dict(), None), (dict(out_fmt=4, min_cov=2), None), (dict(only_full_length=1, single_copy=1), ad)):

@@ -37,7 +37,7 @@ static int host_fail(const char *m) { snprintf(g_err, sizeof(g_err), "%s", m); f
  * gaps between its launches, and a second stream fills both -- measured with two ranks sharing one GPU: +7 % reads/s at the headline
  * shape, +20 % on config 5 (tools/gpu_tworank.sh).  Reads are independent, so the halves exchange nothing; results are merged by
  * read index.  Small batches (tests, the file driver's own two workers) use one pipeline. */
-#define TH_MAX_SUB 2
+#define TH_MAX_SUB 4
 struct th_handle {
     th_para_t para;              /* snapshot (adapter strings are borrowed from the caller's th_para_t) */
     th_gpu_t *gpu[TH_MAX_SUB]; int n_sub_max, n_sub, sub_min, sub_off[TH_MAX_SUB + 1];
@@ -568,7 +568,7 @@ static th_handle_t *th_init_sub(const th_para_t *p, int device, int n_sub_max)
 }
 th_handle_t *th_init(const th_para_t *p, int device)
 {
-    int ns = TH_MAX_SUB;
+    int ns = 2;
     const char *e = getenv("TH_SUBBATCH");
     if (e && atoi(e) >= 1) ns = atoi(e);
     return th_init_sub(p, device, ns);
@@ -578,14 +578,16 @@ void th_destroy(th_handle_t *h) { if (!h) return; for (int s = 0; s < h->n_sub_m
 int th_batch_upload(th_handle_t *h, const char *const *seqs, const int *lens, int n)
 {
     h->n = n; h->seqs = seqs; h->lens = lens;
-    h->n_sub = (h->n_sub_max >= 2 && n >= h->sub_min) ? 2 : 1;
+    h->n_sub = (h->n_sub_max >= 2 && n >= h->sub_min) ? h->n_sub_max : 1;
     h->sub_off[0] = 0; h->sub_off[h->n_sub] = n;
-    if (h->n_sub == 2) {                       /* two halves balanced by bases (cost ~ bases) */
+    if (h->n_sub > 1) {                        /* parts balanced by bases (cost ~ bases) */
         long long tot = 0, acc = 0; int cut = 0;
         for (int i = 0; i < n; ++i) tot += lens[i];
-        while (cut < n - 1 && 2 * (acc + lens[cut]) <= tot) acc += lens[cut++];
-        if (cut < 1) cut = 1;
-        h->sub_off[1] = cut;
+        for (int s = 1; s < h->n_sub; ++s) {
+            while (cut < n - (h->n_sub - s) && (acc + lens[cut]) * h->n_sub <= tot * s) acc += lens[cut++];
+            if (cut < s) { acc += lens[cut]; ++cut; }          /* never an empty part */
+            h->sub_off[s] = cut;
+        }
     }
     for (int s = 0; s < h->n_sub; ++s)
         if (th_gpu_upload(h->gpu[s], seqs + h->sub_off[s], lens + h->sub_off[s], h->sub_off[s + 1] - h->sub_off[s])) return -1;
@@ -593,7 +595,7 @@ int th_batch_upload(th_handle_t *h, const char *const *seqs, const int *lens, in
 }
 int th_batch_reserve(th_handle_t *h, int max_reads, long long max_bases)
 {
-    const int ns = (h->n_sub_max >= 2 && max_reads >= h->sub_min) ? 2 : 1;
+    const int ns = (h->n_sub_max >= 2 && max_reads >= h->sub_min) ? h->n_sub_max : 1;
     for (int s = 0; s < ns; ++s) if (th_gpu_reserve(h->gpu[s], max_reads / ns + 64, max_bases / ns + max_bases / 16)) return -1;
     return 0;
 }
@@ -603,12 +605,12 @@ static void *sub_run(void *arg) { return (void *)(intptr_t)th_gpu_run((th_gpu_t 
 int th_batch_run(th_handle_t *h)
 {
     if (h->n_sub == 1) return th_gpu_run(h->gpu[0]);
-    pthread_t tid; void *r1 = NULL;
-    if (pthread_create(&tid, NULL, sub_run, h->gpu[1]) != 0) return host_fail("pthread_create failed");
+    pthread_t tid[TH_MAX_SUB]; int bad = 0;
+    for (int s = 1; s < h->n_sub; ++s) if (pthread_create(&tid[s], NULL, sub_run, h->gpu[s]) != 0) { for (int x = 1; x < s; ++x) pthread_join(tid[x], NULL); return host_fail("pthread_create failed"); }
     const int r0 = th_gpu_run(h->gpu[0]);
-    pthread_join(tid, &r1);
-    if (r1 != NULL && !g_err[0]) snprintf(g_err, sizeof(g_err), "the second half of the batch failed on the device (see stderr)");
-    return (r0 || r1 != NULL) ? -1 : 0;
+    for (int s = 1; s < h->n_sub; ++s) { void *r = NULL; pthread_join(tid[s], &r); if (r != NULL) bad = 1; }
+    if (bad && !g_err[0]) snprintf(g_err, sizeof(g_err), "a part of the batch failed on the device (see stderr)");
+    return (r0 || bad) ? -1 : 0;
 }
 /* device milliseconds of the last run per kernel, summed over the concurrent halves; th_batch_launches() says how many there were */
 int th_batch_timing(th_handle_t *h, double *ms_kernel, int n)
@@ -794,13 +796,21 @@ int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out)
     if (nth > 64) nth = 64;
     if (h->n < 256 * nth) nth = 1;
     collect_arg_t arg[64]; pthread_t tid[64];
-    if (h->n_sub == 2 && nth < 2) nth = 2;
-    for (int t = 0; t < nth; ++t) {          /* the threads are shared out over the halves in proportion to their reads */
-        const int t_split = h->n_sub == 2 ? (int)((long long)nth * h->sub_off[1] / (h->n ? h->n : 1)) : nth;
-        const int ts = h->n_sub == 2 ? (t_split < 1 ? 1 : t_split > nth - 1 ? nth - 1 : t_split) : nth;
-        const int s = t < ts ? 0 : 1, k = s ? t - ts : t, m = s ? nth - ts : ts, cnt = h->sub_off[s + 1] - h->sub_off[s];
-        arg[t].h = h; arg[t].o = &o[s]; arg[t].out = out; arg[t].rb = h->sub_off[s];
-        arg[t].r0 = (int)((long long)cnt * k / m); arg[t].r1 = (int)((long long)cnt * (k + 1) / m);
+    if (nth < h->n_sub) nth = h->n_sub;
+    {   /* the threads are shared out over the parts in proportion to their reads, at least one each */
+        int first[TH_MAX_SUB + 1]; first[0] = 0;
+        for (int sp = 1; sp <= h->n_sub; ++sp) {
+            int f = sp == h->n_sub ? nth : (int)((long long)nth * h->sub_off[sp] / (h->n ? h->n : 1));
+            if (f < first[sp - 1] + 1) f = first[sp - 1] + 1;
+            if (f > nth - (h->n_sub - sp)) f = nth - (h->n_sub - sp);
+            first[sp] = f;
+        }
+        for (int sp = 0; sp < h->n_sub; ++sp)
+            for (int t = first[sp]; t < first[sp + 1]; ++t) {
+                const int k = t - first[sp], m = first[sp + 1] - first[sp], cnt = h->sub_off[sp + 1] - h->sub_off[sp];
+                arg[t].h = h; arg[t].o = &o[sp]; arg[t].out = out; arg[t].rb = h->sub_off[sp];
+                arg[t].r0 = (int)((long long)cnt * k / m); arg[t].r1 = (int)((long long)cnt * (k + 1) / m);
+            }
     }
     for (int t = 1; t < nth; ++t) pthread_create(&tid[t], NULL, collect_range, &arg[t]);
     collect_range(&arg[0]);
