@@ -60,6 +60,7 @@ struct ThUnit { int start, len; };   // start = index of the unit's first base i
 #ifdef TH_CPU_EMUL
 #define TH_READLANE(v, l) __shfl((v), (l))
 #define TH_WRITELANE(old, v, l) (TH_LANE() == (l) ? (v) : (old))
+#define th_writelane6(a, b, c, d, e, f, va, vb, vc, vd, ve, vf, l) do { if (TH_LANE() == (l)) { a = (va); b = (vb); c = (vc); d = (vd); e = (ve); f = (vf); } } while (0)
 __device__ __forceinline__ int th_shr1(int v, int fill) { int o = __shfl_up(v, 1); return TH_LANE() == 0 ? fill : o; }
 __device__ __forceinline__ int th_shl1(int v, int fill) { int o = __shfl_down(v, 1); return TH_LANE() == 63 ? fill : o; }
 // lane l <- lane l-1, lane 0 <- lane 0 of `inj` (a per-lane register: only its lane 0 matters)
@@ -87,6 +88,13 @@ __device__ __forceinline__ int th_writelane(int old, int v, int l)
     int keep;
     asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(old), "=&s"(keep) : "s"(v), "s"(l));
     return old;
+}
+// six registers, one lane select: m0 is loaded once (the compiler is told it is clobbered instead of saving it around each write)
+__device__ __forceinline__ void th_writelane6(int &a, int &b, int &c, int &d, int &e, int &f, int va, int vb, int vc, int vd, int ve, int vf, int l)
+{
+    asm("s_mov_b32 m0, %12\n\tv_writelane_b32 %0, %6, m0\n\tv_writelane_b32 %1, %7, m0\n\tv_writelane_b32 %2, %8, m0\n\t"
+        "v_writelane_b32 %3, %9, m0\n\tv_writelane_b32 %4, %10, m0\n\tv_writelane_b32 %5, %11, m0"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "s"(va), "s"(vb), "s"(vc), "s"(vd), "s"(ve), "s"(vf), "s"(l) : "m0");
 }
 #define TH_WRITELANE(old, v, l) th_writelane((old), (v), (l))
 #define TH_DPP(old, src, ctrl, rmask, bmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), (bmask), false)

@@ -888,7 +888,7 @@ void th_output(FILE *fp, int n, const char *const *names, const char *const *seq
  * work on batch i.  Output order = input order (src/main.c:217). */
 enum { SLOT_EMPTY = 0, SLOT_FILLED = 1, SLOT_DONE = 2 };
 #define TH_MAX_DEV 16
-#define TH_MAX_WORKER (2 * TH_MAX_DEV)          /* up to two workers (handles, streams) per device */
+#define TH_MAX_WORKER (4 * TH_MAX_DEV)          /* up to four workers (handles, streams) per device */
 #define TH_MAX_SLOT (2 * TH_MAX_WORKER + 1)
 typedef struct { char **names, **seqs; int *lens; int n, state, batch; th_tandem_seq_t *ts; th_str_t arena; size_t *noff, *soff; } th_slot_t;   /* batch: index of the batch the slot holds */
 typedef struct {
@@ -898,6 +898,7 @@ typedef struct {
     int eof_batch;               /* index of the empty batch that ends the input (-1 until the reader meets it) */
     int next_batch;              /* ticket counter of the device workers (the reference's THREAD_READ_I, src/main.c:277-281, at batch granularity) */
     double t_read, t_write;      /* busy seconds of the two side threads (TH_TRACE=1 prints them) */
+    double t_start; int trace;
 } th_pipe_t;
 typedef struct { th_pipe_t *q; int dev_index, device; int rc, total, batches; double busy; } th_dev_worker_t;
 
@@ -963,8 +964,11 @@ static void *pipe_writer(void *arg)
 static void *pipe_device(void *arg)
 {
     th_dev_worker_t *w = (th_dev_worker_t *)arg; th_pipe_t *q = w->q;
-    th_handle_t *h = th_init_sub(q->p, w->device, 1);      /* the driver's two workers per device already give the device two streams */
+    int fsub = 1;                                          /* the driver's two workers per device already give the device two streams */
+    { const char *e = getenv("TH_FILE_SUB"); if (e && atoi(e) >= 1 && atoi(e) <= TH_MAX_SUB) fsub = atoi(e); }
+    th_handle_t *h = th_init_sub(q->p, w->device, fsub);
     if (!h) { w->rc = -1; q->stop = 1; }
+    if (q->trace) fprintf(stderr, "[th_run_file]   worker %d: handle ready at %.3f s\n", w->dev_index, now_s() - q->t_start);
     for (;;) {
         const int i = __atomic_fetch_add(&q->next_batch, 1, __ATOMIC_RELAXED);
         th_slot_t *s = &q->slot[i % q->n_slot];
@@ -977,6 +981,7 @@ static void *pipe_device(void *arg)
             }
             const int rc = th_process_batch(h, (const char *const *)s->seqs, s->lens, s->n, s->ts);
             w->busy += now_s() - t0;
+            if (q->trace) fprintf(stderr, "[th_run_file]   worker %d: batch %d (%d reads) from %.3f to %.3f s\n", w->dev_index, i, s->n, t0 - q->t_start, now_s() - q->t_start);
             if (rc) { w->rc = -1; q->stop = 1; } else w->total += s->n;   /* never partial output: a failed batch and everything after it are dropped */
         }
         const int last = s->n == 0;
@@ -996,7 +1001,7 @@ int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *d
      * its next batch (pinned staging + H2D) and does the host-side record arithmetic of its previous one, so the device does
      * not idle between batches.  TH_WORKERS_PER_DEV=1 restores one worker per device. */
     int wpd = 2;
-    { const char *e = getenv("TH_WORKERS_PER_DEV"); if (e && atoi(e) >= 1 && atoi(e) <= 2) wpd = atoi(e); }
+    { const char *e = getenv("TH_WORKERS_PER_DEV"); if (e && atoi(e) >= 1 && atoi(e) <= 4) wpd = atoi(e); }
     int devices[TH_MAX_WORKER], n_dev = 0;
     for (int r = 0; r < wpd; ++r) for (int d = 0; d < n_dev_in; ++d) devices[n_dev++] = devices_in[d];
     if (p->five_fn && p->three_fn && !p->five_seq) if (th_load_adapters(p)) return -1;
@@ -1014,6 +1019,7 @@ int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *d
     }
     pthread_t t_rd, t_wr, t_dev[TH_MAX_WORKER]; th_dev_worker_t w[TH_MAX_WORKER];
     const double t_start = now_s();
+    q->t_start = t_start; q->trace = getenv("TH_TRACE") != NULL;
     pthread_create(&t_rd, NULL, pipe_reader, q); pthread_create(&t_wr, NULL, pipe_writer, q);
     for (int d = 0; d < n_dev; ++d) { memset(&w[d], 0, sizeof(w[d])); w[d].q = q; w[d].dev_index = d; w[d].device = devices[d]; pthread_create(&t_dev[d], NULL, pipe_device, &w[d]); }
     int total = 0, rc = 0; double busy = 0;

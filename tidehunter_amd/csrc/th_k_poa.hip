@@ -80,7 +80,7 @@ struct ThPoaG {
     int *r_off, *r_foff;       // offset of a row's band start among the direction words / among the full cells (rows that store them)
     int *cntB, *headB, *aft;
     int *ops, *pv, *glo, *pth;
-    int4 *cell; uint16_t *dcell; long long cell_bytes;     // full cells (rows some far row will read, rows of in-degree > 4) / 16-bit direction words (all other rows)
+    int4 *cell; uint16_t *dcell; uint32_t cell_u2;     // cell_u2: size of the region in 2-byte units (clamped to 2^31: row offsets are ints); full cells (rows some far row will read, rows of in-degree > 4) / 16-bit direction words (all other rows)
 };
 
 __device__ __forceinline__ int th_poa_in(const ThPoaG &g, int v, int ord)
@@ -272,7 +272,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     const int M = P.match, X = P.mismatch, O1 = P.go1, E1 = P.ge1, O2 = P.go2, E2 = P.ge2;
     qlen = TH_UNI(qlen);
     const int n = TH_UNI(g.n_node), w = TH_POA_WB + qlen / 100;
-    long long ncell = 0, nfull = 0;
+    uint32_t ncell = 0, nfull = 0;          // direction words / full cells handed out so far (32-bit: the region is clamped to 2^31 words)
     // Every real score lies within +-real_b: a path to (i, j) has at most i + j unit steps, the dearest of which is a
     // mismatch (X for two units) or a one-base gap (open + extend for one unit); E'/F carry one more open + extend.
     // Rows are cached as int16 (and packed rows are used) only if that, the upward drift of unreachable cells (M per
@@ -363,7 +363,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         // rows that store them: g.cell points at the END of the region and their offsets are negative) grow downwards from its end.
         // A wave's scratch shrinks from ~18 to ~3-6 bytes per band cell, whatever the share of rows stored in full.
         if (store_full) nfull += span;
-        if ((ncell + span) * 2 + nfull * 16 > g.cell_bytes) return -3;
+        if (ncell + (uint32_t)span + nfull * 8u > g.cell_u2) return -3;
         const int my_off = (int)ncell + (b - B0);                // offset of column b, as every reader expects
         const int my_foff = store_full ? -(int)nfull + (b - B0) : 0;
         int4 *row = g.cell + my_foff; uint16_t *drow = g.dcell + my_off;
@@ -544,8 +544,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
           const int cat = pk ? 0 : inn != 1 ? 1 : p0 != i - 1 ? 2 : needfull ? 3 : 4;     // packed / several predecessors / one far predecessor / stores full cells / other
           pf_n[cat] += 1; pf_t[cat] += dt; }
 #endif
-        m_beg = TH_WRITELANE(m_beg, b, sl); m_end = TH_WRITELANE(m_end, e, sl); m_left = TH_WRITELANE(m_left, L_l, sl); m_right = TH_WRITELANE(m_right, L_r, sl);
-        m_off = TH_WRITELANE(m_off, my_off, sl); m_foff = TH_WRITELANE(m_foff, my_foff, sl);
+        th_writelane6(m_beg, m_end, m_left, m_right, m_off, m_foff, b, e, L_l, L_r, my_off, my_foff, sl);
         if (sl == 63 || i + 2 >= n) {          // chunk complete (or last row): its rows' metadata to the tables, coalesced
             const int r = (i & ~63) + lane;
             if (r <= i) { g.r_beg[r] = m_beg; g.r_end[r] = m_end; g.r_off[r] = m_off; g.r_foff[r] = m_foff; g.r_mpl[r] = m_left; g.r_mpr[r] = m_right; }
@@ -826,10 +825,10 @@ th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict
         g.ops = th_carve(p, 2 * opn); g.pv = th_carve(p, opn); g.glo = th_carve(p, opn); g.pth = th_carve(p, opn + 2);
         {
             const long long avail = (scratch_ints - (p - my)) & ~3LL;
-            g.cell_bytes = avail * 4; g.dcell = (uint16_t *)p; g.cell = (int4 *)(p + avail);
+            g.cell_u2 = (uint32_t)min(avail * 2, 0x7ff00000LL); g.dcell = (uint16_t *)p; g.cell = (int4 *)(p + avail);
         }
         int st = 0;
-        if (p - my > scratch_ints || g.cell_bytes < 4096) st = 1;
+        if (p - my > scratch_ints || g.cell_u2 < 2048) st = 1;
         if (!st) th_poa_seed(g, rb + U[0].start, U[0].len);
         for (int s = 1; s < T.n_units && !st; ++s) {
             const uint8_t *q = rb + U[s].start; const int qlen = U[s].len;

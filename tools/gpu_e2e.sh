@@ -11,9 +11,9 @@ with open("/dev/shm/c3.fa", "wb") as f:
 PY
 rm -f $O/e2e.txt
 for v in ${E2E_CASES:-1:65536:1000000 2:65536:0 2:32768:0}; do set -- ${v//:/ }
-  echo "== workers/dev $1 batch $2 ramp0 $3" >> $O/e2e.txt
+  echo "== workers/dev $1 batch $2 ramp0 $3 sub ${4:-1} submin ${5:-16384}" >> $O/e2e.txt
   if [ "$3" = "0" ]; then unset TH_RAMP0; else export TH_RAMP0=$3; fi
-  TH_WORKERS_PER_DEV=$1 TH_TRACE=1 $R/tidehunter_amd/TideHunter-amd -b $2 -o /dev/shm/c3.out /dev/shm/c3.fa 2>&1 | grep -v "^$" >> $O/e2e.txt
+  TH_FILE_SUB=${4:-1} TH_SUBBATCH_MIN=${5:-16384} TH_WORKERS_PER_DEV=$1 TH_TRACE=1 $R/tidehunter_amd/TideHunter-amd -b $2 -o /dev/shm/c3.out /dev/shm/c3.fa 2>&1 | grep -v "^$" >> $O/e2e.txt
   echo "records: $(grep -c '^>' /dev/shm/c3.out) md5: $(md5sum < /dev/shm/c3.out)" >> $O/e2e.txt
 done
 rm -f /dev/shm/c3.fa /dev/shm/c3.out
