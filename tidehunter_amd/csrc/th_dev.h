@@ -181,6 +181,9 @@ __device__ __forceinline__ int th_queue_pop(int *queue)
 #endif
 __device__ __forceinline__ int th_ctz64(unsigned long long m) { return m ? __ffsll((long long)m) - 1 : 64; }
 __device__ __forceinline__ int th_msb64(unsigned long long m) { return 63 - __clzll((long long)m); }   // m != 0
+// the same for masks known to be non-zero: bare s_ff1 / s_flbit, no zero fix-ups
+__device__ __forceinline__ int th_ctz64nz(unsigned long long m) { return __builtin_ctzll(m); }
+__device__ __forceinline__ int th_msb64nz(unsigned long long m) { return 63 - __builtin_clzll(m); }
 
 // ---- packed int16 pairs (two DP cells per lane): v_pk_add_i16 clamp / v_pk_sub_i16 clamp / v_pk_max_i16 ----
 #define TH_PK_NEG 0x80008000u            // (-32768, -32768): "minus infinity" in both halves

@@ -233,7 +233,7 @@ __device__ int th_poa_rows(ThPoaG &g)
 }
 
 #if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
-__device__ unsigned long long th_poa_prof[18];
+__device__ unsigned long long th_poa_prof[20];    // 0..3 phase cycles; 8..13 rows per category, 14..19 their cycles
 #define TH_PROF_CNT(k, v) ((void)0)
 #define TH_PROF_T0() unsigned long long pt_ = __builtin_amdgcn_s_memtime()
 #define TH_PROF(k) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (TH_LANE() == 0) atomicAdd(&th_poa_prof[k], n_ - pt_); pt_ = n_; } while (0)
@@ -262,6 +262,103 @@ __device__ unsigned long long th_poa_prof[18];
 #define TH_RING_ST(v) ((RT)(WIDE ? (v) : max((v), -32768)))
 #define TH_RIDX(j, beg) ((j) - ((beg) & ~1) + TH_POA_PAD)
 
+// One packed row: lane l owns columns B0 + 128 t + 2 l and the next one; every predecessor (npk of them, ring slot q_slot*, even
+// band base q_pb*) sits clean in the LDS ring.  Writes the row's ring slot and its 16-bit direction words (drow: column b), returns
+// the row maximum and its first / last column through rmax / left / right.  Forced inline: the row loop calls it twice, once
+// with npk = 1 and the previous row's slot as constants (the common row), once in general.
+template <int QCAP, typename RT>
+__device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[3][TH_POA_RS], uint16_t *drow, const int lane, const int b, const int e, const int B0,
+                                               const int myslot, const int nb, const int M, const uint32_t TX, const int npk,
+                                               const int q_slot0, const int q_slot1, const int q_slot2, const int q_slot3, const int q_pb0, const int q_pb1, const int q_pb2, const int q_pb3,
+                                               const int E1, const int E2, const uint32_t O1P, const uint32_t O2P, const uint32_t E1P, const uint32_t E2P, int &rmax, int &left, int &right)
+{
+    // ================= packed row: lane l owns columns B0 + 128 t + 2 l and the next one =================
+    const uint32_t T = nb == 4 ? 0x20820820u : ((TX & ~(63u << (6 * nb))) | (uint32_t)(32 + M) << (6 * nb));
+    uint32_t *wH = (uint32_t *)s_ring[myslot][0], *wE1 = (uint32_t *)s_ring[myslot][1], *wE2 = (uint32_t *)s_ring[myslot][2];
+    int carry1 = -32768, carry2 = -32768;                   // F1 / F2 running maxima in the column-offset domain
+    for (int t0 = 0; t0 < 256; t0 += 128) {
+        const int jr = t0 + 2 * lane, j0 = B0 + jr;
+        const int wi = (jr + TH_POA_PAD) >> 1;              // this lane's pair in the row being written
+        if (t0 && B0 + t0 > e) {                             // one trip was enough: clear the rest of the slot
+            if (wi < TH_POA_RS / 2) { wH[wi] = TH_PK_NEG; wE1[wi] = TH_PK_NEG; wE2[wi] = TH_PK_NEG; }
+            break;
+        }
+        const bool lo_ok = j0 >= b && j0 <= e, hi_ok = j0 + 1 <= e;
+        const uint32_t IM = (lo_ok ? 0xffffu : 0u) | (hi_ok ? 0xffff0000u : 0u);
+        // substitution scores of the two columns from the row's table
+        const uint32_t qx = s_qs[min(j0, QCAP) >> 1];                        // the pair's two 4-bit query codes
+        const uint32_t SC = th_pk_sub(th_ubfe(T, 6u * (qx & 15u), 6) | th_ubfe(T, 6u * (qx >> 4), 6) << 16, 0x00200020u);
+        // predecessor rows (all in the ring): diagonal pair (j0-1, j0) and vertical pairs (j0, j0+1) of each; anything outside
+        // a row's band reads -inf (its slot is clean, indices beyond either end are sent to the padding).  The first
+        // predecessor in edge order wins ties, as in the one-column-per-lane path; PMV / PE1V / PE2V hold the winners' edge
+        // indices, already shifted to their place in the 16-bit direction word
+        uint32_t m = 0, e1v = 0, e2v = 0, PMV = 0, PE1V = 0, PE2V = 0;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            if (o < npk) {
+                const int qs = o == 0 ? q_slot0 : o == 1 ? q_slot1 : o == 2 ? q_slot2 : q_slot3, qb = o == 0 ? q_pb0 : o == 1 ? q_pb1 : o == 2 ? q_pb2 : q_pb3;
+                const uint32_t *rH = (const uint32_t *)s_ring[qs][0], *rE1 = (const uint32_t *)s_ring[qs][1], *rE2 = (const uint32_t *)s_ring[qs][2];
+                int pi = j0 - qb + TH_POA_PAD;
+                pi = pi <= TH_POA_RS - 2 ? pi : 2;
+                pi = max(pi, 2);
+                const uint32_t Hm = rH[(pi >> 1) - 1], Hc = rH[pi >> 1], c1 = rE1[pi >> 1], c2 = rE2[pi >> 1];
+                const uint32_t mo = th_pk_add(th_alignbit16(Hc, Hm), SC);
+                if (o == 0) { m = mo; e1v = c1; e2v = c2; }
+                else {
+                    const uint32_t gm = th_pk_negmask_op(th_pk_sub(m, mo)), ge1 = th_pk_negmask_op(th_pk_sub(e1v, c1)), ge2 = th_pk_negmask_op(th_pk_sub(e2v, c2));
+                    m = th_pk_max(m, mo); e1v = th_pk_max(e1v, c1); e2v = th_pk_max(e2v, c2);
+                    PMV = th_sel(gm, TH_PK_DUP(o << 8), PMV); PE1V = th_sel(ge1, TH_PK_DUP(o << 10), PE1V); PE2V = th_sel(ge2, TH_PK_DUP(o << 12), PE2V);
+                }
+            }
+        }
+        const uint32_t hnf1 = th_pk_max(m, e1v), dg1 = th_pk_sub(m, e1v);           // sign of dg1: E1 strictly better
+        const uint32_t hnf = th_pk_max(hnf1, e2v), dg2 = th_pk_sub(hnf1, e2v);
+        // F1 / F2: max-plus prefix over the row in the domain value + column * extension
+        const uint32_t JR = TH_PK(jr, jr + 1);
+        const uint32_t JE1 = TH_PK(TH_PK_LO(JR) * E1, TH_PK_HI(JR) * E1), JE2 = TH_PK(TH_PK_LO(JR) * E2, TH_PK_HI(JR) * E2);
+        const uint32_t a1 = th_sel(IM, th_pk_add(th_pk_sub(hnf, O1P), JE1), TH_PK_NEG);
+        const uint32_t a2 = th_sel(IM, th_pk_add(th_pk_sub(hnf, O2P), JE2), TH_PK_NEG);
+        // lane totals are scanned as two 32-bit values: v_max_i32 takes the DPP operand directly (one instruction per
+        // step), a packed max would need a move and an identity fill per step
+        const int a1l = TH_PK_LO(a1), a2l = TH_PK_LO(a2);
+        const int i1 = th_wave_incl_max(max(a1l, TH_PK_HI(a1))), i2 = th_wave_incl_max(max(a2l, TH_PK_HI(a2)));
+        const int b1 = max(th_shr1(i1, carry1), carry1), b2 = max(th_shr1(i2, carry2), carry2);    // best before this lane's pair
+        carry1 = max(carry1, TH_READLANE(i1, 63)); carry2 = max(carry2, TH_READLANE(i2, 63));
+        const uint32_t x1 = TH_PK(b1, max(b1, a1l)), x2 = TH_PK(b2, max(b2, a2l));                 // (before lo, before hi)
+        const uint32_t f1 = th_pk_sub(x1, JE1), f2 = th_pk_sub(x2, JE2);
+        const uint32_t h3 = th_pk_max(hnf, f1), dg3 = th_pk_sub(hnf, f1);
+        const uint32_t h = th_pk_max(h3, f2), dg4 = th_pk_sub(h3, f2);
+        // direction word of the two columns: the sign bits of eight saturating differences, the first one ending in bit 7
+        const uint32_t hO1 = th_pk_sub(h, O1P), hO2 = th_pk_sub(h, O2P);
+        uint32_t code = th_pk_sign(dg1);
+        code = (code << 1) | th_pk_sign(dg2);
+        code = (code << 1) | th_pk_sign(dg3);
+        code = (code << 1) | th_pk_sign(dg4);
+        code = (code << 1) | th_pk_sign(th_pk_sub(hO1, e1v));
+        code = (code << 1) | th_pk_sign(th_pk_sub(hO2, e2v));
+        code = (code << 1) | th_pk_sign(th_pk_sub(hO1, f1));
+        code = (code << 1) | th_pk_sign(th_pk_sub(hO2, f2));
+        if (npk > 1) code |= PMV | PE1V | PE2V;
+        const uint32_t n1 = th_pk_sub(th_pk_max(hO1, e1v), E1P), n2 = th_pk_sub(th_pk_max(hO2, e2v), E2P);
+        if (j0 <= e) *(uint32_t *)(drow + (j0 - b)) = code;      // column b-1 / e+1 of an odd edge land in the row's own padding
+        if (wi < TH_POA_RS / 2) { wH[wi] = th_sel(IM, h, TH_PK_NEG); wE1[wi] = th_sel(IM, n1, TH_PK_NEG); wE2[wi] = th_sel(IM, n2, TH_PK_NEG); }
+        // row maximum and its first / last column: the maximum of H is a maximum of hnf (an F value is always
+        // below the hnf it came from), and H == max only where hnf == max
+        const uint32_t hm2 = th_sel(IM, hnf, TH_PK_NEG);
+        const int hm = th_wave_max(max(TH_PK_LO(hm2), TH_PK_HI(hm2)));
+        const uint32_t eqx = hm2 ^ TH_PK_DUP(hm);
+        const unsigned long long mlo = __ballot((eqx & 0xffffu) == 0), mhi = __ballot((eqx >> 16) == 0);
+        const unsigned long long many = mlo | mhi;
+        if (hm >= rmax && many) {
+            // first / last column holding the maximum: the first / last lane with either half set, then which half
+            const int fa = th_ctz64nz(many), la = th_msb64nz(many);
+            const int fl = B0 + t0 + 2 * fa + (int)(~(mlo >> fa) & 1ull);
+            const int lr = B0 + t0 + 2 * la + (int)((mhi >> la) & 1ull);
+            if (hm > rmax) { rmax = hm; left = fl; right = lr; } else right = lr;
+        }
+    }
+}
+
 // QCAP > 0: the query is staged in LDS (s_qs); RT = short: int16 ring with packed rows, RT = int: 32-bit ring (exact for any
 // score range, one column per lane).  The int16 variant returns -5 when the alignment's scores may not fit.
 template <int QCAP, typename RT>
@@ -271,7 +368,9 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     const int lane = TH_LANE();
     const int M = P.match, X = P.mismatch, O1 = P.go1, E1 = P.ge1, O2 = P.go2, E2 = P.ge2;
     qlen = TH_UNI(qlen);
-    const int n = TH_UNI(g.n_node), w = TH_POA_WB + qlen / 100;
+    // noband (the rerun of a job whose adaptive band failed): a half-width beyond any column makes every row span 0..qlen through
+    // the ordinary band arithmetic (a row's start is max(0, . - w) and never below a predecessor's, its end min(qlen, . + w))
+    const int n = TH_UNI(g.n_node), w = noband ? qlen + 8 : TH_POA_WB + qlen / 100;
     uint32_t ncell = 0, nfull = 0;          // direction words / full cells handed out so far (32-bit: the region is clamped to 2^31 words)
     // Every real score lies within +-real_b: a path to (i, j) has at most i + j unit steps, the dearest of which is a
     // mismatch (X for two units) or a one-base gap (open + extend for one unit); E'/F carry one more open + extend.
@@ -303,7 +402,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     for (int x = lane; x < TH_POA_RING * 3 * TH_POA_PAD; x += TH_WAVE) s_ring[x / (3 * TH_POA_PAD)][(x / TH_POA_PAD) % 3][x % TH_POA_PAD] = (RT)(WIDE ? TH_NEG : -32768);
     TH_WAVE_FENCE();
 #if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
-    unsigned long long pf_n[5] = { 0, 0, 0, 0, 0 }, pf_t[5] = { 0, 0, 0, 0, 0 };
+    unsigned long long pf_n[6] = { 0, 0, 0, 0, 0, 0 }, pf_t[6] = { 0, 0, 0, 0, 0, 0 };
 #endif
     for (int i = 0; i + 1 < n; ++i) {
         if ((i & 63) == 0) {
@@ -319,9 +418,39 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
 #endif
         const int sl = i & 63;
         const int meta = TH_READLANE(c_meta, sl), rm = TH_READLANE(c_rem, sl);
+        const int p0 = TH_READLANE(c_p0, sl);
+        if (!WIDE && LQ) {
+            // ---- the common row (58 % at the headline shape): one predecessor, the previous row, clean in its ring slot; no far row
+            // will read this one; its band fits the ring.  Straight-line scalar set-up, then the packed row with one predecessor.
+            const int not_common = (((meta >> 8) & 0xff) ^ 1) | (p0 ^ (i - 1)) | (L_c ^ 3) | ((meta >> 24) & 1);
+            if (not_common == 0) {
+                const int xd = qlen - rm;
+                const int b = max(max(0, min(L_l + 1, xd) - w), L_b), e = min(qlen, max(L_r + 1, xd) + w);
+                if (b > e) return -2;
+                if (e - b < TH_POA_RW) {
+                    const int B0 = b & ~1, span = (e | 1) - B0 + 1;
+                    if (ncell + (uint32_t)span + nfull * 8u > g.cell_u2) return -3;
+                    const int my_off = (int)ncell + (b - B0);
+                    ncell += span;
+                    int rmax = TH_NEG - 0x10000000, left = b, right = b;
+                    th_poa_pk_row<QCAP, RT>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, meta & 0xff, M, TX, 1, (i - 1) & 3, 0, 0, 0, L_b & ~1, 0, 0, 0,
+                                            E1, E2, O1P, O2P, E1P, E2P, rmax, left, right);
+                    L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = 3;
+#if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
+                    { pf_n[0] += 1; pf_t[0] += __builtin_amdgcn_s_memtime() - row_t0; }
+#endif
+                    th_writelane6(m_beg, m_end, m_left, m_right, m_off, m_foff, b, e, L_l, L_r, my_off, 0, sl);
+                    if (sl == 63 || i + 2 >= n) {
+                        const int r = (i & ~63) + lane;
+                        if (r <= i) { g.r_beg[r] = m_beg; g.r_end[r] = m_end; g.r_off[r] = m_off; g.r_foff[r] = m_foff; g.r_mpl[r] = m_left; g.r_mpr[r] = m_right; }
+                    }
+                    TH_WAVE_FENCE();
+                    continue;
+                }
+            }
+        }
         const int nb = meta & 0xff, inn = (meta >> 8) & 0xff;
         const bool needfull = (meta >> 24) & 1;
-        const int p0 = TH_READLANE(c_p0, sl);
         const bool fast = inn == 1 && p0 == i - 1 && L_c;        // one predecessor, the previous row, cached in LDS
         int p1 = -1, p2 = -1, p3 = -1, vid = 0;
         // predecessors as the packed row reads them: ring slot and even band base of each; ring_all: every predecessor is one of
@@ -351,7 +480,6 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             if (i > 0) { b = max(0, min(mpl, qlen - rm) - w); b = max(b, mb); }
             e = min(qlen, max(mpr, qlen - rm) + w);
         }
-        if (noband) { b = 0; e = qlen; }          // retry of a job whose adaptive band failed (status 3 / 4): full rows
         b = TH_UNI(b); e = TH_UNI(e);
         if (b > e) return -2;
         // a row owns the cells of columns (b & ~1) .. (e | 1): packed rows store column pairs
@@ -372,88 +500,8 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         const bool pk = !WIDE && LQ && ring_all && cache_me && !needfull;    // rows some far row will read take the 32-bit path (they store whole cells)
         const int npk = fast ? 1 : inn;
         if (pk) {
-            // ================= packed row: lane l owns columns B0 + 128 t + 2 l and the next one =================
-            const uint32_t T = nb == 4 ? 0x20820820u : ((TX & ~(63u << (6 * nb))) | (uint32_t)(32 + M) << (6 * nb));
-            uint32_t *wH = (uint32_t *)s_ring[myslot][0], *wE1 = (uint32_t *)s_ring[myslot][1], *wE2 = (uint32_t *)s_ring[myslot][2];
-            int carry1 = -32768, carry2 = -32768;                   // F1 / F2 running maxima in the column-offset domain
-            for (int t0 = 0; t0 < 256; t0 += 128) {
-                const int jr = t0 + 2 * lane, j0 = B0 + jr;
-                const int wi = (jr + TH_POA_PAD) >> 1;              // this lane's pair in the row being written
-                if (t0 && B0 + t0 > e) {                             // one trip was enough: clear the rest of the slot
-                    if (wi < TH_POA_RS / 2) { wH[wi] = TH_PK_NEG; wE1[wi] = TH_PK_NEG; wE2[wi] = TH_PK_NEG; }
-                    break;
-                }
-                const bool lo_ok = j0 >= b && j0 <= e, hi_ok = j0 + 1 <= e;
-                const uint32_t IM = (lo_ok ? 0xffffu : 0u) | (hi_ok ? 0xffff0000u : 0u);
-                // substitution scores of the two columns from the row's table
-                const uint32_t qx = s_qs[min(j0, QCAP) >> 1];                        // the pair's two 4-bit query codes
-                const uint32_t SC = th_pk_sub(th_ubfe(T, 6u * (qx & 15u), 6) | th_ubfe(T, 6u * (qx >> 4), 6) << 16, 0x00200020u);
-                // predecessor rows (all in the ring): diagonal pair (j0-1, j0) and vertical pairs (j0, j0+1) of each; anything outside
-                // a row's band reads -inf (its slot is clean, indices beyond either end are sent to the padding).  The first
-                // predecessor in edge order wins ties, as in the one-column-per-lane path; PMV / PE1V / PE2V hold the winners' edge
-                // indices, already shifted to their place in the 16-bit direction word
-                uint32_t m = 0, e1v = 0, e2v = 0, PMV = 0, PE1V = 0, PE2V = 0;
-#pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    if (o < npk) {
-                        const int qs = o == 0 ? q_slot0 : o == 1 ? q_slot1 : o == 2 ? q_slot2 : q_slot3, qb = o == 0 ? q_pb0 : o == 1 ? q_pb1 : o == 2 ? q_pb2 : q_pb3;
-                        const uint32_t *rH = (const uint32_t *)s_ring[qs][0], *rE1 = (const uint32_t *)s_ring[qs][1], *rE2 = (const uint32_t *)s_ring[qs][2];
-                        int pi = j0 - qb + TH_POA_PAD;
-                        pi = pi <= TH_POA_RS - 2 ? pi : 2;
-                        pi = max(pi, 2);
-                        const uint32_t Hm = rH[(pi >> 1) - 1], Hc = rH[pi >> 1], c1 = rE1[pi >> 1], c2 = rE2[pi >> 1];
-                        const uint32_t mo = th_pk_add(th_alignbit16(Hc, Hm), SC);
-                        if (o == 0) { m = mo; e1v = c1; e2v = c2; }
-                        else {
-                            const uint32_t gm = th_pk_negmask_op(th_pk_sub(m, mo)), ge1 = th_pk_negmask_op(th_pk_sub(e1v, c1)), ge2 = th_pk_negmask_op(th_pk_sub(e2v, c2));
-                            m = th_pk_max(m, mo); e1v = th_pk_max(e1v, c1); e2v = th_pk_max(e2v, c2);
-                            PMV = th_sel(gm, TH_PK_DUP(o << 8), PMV); PE1V = th_sel(ge1, TH_PK_DUP(o << 10), PE1V); PE2V = th_sel(ge2, TH_PK_DUP(o << 12), PE2V);
-                        }
-                    }
-                }
-                const uint32_t hnf1 = th_pk_max(m, e1v), dg1 = th_pk_sub(m, e1v);           // sign of dg1: E1 strictly better
-                const uint32_t hnf = th_pk_max(hnf1, e2v), dg2 = th_pk_sub(hnf1, e2v);
-                // F1 / F2: max-plus prefix over the row in the domain value + column * extension
-                const uint32_t JR = TH_PK(jr, jr + 1);
-                const uint32_t JE1 = TH_PK(TH_PK_LO(JR) * E1, TH_PK_HI(JR) * E1), JE2 = TH_PK(TH_PK_LO(JR) * E2, TH_PK_HI(JR) * E2);
-                const uint32_t a1 = th_sel(IM, th_pk_add(th_pk_sub(hnf, O1P), JE1), TH_PK_NEG);
-                const uint32_t a2 = th_sel(IM, th_pk_add(th_pk_sub(hnf, O2P), JE2), TH_PK_NEG);
-                // lane totals are scanned as two 32-bit values: v_max_i32 takes the DPP operand directly (one instruction per
-                // step), a packed max would need a move and an identity fill per step
-                const int a1l = TH_PK_LO(a1), a2l = TH_PK_LO(a2);
-                const int i1 = th_wave_incl_max(max(a1l, TH_PK_HI(a1))), i2 = th_wave_incl_max(max(a2l, TH_PK_HI(a2)));
-                const int b1 = max(th_shr1(i1, carry1), carry1), b2 = max(th_shr1(i2, carry2), carry2);    // best before this lane's pair
-                carry1 = max(carry1, TH_READLANE(i1, 63)); carry2 = max(carry2, TH_READLANE(i2, 63));
-                const uint32_t x1 = TH_PK(b1, max(b1, a1l)), x2 = TH_PK(b2, max(b2, a2l));                 // (before lo, before hi)
-                const uint32_t f1 = th_pk_sub(x1, JE1), f2 = th_pk_sub(x2, JE2);
-                const uint32_t h3 = th_pk_max(hnf, f1), dg3 = th_pk_sub(hnf, f1);
-                const uint32_t h = th_pk_max(h3, f2), dg4 = th_pk_sub(h3, f2);
-                // direction word of the two columns: the sign bits of eight saturating differences, the first one ending in bit 7
-                const uint32_t hO1 = th_pk_sub(h, O1P), hO2 = th_pk_sub(h, O2P);
-                uint32_t code = th_pk_sign(dg1);
-                code = (code << 1) | th_pk_sign(dg2);
-                code = (code << 1) | th_pk_sign(dg3);
-                code = (code << 1) | th_pk_sign(dg4);
-                code = (code << 1) | th_pk_sign(th_pk_sub(hO1, e1v));
-                code = (code << 1) | th_pk_sign(th_pk_sub(hO2, e2v));
-                code = (code << 1) | th_pk_sign(th_pk_sub(hO1, f1));
-                code = (code << 1) | th_pk_sign(th_pk_sub(hO2, f2));
-                if (npk > 1) code |= PMV | PE1V | PE2V;
-                const uint32_t n1 = th_pk_sub(th_pk_max(hO1, e1v), E1P), n2 = th_pk_sub(th_pk_max(hO2, e2v), E2P);
-                if (j0 <= e) *(uint32_t *)(drow + (j0 - b)) = code;      // column b-1 / e+1 of an odd edge land in the row's own padding
-                if (wi < TH_POA_RS / 2) { wH[wi] = th_sel(IM, h, TH_PK_NEG); wE1[wi] = th_sel(IM, n1, TH_PK_NEG); wE2[wi] = th_sel(IM, n2, TH_PK_NEG); }
-                // row maximum and its first / last column: the maximum of H is a maximum of hnf (an F value is always
-                // below the hnf it came from), and H == max only where hnf == max
-                const uint32_t hm2 = th_sel(IM, hnf, TH_PK_NEG);
-                const int hm = th_wave_max(max(TH_PK_LO(hm2), TH_PK_HI(hm2)));
-                const uint32_t eqx = hm2 ^ TH_PK_DUP(hm);
-                const unsigned long long mlo = __ballot((eqx & 0xffffu) == 0), mhi = __ballot((eqx >> 16) == 0);
-                if (hm >= rmax && (mlo | mhi)) {
-                    const int fl = B0 + t0 + min(mlo ? 2 * th_ctz64(mlo) : 1 << 20, mhi ? 2 * th_ctz64(mhi) + 1 : 1 << 20);
-                    const int lr = B0 + t0 + max(mlo ? 2 * th_msb64(mlo) : -1, mhi ? 2 * th_msb64(mhi) + 1 : -1);
-                    if (hm > rmax) { rmax = hm; left = fl; right = lr; } else right = lr;
-                }
-            }
+            th_poa_pk_row<QCAP, RT>(s_qs, s_ring, drow, lane, b, e, B0, myslot, nb, M, TX, npk, q_slot0, q_slot1, q_slot2, q_slot3, q_pb0, q_pb1, q_pb2, q_pb3,
+                                    E1, E2, O1P, O2P, E1P, E2P, rmax, left, right);
         } else {
         if (!WIDE && cache_me) {      // leave the slot clean for a packed successor: minus infinity wherever this row stores nothing
             uint32_t *wH = (uint32_t *)s_ring[myslot][0], *wE1 = (uint32_t *)s_ring[myslot][1], *wE2 = (uint32_t *)s_ring[myslot][2];
@@ -541,7 +589,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = cstate;
 #if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
         { const unsigned long long dt = __builtin_amdgcn_s_memtime() - row_t0;
-          const int cat = pk ? 0 : inn != 1 ? 1 : p0 != i - 1 ? 2 : needfull ? 3 : 4;     // packed / several predecessors / one far predecessor / stores full cells / other
+          const int cat = pk ? 1 : inn != 1 ? 2 : p0 != i - 1 ? 3 : needfull ? 4 : 5;     // (0: common packed row) / other packed / several predecessors / one far predecessor / stores full cells / other
           pf_n[cat] += 1; pf_t[cat] += dt; }
 #endif
         th_writelane6(m_beg, m_end, m_left, m_right, m_off, m_foff, b, e, L_l, L_r, my_off, my_foff, sl);
@@ -552,7 +600,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         TH_WAVE_FENCE();
     }
 #if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
-    if (lane == 0) for (int c = 0; c < 5; ++c) { atomicAdd(&th_poa_prof[8 + c], pf_n[c]); atomicAdd(&th_poa_prof[13 + c], pf_t[c]); }
+    if (lane == 0) for (int c = 0; c < 6; ++c) { atomicAdd(&th_poa_prof[8 + c], pf_n[c]); atomicAdd(&th_poa_prof[14 + c], pf_t[c]); }
 #endif
     // global end: best predecessor row of the sink (row n-1) at column qlen, first in edge order
     int bi = -1, bs = 0;

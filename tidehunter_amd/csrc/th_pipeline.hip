@@ -587,11 +587,11 @@ extern "C" int th_gpu_run(th_gpu_t *g)
         }
         if (!todo.empty()) return th_fail("POA scratch still too small after 8 attempts");
 #if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
-        { unsigned long long pr[18]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(th_poa_prof), sizeof(pr));
+        { unsigned long long pr[20]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(th_poa_prof), sizeof(pr));
           fprintf(stderr, "[poa_prof] rows %llu dp %llu traceback %llu merge %llu (cycles summed over waves)\n", pr[0], pr[1], pr[2], pr[3]);
-          const char *cat[5] = { "packed", "several predecessors", "one far predecessor", "stores full cells", "other" };
-          for (int c = 0; c < 5; ++c) fprintf(stderr, "[poa_prof]   %-22s rows %12llu cycles %16llu (%.0f per row)\n", cat[c], pr[8 + c], pr[13 + c], pr[8 + c] ? (double)pr[13 + c] / pr[8 + c] : 0.0);
-          unsigned long long z[18] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(th_poa_prof), z, sizeof(z)); }
+          const char *cat[6] = { "common packed", "other packed", "several predecessors", "one far predecessor", "stores full cells", "other" };
+          for (int c = 0; c < 6; ++c) fprintf(stderr, "[poa_prof]   %-22s rows %12llu cycles %16llu (%.0f per row)\n", cat[c], pr[8 + c], pr[14 + c], pr[8 + c] ? (double)pr[14 + c] / pr[8 + c] : 0.0);
+          unsigned long long z[20] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(th_poa_prof), z, sizeof(z)); }
 #endif
         // ---- unit-vs-consensus alignments and flank extensions ----
         // Items whose two sequences fit the small staging area of the anti-diagonal engine (4 KB: 5 waves per SIMD) go first; tasks
