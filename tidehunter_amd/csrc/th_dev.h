@@ -201,6 +201,13 @@ static inline uint32_t th_alignbit16(uint32_t hi, uint32_t lo) { return (lo >> 1
 static inline uint32_t th_pk_negmask_op(uint32_t a) { return th_pk_negmask(a); }
 static inline uint32_t th_pk_sign(uint32_t a) { return (TH_PK_LO(a) < 0 ? 1u : 0u) | (TH_PK_HI(a) < 0 ? 0x10000u : 0u); }
 static inline uint32_t th_ubfe(uint32_t v, uint32_t off, uint32_t w) { return (v >> (off & 31)) & ((1u << w) - 1); }
+// v_perm_b32: result byte k is picked by selector byte k: 0..3 byte of s1, 4..7 byte of s0, 12 the constant 0 (the other codes are not used here)
+static inline uint32_t th_perm(uint32_t s0, uint32_t s1, uint32_t sel)
+{
+    const unsigned long long src = ((unsigned long long)s0 << 32) | s1; uint32_t r = 0;
+    for (int k = 0; k < 4; ++k) { const uint32_t c = (sel >> (8 * k)) & 0xff; r |= (c < 8 ? (uint32_t)((src >> (8 * c)) & 0xff) : c >= 13 ? 0xffu : 0u) << (8 * k); }
+    return r;
+}
 __device__ __forceinline__ uint32_t th_wave_incl_pkmax(uint32_t v)
 {
     const int lane = TH_LANE();
@@ -220,6 +227,7 @@ __device__ __forceinline__ uint32_t th_pk_negmask_op(uint32_t a) { uint32_t r; a
 // sign bits of the two halves as 0 / 1 in bits 0 and 16: one v_pk_lshrrev_b16 (kept opaque for the same reason)
 __device__ __forceinline__ uint32_t th_pk_sign(uint32_t a) { uint32_t r; asm("v_pk_lshrrev_b16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }
 __device__ __forceinline__ uint32_t th_ubfe(uint32_t v, uint32_t off, uint32_t w) { return __builtin_amdgcn_ubfe(v, off, w); }
+__device__ __forceinline__ uint32_t th_perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
 __device__ __forceinline__ uint32_t th_wave_incl_pkmax(uint32_t v)
 {
     const int id = (int)TH_PK_NEG;

@@ -153,29 +153,98 @@ __device__ void th_poa_seed(ThPoaG &g, const uint8_t *__restrict__ q, int L)
     TH_WAVE_FENCE();
 }
 
+__device__ __forceinline__ int *th_carve(int *&p, long long cnt) { int *r = p; p += (cnt + 3) & ~3LL; return r; }
+// the arrays of one job's graph inside the wave's scratch; returns the first unused int (the cell region starts there)
+__device__ __forceinline__ int *th_poa_carve(ThPoaG &g, int *my, long long cap, long long ocap, long long opn)
+{
+    int *p = my;
+    g.nbase = th_carve(p, cap); g.nread = th_carve(p, cap); g.ring = th_carve(p, cap); g.inn = th_carve(p, cap); g.outn = th_carve(p, cap);
+    g.in4 = th_carve(p, cap * TH_POA_INL); g.out4 = th_carve(p, cap * TH_POA_INL);
+    g.in_oh = th_carve(p, cap); g.in_ot = th_carve(p, cap); g.out_oh = th_carve(p, cap); g.out_ot = th_carve(p, cap); g.pos = th_carve(p, cap);
+    g.ovf_val = th_carve(p, ocap); g.ovf_next = th_carve(p, ocap); g.ovf_cnt = th_carve(p, 4);
+    g.order = th_carve(p, cap); g.order2 = th_carve(p, cap);
+    g.r_meta = th_carve(p, cap); g.r_p = th_carve(p, cap * 4); g.r_s = th_carve(p, cap * 4); g.r_rem = th_carve(p, cap);
+    g.r_beg = th_carve(p, cap); g.r_end = th_carve(p, cap); g.r_mpl = th_carve(p, cap); g.r_mpr = th_carve(p, cap);
+    g.r_off = th_carve(p, cap); g.r_foff = th_carve(p, cap);
+    g.cntB = th_carve(p, cap); g.headB = th_carve(p, cap); g.aft = th_carve(p, cap);
+    g.ops = th_carve(p, 2 * opn); g.pv = th_carve(p, opn); g.glo = th_carve(p, opn); g.pth = th_carve(p, opn + 2);
+    return p;
+}
+
 // ---- remain (longest node count to the sink) + row tables, 64 rows per trip from the end ----
-__device__ int th_poa_rows(ThPoaG &g)
+// What a chunk needs from the graph -- node id, degrees, base, successor / predecessor ROW indices -- is three levels of dependent
+// loads (order -> node arrays -> pos), and a successor's remain a fourth.  The phase was bound by that latency chain, not by the
+// relaxation, so it is software-pipelined: each trip issues level 1 for the chunk three trips ahead, level 2 for the one two ahead,
+// level 3 for the next one, and stores the PREVIOUS chunk's results; everything a trip consumes was issued a trip earlier.  The
+// remain of a successor in the chunk just finished comes from that chunk's registers (a lane shuffle), not from memory.
+struct ThPoaRows2 { int u, on, in, nb, o4[TH_POA_INL], i4[TH_POA_INL]; };
+struct ThPoaRows3 { int u, on, in, nb, s[TH_POA_INL], p[TH_POA_INL]; };
+__device__ __forceinline__ int th_poa_rows_l1(const ThPoaG &g, int c0, int n)
+{
+    const int idx = c0 + TH_LANE();
+    return (c0 >= 0 && idx < n) ? g.order[idx] : 0;
+}
+__device__ __forceinline__ void th_poa_rows_l2(const ThPoaG &g, int c0, int n, int u, ThPoaRows2 &a)
+{
+    const int idx = c0 + TH_LANE(); const bool ok = c0 >= 0 && idx < n;
+    a.u = u; a.on = ok ? g.outn[u] : 0; a.in = ok ? g.inn[u] : 0; a.nb = ok ? g.nbase[u] : 0;
+#pragma unroll
+    for (int k = 0; k < TH_POA_INL; ++k) { a.o4[k] = ok ? g.out4[u * TH_POA_INL + k] : 0; a.i4[k] = ok ? g.in4[u * TH_POA_INL + k] : 0; }
+}
+__device__ __forceinline__ void th_poa_rows_l3(const ThPoaG &g, int c0, int n, const ThPoaRows2 &a, ThPoaRows3 &r)
+{
+    const int idx = c0 + TH_LANE(); const bool ok = c0 >= 0 && idx < n;
+    r.u = a.u; r.on = a.on; r.in = a.in; r.nb = a.nb;
+#pragma unroll
+    for (int k = 0; k < TH_POA_INL; ++k) { r.s[k] = (ok && k < a.on) ? g.pos[a.o4[k]] : -1; r.p[k] = (ok && k < a.in) ? g.pos[a.i4[k]] : -1; }
+}
+__device__ __forceinline__ int th_poa_rows_body(const ThPoaG &g)
 {
     const int lane = TH_LANE(), n = g.n_node;
+    const int c_top = (n - 1) & ~63;
     int maxdeg = 0;
-    for (int c0 = (n - 1) & ~63; c0 >= 0; c0 -= TH_WAVE) {
+    int a1; ThPoaRows2 a2; ThPoaRows3 a3;
+    // fill the pipeline (these waits are paid once per call)
+    a1 = th_poa_rows_l1(g, c_top, n); th_poa_rows_l2(g, c_top, n, a1, a2); th_poa_rows_l3(g, c_top, n, a2, a3);
+    a1 = th_poa_rows_l1(g, c_top - TH_WAVE, n); th_poa_rows_l2(g, c_top - TH_WAVE, n, a1, a2);
+    a1 = th_poa_rows_l1(g, c_top - 2 * TH_WAVE, n);
+    int prev_rem = -TH_BIG;                                   // remain of the chunk above (lane = row & 63)
+    int st_idx = -1, st_rem = 0, st_meta = 0, st_p[TH_POA_INL] = { 0, 0, 0, 0 };       // results of the chunk above, stored one trip late
+    for (int c0 = c_top; c0 >= 0; c0 -= TH_WAVE) {
         const int idx = c0 + lane; const bool ok = idx < n;
-        const int u = ok ? g.order[idx] : 0;
-        const int on = ok ? g.outn[u] : 0, in = ok ? g.inn[u] : 0;
+        const ThPoaRows3 a = a3;
+        TH_WAVE_FENCE();
+        th_poa_rows_l3(g, c0 - TH_WAVE, n, a2, a3);
+        th_poa_rows_l2(g, c0 - 2 * TH_WAVE, n, a1, a2);
+        a1 = th_poa_rows_l1(g, c0 - 3 * TH_WAVE, n);
+        if (st_idx >= 0) {
+            g.r_rem[st_idx] = st_rem; g.r_meta[st_idx] = st_meta;
+#pragma unroll
+            for (int k = 0; k < TH_POA_INL; ++k) g.r_p[st_idx * TH_POA_INL + k] = st_p[k];
+        }
+        TH_WAVE_FENCE();
+        const int u = a.u, on = a.on, in = a.in;
         int s[TH_POA_INL], p[TH_POA_INL];
 #pragma unroll
-        for (int k = 0; k < TH_POA_INL; ++k) {
-            s[k] = (ok && k < on) ? g.pos[g.out4[u * TH_POA_INL + k]] : -1;
-            p[k] = (ok && k < in) ? g.pos[g.in4[u * TH_POA_INL + k]] : -1;
-        }
-        // successors outside the chunk are final; in-chunk ones are relaxed in registers
+        for (int k = 0; k < TH_POA_INL; ++k) { s[k] = a.s[k]; p[k] = a.p[k]; }
+        // successors outside the chunk are final: the chunk above hands its values over in registers, anything further up (rare: an
+        // edge over more than 64 rows) is read from the table; in-chunk ones are relaxed in registers
         int base = (ok && u == 1) ? -1 : -TH_BIG;
+        bool far = false;
 #pragma unroll
-        for (int k = 0; k < TH_POA_INL; ++k) if (s[k] >= c0 + TH_WAVE) base = max(base, g.r_rem[s[k]] + 1);
+        for (int k = 0; k < TH_POA_INL; ++k) {
+            const int o = __shfl(prev_rem, (s[k] - c0) & 63);
+            if (s[k] >= c0 + TH_WAVE) { if (s[k] < c0 + 2 * TH_WAVE) base = max(base, o + 1); else far = true; }
+        }
         const bool big = ok && on > TH_POA_INL;
-        if (big) {          // overflow successors that are already final
-            int e = g.out_oh[u];
-            for (int x = TH_POA_INL; x < on; ++x) { const int sx = g.pos[g.ovf_val[e]]; e = g.ovf_next[e]; if (sx >= c0 + TH_WAVE) base = max(base, g.r_rem[sx] + 1); }
+        if (__any(far || big)) {
+            // (every chunk above this one is in the table by now: the last one was stored at the top of this trip)
+#pragma unroll
+            for (int k = 0; k < TH_POA_INL; ++k) if (s[k] >= c0 + 2 * TH_WAVE) base = max(base, g.r_rem[s[k]] + 1);
+            if (big) {          // overflow successors that are already final
+                int e = g.out_oh[u];
+                for (int x = TH_POA_INL; x < on; ++x) { const int sx = g.pos[g.ovf_val[e]]; e = g.ovf_next[e]; if (sx >= c0 + TH_WAVE) base = max(base, g.r_rem[sx] + 1); }
+            }
         }
         const bool hard = __any(big);
         // in-chunk successors are almost always 1..3 rows ahead: then a relaxation round is three lane shifts
@@ -217,19 +286,57 @@ __device__ int th_poa_rows(ThPoaG &g)
             cur = v;
             if (!__any(ch)) break;
         }
-        if (ok) {
-            g.r_rem[idx] = cur;
+        {
             int needfull = on > TH_POA_INL;
 #pragma unroll
             for (int k = 0; k < TH_POA_INL; ++k) if (s[k] >= 0 && (s[k] - idx >= TH_POA_RING || s[k] == n - 1)) needfull = 1;
-            g.r_meta[idx] = g.nbase[u] | min(in, 255) << 8 | min(on, 255) << 16 | needfull << 24;
+            st_idx = ok ? idx : -1; st_rem = cur; st_meta = a.nb | min(in, 255) << 8 | min(on, 255) << 16 | needfull << 24;
 #pragma unroll
-            for (int k = 0; k < TH_POA_INL; ++k) g.r_p[idx * TH_POA_INL + k] = p[k];
+            for (int k = 0; k < TH_POA_INL; ++k) st_p[k] = p[k];
         }
+        prev_rem = cur;
         maxdeg = max(maxdeg, in);
-        TH_WAVE_FENCE();
     }
+    if (st_idx >= 0) {
+        g.r_rem[st_idx] = st_rem; g.r_meta[st_idx] = st_meta;
+#pragma unroll
+        for (int k = 0; k < TH_POA_INL; ++k) g.r_p[st_idx * TH_POA_INL + k] = st_p[k];
+    }
+    TH_WAVE_FENCE();
     return th_wave_max(maxdeg);
+}
+
+
+// The phase as a function of its own (not inlined on the device): its registers -- three chunks in flight -- are allocated apart
+// from the DP row loop's, which loses its loop-invariant registers to scratch otherwise.  The graph descriptor is rebuilt from the
+// wave's scratch base and the job's capacities (a by-reference descriptor would have to live in memory).
+#if defined(TH_CPU_EMUL) || defined(TH_POA_ROWS_INLINE)
+#define TH_NOINLINE
+#else
+#define TH_NOINLINE __attribute__((noinline))
+#endif
+__device__ TH_NOINLINE int th_poa_rows(int *my, int cap, int ocap, int opn, int n_node, int order_swapped)
+{
+#ifndef TH_CPU_EMUL
+    my = (int *)(((unsigned long long)(uint32_t)TH_UNI((int)((unsigned long long)my >> 32)) << 32) | (uint32_t)TH_UNI((int)(unsigned long long)my));
+#endif
+    ThPoaG g;
+    th_poa_carve(g, my, TH_UNI(cap), TH_UNI(ocap), TH_UNI(opn));
+    g.cap = TH_UNI(cap); g.n_node = TH_UNI(n_node);
+    if (TH_UNI(order_swapped)) { int *t = g.order; g.order = g.order2; g.order2 = t; }     // th_poa_merge swaps the two order arrays after every alignment
+    const int r_ = th_poa_rows_body(g);
+#if defined(TH_CPU_EMUL) && defined(TH_ROWS_DEBUG)
+    if (TH_LANE() == 0) {
+        const int n = g.n_node; static thread_local int ref[1 << 20];
+        for (int i = n - 1; i >= 0; --i) {
+            const int u = g.order[i]; int best = u == 1 ? -1 : -TH_BIG;
+            for (int o = 0; o < g.outn[u]; ++o) { const int sx = g.pos[th_poa_out(g, u, o)]; best = max(best, ref[sx] + 1); }
+            ref[i] = best;
+            if (g.r_rem[i] != best) { fprintf(stderr, "[rows debug] n %d row %d: remain %d, reference %d (outn %d)\n", n, i, g.r_rem[i], best, g.outn[u]); break; }
+        }
+    }
+#endif
+    return r_;
 }
 
 #if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
@@ -265,29 +372,38 @@ __device__ unsigned long long th_poa_prof[20];    // 0..3 phase cycles; 8..13 ro
 // One packed row: lane l owns columns B0 + 128 t + 2 l and the next one; every predecessor (npk of them, ring slot q_slot*, even
 // band base q_pb*) sits clean in the LDS ring.  Writes the row's ring slot and its 16-bit direction words (drow: column b), returns
 // the row maximum and its first / last column through rmax / left / right.  Forced inline: the row loop calls it twice, once
-// with npk = 1 and the previous row's slot as constants (the common row), once in general.
-template <int QCAP, typename RT>
+// with npk = 1 and the previous row's slot as constants (the common row: COMMON, its band never starts left of its predecessor's), once in general.
+template <int QCAP, typename RT, bool COMMON>
 __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[3][TH_POA_RS], uint16_t *drow, const int lane, const int b, const int e, const int B0,
-                                               const int myslot, const int nb, const int M, const uint32_t TX, const int npk,
+                                               const int myslot, const uint32_t T, const int npk,
                                                const int q_slot0, const int q_slot1, const int q_slot2, const int q_slot3, const int q_pb0, const int q_pb1, const int q_pb2, const int q_pb3,
-                                               const int E1, const int E2, const uint32_t O1P, const uint32_t O2P, const uint32_t E1P, const uint32_t E2P, int &rmax, int &left, int &right)
+                                               const int E1, const int E2, const uint32_t O1P, const uint32_t O2P, const uint32_t E1P, const uint32_t E2P, int &tail_dirty, int &rmax, int &left, int &right)
 {
     // ================= packed row: lane l owns columns B0 + 128 t + 2 l and the next one =================
-    const uint32_t T = nb == 4 ? 0x20820820u : ((TX & ~(63u << (6 * nb))) | (uint32_t)(32 + M) << (6 * nb));
     uint32_t *wH = (uint32_t *)s_ring[myslot][0], *wE1 = (uint32_t *)s_ring[myslot][1], *wE2 = (uint32_t *)s_ring[myslot][2];
     int carry1 = -32768, carry2 = -32768;                   // F1 / F2 running maxima in the column-offset domain
     for (int t0 = 0; t0 < 256; t0 += 128) {
         const int jr = t0 + 2 * lane, j0 = B0 + jr;
         const int wi = (jr + TH_POA_PAD) >> 1;              // this lane's pair in the row being written
-        if (t0 && B0 + t0 > e) {                             // one trip was enough: clear the rest of the slot
-            if (wi < TH_POA_RS / 2) { wH[wi] = TH_PK_NEG; wE1[wi] = TH_PK_NEG; wE2[wi] = TH_PK_NEG; }
+        if (t0 && B0 + t0 > e) {                             // one trip was enough: clear the rest of the slot, unless it is clean already
+            if (tail_dirty & (1 << myslot)) {                // (bit s of tail_dirty: slot s may hold values beyond its first 128 columns)
+                if (wi < TH_POA_RS / 2) { wH[wi] = TH_PK_NEG; wE1[wi] = TH_PK_NEG; wE2[wi] = TH_PK_NEG; }
+                tail_dirty &= ~(1 << myslot);
+            }
             break;
         }
+        if (t0) tail_dirty |= 1 << myslot;
         const bool lo_ok = j0 >= b && j0 <= e, hi_ok = j0 + 1 <= e;
         const uint32_t IM = (lo_ok ? 0xffffu : 0u) | (hi_ok ? 0xffff0000u : 0u);
         // substitution scores of the two columns from the row's table
+#ifdef TH_CPU_EMUL
         const uint32_t qx = s_qs[min(j0, QCAP) >> 1];                        // the pair's two 4-bit query codes
-        const uint32_t SC = th_pk_sub(th_ubfe(T, 6u * (qx & 15u), 6) | th_ubfe(T, 6u * (qx >> 4), 6) << 16, 0x00200020u);
+#else
+        const uint32_t qx = s_qs[j0 >> 1];      // columns beyond e may read past the staged codes (still inside the workgroup's LDS): they are masked out below
+#endif
+        // T: the four biased scores of this row's node base against A, C, G, T, one per byte; code 4 (N, and the column 0 / beyond-the-
+        // query filler) selects byte 0 of the other source, the bias itself.  One byte permute looks both columns up.
+        const uint32_t SC = th_pk_sub(th_perm(32u, T, (((qx << 12) | qx) & 0x000f000fu) | 0x0c000c00u), 0x00200020u);
         // predecessor rows (all in the ring): diagonal pair (j0-1, j0) and vertical pairs (j0, j0+1) of each; anything outside
         // a row's band reads -inf (its slot is clean, indices beyond either end are sent to the padding).  The first
         // predecessor in edge order wins ties, as in the one-column-per-lane path; PMV / PE1V / PE2V hold the winners' edge
@@ -300,7 +416,7 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
                 const uint32_t *rH = (const uint32_t *)s_ring[qs][0], *rE1 = (const uint32_t *)s_ring[qs][1], *rE2 = (const uint32_t *)s_ring[qs][2];
                 int pi = j0 - qb + TH_POA_PAD;
                 pi = pi <= TH_POA_RS - 2 ? pi : 2;
-                pi = max(pi, 2);
+                if (!COMMON) pi = max(pi, 2);      // (the common row starts at or right of its predecessor's even base)
                 const uint32_t Hm = rH[(pi >> 1) - 1], Hc = rH[pi >> 1], c1 = rE1[pi >> 1], c2 = rE2[pi >> 1];
                 const uint32_t mo = th_pk_add(th_alignbit16(Hc, Hm), SC);
                 if (o == 0) { m = mo; e1v = c1; e2v = c2; }
@@ -313,6 +429,10 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
         }
         const uint32_t hnf1 = th_pk_max(m, e1v), dg1 = th_pk_sub(m, e1v);           // sign of dg1: E1 strictly better
         const uint32_t hnf = th_pk_max(hnf1, e2v), dg2 = th_pk_sub(hnf1, e2v);
+        // row maximum: the maximum of H is a maximum of hnf (an F value is always below the hnf it came from), and H == max only
+        // where hnf == max.  Scanned here, next to the two F scans: three independent dependency chains fill each other's wait states
+        const uint32_t hm2 = th_sel(IM, hnf, TH_PK_NEG);
+        const int hmv = th_wave_incl_max(max(TH_PK_LO(hm2), TH_PK_HI(hm2)));
         // F1 / F2: max-plus prefix over the row in the domain value + column * extension
         const uint32_t JR = TH_PK(jr, jr + 1);
         const uint32_t JE1 = TH_PK(TH_PK_LO(JR) * E1, TH_PK_HI(JR) * E1), JE2 = TH_PK(TH_PK_LO(JR) * E2, TH_PK_HI(JR) * E2);
@@ -340,24 +460,42 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
         code = (code << 1) | th_pk_sign(th_pk_sub(hO2, f2));
         if (npk > 1) code |= PMV | PE1V | PE2V;
         const uint32_t n1 = th_pk_sub(th_pk_max(hO1, e1v), E1P), n2 = th_pk_sub(th_pk_max(hO2, e2v), E2P);
-        if (j0 <= e) *(uint32_t *)(drow + (j0 - b)) = code;      // column b-1 / e+1 of an odd edge land in the row's own padding
+        // column b-1 / e+1 of an odd edge land in the row's own padding.  Wave-uniform base + the lane's constant byte offset:
+        // the store takes its address as scalar pair + 32-bit vector offset, no per-row 64-bit address arithmetic
+        if (j0 <= e) *(uint32_t *)((char *)(drow + (B0 + t0 - b)) + (uint32_t)(4 * lane)) = code;
         if (wi < TH_POA_RS / 2) { wH[wi] = th_sel(IM, h, TH_PK_NEG); wE1[wi] = th_sel(IM, n1, TH_PK_NEG); wE2[wi] = th_sel(IM, n2, TH_PK_NEG); }
-        // row maximum and its first / last column: the maximum of H is a maximum of hnf (an F value is always
-        // below the hnf it came from), and H == max only where hnf == max
-        const uint32_t hm2 = th_sel(IM, hnf, TH_PK_NEG);
-        const int hm = th_wave_max(max(TH_PK_LO(hm2), TH_PK_HI(hm2)));
+        // the row maximum's first / last column: the first / last lane with either half at the maximum, then which half.  (Some
+        // in-band lane holds the maximum, so the masks are never both empty; the first trip always sets all three.)
+        const int hm = TH_READLANE(hmv, 63);
         const uint32_t eqx = hm2 ^ TH_PK_DUP(hm);
         const unsigned long long mlo = __ballot((eqx & 0xffffu) == 0), mhi = __ballot((eqx >> 16) == 0);
         const unsigned long long many = mlo | mhi;
-        if (hm >= rmax && many) {
-            // first / last column holding the maximum: the first / last lane with either half set, then which half
+        if (t0 == 0 || (hm >= rmax && many)) {
             const int fa = th_ctz64nz(many), la = th_msb64nz(many);
             const int fl = B0 + t0 + 2 * fa + (int)(~(mlo >> fa) & 1ull);
             const int lr = B0 + t0 + 2 * la + (int)((mhi >> la) & 1ull);
-            if (hm > rmax) { rmax = hm; left = fl; right = lr; } else right = lr;
+            if (t0 == 0 || hm > rmax) { rmax = hm; left = fl; right = lr; } else right = lr;
         }
     }
 }
+
+// end of a packed row taken by one of the two straight-line paths of the row loop: the row becomes "the previous row", its band /
+// maximum columns / direction-word offset go into lane (row & 63) of the chunk registers, a complete chunk goes to the row tables
+#if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
+#define TH_POA_PK_PROF(cat) { pf_n[cat] += 1; pf_t[cat] += __builtin_amdgcn_s_memtime() - row_t0; }
+#else
+#define TH_POA_PK_PROF(cat)
+#endif
+#define TH_POA_PK_ROW_DONE(cat) do { \
+        L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = 3; \
+        TH_POA_PK_PROF(cat) \
+        th_writelane6(m_beg, m_end, m_left, m_right, m_off, m_foff, b, e, L_l, L_r, my_off, 0, sl); \
+        if (sl == 63 || i + 2 >= n) { \
+            const int r_ = (i & ~63) + lane; \
+            if (r_ <= i) { g.r_beg[r_] = m_beg; g.r_end[r_] = m_end; g.r_off[r_] = m_off; g.r_foff[r_] = m_foff; g.r_mpl[r_] = m_left; g.r_mpr[r_] = m_right; } \
+        } \
+        TH_WAVE_FENCE(); \
+    } while (0)
 
 // QCAP > 0: the query is staged in LDS (s_qs); RT = short: int16 ring with packed rows, RT = int: 32-bit ring (exact for any
 // score range, one column per lane).  The int16 variant returns -5 when the alignment's scores may not fit.
@@ -365,7 +503,13 @@ template <int QCAP, typename RT>
 __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t *s_qs, RT (*s_ring)[3][TH_POA_RS], int (*s_rmeta)[8], int qlen, const ThDevPara &P, const bool noband)
 {
     constexpr bool LQ = QCAP > 0, WIDE = sizeof(RT) == 4;
-    const int lane = TH_LANE();
+    int lane = TH_LANE();
+#ifndef TH_CPU_EMUL
+    // the per-lane constants of the row loop (column offsets times the gap extensions, ring addresses ...) are derived from this copy:
+    // they are rebuilt at every call instead of being hoisted out of the job's alignment loop, where they would stay live -- and
+    // get spilled to scratch, to be reloaded INSIDE the row loop -- across the other phases
+    asm volatile("" : "+v"(lane));
+#endif
     const int M = P.match, X = P.mismatch, O1 = P.go1, E1 = P.ge1, O2 = P.go2, E2 = P.ge2;
     qlen = TH_UNI(qlen);
     // noband (the rerun of a job whose adaptive band failed): a half-width beyond any column makes every row span 0..qlen through
@@ -388,8 +532,10 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     // v_readlane -- a vector instruction -- at every use: the four constants every packed row uses several times live in VGPRs instead
     asm volatile("" : "+v"(O1P), "+v"(O2P), "+v"(E1P), "+v"(E2P));
 #endif
-    uint32_t TX = 32u << 24;                                         // score table, 6 bits per query code (x 6), biased by 32
-    for (int c = 0; c < 4; ++c) TX |= (uint32_t)(32 - X) << (6 * c);
+    const uint32_t TXB = (uint32_t)(32 - X) * 0x01010101u;           // score table of a packed row: one byte per query code A, C, G, T, biased by 32 ...
+    // ... and with the match score in place for each node base: lane nb (0..4; 4 = N scores 0 against everything) of one register,
+    // a row fetches its table with one v_readlane
+    const uint32_t v_T = lane >= 4 ? 0x20202020u : ((TXB & ~(0xffu << (8 * lane))) | (uint32_t)(32 + M) << (8 * lane));
     int c_meta = 0, c_rem = 0, c_p0 = -1, c_p1 = -1, c_p2 = -1, c_p3 = -1, c_id = 0;   // row-table chunk cache
     // the previous row's band / row-maximum columns / cache state stay in wave-uniform registers (the common row has
     // exactly that predecessor); older ring slots keep theirs in s_rmeta[slot][]:
@@ -399,6 +545,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     // (one v_writelane each per row); they go to the row tables in HBM 64 rows at a time, so the common row issues no
     // metadata store at all.  A predecessor inside the chunk is read back with v_readlane, an older one from the tables.
     int m_beg = 0, m_end = 0, m_left = 0, m_right = 0, m_off = 0, m_foff = 0;
+    int tail_dirty = (1 << TH_POA_RING) - 1;      // ring slots whose columns beyond the first 128 are not known to hold minus infinity (see th_poa_pk_row)
     for (int x = lane; x < TH_POA_RING * 3 * TH_POA_PAD; x += TH_WAVE) s_ring[x / (3 * TH_POA_PAD)][(x / TH_POA_PAD) % 3][x % TH_POA_PAD] = (RT)(WIDE ? TH_NEG : -32768);
     TH_WAVE_FENCE();
 #if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
@@ -433,19 +580,52 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                     const int my_off = (int)ncell + (b - B0);
                     ncell += span;
                     int rmax = TH_NEG - 0x10000000, left = b, right = b;
-                    th_poa_pk_row<QCAP, RT>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, meta & 0xff, M, TX, 1, (i - 1) & 3, 0, 0, 0, L_b & ~1, 0, 0, 0,
-                                            E1, E2, O1P, O2P, E1P, E2P, rmax, left, right);
-                    L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = 3;
-#if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
-                    { pf_n[0] += 1; pf_t[0] += __builtin_amdgcn_s_memtime() - row_t0; }
-#endif
-                    th_writelane6(m_beg, m_end, m_left, m_right, m_off, m_foff, b, e, L_l, L_r, my_off, 0, sl);
-                    if (sl == 63 || i + 2 >= n) {
-                        const int r = (i & ~63) + lane;
-                        if (r <= i) { g.r_beg[r] = m_beg; g.r_end[r] = m_end; g.r_off[r] = m_off; g.r_foff[r] = m_foff; g.r_mpl[r] = m_left; g.r_mpr[r] = m_right; }
-                    }
-                    TH_WAVE_FENCE();
+                    th_poa_pk_row<QCAP, RT, true>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), 1, (i - 1) & 3, 0, 0, 0, L_b & ~1, 0, 0, 0,
+                                            E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
+                    TH_POA_PK_ROW_DONE(0);
                     continue;
+                }
+            }
+            // ---- the branch / merge rows of bubbles (35 %): up to four predecessors, each one of the three rows before this one, in
+            // this 64-row chunk (or the previous row) and clean in its ring slot; no far row will read this one.  Same thing, unrolled.
+            const int inn_ = (meta >> 8) & 0xff;
+            if (i > 0 && inn_ >= 1 && inn_ <= 4 && !((meta >> 24) & 1)) {
+                const int cb = i & ~63;
+                int mpl = 0x7fffffff, mpr = 0, mb = 0x7fffffff, bad = 0;
+                int qs0 = 0, qs1 = 0, qs2 = 0, qs3 = 0, qb0 = 0, qb1 = 0, qb2 = 0, qb3 = 0;
+#define TH_POA_RING_PRED(PI, QS, QB) do { \
+                    const int pi_ = (PI); int pb_, pl_, pr_; \
+                    if (pi_ == i - 1) { pb_ = L_b; pl_ = L_l; pr_ = L_r; bad |= L_c ^ 3; } \
+                    else { \
+                        const int x_ = pi_ & 63; \
+                        pb_ = TH_READLANE(m_beg, x_); pl_ = TH_READLANE(m_left, x_); pr_ = TH_READLANE(m_right, x_); \
+                        bad |= (pi_ < cb) | (pi_ >= i) | (i - pi_ >= TH_POA_RING) | (TH_READLANE(m_end, x_) - pb_ >= TH_POA_RW); \
+                    } \
+                    mpl = min(mpl, pl_ + 1); mpr = max(mpr, pr_ + 1); mb = min(mb, pb_); QS = pi_ & 3; QB = pb_ & ~1; \
+                } while (0)
+                TH_POA_RING_PRED(p0, qs0, qb0);
+                if (inn_ > 1) {
+                    TH_POA_RING_PRED(TH_READLANE(c_p1, sl), qs1, qb1);
+                    if (inn_ > 2) {
+                        TH_POA_RING_PRED(TH_READLANE(c_p2, sl), qs2, qb2);
+                        if (inn_ > 3) TH_POA_RING_PRED(TH_READLANE(c_p3, sl), qs3, qb3);
+                    }
+                }
+                if (!bad) {
+                    const int xd = qlen - rm;
+                    const int b = max(max(0, min(mpl, xd) - w), mb), e = min(qlen, max(mpr, xd) + w);
+                    if (b > e) return -2;
+                    if (e - b < TH_POA_RW) {
+                        const int B0 = b & ~1, span = (e | 1) - B0 + 1;
+                        if (ncell + (uint32_t)span + nfull * 8u > g.cell_u2) return -3;
+                        const int my_off = (int)ncell + (b - B0);
+                        ncell += span;
+                        int rmax = TH_NEG - 0x10000000, left = b, right = b;
+                        th_poa_pk_row<QCAP, RT, false>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), inn_, qs0, qs1, qs2, qs3, qb0, qb1, qb2, qb3,
+                                                E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
+                        TH_POA_PK_ROW_DONE(1);
+                        continue;
+                    }
                 }
             }
         }
@@ -500,13 +680,14 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         const bool pk = !WIDE && LQ && ring_all && cache_me && !needfull;    // rows some far row will read take the 32-bit path (they store whole cells)
         const int npk = fast ? 1 : inn;
         if (pk) {
-            th_poa_pk_row<QCAP, RT>(s_qs, s_ring, drow, lane, b, e, B0, myslot, nb, M, TX, npk, q_slot0, q_slot1, q_slot2, q_slot3, q_pb0, q_pb1, q_pb2, q_pb3,
-                                    E1, E2, O1P, O2P, E1P, E2P, rmax, left, right);
+            th_poa_pk_row<QCAP, RT, false>(s_qs, s_ring, drow, lane, b, e, B0, myslot, (uint32_t)TH_READLANE((int)v_T, nb), npk, q_slot0, q_slot1, q_slot2, q_slot3, q_pb0, q_pb1, q_pb2, q_pb3,
+                                    E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
         } else {
         if (!WIDE && cache_me) {      // leave the slot clean for a packed successor: minus infinity wherever this row stores nothing
             uint32_t *wH = (uint32_t *)s_ring[myslot][0], *wE1 = (uint32_t *)s_ring[myslot][1], *wE2 = (uint32_t *)s_ring[myslot][2];
             for (int x = TH_POA_PAD / 2 + lane; x < TH_POA_RS / 2; x += TH_WAVE) { wH[x] = TH_PK_NEG; wE1[x] = TH_PK_NEG; wE2[x] = TH_PK_NEG; }
             TH_WAVE_FENCE();
+            tail_dirty |= 1 << myslot;            // the cells written below may reach beyond the slot's first 128 columns
         }
         int carry1 = TH_NEG + b * E1, carry2 = TH_NEG + b * E2;
         for (int c0 = b; c0 <= e; c0 += TH_WAVE) {
@@ -820,7 +1001,6 @@ __device__ int th_poa_consensus(ThPoaG &g, int n_seqs, uint8_t *__restrict__ con
     return __any(over) ? -1 : cl;
 }
 
-__device__ __forceinline__ int *th_carve(int *&p, long long cnt) { int *r = p; p += (cnt + 3) & ~3LL; return r; }
 
 // status: 0 ok, 1 scratch too small for the graph, 2 band cells overflow, 3 empty band, 4 band lost the path,
 //         5 in-degree > 255, 6 consensus longer than cons_cap, 7 scores may not fit the int16 ring (rerun on the 32-bit variant)
@@ -859,18 +1039,9 @@ th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict
         }
         ThPoaG g;
         const long long cap = T.sum_len + 2, ocap = 2LL * (T.sum_len + T.n_units + 8), opn = cap + T.max_len + 2;
-        int *p = my;
         g.cap = (int)cap; g.n_node = 0;
-        g.nbase = th_carve(p, cap); g.nread = th_carve(p, cap); g.ring = th_carve(p, cap); g.inn = th_carve(p, cap); g.outn = th_carve(p, cap);
-        g.in4 = th_carve(p, cap * TH_POA_INL); g.out4 = th_carve(p, cap * TH_POA_INL);
-        g.in_oh = th_carve(p, cap); g.in_ot = th_carve(p, cap); g.out_oh = th_carve(p, cap); g.out_ot = th_carve(p, cap); g.pos = th_carve(p, cap);
-        g.ovf_val = th_carve(p, ocap); g.ovf_next = th_carve(p, ocap); g.ovf_cnt = th_carve(p, 4);
-        g.order = th_carve(p, cap); g.order2 = th_carve(p, cap);
-        g.r_meta = th_carve(p, cap); g.r_p = th_carve(p, cap * 4); g.r_s = th_carve(p, cap * 4); g.r_rem = th_carve(p, cap);
-        g.r_beg = th_carve(p, cap); g.r_end = th_carve(p, cap); g.r_mpl = th_carve(p, cap); g.r_mpr = th_carve(p, cap);
-        g.r_off = th_carve(p, cap); g.r_foff = th_carve(p, cap);
-        g.cntB = th_carve(p, cap); g.headB = th_carve(p, cap); g.aft = th_carve(p, cap);
-        g.ops = th_carve(p, 2 * opn); g.pv = th_carve(p, opn); g.glo = th_carve(p, opn); g.pth = th_carve(p, opn + 2);
+        int *p = th_poa_carve(g, my, cap, ocap, opn);
+        const int *order0 = g.order;       // (th_poa_merge swaps order / order2)
         {
             const long long avail = (scratch_ints - (p - my)) & ~3LL;
             g.cell_u2 = (uint32_t)min(avail * 2, 0x7ff00000LL); g.dcell = (uint16_t *)p; g.cell = (int4 *)(p + avail);
@@ -887,13 +1058,19 @@ th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict
             }
             TH_WAVE_FENCE();
             TH_PROF_T0();
-            const int deg = th_poa_rows(g);
+#ifdef TH_POA_DUP_ROWS      // measurement only: the phase twice (it is idempotent), to read its marginal cost off the kernel time
+            th_poa_rows(my, (int)cap, (int)ocap, (int)opn, g.n_node, g.order != order0);
+#endif
+            const int deg = th_poa_rows(my, (int)cap, (int)ocap, (int)opn, g.n_node, g.order != order0);
             TH_PROF(0);
             if (deg > 255) { st = 5; break; }
             int bi = th_poa_dp<QCAP, RT>(g, q, s_qs, s_ring, s_rmeta, qlen, P, noband);
             if (test_fail && !noband && t % test_fail == 0 && bi >= 0) bi = -4;
             TH_PROF(1);
             if (bi < 0) { st = bi == -3 ? 2 : bi == -5 ? 7 : bi == -2 ? 3 : 4; break; }
+#ifdef TH_POA_DUP_TB
+            th_poa_traceback(g, bi, qlen);
+#endif
             const int no = th_poa_traceback(g, bi, qlen);
             TH_PROF(2);
             th_poa_merge(g, q, no);
