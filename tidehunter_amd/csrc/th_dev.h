@@ -181,6 +181,28 @@ __device__ __forceinline__ int th_queue_pop(int *queue)
 #endif
 __device__ __forceinline__ int th_ctz64(unsigned long long m) { return m ? __ffsll((long long)m) - 1 : 64; }
 __device__ __forceinline__ int th_msb64(unsigned long long m) { return 63 - __clzll((long long)m); }   // m != 0
+#ifdef TH_CPU_EMUL
+#define TH_BALLOT(b) __ballot(b)
+#define TH_LDS_READ64_ASYNC(p) (*(p))
+#define TH_LDS_ASYNC_WAIT(v) ((void)0)
+#define TH_LANE_OF_MASK(m, lane) (((m) >> (lane)) & 1ull)
+#define TH_CLZ_NZ(x) ((unsigned)(x) ? __builtin_clz((unsigned)(x)) : 32)
+static inline int __mul24(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+#else
+#define TH_BALLOT(b) __builtin_amdgcn_ballot_w64(b)      // straight from the comparison's lane mask (__ballot goes through a 0/1 register)
+// An LDS read the compiler does not wait for: the value may be used only after TH_LDS_ASYNC_WAIT(value) -- which must come before
+// ANY use or copy of it, loop-carried copies included -- so that a whole loop trip can pass between request and use.
+__device__ __forceinline__ unsigned long long th_lds_read64_async(const void *p)
+{
+    unsigned long long v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
+    return v;
+}
+#define TH_LDS_READ64_ASYNC(p) th_lds_read64_async(p)
+#define TH_LDS_ASYNC_WAIT(v) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory")
+#define TH_LANE_OF_MASK(m, lane) __builtin_amdgcn_inverse_ballot_w64(m)      // this lane's bit of a wave-uniform mask: the mask IS the condition register
+#define TH_CLZ_NZ(x) __builtin_clz((unsigned)(x))          // x != 0 where the result is used (garbage lanes are discarded by the caller)
+#endif
 // the same for masks known to be non-zero: bare s_ff1 / s_flbit, no zero fix-ups
 __device__ __forceinline__ int th_ctz64nz(unsigned long long m) { return __builtin_ctzll(m); }
 __device__ __forceinline__ int th_msb64nz(unsigned long long m) { return 63 - __builtin_clzll(m); }

@@ -64,13 +64,19 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
     }
     TH_WAVE_FENCE();
     if (RING && lane < n) ring[lane] = R[lane];                      // chunk 0
+    // end / period of the 64 hits of cur's chunk, one per lane: the current hit's pair is a v_readlane away -- a load per hit
+    // (two dependent round trips to L2 before the first trip could start) was a quarter of the kernel's time
+    int c_e = lane < n ? E[lane] : 0, c_p = lane < n ? Pd[lane] : 1;
     for (int cur = 1; cur < n; ++cur) {
-        if (RING && (cur & 63) == 0) {                               // the chunk cur .. cur+63 enters the ring (its scores are still the initial ones)
-            if (cur + lane < n) ring[RP2 ? ((cur + lane) & (RING - 1)) : (int)min((uint32_t)(cur_slot + lane), (uint32_t)(cur_slot + lane - RING))] = R[cur + lane];
-            TH_WAVE_FENCE();
+        if ((cur & 63) == 0) {
+            if (RING) {                                                // the chunk cur .. cur+63 enters the ring (its scores are still the initial ones)
+                if (cur + lane < n) ring[RP2 ? ((cur + lane) & (RING - 1)) : (int)min((uint32_t)(cur_slot + lane), (uint32_t)(cur_slot + lane - RING))] = R[cur + lane];
+                TH_WAVE_FENCE();
+            }
+            if (cur + lane < n) { c_e = E[cur + lane]; c_p = Pd[cur + lane]; }
         }
         const int ring_lo = RING ? (cur | 63) + 1 - RING : 0;      // oldest hit index the ring still holds
-        const int ce = TH_UNI(E[cur]), cp = TH_UNI(Pd[cur]), cs = ce - cp;       // the same in every lane: scalar registers
+        const int ce = TH_READLANE(c_e, cur & 63), cp = TH_READLANE(c_p, cur & 63), cs = ce - cp;       // the same in every lane: scalar registers
         const int init = k + min(k, cp);
         int best = init, bi = -1, iter = 0;
         const int max_h = cp;
@@ -78,52 +84,72 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
         // 5 pp >= 9 cp <=> pp >= ceil(9 cp / 5), so a connection needs plo < pp < phi
         const uint32_t plo = (5u * (uint32_t)cp) / 9u, phi = (9u * (uint32_t)cp + 4u) / 5u;
         int bslot = RP2 ? 0 : (cur_slot == 0 ? RING - 1 : cur_slot - 1);      // (cur - 1) mod RING
+        // The packed records of a trip: 64 hits base, base-1, ... -- from the ring when the whole trip lies inside it, else from HBM (two
+        // different loads under a wave-uniform branch: a select between the two POINTERS would become one flat load, which waits for the
+        // wave's outstanding global stores -- the previous hit's results -- before every trip).  Lanes before the first hit read some
+        // record and are discarded by the `valid` mask.  Slot of idx = base - lane: (cur_slot - (cur - base) - lane) mod RING, the
+        // wave-uniform part reduced on the scalar unit.
+        auto fetch = [&](int base_, int bslot_) -> unsigned long long {
+            const int idx_ = base_ - lane;
+            if (RING && base_ - (TH_WAVE - 1) >= ring_lo)
+                return TH_LDS_READ64_ASYNC(&s_ring[RING ? (threadIdx.x >> 6) : 0][RP2 ? (idx_ & (RING - 1)) : (int)min((uint32_t)(bslot_ - lane), (uint32_t)(bslot_ - lane + RING))]);
+            return R[max(idx_, 0)];
+        };
+        // The next trip's records are requested before this trip is resolved (seven scans in eight go on): the trip is a chain of
+        // dependent steps -- load, score, prefix maximum, masks, branch -- and the wave has nothing else to overlap the load with.
+        unsigned long long rec_next = PK ? fetch(cur - 1, bslot) : 0ull;
+        TH_LDS_ASYNC_WAIT(rec_next);
         for (int base = cur - 1; base >= 0; base -= TH_WAVE, bslot = RP2 ? 0 : (bslot >= TH_WAVE ? bslot - TH_WAVE : bslot - TH_WAVE + RING)) {
             const int idx = base - lane;
             const bool valid = idx >= 0;
             int pe, pp, psc;
             if (PK) {
-                // lanes before the first hit read some record and are discarded by `valid`
-                // slot of idx = base - lane: (cur_slot - (cur - base) - lane) mod RING, the wave-uniform part reduced on the scalar unit
-                const unsigned long long rec = (RING && base - (TH_WAVE - 1) >= ring_lo)
-                    ? ring[RP2 ? (idx & (RING - 1)) : (int)min((uint32_t)(bslot - lane), (uint32_t)(bslot - lane + RING))] : R[max(idx, 0)];
+                const unsigned long long rec = rec_next;
+                if (base >= TH_WAVE) rec_next = fetch(base - TH_WAVE, RP2 ? 0 : (bslot >= TH_WAVE ? bslot - TH_WAVE : bslot - TH_WAVE + RING));
                 pe = (int)((uint32_t)rec >> 16); pp = (int)((uint32_t)rec & 0xffffu); psc = (int)(rec >> 32);
             } else { pe = valid ? E[idx] : 0; pp = valid ? Pd[idx] : 1; psc = valid ? S[idx] : 0; }
             const int ps = pe - pp;
-            const bool dstop = !valid || pe < cs;                  // :331  predecessor ends before cur starts
+            // The rules are evaluated as 64-bit lane masks of single comparisons, combined on the scalar unit (a boolean expression per
+            // lane would be materialised as 0/1 registers and compared again for every ballot).
+            unsigned long long dstopm = TH_BALLOT(pe < cs);                              // :331  predecessor ends before cur starts
+            if (base < TH_WAVE - 1) dstopm |= ~0ull << (base + 1);                      // ... or does not exist (idx = base - lane < 0): last trip only
             // :154 compares cp >= pp * 1.8 in double.  fl(1.8) exceeds 1.8 by a relative 2.5e-17, less than half an ulp,
             // so pp * fl(1.8) rounds to exactly 1.8 pp whenever that is an integer and stays > 0.19 away from every
             // integer otherwise: the comparison equals 5 cp >= 9 pp for all periods below 2^28 (th_gpu_upload checks).
-            const bool is_con = !dstop && cs > ps && (uint32_t)pp - plo - 1u < phi - plo - 1u;     // anything but NO_CON
+            const unsigned long long conm = ~dstopm & TH_BALLOT(cs > ps) & TH_BALLOT((uint32_t)pp - plo - 1u < phi - plo - 1u);     // anything but NO_CON
             // Every lane scores (a skipped lane costs the same issue slot as a computing one); lanes without a connection
-            // produce garbage that the selects below discard.  Hits are sorted by end, so pe <= ce, and cs > ps holds where it
+            // produce garbage that the select below discards.  Hits are sorted by end, so pe <= ce, and cs > ps holds where it
             // matters: both distances are plain differences and their sum is positive there (ilog2 needs no guard).
             const int dis1 = ce - pe, dis2 = cs - ps;
-            const int matched = min(dis1, k) + min(dis2, k);
+            const int matched15 = min(dis1, k) + min(dis2, k) - 15;       // (the -15 belongs to the logarithm term below)
             const int dq = cp - pp;
-            const int gap = (int)((uint32_t)(dq * dq) >> 1) + ((31 - __clz(dis1 + dis2)) >> 1);   // :128-142
-            const bool same0 = cp == pp, ovl = same0 && matched < 2 * k;       // SAME or OVL / OVL (where is_con)
-            const int s = is_con ? psc + matched - gap : -0x40000000;
+            // :128-142  gap = dq^2 / 2 + ilog2(dis1 + dis2) / 2.  Packed records mean periods below 65536: the square is a full-rate
+            // 24-bit multiply (v_mul_lo_u32 runs at quarter rate), and (31 - clz(x)) >> 1 == 15 - (clz(x) >> 1) folds into the sums
+            const int dq2h = (int)((uint32_t)(PK ? __mul24(dq, dq) : dq * dq) >> 1);
+            const int clzh = TH_CLZ_NZ(dis1 + dis2) >> 1;
+            const int s = TH_LANE_OF_MASK(conm, lane) ? (psc + matched15 + clzh) - dq2h : -0x40000000;
             const int rb = th_wave_excl_max(s, best);              // best as seen just before this lane
-            const bool imp = is_con && s > rb;
-            const unsigned long long impm = __ballot(imp);
-            // stop rules in scan order: :331 (dstop); :342 improving SAME/OVL and :344-346 non-improving OVL, so OVL
-            // always stops; :349 max_h consecutive non-improving predecessors (only evaluated when reachable)
-            bool stop = dstop || (is_con && (ovl || (imp && same0)));
+            const unsigned long long impm = TH_BALLOT(s > rb);     // (a lane without a connection holds -2^30, below every best)
+            // stop rules in scan order: :331 (dstop); :342 improving SAME/OVL and :344-346 non-improving OVL (SAME with fewer than 2k
+            // matched bases), so OVL always stops; :349 max_h consecutive non-improving predecessors (only evaluated when reachable)
+            unsigned long long stopm = dstopm | (conm & TH_BALLOT(cp == pp) & (impm | TH_BALLOT(matched15 < 2 * k - 15)));
             if (iter + TH_WAVE >= max_h) {
                 const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1);
                 const unsigned long long below = impm & upto;
                 const int iter_after = below ? lane - th_msb64(below) : iter + lane + 1;
-                stop = stop || (!imp && iter_after >= max_h);
+                stopm |= ~impm & TH_BALLOT(iter_after >= max_h);
             }
-            const unsigned long long stopm = __ballot(stop);
-            const int f = th_ctz64(stopm);
-            const unsigned long long lim = f >= 63 ? ~0ull : ((2ull << f) - 1);
-            const unsigned long long taken = impm & lim;
-            if (taken) { const int last = th_msb64(taken); best = TH_READLANE(s, last); bi = base - last; }
-            if (f < 64) break;
-            iter = impm ? 63 - th_msb64(impm) : iter + TH_WAVE;
+            // the improvements taken are those up to the first stopping lane; the last of them is the new best
+            if (stopm) {
+                const unsigned long long taken = impm & (stopm ^ (stopm - 1));          // lanes up to and including the lowest set bit
+                if (taken) { const int last = th_msb64nz(taken); best = TH_READLANE(s, last); bi = base - last; }
+                break;
+            }
+            if (impm) { const int last = th_msb64nz(impm); best = TH_READLANE(s, last); bi = base - last; iter = 63 - last; }
+            else iter += TH_WAVE;
+            TH_LDS_ASYNC_WAIT(rec_next);       // (here, before the value is copied or used: the compiler does not track the asynchronous read)
         }
+        TH_LDS_ASYNC_WAIT(rec_next);           // a scan that stopped leaves its last request in flight: its registers stay reserved until it lands
         if (lane == 0 && best > init) {                                                                 // :352-354
             S[cur] = best; F[cur] = bi;
             if (PK) ((int *)(R + cur))[1] = best;
