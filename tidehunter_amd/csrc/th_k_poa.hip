@@ -463,7 +463,7 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
         // column b-1 / e+1 of an odd edge land in the row's own padding.  Wave-uniform base + the lane's constant byte offset:
         // the store takes its address as scalar pair + 32-bit vector offset, no per-row 64-bit address arithmetic
         if (j0 <= e) *(uint32_t *)((char *)(drow + (B0 + t0 - b)) + (uint32_t)(4 * lane)) = code;
-        if (wi < TH_POA_RS / 2) { wH[wi] = th_sel(IM, h, TH_PK_NEG); wE1[wi] = th_sel(IM, n1, TH_PK_NEG); wE2[wi] = th_sel(IM, n2, TH_PK_NEG); }
+        if (t0 == 0 || wi < TH_POA_RS / 2) { wH[wi] = th_sel(IM, h, TH_PK_NEG); wE1[wi] = th_sel(IM, n1, TH_PK_NEG); wE2[wi] = th_sel(IM, n2, TH_PK_NEG); }     // (every lane of the first trip is inside the slot)
         // the row maximum's first / last column: the first / last lane with either half at the maximum, then which half.  (Some
         // in-band lane holds the maximum, so the masks are never both empty; the first trip always sets all three.)
         const int hm = TH_READLANE(hmv, 63);
@@ -822,9 +822,14 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
             const int row = ti - (lane >> 2), col = tj - (lane >> 2) + (lane & 3) - 1;
             t_ok = 0; t_d = 0;
             if (row >= 1) {
-                const int rb = g.r_beg[row], re = g.r_end[row];
+                // everything indexed by the row is requested at once; the direction word is the only dependent load (the walk waits
+                // for the whole chain at every tile: it was four round trips long)
+                const int rb = g.r_beg[row], re = g.r_end[row], meta = g.r_meta[row], roff = g.r_off[row], rfoff = g.r_foff[row];
                 t_p0 = g.r_p[row * 4]; t_p1 = g.r_p[row * 4 + 1]; t_p2 = g.r_p[row * 4 + 2]; t_p3 = g.r_p[row * 4 + 3];
-                if (col >= rb && col <= re) { t_d = (int)th_poa_dir(g, row, col - rb); t_ok = 1; }
+                if (col >= rb && col <= re) {
+                    t_d = ((meta >> 8) & 0xff) > TH_D16_WIDE_DEG ? g.cell[rfoff + (col - rb)].w : (int)th_d16_expand(g.dcell[roff + (col - rb)]);
+                    t_ok = 1;
+                }
             }
             {
                 const int want = (int)TH_D_PM((uint32_t)t_d);
