@@ -97,54 +97,7 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
         };
         // The next trip's records are requested before this trip is resolved (seven scans in eight go on): the trip is a chain of
         // dependent steps -- load, score, prefix maximum, masks, branch -- and the wave has nothing else to overlap the load with.
-        int base0 = cur - 1; bool done = false;
-#ifndef TH_CHAIN_NO_DOUBLE
-        if (PK && RING && RP2) {
-            // Double trips: 128 predecessors at once, two per lane (blocks A: base - lane, B: base - 64 - lane), while both blocks lie in
-            // the ring, all 128 exist and the max_h rule is out of reach.  The kernel is bound by the serial chain of a trip, not by its
-            // arithmetic: the two blocks' loads, scores and prefix maxima are independent and interleave, the scalar resolution runs A
-            // then B.  B's candidates are judged against the best after ALL of A, which is what the sequential scan holds when A did not stop.
-            const unsigned long long *rg = s_ring[RING ? (threadIdx.x >> 6) : 0];
-            while (base0 - (2 * TH_WAVE - 1) >= max(ring_lo, 0) && iter + 2 * TH_WAVE < max_h) {
-                const int iA = base0 - lane;
-                const unsigned long long recA = rg[iA & (RING - 1)], recB = rg[(iA - TH_WAVE) & (RING - 1)];
-                unsigned long long dsA, cnA, smA, mtA, dsB, cnB, smB, mtB;
-                auto score = [&](unsigned long long rec, unsigned long long &dstopm, unsigned long long &conm, unsigned long long &samem, unsigned long long &mtm) -> int {
-                    const int pe = (int)((uint32_t)rec >> 16), pp = (int)((uint32_t)rec & 0xffffu), psc = (int)(rec >> 32), ps = pe - pp;
-                    dstopm = TH_BALLOT(pe < cs);
-                    conm = ~dstopm & TH_BALLOT(cs > ps) & TH_BALLOT((uint32_t)pp - plo - 1u < phi - plo - 1u);
-                    const int dis1 = ce - pe, dis2 = cs - ps;
-                    const int matched15 = min(dis1, k) + min(dis2, k) - 15;
-                    const int dq = cp - pp;
-                    const int dq2h = (int)((uint32_t)__mul24(dq, dq) >> 1);
-                    const int clzh = TH_CLZ_NZ(dis1 + dis2) >> 1;
-                    samem = TH_BALLOT(cp == pp); mtm = TH_BALLOT(matched15 < 2 * k - 15);
-                    return TH_LANE_OF_MASK(conm, lane) ? (psc + matched15 + clzh) - dq2h : -0x40000000;
-                };
-                const int sA = score(recA, dsA, cnA, smA, mtA), sB = score(recB, dsB, cnB, smB, mtB);
-                const int inA = th_wave_incl_max(sA), inB = th_wave_incl_max(sB);
-                const int totA = max(best, TH_READLANE(inA, 63));
-                const int rbA = max(th_shr1(inA, best), best), rbB = max(th_shr1(inB, totA), totA);
-                const unsigned long long impA = TH_BALLOT(sA > rbA), impB = TH_BALLOT(sB > rbB);
-                const unsigned long long stopA = dsA | (cnA & smA & (impA | mtA));
-                if (stopA) {
-                    const unsigned long long taken = impA & (stopA ^ (stopA - 1));
-                    if (taken) { const int last = th_msb64nz(taken); best = TH_READLANE(sA, last); bi = base0 - last; }
-                    done = true; break;
-                }
-                if (impA) { const int last = th_msb64nz(impA); best = TH_READLANE(sA, last); bi = base0 - last; iter = 63 - last; } else iter += TH_WAVE;
-                const unsigned long long stopB = dsB | (cnB & smB & (impB | mtB));
-                if (stopB) {
-                    const unsigned long long taken = impB & (stopB ^ (stopB - 1));
-                    if (taken) { const int last = th_msb64nz(taken); best = TH_READLANE(sB, last); bi = base0 - TH_WAVE - last; }
-                    done = true; break;
-                }
-                if (impB) { const int last = th_msb64nz(impB); best = TH_READLANE(sB, last); bi = base0 - TH_WAVE - last; iter = 63 - last; } else iter += TH_WAVE;
-                base0 -= 2 * TH_WAVE;
-            }
-        }
-#endif
-        if (done) base0 = -1;
+        const int base0 = cur - 1;
         unsigned long long rec_next = (PK && base0 >= 0) ? fetch(base0, bslot) : 0ull;
         TH_LDS_ASYNC_WAIT(rec_next);
         for (int base = base0; base >= 0; base -= TH_WAVE, bslot = RP2 ? 0 : (bslot >= TH_WAVE ? bslot - TH_WAVE : bslot - TH_WAVE + RING)) {
