@@ -256,14 +256,23 @@ __device__ __forceinline__ int th_poa_rows_body(const ThPoaG &g)
         }
         const bool fastrel = !hard && !__any(!nearok);
         int cur = base;
+        if (fastrel) {
+            // the usual chunk: three lane shifts, three adds, two max3 per round (an edge that does not exist adds minus "infinity";
+            // values near -TH_BIG are "no path yet" and lose every maximum against a real one), two rounds per convergence test
+            const int inc1 = has1 ? 1 : -TH_BIG, inc2 = has2 ? 1 : -TH_BIG, inc3 = has3 ? 1 : -TH_BIG;
+            for (int it = 0; it < TH_WAVE / 2 + 1; ++it) {
+                int c1 = th_shl1(cur, -TH_BIG), c2 = th_shl1(c1, -TH_BIG), c3 = th_shl1(c2, -TH_BIG);
+                const int v1 = max(max(base, c1 + inc1), max(c2 + inc2, c3 + inc3));
+                c1 = th_shl1(v1, -TH_BIG); c2 = th_shl1(c1, -TH_BIG); c3 = th_shl1(c2, -TH_BIG);
+                const int v2 = max(max(base, c1 + inc1), max(c2 + inc2, c3 + inc3));
+                const bool ch = v2 != cur;
+                cur = v2;
+                if (!__any(ch)) break;
+            }
+        } else
         for (int it = 0; it < TH_WAVE + 1; ++it) {
             int v = base;
-            if (fastrel) {
-                const int c1 = th_shl1(cur, -TH_BIG), c2 = th_shl1(c1, -TH_BIG), c3 = th_shl1(c2, -TH_BIG);
-                if (has1 && c1 > -TH_BIG) v = max(v, c1 + 1);
-                if (has2 && c2 > -TH_BIG) v = max(v, c2 + 1);
-                if (has3 && c3 > -TH_BIG) v = max(v, c3 + 1);
-            } else {
+            {
 #pragma unroll
                 for (int k = 0; k < TH_POA_INL; ++k) {
                     const int o = __shfl(cur, (s[k] - c0) & 63);
