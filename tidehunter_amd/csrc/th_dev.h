@@ -183,6 +183,7 @@ __device__ __forceinline__ int th_ctz64(unsigned long long m) { return m ? __ffs
 __device__ __forceinline__ int th_msb64(unsigned long long m) { return 63 - __clzll((long long)m); }   // m != 0
 #ifdef TH_CPU_EMUL
 #define TH_BALLOT(b) __ballot(b)
+#define TH_STORE_U32_SADDR(base, off, v) (*(uint32_t *)((char *)(base) + (uint32_t)(off)) = (v))
 #define TH_LDS_READ64_ASYNC(p) (*(p))
 #define TH_LDS_ASYNC_WAIT(v) ((void)0)
 #define TH_LANE_OF_MASK(m, lane) (((m) >> (lane)) & 1ull)
@@ -190,6 +191,14 @@ __device__ __forceinline__ int th_msb64(unsigned long long m) { return 63 - __cl
 static inline int __mul24(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
 #else
 #define TH_BALLOT(b) __builtin_amdgcn_ballot_w64(b)      // straight from the comparison's lane mask (__ballot goes through a 0/1 register)
+// 32-bit store to a wave-uniform base (scalar register pair) plus a 32-bit per-lane byte offset: the addressing mode the compiler does
+// not pick when it can hoist `base + offset` into a loop-invariant 64-bit register pair per lane (two VGPRs that the POA row loop does
+// not have to spare)
+__device__ __forceinline__ void th_store_u32_saddr(const void *base, uint32_t off, uint32_t v)
+{
+    asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
+}
+#define TH_STORE_U32_SADDR(base, off, v) th_store_u32_saddr((base), (uint32_t)(off), (v))
 // An LDS read the compiler does not wait for: the value may be used only after TH_LDS_ASYNC_WAIT(value) -- which must come before
 // ANY use or copy of it, loop-carried copies included -- so that a whole loop trip can pass between request and use.
 __device__ __forceinline__ unsigned long long th_lds_read64_async(const void *p)
@@ -223,6 +232,7 @@ static inline uint32_t th_alignbit16(uint32_t hi, uint32_t lo) { return (lo >> 1
 static inline uint32_t th_pk_negmask_op(uint32_t a) { return th_pk_negmask(a); }
 static inline uint32_t th_pk_sign(uint32_t a) { return (TH_PK_LO(a) < 0 ? 1u : 0u) | (TH_PK_HI(a) < 0 ? 0x10000u : 0u); }
 static inline uint32_t th_ubfe(uint32_t v, uint32_t off, uint32_t w) { return (v >> (off & 31)) & ((1u << w) - 1); }
+static inline uint32_t th_cvt_pk_i16(int lo, int hi) { return TH_PK(th_sat16_(lo), th_sat16_(hi)); }     // two ints to a saturated int16 pair
 // v_perm_b32: result byte k is picked by selector byte k: 0..3 byte of s1, 4..7 byte of s0, 12 the constant 0 (the other codes are not used here)
 static inline uint32_t th_perm(uint32_t s0, uint32_t s1, uint32_t sel)
 {
@@ -249,6 +259,7 @@ __device__ __forceinline__ uint32_t th_pk_negmask_op(uint32_t a) { uint32_t r; a
 // sign bits of the two halves as 0 / 1 in bits 0 and 16: one v_pk_lshrrev_b16 (kept opaque for the same reason)
 __device__ __forceinline__ uint32_t th_pk_sign(uint32_t a) { uint32_t r; asm("v_pk_lshrrev_b16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }
 __device__ __forceinline__ uint32_t th_ubfe(uint32_t v, uint32_t off, uint32_t w) { return __builtin_amdgcn_ubfe(v, off, w); }
+__device__ __forceinline__ uint32_t th_cvt_pk_i16(int lo, int hi) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(lo, hi)); }
 __device__ __forceinline__ uint32_t th_perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
 __device__ __forceinline__ uint32_t th_wave_incl_pkmax(uint32_t v)
 {

@@ -382,11 +382,16 @@ __device__ unsigned long long th_poa_prof[20];    // 0..3 phase cycles; 8..13 ro
 // band base q_pb*) sits clean in the LDS ring.  Writes the row's ring slot and its 16-bit direction words (drow: column b), returns
 // the row maximum and its first / last column through rmax / left / right.  Forced inline: the row loop calls it twice, once
 // with npk = 1 and the previous row's slot as constants (the common row: COMMON, its band never starts left of its predecessor's), once in general.
-template <int QCAP, typename RT, bool COMMON>
+// FAR: one predecessor (edge index far_o; none if negative) is NOT in the ring -- more than three rows back, or too wide to be cached --
+// and is read from its full cells in HBM (far_row: its cell of column far_pb; band far_pb..far_pe), converted to int16 with saturation
+// (its values are exact 32-bit ones; minus infinity becomes -32768 like everything outside a ring row's band); full_row (or null):
+// the row's own full cells {H, E1', E2', -} are written for a far reader, minus infinity widened back to TH_NEG below neg_thr.
+template <int QCAP, typename RT, bool COMMON, bool FAR>
 __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[3][TH_POA_RS], uint16_t *drow, const int lane, const int b, const int e, const int B0,
                                                const int myslot, const uint32_t T, const int npk,
                                                const int q_slot0, const int q_slot1, const int q_slot2, const int q_slot3, const int q_pb0, const int q_pb1, const int q_pb2, const int q_pb3,
-                                               const int E1, const int E2, const uint32_t O1P, const uint32_t O2P, const uint32_t E1P, const uint32_t E2P, int &tail_dirty, int &rmax, int &left, int &right)
+                                               const int E1, const int E2, const uint32_t O1P, const uint32_t O2P, const uint32_t E1P, const uint32_t E2P, int &tail_dirty, int &rmax, int &left, int &right,
+                                               const int far_o = -1, const int far_pb = 0, const int far_pe = -1, const int4 *far_row = nullptr, int4 *full_row = nullptr, const int neg_thr = 0)
 {
     // ================= packed row: lane l owns columns B0 + 128 t + 2 l and the next one =================
     uint32_t *wH = (uint32_t *)s_ring[myslot][0], *wE1 = (uint32_t *)s_ring[myslot][1], *wE2 = (uint32_t *)s_ring[myslot][2];
@@ -426,8 +431,19 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
                 int pi = j0 - qb + TH_POA_PAD;
                 pi = pi <= TH_POA_RS - 2 ? pi : 2;
                 if (!COMMON) pi = max(pi, 2);      // (the common row starts at or right of its predecessor's even base)
-                const uint32_t Hm = rH[(pi >> 1) - 1], Hc = rH[pi >> 1], c1 = rE1[pi >> 1], c2 = rE2[pi >> 1];
-                const uint32_t mo = th_pk_add(th_alignbit16(Hc, Hm), SC);
+                uint32_t mo, c1, c2;
+                if (FAR && o == far_o) {
+                    const int ja = j0 - 1, jc = j0 + 1;
+                    int ha = TH_NEG, hb = TH_NEG, e1b = TH_NEG, e2b = TH_NEG, e1c = TH_NEG, e2c = TH_NEG;
+                    if (ja >= far_pb && ja <= far_pe) ha = far_row[ja - far_pb].x;
+                    if (j0 >= far_pb && j0 <= far_pe) { const int4 cc = far_row[j0 - far_pb]; hb = cc.x; e1b = cc.y; e2b = cc.z; }
+                    if (jc >= far_pb && jc <= far_pe) { const int4 cc = far_row[jc - far_pb]; e1c = cc.y; e2c = cc.z; }
+                    mo = th_pk_add(th_cvt_pk_i16(ha, hb), SC); c1 = th_cvt_pk_i16(e1b, e1c); c2 = th_cvt_pk_i16(e2b, e2c);
+                } else {
+                    const uint32_t Hm = rH[(pi >> 1) - 1], Hc = rH[pi >> 1];
+                    c1 = rE1[pi >> 1]; c2 = rE2[pi >> 1];
+                    mo = th_pk_add(th_alignbit16(Hc, Hm), SC);
+                }
                 if (o == 0) { m = mo; e1v = c1; e2v = c2; }
                 else {
                     const uint32_t gm = th_pk_negmask_op(th_pk_sub(m, mo)), ge1 = th_pk_negmask_op(th_pk_sub(e1v, c1)), ge2 = th_pk_negmask_op(th_pk_sub(e2v, c2));
@@ -471,8 +487,13 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
         const uint32_t n1 = th_pk_sub(th_pk_max(hO1, e1v), E1P), n2 = th_pk_sub(th_pk_max(hO2, e2v), E2P);
         // column b-1 / e+1 of an odd edge land in the row's own padding.  Wave-uniform base + the lane's constant byte offset:
         // the store takes its address as scalar pair + 32-bit vector offset, no per-row 64-bit address arithmetic
-        if (j0 <= e) *(uint32_t *)((char *)(drow + (B0 + t0 - b)) + (uint32_t)(4 * lane)) = code;
+        if (j0 <= e) TH_STORE_U32_SADDR(drow + (B0 + t0 - b), 4 * lane, code);
         if (t0 == 0 || wi < TH_POA_RS / 2) { wH[wi] = th_sel(IM, h, TH_PK_NEG); wE1[wi] = th_sel(IM, n1, TH_PK_NEG); wE2[wi] = th_sel(IM, n2, TH_PK_NEG); }     // (every lane of the first trip is inside the slot)
+        if (FAR && full_row) {
+            const int hl = TH_PK_LO(h), hh = TH_PK_HI(h), n1l = TH_PK_LO(n1), n1h = TH_PK_HI(n1), n2l = TH_PK_LO(n2), n2h = TH_PK_HI(n2);
+            if (lo_ok) { int4 cv; cv.x = hl < neg_thr ? TH_NEG : hl; cv.y = n1l < neg_thr ? TH_NEG : n1l; cv.z = n2l < neg_thr ? TH_NEG : n2l; cv.w = 0; full_row[j0 - b] = cv; }
+            if (hi_ok) { int4 cv; cv.x = hh < neg_thr ? TH_NEG : hh; cv.y = n1h < neg_thr ? TH_NEG : n1h; cv.z = n2h < neg_thr ? TH_NEG : n2h; cv.w = 0; full_row[j0 + 1 - b] = cv; }
+        }
         // the row maximum's first / last column: the first / last lane with either half at the maximum, then which half.  (Some
         // in-band lane holds the maximum, so the masks are never both empty; the first trip always sets all three.)
         const int hm = TH_READLANE(hmv, 63);
@@ -495,10 +516,10 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
 #else
 #define TH_POA_PK_PROF(cat)
 #endif
-#define TH_POA_PK_ROW_DONE(cat) do { \
+#define TH_POA_PK_ROW_DONE(cat, FOFF) do { \
         L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = 3; \
         TH_POA_PK_PROF(cat) \
-        th_writelane6(m_beg, m_end, m_left, m_right, m_off, m_foff, b, e, L_l, L_r, my_off, 0, sl); \
+        th_writelane6(m_beg, m_end, m_left, m_right, m_off, m_foff, b, e, L_l, L_r, my_off, (FOFF), sl); \
         if (sl == 63 || i + 2 >= n) { \
             const int r_ = (i & ~63) + lane; \
             if (r_ <= i) { g.r_beg[r_] = m_beg; g.r_end[r_] = m_end; g.r_off[r_] = m_off; g.r_foff[r_] = m_foff; g.r_mpl[r_] = m_left; g.r_mpr[r_] = m_right; } \
@@ -589,9 +610,9 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                     const int my_off = (int)ncell + (b - B0);
                     ncell += span;
                     int rmax = TH_NEG - 0x10000000, left = b, right = b;
-                    th_poa_pk_row<QCAP, RT, true>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), 1, (i - 1) & 3, 0, 0, 0, L_b & ~1, 0, 0, 0,
+                    th_poa_pk_row<QCAP, RT, true, false>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), 1, (i - 1) & 3, 0, 0, 0, L_b & ~1, 0, 0, 0,
                                             E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
-                    TH_POA_PK_ROW_DONE(0);
+                    TH_POA_PK_ROW_DONE(0, 0);
                     continue;
                 }
             }
@@ -630,9 +651,56 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                         const int my_off = (int)ncell + (b - B0);
                         ncell += span;
                         int rmax = TH_NEG - 0x10000000, left = b, right = b;
-                        th_poa_pk_row<QCAP, RT, false>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), inn_, qs0, qs1, qs2, qs3, qb0, qb1, qb2, qb3,
+                        th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), inn_, qs0, qs1, qs2, qs3, qb0, qb1, qb2, qb3,
                                                 E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
-                        TH_POA_PK_ROW_DONE(1);
+                        TH_POA_PK_ROW_DONE(1, 0);
+                        continue;
+                    }
+                }
+            }
+            // ---- rows one step further out (~5 %): as above, but ONE predecessor may lie outside the ring (an edge over more than three
+            // rows, or a predecessor too wide to be cached) -- it is read from its full cells in HBM -- and / or some far row will read
+            // this one, which then also stores its cells in full.  Everything still inside this 64-row chunk; the rest goes on to the
+            // general path below (one column per lane in 32 bits).
+            if (i > 0 && inn_ >= 1 && inn_ <= 4) {
+                const int cb = i & ~63;
+                int mpl = 0x7fffffff, mpr = 0, mb = 0x7fffffff, bad = 0;
+                int qs0 = 0, qs1 = 0, qs2 = 0, qs3 = 0, qb0 = 0, qb1 = 0, qb2 = 0, qb3 = 0;
+                int far_o = -1, far_pb = 0, far_pe = -1, far_po = 0;
+#define TH_POA_FAR_PRED(O, PI, QS, QB) do { \
+                    const int pi_ = (PI); int pb_ = 0, pl_ = 0, pr_ = 0; \
+                    if (pi_ == i - 1 && L_c == 3) { pb_ = L_b; pl_ = L_l; pr_ = L_r; } \
+                    else if (pi_ >= cb && pi_ < i) { \
+                        const int x_ = pi_ & 63; \
+                        pb_ = TH_READLANE(m_beg, x_); pl_ = TH_READLANE(m_left, x_); pr_ = TH_READLANE(m_right, x_); \
+                        const int pe_ = TH_READLANE(m_end, x_); \
+                        if (i - pi_ >= TH_POA_RING || pe_ - pb_ >= TH_POA_RW) { bad |= far_o >= 0; far_o = (O); far_pb = pb_; far_pe = pe_; far_po = TH_READLANE(m_foff, x_); } \
+                    } else bad = 1; \
+                    mpl = min(mpl, pl_ + 1); mpr = max(mpr, pr_ + 1); mb = min(mb, pb_); QS = pi_ & 3; QB = pb_ & ~1; \
+                } while (0)
+                TH_POA_FAR_PRED(0, p0, qs0, qb0);
+                if (inn_ > 1) {
+                    TH_POA_FAR_PRED(1, TH_READLANE(c_p1, sl), qs1, qb1);
+                    if (inn_ > 2) {
+                        TH_POA_FAR_PRED(2, TH_READLANE(c_p2, sl), qs2, qb2);
+                        if (inn_ > 3) TH_POA_FAR_PRED(3, TH_READLANE(c_p3, sl), qs3, qb3);
+                    }
+                }
+                if (!bad) {
+                    const int xd = qlen - rm;
+                    const int b = max(max(0, min(mpl, xd) - w), mb), e = min(qlen, max(mpr, xd) + w);
+                    if (b > e) return -2;
+                    if (e - b < TH_POA_RW) {
+                        const int B0 = b & ~1, span = (e | 1) - B0 + 1;
+                        const int full = (meta >> 24) & 1;
+                        if (full) nfull += span;
+                        if (ncell + (uint32_t)span + nfull * 8u > g.cell_u2) return -3;
+                        const int my_off = (int)ncell + (b - B0), my_foff = full ? -(int)nfull + (b - B0) : 0;
+                        ncell += span;
+                        int rmax = TH_NEG - 0x10000000, left = b, right = b;
+                        th_poa_pk_row<QCAP, RT, false, true>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), inn_, qs0, qs1, qs2, qs3, qb0, qb1, qb2, qb3,
+                                                E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right, far_o, far_pb, far_pe, g.cell + far_po, full ? g.cell + my_foff : nullptr, neg_thr);
+                        TH_POA_PK_ROW_DONE(2, my_foff);
                         continue;
                     }
                 }
@@ -689,7 +757,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         const bool pk = !WIDE && LQ && ring_all && cache_me && !needfull;    // rows some far row will read take the 32-bit path (they store whole cells)
         const int npk = fast ? 1 : inn;
         if (pk) {
-            th_poa_pk_row<QCAP, RT, false>(s_qs, s_ring, drow, lane, b, e, B0, myslot, (uint32_t)TH_READLANE((int)v_T, nb), npk, q_slot0, q_slot1, q_slot2, q_slot3, q_pb0, q_pb1, q_pb2, q_pb3,
+            th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, drow, lane, b, e, B0, myslot, (uint32_t)TH_READLANE((int)v_T, nb), npk, q_slot0, q_slot1, q_slot2, q_slot3, q_pb0, q_pb1, q_pb2, q_pb3,
                                     E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
         } else {
         if (!WIDE && cache_me) {      // leave the slot clean for a packed successor: minus infinity wherever this row stores nothing
