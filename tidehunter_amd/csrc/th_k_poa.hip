@@ -349,8 +349,8 @@ __device__ TH_NOINLINE int th_poa_rows(int *my, int cap, int ocap, int opn, int 
 }
 
 #if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
-__device__ unsigned long long th_poa_prof[20];    // 0..3 phase cycles; 8..13 rows per category, 14..19 their cycles
-#define TH_PROF_CNT(k, v) ((void)0)
+__device__ unsigned long long th_poa_prof[20];    // 0..3 phase cycles; 4..7 traceback events (tiles loaded, run trips, run steps, single steps); 8..13 rows per category, 14..19 their cycles
+#define TH_PROF_CNT(k, v) do { if (TH_LANE() == 0) atomicAdd(&th_poa_prof[k], (unsigned long long)(v)); } while (0)
 #define TH_PROF_T0() unsigned long long pt_ = __builtin_amdgcn_s_memtime()
 #define TH_PROF(k) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (TH_LANE() == 0) atomicAdd(&th_poa_prof[k], n_ - pt_); pt_ = n_; } while (0)
 #else
@@ -651,8 +651,11 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                         const int my_off = (int)ncell + (b - B0);
                         ncell += span;
                         int rmax = TH_NEG - 0x10000000, left = b, right = b;
-                        th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), inn_, qs0, qs1, qs2, qs3, qb0, qb1, qb2, qb3,
-                                                E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
+                        const uint32_t T_ = (uint32_t)TH_READLANE((int)v_T, meta & 0xff);
+                        // (one or two predecessors as compile-time constants: the body's per-predecessor tests disappear)
+                        if (inn_ == 1) th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, T_, 1, qs0, 0, 0, 0, qb0, 0, 0, 0, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
+                        else if (inn_ == 2) th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, T_, 2, qs0, qs1, 0, 0, qb0, qb1, 0, 0, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
+                        else th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, T_, inn_, qs0, qs1, qs2, qs3, qb0, qb1, qb2, qb3, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
                         TH_POA_PK_ROW_DONE(1, 0);
                         continue;
                     }
@@ -886,16 +889,20 @@ __device__ __forceinline__ uint32_t th_poa_dir(const ThPoaG &g, int row, int o)
 __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
 {
     const int lane = TH_LANE();
-    int no = 0, ci = bi, cj = qlen, st = 0;
+    int no = 0, ci = TH_UNI(bi), cj = TH_UNI(qlen), st = 0;
     int ti = -1000000, tj = 0;              // tile anchor; lane l = 4*k + o holds cell (ti - k, tj - k + o - 1)
     int t_d = 0, t_p0 = -1, t_p1 = -1, t_p2 = -1, t_p3 = -1, t_ok = 0;
     unsigned long long t_run = 0;           // tile cells that are plain diagonal steps: match state, predecessor = the row above
     while (ci > 0) {
+        // the walk is wave-uniform; saying so at every trip keeps its state in scalar registers and its branches scalar (the compiler
+        // otherwise treats the loop-carried state as divergent and compiles every step under exec masks)
+        ci = TH_UNI(ci); cj = TH_UNI(cj); st = TH_UNI(st); no = TH_UNI(no); ti = TH_UNI(ti); tj = TH_UNI(tj);
         int k = ti - ci, o = cj - (tj - k) + 1;
         bool hit0 = k >= 0 && k <= 15 && o >= 0 && o <= 3;
         const int ok0 = TH_READLANE(t_ok, hit0 ? (k * 4 + o) : 0);
         if (!hit0 || !ok0) {
             ti = ci; tj = cj;
+            TH_PROF_CNT(4, 1);
             const int row = ti - (lane >> 2), col = tj - (lane >> 2) + (lane & 3) - 1;
             t_ok = 0; t_d = 0;
             if (row >= 1) {
@@ -903,6 +910,9 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
                 // for the whole chain at every tile: it was four round trips long)
                 const int rb = g.r_beg[row], re = g.r_end[row], meta = g.r_meta[row], roff = g.r_off[row], rfoff = g.r_foff[row];
                 t_p0 = g.r_p[row * 4]; t_p1 = g.r_p[row * 4 + 1]; t_p2 = g.r_p[row * 4 + 2]; t_p3 = g.r_p[row * 4 + 3];
+#ifndef TH_CPU_EMUL
+                asm volatile("" : : "v"(rb), "v"(re), "v"(meta), "v"(roff), "v"(rfoff));     // (all five in flight together: the compiler would sink each load behind the test that needs it)
+#endif
                 if (col >= rb && col <= re) {
                     t_d = ((meta >> 8) & 0xff) > TH_D16_WIDE_DEG ? g.cell[rfoff + (col - rb)].w : (int)th_d16_expand(g.dcell[roff + (col - rb)]);
                     t_ok = 1;
@@ -924,9 +934,11 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
             if (lim > 0) {
                 if (lane < lim) { g.ops[2 * (no + lane)] = 0 | (ci - lane) << 2; g.ops[2 * (no + lane) + 1] = cj - 1 - lane; }
                 no += lim; ci -= lim; cj -= lim;
+                TH_PROF_CNT(5, 1); TH_PROF_CNT(6, lim);
                 continue;
             }
         }
+        TH_PROF_CNT(7, 1);
         const uint32_t d = (uint32_t)TH_READLANE(t_d, tl);
         const int a0 = TH_READLANE(t_p0, tl), a1 = TH_READLANE(t_p1, tl), a2 = TH_READLANE(t_p2, tl), a3 = TH_READLANE(t_p3, tl);
         if (st == 0) st = TH_D_SRC(d);
@@ -935,7 +947,7 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
             const int want = st == 0 ? TH_D_PM(d) : st == 1 ? TH_D_PE1(d) : TH_D_PE2(d);
             int pi;
             if (want < TH_POA_INL) pi = want == 0 ? a0 : want == 1 ? a1 : want == 2 ? a2 : a3;
-            else pi = g.pos[th_poa_in(g, g.order[ci], want)];
+            else pi = TH_UNI(g.pos[th_poa_in(g, g.order[ci], want)]);
             if (st == 0) { if (lane == 0) { g.ops[2 * no] = 0 | ci << 2; g.ops[2 * no + 1] = cj - 1; } ++no; ci = pi; --cj; }
             else { if (lane == 0) { g.ops[2 * no] = 2 | ci << 2; g.ops[2 * no + 1] = -1; } ++no; ci = pi; moved_gap = 1; }
         } else { if (lane == 0) { g.ops[2 * no] = 1; g.ops[2 * no + 1] = cj - 1; } ++no; --cj; moved_gap = 1; }
@@ -949,7 +961,7 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
                 else {
                     uint32_t pd;
                     if (hit && okv) pd = (uint32_t)dv;
-                    else pd = th_poa_dir(g, ci, cj - g.r_beg[ci]);
+                    else pd = (uint32_t)TH_UNI((int)th_poa_dir(g, ci, cj - g.r_beg[ci]));
                     const uint32_t bit = st == 1 ? TH_D_XE1 : st == 2 ? TH_D_XE2 : st == 3 ? TH_D_XF1 : TH_D_XF2;
                     if (!(pd & bit)) st = 0;
                 }
@@ -1147,6 +1159,7 @@ th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict
             TH_PROF(0);
             if (deg > 255) { st = 5; break; }
             int bi = th_poa_dp<QCAP, RT>(g, q, s_qs, s_ring, s_rmeta, qlen, P, noband);
+            bi = TH_UNI(bi);         // (the same in every lane, but loaded: a divergent `break` below would put the other phases under exec masks)
             if (test_fail && !noband && t % test_fail == 0 && bi >= 0) bi = -4;
             TH_PROF(1);
             if (bi < 0) { st = bi == -3 ? 2 : bi == -5 ? 7 : bi == -2 ? 3 : 4; break; }

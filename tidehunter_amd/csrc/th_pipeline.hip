@@ -589,6 +589,7 @@ extern "C" int th_gpu_run(th_gpu_t *g)
 #if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
         { unsigned long long pr[20]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(th_poa_prof), sizeof(pr));
           fprintf(stderr, "[poa_prof] rows %llu dp %llu traceback %llu merge %llu (cycles summed over waves)\n", pr[0], pr[1], pr[2], pr[3]);
+          fprintf(stderr, "[poa_prof]   traceback: %llu tiles loaded, %llu run trips emitting %llu steps, %llu single steps\n", pr[4], pr[5], pr[6], pr[7]);
           const char *cat[6] = { "common packed", "other packed", "several predecessors", "one far predecessor", "stores full cells", "other" };
           for (int c = 0; c < 6; ++c) fprintf(stderr, "[poa_prof]   %-22s rows %12llu cycles %16llu (%.0f per row)\n", cat[c], pr[8 + c], pr[14 + c], pr[8 + c] ? (double)pr[14 + c] / pr[8 + c] : 0.0);
           unsigned long long z[20] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(th_poa_prof), z, sizeof(z)); }
