@@ -893,6 +893,7 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
     int ti = -1000000, tj = 0;              // tile anchor; lane l = 4*k + o holds cell (ti - k, tj - k + o - 1)
     int t_d = 0, t_p0 = -1, t_p1 = -1, t_p2 = -1, t_p3 = -1, t_ok = 0;
     unsigned long long t_run = 0;           // tile cells that are plain diagonal steps: match state, predecessor = the row above
+    unsigned long long t_any = 0; int t_pr = 0;     // ... diagonal steps in match state to ANY predecessor row (t_pr: that row): one short trip each
     while (ci > 0) {
         // the walk is wave-uniform; saying so at every trip keeps its state in scalar registers and its branches scalar (the compiler
         // otherwise treats the loop-carried state as divergent and compiles every step under exec masks)
@@ -921,7 +922,9 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
             {
                 const int want = (int)TH_D_PM((uint32_t)t_d);
                 const int pr = want == 0 ? t_p0 : want == 1 ? t_p1 : want == 2 ? t_p2 : t_p3;
-                t_run = __ballot(t_ok && TH_D_SRC((uint32_t)t_d) == 0 && want < TH_POA_INL && pr == row - 1);
+                t_any = __ballot(t_ok && TH_D_SRC((uint32_t)t_d) == 0 && want < TH_POA_INL);
+                t_run = t_any & __ballot(pr == row - 1);
+                t_pr = pr;
             }
             k = 0; o = 1;
         }
@@ -935,6 +938,15 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
                 if (lane < lim) { g.ops[2 * (no + lane)] = 0 | (ci - lane) << 2; g.ops[2 * (no + lane) + 1] = cj - 1 - lane; }
                 no += lim; ci -= lim; cj -= lim;
                 TH_PROF_CNT(5, 1); TH_PROF_CNT(6, lim);
+                continue;
+            }
+            // a diagonal step to another predecessor (the branch / merge rows of bubbles: every run above ends at one): the same
+            // step the general code below would take, without its five lane reads, state machine and second look-up
+            if ((t_any >> tl) & 1) {
+                const int pr = TH_READLANE(t_pr, tl);
+                if (lane == 0) { g.ops[2 * no] = 0 | ci << 2; g.ops[2 * no + 1] = cj - 1; }
+                ++no; ci = pr; --cj;
+                TH_PROF_CNT(7, 1);
                 continue;
             }
         }
