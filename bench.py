@@ -183,6 +183,12 @@ def main():
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d; launch with `python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
                  "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...`" % (a.gpus, world, a.gpus, a.gpus))
     rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    # The contract is ONE JSON line on stdout.  Libraries under us write there too (torch's gloo backend announces its peers on
+    # stdout, the ROCm runtime complains about a missing amdgpu.ids): from here on file descriptor 1 is stderr, and the result
+    # line goes to the saved original stdout at the very end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     cfg = dict(CONFIGS[a.config])
     B = a.batch if a.batch > 0 else cfg["batch"]
 
@@ -411,7 +417,8 @@ def main():
         if world == 1 and a.cpu_sample != 0:
             n_cpu = a.cpu_sample if a.cpu_sample > 0 else min(4096, max(64, 24 * effective_cpus()))
             out["cpu_baseline"] = cpu_baseline(lib, make_read, n_cpu, cfg)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if a.config == "c5":
         for fn in kw["adapters"]:
             os.unlink(fn)
