@@ -129,6 +129,7 @@ __device__ __forceinline__ int th_wave_incl_sum(int v)
     return x;
 }
 #endif
+#define TH_INT_MIN (-0x7fffffff - 1)
 __device__ __forceinline__ int th_wave_excl_max(int v, int seed) { return max(th_shr1(th_wave_incl_max(v), seed), seed); }
 __device__ __forceinline__ int th_wave_max(int v) { return TH_READLANE(th_wave_incl_max(v), 63); }
 __device__ __forceinline__ int th_wave_min(int v) { return -TH_READLANE(th_wave_incl_max(-v), 63); }

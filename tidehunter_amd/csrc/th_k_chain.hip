@@ -78,7 +78,7 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
         const int ring_lo = RING ? (cur | 63) + 1 - RING : 0;      // oldest hit index the ring still holds
         const int ce = TH_READLANE(c_e, cur & 63), cp = TH_READLANE(c_p, cur & 63), cs = ce - cp;       // the same in every lane: scalar registers
         const int init = k + min(k, cp);
-        int best = init, bi = -1, iter = 0;
+        int best = init + 15, bi = -1, iter = 0;       // best and the candidates are kept 15 above their value inside the scan (the constant of the logarithm term)
         const int max_h = cp;
         // the two period-ratio tests below as one range test on the predecessor's period: 5 cp >= 9 pp <=> pp <= (5 cp) / 9 and
         // 5 pp >= 9 cp <=> pp >= ceil(9 cp / 5), so a connection needs plo < pp < phi
@@ -122,18 +122,18 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             // produce garbage that the select below discards.  Hits are sorted by end, so pe <= ce, and cs > ps holds where it
             // matters: both distances are plain differences and their sum is positive there (ilog2 needs no guard).
             const int dis1 = ce - pe, dis2 = cs - ps;
-            const int matched15 = min(dis1, k) + min(dis2, k) - 15;       // (the -15 belongs to the logarithm term below)
+            const int matched = min(dis1, k) + min(dis2, k);
             const int dq = cp - pp;
             // :128-142  gap = dq^2 / 2 + ilog2(dis1 + dis2) / 2.  Packed records mean periods below 65536: the square is a full-rate
             // 24-bit multiply (v_mul_lo_u32 runs at quarter rate), and (31 - clz(x)) >> 1 == 15 - (clz(x) >> 1) folds into the sums
             const int dq2h = (int)((uint32_t)(PK ? __mul24(dq, dq) : dq * dq) >> 1);
             const int clzh = TH_CLZ_NZ(dis1 + dis2) >> 1;
-            const int s = TH_LANE_OF_MASK(conm, lane) ? (psc + matched15 + clzh) - dq2h : -0x40000000;
-            const int rb = th_wave_excl_max(s, best);              // best as seen just before this lane
+            const int s = TH_LANE_OF_MASK(conm, lane) ? (psc + matched + clzh) - dq2h : -0x40000000;        // score + 15
+            const int rb = max(th_shr1(th_wave_incl_max(s), TH_INT_MIN), best);      // best as seen just before this lane (lane 0: the running best)
             const unsigned long long impm = TH_BALLOT(s > rb);     // (a lane without a connection holds -2^30, below every best)
             // stop rules in scan order: :331 (dstop); :342 improving SAME/OVL and :344-346 non-improving OVL (SAME with fewer than 2k
             // matched bases), so OVL always stops; :349 max_h consecutive non-improving predecessors (only evaluated when reachable)
-            unsigned long long stopm = dstopm | (conm & TH_BALLOT(cp == pp) & (impm | TH_BALLOT(matched15 < 2 * k - 15)));
+            unsigned long long stopm = dstopm | (conm & TH_BALLOT(cp == pp) & (impm | TH_BALLOT(matched < 2 * k)));
             if (iter + TH_WAVE >= max_h) {
                 const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1);
                 const unsigned long long below = impm & upto;
@@ -151,6 +151,7 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             TH_LDS_ASYNC_WAIT(rec_next);       // (here, before the value is copied or used: the compiler does not track the asynchronous read)
         }
         TH_LDS_ASYNC_WAIT(rec_next);           // a scan that stopped leaves its last request in flight: its registers stay reserved until it lands
+        best -= 15;
         if (lane == 0 && best > init) {                                                                 // :352-354
             S[cur] = best; F[cur] = bi;
             if (PK) ((int *)(R + cur))[1] = best;
