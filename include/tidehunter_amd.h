@@ -95,9 +95,18 @@ int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out);
 /* device milliseconds of the last th_batch_run() per kernel, measured with HIP events on the library's own
  * stream(s): [0] encode+hits [1] chain_dp [2] chain_extract [3] partition [4] poa [5] align; returns 6 */
 int th_batch_timing(th_handle_t *h, double *ms_kernel, int n);
-/* A batch of 16384 reads or more (TH_SUBBATCH_MIN) runs as two concurrent halves on two streams of the handle's device (TH_SUBBATCH=1
- * turns that off, 3 or 4 make more parts); th_batch_timing sums the parts, th_batch_launches returns how many the last upload made. */
+/* TH_SUBBATCH=2..4 cuts a batch of 16384 reads or more (TH_SUBBATCH_MIN) into that many parts that run concurrently on streams of
+ * their own (round 2's default; one part since the host left the middle of the pipeline); th_batch_timing sums the parts,
+ * th_batch_launches returns how many the last run had. */
 int th_batch_launches(th_handle_t *h);
+/* host synchronisations (stream drains) of the last th_batch_run(): three per batch -- after the job tables, after the POA, at the end */
+int th_batch_syncs(th_handle_t *h);
+
+/* The batch seam over a SEQUENCE of batches, pipelined: while the kernels of batch i run, batch i+1 is uploaded (own copy stream,
+ * second input set in HBM) and the record arithmetic of batch i-1 fills out[i-1][..] (second result set).  Same results as
+ * n_batches calls of th_process_batch(); this is the loop body of mini_tandem() (src/main.c:396-432) with its three phases
+ * overlapped.  th_run_file() drives the same pipeline from the reader. */
+int th_process_batches(th_handle_t *h, int n_batches, const char *const *const *seqs, const int *const *lens, const int *n, th_tandem_seq_t *const *out);
 
 /* mini_tandem_output(), src/main.c:214-271 (resets the slots after printing, as the reference does) */
 void th_output(FILE *fp, int n, const char *const *names, const char *const *seqs, const int *lens,
@@ -134,9 +143,6 @@ void th_ticket_close(th_ticket_t *t, int unlink_it);
 
 const char *th_last_error(void);
 const char *th_version(void);
-
-/* test hook (tests/ only): see tidehunter_amd/csrc/th_internal.h th_gpu_debug() */
-long long th_debug_stage(th_handle_t *h, int what, void *dst, long long cap);
 
 #ifdef __cplusplus
 }

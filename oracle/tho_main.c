@@ -73,6 +73,8 @@ int main(int argc, char **argv)
     if (p.only_full_length && (!five || !three)) { fprintf(stderr, "\n[main] Error: 5' and 3' adapter sequence need to be provided.\n"); return 0; }
     if (p.w < 1 || p.w > 256) { fprintf(stderr, "[tho_oracle] -w must be in 1..256 (the reference's window array has 256 slots)\n"); return 2; }
     tho_para_load_adapters(&p, five, three);
+    /* the pin kit (tests/test_oracle_ref_full.py) runs the oracle with either consensus tie rule without a rebuild */
+    if (getenv("THO_POA_GAP_TIE")) tho_poa_set_opt(THO_POA_OPT_GAP_TIE, atoi(getenv("THO_POA_GAP_TIE")));
     /* many worker threads: keep freed memory in the per-thread malloc arenas instead of returning it to the kernel (every
      * mmap/munmap/trim takes the process-wide mm lock, which is what limited the scaling of this program on a 256-core host) */
     mallopt(M_MMAP_THRESHOLD, 32 << 20); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_TOP_PAD, 16 << 20);

@@ -69,6 +69,8 @@ def load_library(path=None):
     lib.th_batch_collect.argtypes = [C.c_void_p, C.POINTER(TandemSeq)]
     lib.th_batch_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     lib.th_batch_launches.argtypes = [C.c_void_p]
+    lib.th_batch_syncs.argtypes = [C.c_void_p]
+    lib.th_process_batches.argtypes = [C.c_void_p, C.c_int, C.POINTER(pp), C.POINTER(ip), ip, C.POINTER(C.POINTER(TandemSeq))]
     lib.th_run_file.argtypes = [C.c_char_p, C.POINTER(Para), C.c_void_p, C.c_int, C.c_int]
     lib.th_synth_read.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_char_p, C.c_int]
     lib.th_synth_adapter.argtypes = [C.c_uint64, C.c_int, C.c_char_p, C.c_int]

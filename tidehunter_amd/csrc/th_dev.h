@@ -31,9 +31,41 @@ struct ThTask {
     int cons_off;    // consensus / coverage output offset
     int cons_cap;
     int aln_off;     // first entry of this task in the per-unit iden_n array
-    int pad0, pad1;
+    int narrow;      // 1: the job starts on the int16 POA variant (th_poa_job_is_narrow), 0: on the 32-bit one
+    int noband;      // host, slow path: the job is being rerun without the adaptive band
 };
 struct ThUnit { int start, len; };   // start = index of the unit's first base inside the read
+
+// The pipeline's device counters: one block, zeroed by th_k_encode at the start of a batch.  Kernels get pointers to single fields.
+struct ThCnt {
+    int rec;                 // chain records in the arena (th_k_chain_extract*)
+    int err;                 // error flags (TH_E_*)
+    int q_poa_n, q_poa_w;    // work-queue heads: POA int16 variant / 32-bit variant
+    int q_aln_s;             // ... alignment items, small staging area
+    int par_top;             // top of the par_pos arena (th_k_partition)
+    int q_xw, q_part;        // ... reads of the extraction waves, chains of the partition waves
+    int min_fb;              // reads whose minimizer selection fell back to the sequential replay
+    int q_aln_m, q_aln_b;    // ... alignment items, mid / big staging area
+    int n_retry;             // jobs the POA gave back (status 1-4, 7): the host takes the slow path when this is not 0
+    int n_failed;            // jobs that stay without a consensus (status 5, 6)
+    int pad0[3];
+    // job build (the first six in the column order of th_k_jobs_count: the scan writes them in one go)
+    int par_total, n_task, n_unit, cons_total, aln_total, n_task_n;
+    int max_unit, max_cons_cap;
+    unsigned long long need_n, need_w;       // POA scratch ints per wave the largest job of either variant asks for
+    // item build
+    int n_item_s, n_item_m, n_item_b, cc_total, max_cl, pad1[3];
+    int pad2[28];
+};
+static_assert(sizeof(ThCnt) == 256, "counter block");
+#define TH_E_REC_OVERFLOW 1       // chain record arena too small (rerun the extraction with a larger one)
+#define TH_E_PART_OVERFLOW 2      // a par_pos region or the boundary buffer of the partition was too small
+#define TH_E_ALN_BND 4            // boundary buffer of the alignment kernel too small
+#define TH_E_MINIMIZER 8          // minimizer selection repeated a word or overflowed its buffer
+#define TH_E_ALN_VERIFY 64        // TH_ALN_MODE=2: a banded alignment differs from the full matrix
+#define TH_E_MSA_UNITS 128        // a job with fewer than two units ("Not enough sequences to perform msa.", src/abpoa_cons.c:61)
+#define TH_E_JOB_CAP 256          // job / unit / par_pos tables too small (rerun the build with larger ones)
+
 
 // Point where data written by some lanes of a wave (typically lane 0 after a sequential section) must be
 // visible to the other lanes.  On the hardware the wave runs in lock-step, so program order plus a

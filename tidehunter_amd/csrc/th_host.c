@@ -24,12 +24,13 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <stddef.h>
 #include "tidehunter_amd.h"
 #include "th_internal.h"
 
 static __thread char g_err[512];   /* per thread, like the device layer's message */
 const char *th_last_error(void) { return g_err[0] ? g_err : th_gpu_error(); }
-const char *th_version(void) { return "1.5.5-mi355x.r1"; }
+const char *th_version(void) { return "1.5.5-mi355x.r3"; }
 static int host_fail(const char *m) { snprintf(g_err, sizeof(g_err), "%s", m); fprintf(stderr, "[tidehunter_amd] %s\n", m); return -1; }
 
 /* A handle owns up to two device pipelines (own stream, own buffers) on its GPU.  A large batch is cut in two halves balanced by
@@ -38,10 +39,14 @@ static int host_fail(const char *m) { snprintf(g_err, sizeof(g_err), "%s", m); f
  * shape, +20 % on config 5 (tools/gpu_tworank.sh).  Reads are independent, so the halves exchange nothing; results are merged by
  * read index.  Small batches (tests, the file driver's own two workers) use one pipeline. */
 #define TH_MAX_SUB 4
+typedef struct { int n, n_sub, sub_off[TH_MAX_SUB + 1]; const char *const *seqs; const int *lens; } th_batch_t;   /* one batch (reads borrowed until its collect) */
 struct th_handle {
     th_para_t para;              /* snapshot (adapter strings are borrowed from the caller's th_para_t) */
-    th_gpu_t *gpu[TH_MAX_SUB]; int n_sub_max, n_sub, sub_min, sub_off[TH_MAX_SUB + 1];
-    int n; const char *const *seqs; const int *lens;   /* the resident batch (borrowed until collect) */
+    th_gpu_t *gpu[TH_MAX_SUB]; int n_sub_max, sub_min;
+    /* Two input sets and two result sets per pipeline (th_internal.h): `up[s]` is the batch uploaded into input set s, `res[s]` the
+     * batch whose results sit in result set s.  The three-step calls of the public API use set 0; the file driver and
+     * th_process_batches() alternate, so that the upload of batch i+1 and the record arithmetic of batch i-1 overlap the kernels of batch i. */
+    th_batch_t up[2], res[2];
 };
 
 /* ---------------------------------------------------------------- parameters */
@@ -557,7 +562,7 @@ static th_handle_t *th_init_sub(const th_para_t *p, int device, int n_sub_max)
         gp.ad_k[0] = gp.ad_k[2] = (int)(p->five_len * (1 - p->ada_match_rat)); gp.ad_k[1] = gp.ad_k[3] = (int)(p->three_len * (1 - p->ada_match_rat));
     }
     th_handle_t *h = (th_handle_t *)calloc(1, sizeof(*h));
-    h->para = *p; h->n_sub_max = n_sub_max < 1 ? 1 : n_sub_max > TH_MAX_SUB ? TH_MAX_SUB : n_sub_max; h->n_sub = 1;
+    h->para = *p; h->n_sub_max = n_sub_max < 1 ? 1 : n_sub_max > TH_MAX_SUB ? TH_MAX_SUB : n_sub_max; h->up[0].n_sub = h->up[1].n_sub = h->res[0].n_sub = h->res[1].n_sub = 1;
     h->sub_min = 16384;
     { const char *e = getenv("TH_SUBBATCH_MIN"); if (e && atoi(e) > 0) h->sub_min = atoi(e); }
     for (int s = 0; s < h->n_sub_max; ++s) {
@@ -575,24 +580,26 @@ th_handle_t *th_init(const th_para_t *p, int device)
 }
 void th_destroy(th_handle_t *h) { if (!h) return; for (int s = 0; s < h->n_sub_max; ++s) th_gpu_destroy(h->gpu[s]); free(h); }
 
-int th_batch_upload(th_handle_t *h, const char *const *seqs, const int *lens, int n)
+static int batch_upload_s(th_handle_t *h, int slot, const char *const *seqs, const int *lens, int n, int wait)
 {
-    h->n = n; h->seqs = seqs; h->lens = lens;
-    h->n_sub = (h->n_sub_max >= 2 && n >= h->sub_min) ? h->n_sub_max : 1;
-    h->sub_off[0] = 0; h->sub_off[h->n_sub] = n;
-    if (h->n_sub > 1) {                        /* parts balanced by bases (cost ~ bases) */
+    th_batch_t *b = &h->up[slot & 1];
+    b->n = n; b->seqs = seqs; b->lens = lens;
+    b->n_sub = (h->n_sub_max >= 2 && n >= h->sub_min) ? h->n_sub_max : 1;
+    b->sub_off[0] = 0; b->sub_off[b->n_sub] = n;
+    if (b->n_sub > 1) {                        /* parts balanced by bases (cost ~ bases) */
         long long tot = 0, acc = 0; int cut = 0;
         for (int i = 0; i < n; ++i) tot += lens[i];
-        for (int s = 1; s < h->n_sub; ++s) {
-            while (cut < n - (h->n_sub - s) && (acc + lens[cut]) * h->n_sub <= tot * s) acc += lens[cut++];
+        for (int s = 1; s < b->n_sub; ++s) {
+            while (cut < n - (b->n_sub - s) && (acc + lens[cut]) * b->n_sub <= tot * s) acc += lens[cut++];
             if (cut < s) { acc += lens[cut]; ++cut; }          /* never an empty part */
-            h->sub_off[s] = cut;
+            b->sub_off[s] = cut;
         }
     }
-    for (int s = 0; s < h->n_sub; ++s)
-        if (th_gpu_upload(h->gpu[s], seqs + h->sub_off[s], lens + h->sub_off[s], h->sub_off[s + 1] - h->sub_off[s])) return -1;
+    for (int s = 0; s < b->n_sub; ++s)
+        if (th_gpu_upload(h->gpu[s], slot, seqs + b->sub_off[s], lens + b->sub_off[s], b->sub_off[s + 1] - b->sub_off[s], wait)) return -1;
     return 0;
 }
+int th_batch_upload(th_handle_t *h, const char *const *seqs, const int *lens, int n) { return batch_upload_s(h, 0, seqs, lens, n, 1); }
 int th_batch_reserve(th_handle_t *h, int max_reads, long long max_bases)
 {
     const int ns = (h->n_sub_max >= 2 && max_reads >= h->sub_min) ? h->n_sub_max : 1;
@@ -601,29 +608,37 @@ int th_batch_reserve(th_handle_t *h, int max_reads, long long max_bases)
 }
 /* (Tried: starting the second half only when the first has finished stages 1-3, so that the halves sit in different stages.  Worse:
  * the late half's first kernels queue behind the POA grid -- config 3 88.1 k against 92.0 k reads/s, config 2 171 k against 185 k.) */
-static void *sub_run(void *arg) { return (void *)(intptr_t)th_gpu_run((th_gpu_t *)arg); }
-int th_batch_run(th_handle_t *h)
+typedef struct { th_gpu_t *g; int in_slot, out_slot; } sub_run_arg_t;
+static void *sub_run(void *arg) { sub_run_arg_t *a = (sub_run_arg_t *)arg; return (void *)(intptr_t)th_gpu_run(a->g, a->in_slot, a->out_slot); }
+static int batch_run_s(th_handle_t *h, int in_slot, int out_slot)
 {
-    if (h->n_sub == 1) return th_gpu_run(h->gpu[0]);
-    pthread_t tid[TH_MAX_SUB]; int bad = 0;
-    for (int s = 1; s < h->n_sub; ++s) if (pthread_create(&tid[s], NULL, sub_run, h->gpu[s]) != 0) { for (int x = 1; x < s; ++x) pthread_join(tid[x], NULL); return host_fail("pthread_create failed"); }
-    const int r0 = th_gpu_run(h->gpu[0]);
-    for (int s = 1; s < h->n_sub; ++s) { void *r = NULL; pthread_join(tid[s], &r); if (r != NULL) bad = 1; }
+    h->res[out_slot & 1] = h->up[in_slot & 1];
+    const int n_sub = h->res[out_slot & 1].n_sub;
+    if (n_sub == 1) return th_gpu_run(h->gpu[0], in_slot, out_slot);
+    pthread_t tid[TH_MAX_SUB]; sub_run_arg_t arg[TH_MAX_SUB]; int bad = 0;
+    for (int s = 1; s < n_sub; ++s) {
+        arg[s].g = h->gpu[s]; arg[s].in_slot = in_slot; arg[s].out_slot = out_slot;
+        if (pthread_create(&tid[s], NULL, sub_run, &arg[s]) != 0) { for (int x = 1; x < s; ++x) pthread_join(tid[x], NULL); return host_fail("pthread_create failed"); }
+    }
+    const int r0 = th_gpu_run(h->gpu[0], in_slot, out_slot);
+    for (int s = 1; s < n_sub; ++s) { void *r = NULL; pthread_join(tid[s], &r); if (r != NULL) bad = 1; }
     if (bad && !g_err[0]) snprintf(g_err, sizeof(g_err), "a part of the batch failed on the device (see stderr)");
     return (r0 || bad) ? -1 : 0;
 }
-/* device milliseconds of the last run per kernel, summed over the concurrent halves; th_batch_launches() says how many there were */
+int th_batch_run(th_handle_t *h) { return batch_run_s(h, 0, 0); }
+/* device milliseconds of the last run per kernel, summed over the concurrent parts; th_batch_launches() says how many there were */
 int th_batch_timing(th_handle_t *h, double *ms_kernel, int n)
 {
     for (int i = 0; i < n && i < 8; ++i) ms_kernel[i] = 0;
-    for (int s = 0; s < h->n_sub; ++s) {
-        th_gpu_out_t o; th_gpu_get(h->gpu[s], &o);
+    for (int s = 0; s < h->res[0].n_sub; ++s) {
+        th_gpu_out_t o; th_gpu_get(h->gpu[s], 0, &o);
         for (int i = 0; i < n && i < 8; ++i) ms_kernel[i] += o.ms_kernel[i];
     }
     return 6;
 }
-int th_batch_launches(th_handle_t *h) { return h->n_sub; }
-long long th_debug_stage(th_handle_t *h, int what, void *dst, long long cap) { return h->n_sub == 1 ? th_gpu_debug(h->gpu[0], what, dst, cap) : -1; }
+int th_batch_launches(th_handle_t *h) { return h->res[0].n_sub; }
+int th_batch_syncs(th_handle_t *h) { return th_gpu_syncs(h->gpu[0]); }
+long long th_debug_stage(th_handle_t *h, int what, void *dst, long long cap) { return h->res[0].n_sub == 1 ? th_gpu_debug(h->gpu[0], what, dst, cap) : -1; }
 
 typedef struct { int ed, start, end; } ed_res_t;
 static int collect_ed(const th_para_t *p, const char *q, int qlen, const char *seq, int seq_len, ed_res_t *r)   /* src/gen_cons.c:89-110 */
@@ -676,11 +691,12 @@ static int code_of(unsigned char c)
 }
 
 /* host half of seqs_msa()/abpoa_gen_cons() for one run, from the integer evidence the device produced */
-static void finish_job(const th_handle_t *h, const th_gpu_out_t *o, const th_job_t *j, th_tandem_seq_t *t, int rb)
+static void finish_job(const th_handle_t *h, const th_batch_t *B, const th_gpu_out_t *o, const th_job_t *j, th_tandem_seq_t *t, int rb)
 {
     const th_para_t *p = &h->para;
+    const int *ext = o->ext + 4 * (j - o->jobs);            /* max_q_l, max_t_l, max_q_r, max_t_r */
     const int *pos = o->par + j->pos_off; const int pos_n = j->pos_n;
-    const char *seq = h->seqs[rb + j->read]; const int seq_len = h->lens[rb + j->read];      /* rb: first read of the half this job belongs to */
+    const char *seq = B->seqs[rb + j->read]; const int seq_len = B->lens[rb + j->read];      /* rb: first read of the half this job belongs to */
     if (p->only_unit) { write_unit(t, pos, pos_n); return; }
     int cons_len = j->cons_len, n_seqs = j->n_seqs;
     if (cons_len <= 0) return;
@@ -718,10 +734,10 @@ static void finish_job(const th_handle_t *h, const th_gpu_out_t *o, const th_job
     for (int s = 0; s < cons_len; ++s) cons_seq[s] = cb[s] <= 4 ? "ACGTN"[cb[s]] : 'N';
     cons_seq[cons_len] = 0;
     double copy_num = n_seqs;                                      /* :217-223 */
-    int cons_start = pos[0] - j->max_t_l;
-    copy_num += (j->max_q_l + 1.0) / cons_len;
-    int cons_end = pos[pos_n - 1] + j->max_t_r + 1;
-    copy_num += (j->max_q_r + 1.0) / cons_len;
+    int cons_start = pos[0] - ext[1];
+    copy_num += (ext[0] + 1.0) / cons_len;
+    int cons_end = pos[pos_n - 1] + ext[3] + 1;
+    copy_num += (ext[2] + 1.0) / cons_len;
     int full_length = 0, out_len = cons_len;
     if (p->five_seq != NULL && p->three_seq != NULL && cons_len > p->five_len + p->three_len) {   /* :226-291 */
         char *cons2 = (char *)malloc(((size_t)cons_len << 1) + 1); uint8_t *qual2 = NULL;
@@ -766,49 +782,54 @@ WRITE:
 
 /* Record arithmetic of a batch (src/gen_cons.c:208-301 per consensus job): reads are independent and each writes only its
  * own tandem_seq_t slot, so the batch is cut into contiguous read ranges for a few worker threads. */
-typedef struct { th_handle_t *h; const th_gpu_out_t *o; th_tandem_seq_t *out; int r0, r1, rb; } collect_arg_t;   /* reads rb + r0 .. rb + r1 of the batch = r0 .. r1 of the half */
+typedef struct { th_handle_t *h; const th_batch_t *B; const th_gpu_out_t *o; th_tandem_seq_t *out; int r0, r1, rb; } collect_arg_t;   /* reads rb + r0 .. rb + r1 of the batch = r0 .. r1 of the part */
 static void *collect_range(void *arg)
 {
     collect_arg_t *a = (collect_arg_t *)arg;
-    th_handle_t *h = a->h; const th_gpu_out_t *o = a->o; const th_para_t *p = &h->para;
+    th_handle_t *h = a->h; const th_gpu_out_t *o = a->o; const th_para_t *p = &h->para; const th_batch_t *B = a->B;
     int lo = 0, hi = o->n_jobs;                  /* first job of read >= r0 (jobs are ordered by read) */
     while (lo < hi) { int mid = (lo + hi) >> 1; if (o->jobs[mid].read < a->r0) lo = mid + 1; else hi = mid; }
     int ji = lo;
     for (int r = a->r0; r < a->r1; ++r) {
         th_tandem_seq_t *t = &a->out[a->rb + r];
         t->cons_n = 0; t->cons_seq->seq.l = 0; t->cons_seq->qual.l = 0;
-        while (ji < o->n_jobs && o->jobs[ji].read == r) { finish_job(h, o, &o->jobs[ji], t, a->rb); ++ji; }
-        if (h->lens[a->rb + r] >= p->k && p->single_copy == 1 && p->only_full_length && p->five_seq != NULL && p->three_seq != NULL)
-            single_copy(h->lens[a->rb + r], h->seqs[a->rb + r], t, p);   /* src/tidehunter.c:24,49-51 */
+        while (ji < o->n_jobs && o->jobs[ji].read == r) { finish_job(h, B, o, &o->jobs[ji], t, a->rb); ++ji; }
+        if (B->lens[a->rb + r] >= p->k && p->single_copy == 1 && p->only_full_length && p->five_seq != NULL && p->three_seq != NULL)
+            single_copy(B->lens[a->rb + r], B->seqs[a->rb + r], t, p);   /* src/tidehunter.c:24,49-51 */
     }
     return NULL;
 }
-int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out)
+/* threads one handle may use for the record arithmetic: -t if given above the reference's default of 4, else what the host offers
+ * (8, or 16 with 32 cores and more); TH_HOST_THREADS overrides (bench.py sets it to its share of the CPUs when several ranks share a host) */
+static int host_threads(const th_handle_t *h)
 {
-    th_gpu_out_t o[TH_MAX_SUB];
-    for (int s = 0; s < h->n_sub; ++s) th_gpu_get(h->gpu[s], &o[s]);
-    /* worker threads for the record arithmetic (adapter searches are the heavy part): -t if given above the reference's
-     * default of 4, else 16 on hosts with 32 or more cores, else 8; TH_HOST_THREADS overrides */
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
     int nth = h->para.n_thread > 4 ? h->para.n_thread : (ncpu >= 32 ? 16 : 8);
     const char *e = getenv("TH_HOST_THREADS");
     if (e && atoi(e) > 0) nth = atoi(e);
-    if (nth > 64) nth = 64;
-    if (h->n < 256 * nth) nth = 1;
+    return nth > 64 ? 64 : nth;
+}
+static int batch_collect_s(th_handle_t *h, int out_slot, th_tandem_seq_t *out)
+{
+    const th_batch_t *B = &h->res[out_slot & 1];
+    th_gpu_out_t o[TH_MAX_SUB];
+    for (int s = 0; s < B->n_sub; ++s) th_gpu_get(h->gpu[s], out_slot, &o[s]);
+    int nth = host_threads(h);
+    if (B->n < 256 * nth) nth = 1;
     collect_arg_t arg[64]; pthread_t tid[64];
-    if (nth < h->n_sub) nth = h->n_sub;
+    if (nth < B->n_sub) nth = B->n_sub;
     {   /* the threads are shared out over the parts in proportion to their reads, at least one each */
         int first[TH_MAX_SUB + 1]; first[0] = 0;
-        for (int sp = 1; sp <= h->n_sub; ++sp) {
-            int f = sp == h->n_sub ? nth : (int)((long long)nth * h->sub_off[sp] / (h->n ? h->n : 1));
+        for (int sp = 1; sp <= B->n_sub; ++sp) {
+            int f = sp == B->n_sub ? nth : (int)((long long)nth * B->sub_off[sp] / (B->n ? B->n : 1));
             if (f < first[sp - 1] + 1) f = first[sp - 1] + 1;
-            if (f > nth - (h->n_sub - sp)) f = nth - (h->n_sub - sp);
+            if (f > nth - (B->n_sub - sp)) f = nth - (B->n_sub - sp);
             first[sp] = f;
         }
-        for (int sp = 0; sp < h->n_sub; ++sp)
+        for (int sp = 0; sp < B->n_sub; ++sp)
             for (int t = first[sp]; t < first[sp + 1]; ++t) {
-                const int k = t - first[sp], m = first[sp + 1] - first[sp], cnt = h->sub_off[sp + 1] - h->sub_off[sp];
-                arg[t].h = h; arg[t].o = &o[sp]; arg[t].out = out; arg[t].rb = h->sub_off[sp];
+                const int k = t - first[sp], m = first[sp + 1] - first[sp], cnt = B->sub_off[sp + 1] - B->sub_off[sp];
+                arg[t].h = h; arg[t].B = B; arg[t].o = &o[sp]; arg[t].out = out; arg[t].rb = B->sub_off[sp];
                 arg[t].r0 = (int)((long long)cnt * k / m); arg[t].r1 = (int)((long long)cnt * (k + 1) / m);
             }
     }
@@ -817,6 +838,7 @@ int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out)
     for (int t = 1; t < nth; ++t) pthread_join(tid[t], NULL);
     return 0;
 }
+int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out) { return batch_collect_s(h, 0, out); }
 
 int th_process_batch(th_handle_t *h, const char *const *seqs, const int *lens, int n, th_tandem_seq_t *out)
 {
@@ -828,8 +850,8 @@ int th_process_batch(th_handle_t *h, const char *const *seqs, const int *lens, i
     const int rc = th_batch_collect(h, out);
     if (getenv("TH_TRACE")) {
         double km = 0;
-        for (int s = 0; s < h->n_sub; ++s) { th_gpu_out_t o; th_gpu_get(h->gpu[s], &o); km += o.ms_kernels; }
-        fprintf(stderr, "[th_process_batch] %d reads in %d concurrent part(s): upload %.3f s, device run %.3f s (kernels %.3f s summed), collect %.3f s\n", n, h->n_sub, t1 - t0, t2 - t1, km / 1000.0, now_s() - t2);
+        for (int s = 0; s < h->res[0].n_sub; ++s) { th_gpu_out_t o; th_gpu_get(h->gpu[s], 0, &o); km += o.ms_kernels; }
+        fprintf(stderr, "[th_process_batch] %d reads in %d concurrent part(s): upload %.3f s, device run %.3f s (kernels %.3f s summed), collect %.3f s\n", n, h->res[0].n_sub, t1 - t0, t2 - t1, km / 1000.0, now_s() - t2);
     }
     return rc;
 }
@@ -882,25 +904,107 @@ void th_output(FILE *fp, int n, const char *const *names, const char *const *seq
     }
 }
 
+/* ---------------------------------------------------------------- the batch seam, pipelined */
+/* A sequence of batches through one handle as a three-stage software pipeline: while the kernels of batch i run, batch i+1 is
+ * uploaded (own copy stream, second input set) and the record arithmetic of batch i-1 fills its tandem_seq_t slots (second
+ * result set).  The stages are three threads that hand batches on through counters; the same three stages serve the file
+ * driver below (its batches come from the reader instead of an array). */
+typedef struct th_stage3 {
+    th_handle_t *h;
+    pthread_mutex_t mu; pthread_cond_t cv;
+    int up_done, run_done, col_done, n_total;       /* batches past each stage; n_total: how many there will be (-1: not known yet) */
+    int failed;
+    /* batch k of this pipeline: reads and result slots (ring of 8: at most 4 batches are in flight) */
+    struct { const char *const *seqs; const int *lens; int n; th_tandem_seq_t *out; void *tag; } b[8];
+    void (*on_done)(struct th_stage3 *, int k, void *tag);      /* called by the collecting thread when batch k is complete */
+    double busy_up, busy_run, busy_col;
+} th_stage3_t;
+static void st3_init(th_stage3_t *p, th_handle_t *h) { memset(p, 0, sizeof(*p)); p->h = h; p->n_total = -1; pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->cv, NULL); }
+static void st3_destroy(th_stage3_t *p) { pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv); }
+static void st3_bump(th_stage3_t *p, int *ctr) { pthread_mutex_lock(&p->mu); ++*ctr; pthread_cond_broadcast(&p->cv); pthread_mutex_unlock(&p->mu); }
+static void st3_finish(th_stage3_t *p, int n_total) { pthread_mutex_lock(&p->mu); p->n_total = n_total; pthread_cond_broadcast(&p->cv); pthread_mutex_unlock(&p->mu); }
+/* waits until *ctr > k (batch k has passed that stage); returns 0 if the pipeline ends before batch k */
+static int st3_wait(th_stage3_t *p, const int *ctr, int k)
+{
+    int ok = 1;
+    pthread_mutex_lock(&p->mu);
+    while (*ctr <= k) { if (p->n_total >= 0 && k >= p->n_total) { ok = 0; break; } pthread_cond_wait(&p->cv, &p->mu); }
+    pthread_mutex_unlock(&p->mu);
+    return ok;
+}
+/* stage 1, called by whoever produces batches: input set k & 1 is free once batch k-2 has run */
+static int st3_upload(th_stage3_t *p, int k, const char *const *seqs, const int *lens, int n, th_tandem_seq_t *out, void *tag)
+{
+    if (k >= 2) st3_wait(p, &p->run_done, k - 2);
+    const double t0 = now_s();
+    p->b[k & 7].seqs = seqs; p->b[k & 7].lens = lens; p->b[k & 7].n = n; p->b[k & 7].out = out; p->b[k & 7].tag = tag;
+    if (!p->failed && n > 0 && batch_upload_s(p->h, k, seqs, lens, n, 0)) p->failed = 1;
+    p->busy_up += now_s() - t0;
+    st3_bump(p, &p->up_done);
+    return p->failed ? -1 : 0;
+}
+static void *st3_runner(void *arg)
+{
+    th_stage3_t *p = (th_stage3_t *)arg;
+    for (int k = 0;; ++k) {
+        if (!st3_wait(p, &p->up_done, k)) return NULL;
+        if (k >= 2) st3_wait(p, &p->col_done, k - 2);            /* result set k & 1 is free once batch k-2 has been collected */
+        const double t0 = now_s();
+        if (!p->failed && p->b[k & 7].n > 0 && batch_run_s(p->h, k, k)) p->failed = 1;
+        p->busy_run += now_s() - t0;
+        st3_bump(p, &p->run_done);
+    }
+}
+static void *st3_collector(void *arg)
+{
+    th_stage3_t *p = (th_stage3_t *)arg;
+    for (int k = 0;; ++k) {
+        if (!st3_wait(p, &p->run_done, k)) return NULL;
+        const double t0 = now_s();
+        if (!p->failed && p->b[k & 7].n > 0 && batch_collect_s(p->h, k, p->b[k & 7].out)) p->failed = 1;
+        p->busy_col += now_s() - t0;
+        if (p->on_done) p->on_done(p, k, p->b[k & 7].tag);
+        st3_bump(p, &p->col_done);
+    }
+}
+int th_process_batches(th_handle_t *h, int n_batches, const char *const *const *seqs, const int *const *lens, const int *n, th_tandem_seq_t *const *out)
+{
+    th_stage3_t p; st3_init(&p, h);
+    pthread_t t_run, t_col;
+    if (pthread_create(&t_run, NULL, st3_runner, &p) != 0) { st3_destroy(&p); return host_fail("pthread_create failed"); }
+    if (pthread_create(&t_col, NULL, st3_collector, &p) != 0) { st3_finish(&p, 0); pthread_join(t_run, NULL); st3_destroy(&p); return host_fail("pthread_create failed"); }
+    for (int k = 0; k < n_batches; ++k) st3_upload(&p, k, seqs[k], lens[k], n[k], out[k], NULL);
+    st3_finish(&p, n_batches);
+    pthread_join(t_run, NULL); pthread_join(t_col, NULL);
+    const int bad = p.failed;
+    if (getenv("TH_TRACE")) fprintf(stderr, "[th_process_batches] %d batches: busy upload %.3f s, run %.3f s, collect %.3f s\n", n_batches, p.busy_up, p.busy_run, p.busy_col);
+    st3_destroy(&p);
+    if (bad && !g_err[0]) snprintf(g_err, sizeof(g_err), "a batch failed on the device (see stderr)");
+    return bad ? -1 : 0;
+}
+
 /* ---------------------------------------------------------------- whole-file driver, src/main.c:375-436 */
-/* th_run_file = mini_tandem() (src/main.c:377-447).  The reference alternates "read a chunk / fan out / print"; here the
- * three run as a pipeline over three batch slots so that parsing batch i+1 and formatting batch i-1 overlap the device
- * work on batch i.  Output order = input order (src/main.c:217). */
+/* th_run_file = mini_tandem() (src/main.c:377-447).  The reference alternates "read a chunk / fan out / print"; here
+ * reader -> upload -> kernels -> record arithmetic -> writer run as a pipeline over a ring of batch slots, so that parsing and
+ * uploading batch i+1 and collecting / formatting batch i-1 overlap the device work on batch i.  Output
+ * order = input order (src/main.c:217). */
 enum { SLOT_EMPTY = 0, SLOT_FILLED = 1, SLOT_DONE = 2 };
 #define TH_MAX_DEV 16
-#define TH_MAX_WORKER (4 * TH_MAX_DEV)          /* up to four workers (handles, streams) per device */
-#define TH_MAX_SLOT (2 * TH_MAX_WORKER + 1)
+#define TH_MAX_WORKER (4 * TH_MAX_DEV)          /* up to four pipelines (handles) per device */
+#define TH_MAX_SLOT (5 * TH_MAX_WORKER + 2)
 typedef struct { char **names, **seqs; int *lens; int n, state, batch; th_tandem_seq_t *ts; th_str_t arena; size_t *noff, *soff; } th_slot_t;   /* batch: index of the batch the slot holds */
 typedef struct {
     th_slot_t slot[TH_MAX_SLOT]; int n_slot, n_dev;
     pthread_mutex_t mu; pthread_cond_t cv;
     th_reader_t *rd; FILE *out; th_para_t *p; int batch_reads, ramp0; volatile int stop;
     int eof_batch;               /* index of the empty batch that ends the input (-1 until the reader meets it) */
-    int next_batch;              /* ticket counter of the device workers (the reference's THREAD_READ_I, src/main.c:277-281, at batch granularity) */
+    int next_batch;              /* ticket counter of the device pipelines (the reference's THREAD_READ_I, src/main.c:277-281, at batch granularity) */
     double t_read, t_write;      /* busy seconds of the two side threads (TH_TRACE=1 prints them) */
     double t_start; int trace;
+    /* steady-state bookkeeping: when the first full-size batch was complete and how many reads were complete by then */
+    double t_first_full; long long reads_done, reads_at_first_full;
 } th_pipe_t;
-typedef struct { th_pipe_t *q; int dev_index, device; int rc, total, batches; double busy; } th_dev_worker_t;
+typedef struct { th_pipe_t *q; int dev_index, device; int rc, total, batches; th_stage3_t st; } th_dev_worker_t;
 
 /* waits until the slot holds batch `batch` in state `state` (batch < 0: any occupant -- the reader waiting for a free slot);
  * returns 0 if that batch lies beyond the end of the input instead */
@@ -956,39 +1060,55 @@ static void *pipe_writer(void *arg)
         if (n == 0) return NULL;
     }
 }
-/* one worker per device.  Workers take the next batch from a shared ticket counter, as the reference's threads take reads
- * (src/main.c:273-291): a device that finishes early (shorter reads, shorter periods) simply takes more batches -- stealing
- * with no extra mechanism.  Reads are independent, so the shards exchange nothing; the writer restores input order.  At most
- * n_dev tickets are outstanding and the ring has 2 n_dev + 1 slots, so a ticket's slot is never still owned by the writer's
- * backlog of an earlier lap for long. */
+/* the collecting thread of a device pipeline has finished a batch: its slot goes to the writer */
+static void pipe_batch_done(th_stage3_t *st, int k, void *tag)
+{
+    th_dev_worker_t *w = (th_dev_worker_t *)((char *)st - offsetof(th_dev_worker_t, st)); th_pipe_t *q = w->q; th_slot_t *s = (th_slot_t *)tag;
+    (void)k;
+    if (st->failed) { w->rc = -1; q->stop = 1; } else w->total += s->n;     /* never partial output: a failed batch and everything after it are dropped */
+    const double t = now_s();
+    pthread_mutex_lock(&q->mu);
+    q->reads_done += s->n;
+    if (q->t_first_full == 0 && s->n >= q->batch_reads) { q->t_first_full = t; q->reads_at_first_full = q->reads_done; }
+    pthread_mutex_unlock(&q->mu);
+    if (q->trace) fprintf(stderr, "[th_run_file]   pipeline %d: batch %d (%d reads) complete at %.3f s\n", w->dev_index, s->batch, s->n, t - q->t_start);
+    slot_set(q, s, SLOT_DONE);
+}
+/* One pipeline per device: this thread creates the handle (HIP initialisation overlaps the reader's first batch), takes
+ * batches from the shared ticket counter as the reference's threads take reads (src/main.c:273-291) -- a device that finishes
+ * early (shorter reads, shorter periods) simply takes more batches, stealing with no extra mechanism -- and uploads them; two
+ * more threads run the kernels and do the record arithmetic (th_stage3_t).  Reads are independent, so devices exchange
+ * nothing; the writer restores input order.  A pipeline holds at most four batches (uploaded, running, being collected, being
+ * written) and the ring has five slots per pipeline plus the reader's. */
 static void *pipe_device(void *arg)
 {
     th_dev_worker_t *w = (th_dev_worker_t *)arg; th_pipe_t *q = w->q;
-    int fsub = 1;                                          /* the driver's two workers per device already give the device two streams */
+    int fsub = 1;
     { const char *e = getenv("TH_FILE_SUB"); if (e && atoi(e) >= 1 && atoi(e) <= TH_MAX_SUB) fsub = atoi(e); }
     th_handle_t *h = th_init_sub(q->p, w->device, fsub);
     if (!h) { w->rc = -1; q->stop = 1; }
-    if (q->trace) fprintf(stderr, "[th_run_file]   worker %d: handle ready at %.3f s\n", w->dev_index, now_s() - q->t_start);
-    for (;;) {
+    if (q->trace) fprintf(stderr, "[th_run_file]   pipeline %d: handle ready at %.3f s\n", w->dev_index, now_s() - q->t_start);
+    st3_init(&w->st, h); w->st.on_done = pipe_batch_done; w->st.failed = h ? 0 : 1;
+    pthread_t t_run, t_col;
+    pthread_create(&t_run, NULL, st3_runner, &w->st); pthread_create(&t_col, NULL, st3_collector, &w->st);
+    int k = 0;
+    for (;; ++k) {
+        if (k >= 2) st3_wait(&w->st, &w->st.run_done, k - 2);       /* take a ticket only when an input set is free: an idle device gets the batch instead */
         const int i = __atomic_fetch_add(&q->next_batch, 1, __ATOMIC_RELAXED);
         th_slot_t *s = &q->slot[i % q->n_slot];
         if (!slot_wait(q, s, SLOT_FILLED, i)) break;
-        if (s->n > 0 && h && !q->stop) {
-            const double t0 = now_s();
-            if (w->batches == 0 && s->n < q->batch_reads) {      /* first (small) batch of this worker: size the device buffers for full batches */
-                long long bases = 0; for (int k = 0; k < s->n; ++k) bases += s->lens[k];
-                th_batch_reserve(h, q->batch_reads, (long long)((double)bases / s->n * q->batch_reads * 1.1) + 65536);
-            }
-            const int rc = th_process_batch(h, (const char *const *)s->seqs, s->lens, s->n, s->ts);
-            w->busy += now_s() - t0;
-            if (q->trace) fprintf(stderr, "[th_run_file]   worker %d: batch %d (%d reads) from %.3f to %.3f s\n", w->dev_index, i, s->n, t0 - q->t_start, now_s() - q->t_start);
-            if (rc) { w->rc = -1; q->stop = 1; } else w->total += s->n;   /* never partial output: a failed batch and everything after it are dropped */
+        if (s->n > 0 && h && !q->stop && k == 0 && s->n < q->batch_reads) {      /* first (small) batch of this pipeline: size the device buffers for full batches */
+            long long bases = 0; for (int x = 0; x < s->n; ++x) bases += s->lens[x];
+            th_batch_reserve(h, q->batch_reads, (long long)((double)bases / s->n * q->batch_reads * 1.1) + 65536);
         }
-        const int last = s->n == 0;
+        if (q->stop) w->st.failed = 1;
+        st3_upload(&w->st, k, (const char *const *)s->seqs, s->lens, s->n, s->ts, s);
         ++w->batches;
-        slot_set(q, s, SLOT_DONE);
-        if (last) break;
+        if (s->n == 0) { ++k; break; }                              /* the empty batch that ends the input went through (the writer stops on it) */
     }
+    st3_finish(&w->st, k);
+    pthread_join(t_run, NULL); pthread_join(t_col, NULL);
+    if (w->st.failed) w->rc = -1;
     if (h) th_destroy(h);
     return NULL;
 }
@@ -996,11 +1116,10 @@ static void *pipe_device(void *arg)
 int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *devices_in, int n_dev_in, int batch_reads)
 {
     if (n_dev_in < 1 || n_dev_in > TH_MAX_DEV) return host_fail("between 1 and 16 devices");
-    if (batch_reads <= 0) batch_reads = 32768;      /* two workers x (per-position arrays + POA scratch) stay under ~100 GB of HBM */
-    /* Two workers (handle + stream each) per listed device by default: while one batch's kernels run, the other worker uploads
-     * its next batch (pinned staging + H2D) and does the host-side record arithmetic of its previous one, so the device does
-     * not idle between batches.  TH_WORKERS_PER_DEV=1 restores one worker per device. */
-    int wpd = 2;
+    if (batch_reads <= 0) batch_reads = 32768;
+    /* One pipeline (handle + upload / run / collect threads) per listed device.  TH_WORKERS_PER_DEV=2 puts two of them on each
+     * device (round 2's design: two handles whose kernels interleave on the device; kept for A/B measurements). */
+    int wpd = 1;
     { const char *e = getenv("TH_WORKERS_PER_DEV"); if (e && atoi(e) >= 1 && atoi(e) <= 4) wpd = atoi(e); }
     int devices[TH_MAX_WORKER], n_dev = 0;
     for (int r = 0; r < wpd; ++r) for (int d = 0; d < n_dev_in; ++d) devices[n_dev++] = devices_in[d];
@@ -1009,7 +1128,7 @@ int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *d
     if (!r) { char m[300]; snprintf(m, sizeof(m), "fail to open file '%s'", read_fn); return host_fail(m); }
     th_pipe_t *q = (th_pipe_t *)calloc(1, sizeof(th_pipe_t));
     pthread_mutex_init(&q->mu, NULL); pthread_cond_init(&q->cv, NULL);
-    q->rd = r; q->out = out; q->p = p; q->batch_reads = batch_reads; q->n_dev = n_dev; q->n_slot = 2 * n_dev + 1; q->eof_batch = -1;
+    q->rd = r; q->out = out; q->p = p; q->batch_reads = batch_reads; q->n_dev = n_dev; q->n_slot = 5 * n_dev + 1; q->eof_batch = -1;
     q->ramp0 = batch_reads / 4 > 2048 ? batch_reads / 4 : 2048;       /* one small batch, then full ones: a mapped file parses at ~10 GB/s, so only the first launch has to wait */
     { const char *e = getenv("TH_RAMP0"); if (e && atoi(e) > 0) q->ramp0 = atoi(e); }
     for (int i = 0; i < q->n_slot; ++i) {
@@ -1017,22 +1136,27 @@ int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *d
         q->slot[i].lens = (int *)calloc(batch_reads, sizeof(int)); q->slot[i].ts = th_alloc_tandem_seq(batch_reads);
         q->slot[i].noff = (size_t *)calloc(batch_reads, sizeof(size_t)); q->slot[i].soff = (size_t *)calloc(batch_reads, sizeof(size_t));
     }
-    pthread_t t_rd, t_wr, t_dev[TH_MAX_WORKER]; th_dev_worker_t w[TH_MAX_WORKER];
+    pthread_t t_rd, t_wr, t_dev[TH_MAX_WORKER]; th_dev_worker_t *w = (th_dev_worker_t *)calloc(TH_MAX_WORKER, sizeof(th_dev_worker_t));
     const double t_start = now_s();
     q->t_start = t_start; q->trace = getenv("TH_TRACE") != NULL;
     pthread_create(&t_rd, NULL, pipe_reader, q); pthread_create(&t_wr, NULL, pipe_writer, q);
-    for (int d = 0; d < n_dev; ++d) { memset(&w[d], 0, sizeof(w[d])); w[d].q = q; w[d].dev_index = d; w[d].device = devices[d]; pthread_create(&t_dev[d], NULL, pipe_device, &w[d]); }
-    int total = 0, rc = 0; double busy = 0;
-    for (int d = 0; d < n_dev; ++d) { pthread_join(t_dev[d], NULL); total += w[d].total; rc |= w[d].rc; busy += w[d].busy; }
+    for (int d = 0; d < n_dev; ++d) { w[d].q = q; w[d].dev_index = d; w[d].device = devices[d]; pthread_create(&t_dev[d], NULL, pipe_device, &w[d]); }
+    int total = 0, rc = 0; double busy_up = 0, busy_run = 0, busy_col = 0;
+    for (int d = 0; d < n_dev; ++d) { pthread_join(t_dev[d], NULL); total += w[d].total; rc |= w[d].rc; busy_up += w[d].st.busy_up; busy_run += w[d].st.busy_run; busy_col += w[d].st.busy_col; }
     pthread_join(t_rd, NULL); pthread_join(t_wr, NULL);
     if (getenv("TH_TRACE")) {
-        fprintf(stderr, "[th_run_file] %d reads on %d device(s): wall %.3f s; busy: reader %.3f s, device batches %.3f s (summed), writer %.3f s\n",
-                total, n_dev, now_s() - t_start, q->t_read, busy, q->t_write);
-        if (n_dev > 1) for (int d = 0; d < n_dev; ++d) fprintf(stderr, "[th_run_file]   worker %d (device %d): %d batches, %d reads, busy %.3f s\n", d, devices[d], w[d].batches, w[d].total, w[d].busy);
+        const double t_end = now_s();
+        /* steady: the reads completed after the first full-size batch over the time since then (start-up -- HIP initialisation,
+         * device allocation, the ramp -- excluded); 0 when the input is too short to have one */
+        const double steady = (q->t_first_full > 0 && t_end > q->t_first_full && q->reads_done > q->reads_at_first_full) ? (q->reads_done - q->reads_at_first_full) / (t_end - q->t_first_full) : 0;
+        fprintf(stderr, "[th_run_file] %d reads on %d device pipeline(s): wall %.3f s; busy: reader %.3f s, upload %.3f s, device runs %.3f s, record arithmetic %.3f s, writer %.3f s; steady %.1f reads/s over the last %.3f s\n",
+                total, n_dev, t_end - t_start, q->t_read, busy_up, busy_run, busy_col, q->t_write, steady, q->t_first_full > 0 ? t_end - q->t_first_full : 0.0);
+        if (n_dev > 1) for (int d = 0; d < n_dev; ++d) fprintf(stderr, "[th_run_file]   pipeline %d (device %d): %d batches, %d reads, device busy %.3f s\n", d, devices[d], w[d].batches, w[d].total, w[d].st.busy_run);
     }
+    for (int d = 0; d < n_dev; ++d) st3_destroy(&w[d].st);
     for (int i = 0; i < q->n_slot; ++i) { th_free_tandem_seq(q->slot[i].ts, batch_reads); free(q->slot[i].names); free(q->slot[i].seqs); free(q->slot[i].lens); free(q->slot[i].noff); free(q->slot[i].soff); free(q->slot[i].arena.s); }
     pthread_mutex_destroy(&q->mu); pthread_cond_destroy(&q->cv);
-    free(q); rd_close(r);
+    free(q); free(w); rd_close(r);
     return rc ? -1 : total;
 }
 int th_run_file(const char *read_fn, th_para_t *p, FILE *out, int device, int batch_reads)

@@ -25,14 +25,14 @@ typedef struct {
     int n_seqs;             /* units handed to POA (src/abpoa_cons.c:36-48) */
     int cons_off, cons_len; /* consensus codes / coverage inside cons[] / cov[] (cons_len 0 = none) */
     int aln_off;            /* iden[aln_off + u] = identical columns of unit u vs consensus */
-    int max_q_l, max_t_l, max_q_r, max_t_r;   /* ksw2 extension results (src/gen_cons.c:218-223) */
     int status;             /* POA kernel status, 0 = ok */
-} th_job_t;
+} th_job_t;                 /* (written by the device: th_k_jobs_emit / th_k_items_emit) */
 
 typedef struct {
     int n_jobs; const th_job_t *jobs;
     const int *par;         /* compact par_pos values */
     const uint8_t *cons; const int *cov; const int *iden;   /* cov is NULL unless want_cov */
+    const int *ext;         /* 4 ints per job: max_q_l, max_t_l, max_q_r, max_t_r of the ksw2 extensions (src/gen_cons.c:218-223) */
     const int *adapt;       /* 12 ints per job: (ed, start, end) of the four adapter searches on consensus + consensus; NULL when the
                              * device did not run them (no adapters, or an adapter longer than 256 symbols: the host searches) */
     double ms_kernels;      /* device time of the last run (HIP events), all kernels */
@@ -46,11 +46,17 @@ th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device);
 void th_gpu_destroy(th_gpu_t *g);
 /* sizes the per-read / per-base buffers for batches of up to n reads and T bases (optional; avoids re-allocation when batches grow) */
 int th_gpu_reserve(th_gpu_t *g, int n, long long T);
-/* copies the reads into pinned memory and on to HBM; the batch stays resident until the next upload */
-int th_gpu_upload(th_gpu_t *g, const char *const *seqs, const int *lens, int n);
-/* runs the whole device path on the resident batch and brings the small result records back */
-int th_gpu_run(th_gpu_t *g);
-int th_gpu_get(th_gpu_t *g, th_gpu_out_t *out);
+/* A pipeline keeps TWO input sets and TWO result sets (slot 0 / 1), so that a driver can upload batch i+1 and do the record
+ * arithmetic of batch i-1 while the kernels of batch i run: upload(slot) may overlap run() of the other slot (own copy stream),
+ * get(slot) stays valid until the next run into that slot.  One thread at a time per function; run() is the only one that
+ * touches the work buffers. */
+/* copies the reads through pinned staging buffers to HBM; wait != 0: returns when the batch is resident */
+int th_gpu_upload(th_gpu_t *g, int slot, const char *const *seqs, const int *lens, int n, int wait);
+/* runs the whole device path on input set `in_slot` and brings the small result records back into result set `out_slot` */
+int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot);
+int th_gpu_get(th_gpu_t *g, int out_slot, th_gpu_out_t *out);
+/* host synchronisations (hipStreamSynchronize / event waits) of the last run, and seconds this handle spent in device malloc so far */
+int th_gpu_syncs(th_gpu_t *g);
 const char *th_gpu_error(void);
 
 /* test hook: copies an intermediate stage of the resident batch to the host.
@@ -58,6 +64,9 @@ const char *th_gpu_error(void);
  *       6 chain records (8 x i32 each, grouped by read in emission order) 7 cells (i32)
  *       8 roff (u32, n+1)   returns bytes written or -1 */
 long long th_gpu_debug(th_gpu_t *g, int what, void *dst, long long cap);
+/* the same through a handle (exported for tests/, not declared in the public header) */
+struct th_handle;
+long long th_debug_stage(struct th_handle *h, int what, void *dst, long long cap);
 
 #ifdef __cplusplus
 }

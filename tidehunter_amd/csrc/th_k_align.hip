@@ -12,19 +12,6 @@
 #define TH_ALN_OCC
 #endif
 
-struct ThAlnItem { int task, which; };   // which >= 0: unit index in the run; -1 left extension; -2 right extension
-
-// Gathers the scattered per-chain par_pos regions into one compact array (host gives offsets).
-__global__ void th_k_gather_par(int n_rec, const int *__restrict__ par, const int *__restrict__ par_off, const int *__restrict__ par_n,
-                                const int *__restrict__ dst_off, int *__restrict__ dst)
-{
-    const int c = blockIdx.x;
-    if (c >= n_rec) return;
-    const int *src = par + par_off[c];
-    const int n = par_n[c], o = dst_off[c];
-    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[o + i] = src[i];
-}
-
 // Compacts the consensus strings (and, on request, their per-base coverage) from their capacity-sized slots to the
 // actual lengths, so that the device-to-host copy moves ~1.1 KB per read instead of the 3 x unit-length slot.
 __global__ void th_k_gather_cons(int n_tasks, const ThTask *__restrict__ tasks, const int *__restrict__ len, const int *__restrict__ dst_off,

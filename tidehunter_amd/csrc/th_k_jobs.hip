@@ -1,0 +1,241 @@
+// th_k_jobs.hip -- the consensus job tables, built on the device (gfx950).
+//
+// What seqs_msa() does with the partition of one chain (src/gen_cons.c:192-205: split par_pos at the -1 separators, keep runs
+// with more than min_copy boundaries) and abpoa_gen_cons() with the units of one run (src/abpoa_cons.c:36-48: slice the units,
+// drop those that touch the end of the read), as three small kernels per batch instead of a host loop in the middle of the
+// pipeline (the reference has no hop between its stages either, src/main.c:402-425):
+//   th_k_jobs_count   one thread per read: how many par_pos entries, jobs, units, consensus bytes and alignment slots its chains need
+//   th_k_scan_rows    one workgroup: exclusive prefix sums of those counters over the reads, totals into the counter block
+//   th_k_jobs_emit    one thread per read: writes its chains' par_pos compactly, its ThTask / ThUnit / th_job_t entries and the
+//                     task lists of the two POA kernel variants at the offsets the scan assigned -- so the tables come out in
+//                     read order (chains in emission order, runs left to right), exactly as the host loop produced them
+// and, after the POA, the same pattern per JOB for the alignment item lists and the compacted consensus offsets
+// (th_k_items_count / th_k_scan_rows / th_k_items_emit).  The host only reads the 256-byte counter block.
+#include "th_dev.h"
+
+#define TH_JOB_COLS 6             // per-read counters: par_pos entries, jobs, units, consensus bytes, alignment slots, jobs of the int16 POA variant
+#define TH_ITEM_COLS 4            // per-job counters: small / mid / big alignment items, compacted consensus bytes
+
+// Scratch of one POA wave for a job, in ints.  Mirrors the carve in th_k_poa: 39 node / row arrays of `cap`, the overflow pool,
+// the alignment-op arrays, then the cell region.  Cell region: every band cell has a 2-byte direction word; rows that store full
+// cells add 16 bytes per cell -- a few per cent of the rows when the band fits the LDS ring, EVERY row when it does not (the 32-bit
+// variant on long units: measured band ~ 2w + 1 + len / 30 at 15 % error).  Graph rows grow by ~9 % of the unit length per unit
+// (measured: 1.27 x at 4 units of 5000, ~1.5 x at 9 units of 1000, ~2.6 x at 20 units of 200).  cell_factor is the attempt's
+// safety factor (1.5 at first, doubled for the jobs that come back with "scratch too small").
+__host__ __device__ static inline long long th_poa_need_ints(int n_units, int sum_len, int max_len, double cell_factor, bool noband, bool wide)
+{
+    if (n_units <= 2) return 0;
+    const long long cap = sum_len + 2, ocap = 2LL * (sum_len + n_units + 8), opn = cap + max_len + 2;
+    const long long graph = 39 * cap + 2 * ocap + 5 * opn + 512;
+    if (noband) return (graph + (long long)(cap * ((long long)max_len + 4) * (cell_factor > 1.5 ? 1.25 : 1.0) * 4.5) + 63) & ~63LL;   // full rows, all stored in full
+    const long long w = TH_POA_WB + max_len / 100;
+    const long long span = 2 * w + 1 + 48 + max_len / 30;
+    long long rows = (long long)(max_len * (1.0 + 0.09 * (n_units - 1))) + 64;
+    if (rows > cap) rows = cap;
+    const bool all_full = wide && span + 16 >= TH_POA_RW;
+    return (graph + (long long)(rows * span * cell_factor * (all_full ? 4.5 : 1.5)) + 63) & ~63LL;
+}
+// Which POA variant a job starts on.  The int16 variant gives a job back (status 7) when an alignment's scores may not fit
+// (th_poa_dp: cache16_ok, evaluated with the graph's row count at that alignment); with the row estimate above the same test
+// tells beforehand, for nearly every job, that it would -- those start on the 32-bit variant (both are exact: same results).
+__host__ __device__ static inline bool th_poa_job_is_narrow(int n_units, int max_len, const ThDevPara &P)
+{
+    if (max_len > TH_POA_QCAP) return false;
+    const int M = P.match, X = P.mismatch, maxE = P.ge1 > P.ge2 ? P.ge1 : P.ge2;
+    const int g1 = P.go1 + P.ge1, g2 = P.go2 + P.ge2, gap1 = g1 < g2 ? g1 : g2;
+    const int mx = M > X ? (M > gap1 ? M : gap1) : (X > gap1 ? X : gap1);
+    const long long rows = (long long)(max_len * (1.0 + 0.09 * (n_units - 1))) + 64;
+    const long long real_b = (long long)mx * (max_len + rows) + P.go1 + P.go2 + 2 * maxE;
+    return M <= 31 && X <= 31 && real_b + (long long)M * rows + 2LL * (TH_POA_RW + 64) * maxE < 32000;
+}
+
+struct ThJobTables {
+    const uint32_t *roff; const int *read_ch_base, *read_ch_n;
+    const int *par, *par_off, *par_n;                // the partition's arena and each chain's region in it
+    int *par_dst, *parc;                             // compact copy: chain c's boundaries at parc[par_dst[c] ..]
+    ThTask *tasks; ThUnit *units; th_job_t *jobs; int *list_n, *list_w;
+    int task_cap, unit_cap, parc_cap;
+};
+
+// the walk over one read's chains; EMIT = false counts into c[], EMIT = true writes at the offsets in c[] (advancing them)
+template <bool EMIT>
+__device__ __forceinline__ void th_jobs_walk(const ThJobTables &J, const ThDevPara &P, int r, int only_unit, int *c, ThCnt *C)
+{
+    const int L = (int)(J.roff[r + 1] - J.roff[r]);
+    const int min_copy = P.min_copy;
+    const int cb = J.read_ch_base[r], cn = J.read_ch_n[r];
+    for (int ch = cb; ch < cb + cn; ++ch) {
+        const int par_n = J.par_n[ch]; const int *pp = J.par + J.par_off[ch];
+        const int dst = c[0];
+        if (EMIT) { J.par_dst[ch] = dst; for (int i = 0; i < par_n; ++i) J.parc[dst + i] = pp[i]; }
+        c[0] += par_n;
+        if (par_n < min_copy + 1) continue;                            // src/tidehunter.c:42
+        int i = 0;
+        while (i < par_n - min_copy) {
+            if (pp[i] < 0) { ++i; continue; }
+            int j; for (j = i + 1; j < par_n; ++j) if (pp[j] < 0) break;
+            if (j - i > min_copy) {
+                int n_units = 0, sum_len = 0, max_len = 0, first_len = 0;
+                for (int u = i; u < j - 1; ++u) {                      // src/abpoa_cons.c:41-48
+                    const int start = pp[u], end = pp[u + 1];
+                    if (start < 0 || end < 0 || start >= L - 1 || end + 1 > L) continue;
+                    const int len = end - start;
+                    if (EMIT) { ThUnit x = { start + 1, len }; J.units[c[2] + n_units] = x; }
+                    if (n_units == 0) first_len = len;
+                    ++n_units; sum_len += len; max_len = max(max_len, len);
+                }
+                const int cons_cap = n_units <= 2 ? first_len : min(sum_len, 3 * max_len + 64);
+                const bool narrow = th_poa_job_is_narrow(n_units, max_len, P);
+                if (EMIT) {
+                    const int t = c[1];
+                    ThTask T; T.read = r; T.pos_off = dst + i; T.pos_n = j - i; T.unit_off = c[2]; T.n_units = n_units; T.sum_len = sum_len; T.max_len = max_len;
+                    T.cons_off = c[3]; T.cons_cap = cons_cap; T.aln_off = c[4]; T.narrow = narrow ? 1 : 0; T.noband = 0;
+                    J.tasks[t] = T;
+                    th_job_t jb; jb.read = r; jb.pos_off = T.pos_off; jb.pos_n = T.pos_n; jb.n_seqs = n_units; jb.cons_off = 0; jb.cons_len = 0; jb.aln_off = T.aln_off; jb.status = 0;
+                    J.jobs[t] = jb;
+                    if (narrow) J.list_n[c[5]] = t; else J.list_w[t - c[5]] = t;
+                    if (!only_unit) {
+                        if (n_units <= 1) atomicOr(&C->err, TH_E_MSA_UNITS);
+                        atomicMax(narrow ? &C->need_n : &C->need_w, (unsigned long long)th_poa_need_ints(n_units, sum_len, max_len, 1.5, false, !narrow));
+                        atomicMax(&C->max_unit, max_len); atomicMax(&C->max_cons_cap, cons_cap);
+                    }
+                }
+                c[1] += 1; c[2] += n_units; c[3] += (cons_cap + 15) & ~15; c[4] += j - i - 1; c[5] += narrow ? 1 : 0;
+            }
+            i = j + 1;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+th_k_jobs_count(int n_reads, ThJobTables J, ThDevPara P, int only_unit, int *__restrict__ rows, ThCnt *C)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    int c[TH_JOB_COLS] = { 0, 0, 0, 0, 0, 0 };
+    th_jobs_walk<false>(J, P, r, only_unit, c, C);
+#pragma unroll
+    for (int k = 0; k < TH_JOB_COLS; ++k) rows[(long long)r * TH_JOB_COLS + k] = c[k];
+}
+
+__global__ void __launch_bounds__(256)
+th_k_jobs_emit(int n_reads, ThJobTables J, ThDevPara P, int only_unit, const int *__restrict__ rows, ThCnt *C)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    if (C->err & TH_E_JOB_CAP) return;              // the tables are too small: nothing is written, the host reruns the build
+    int c[TH_JOB_COLS];
+#pragma unroll
+    for (int k = 0; k < TH_JOB_COLS; ++k) c[k] = rows[(long long)r * TH_JOB_COLS + k];
+    th_jobs_walk<true>(J, P, r, only_unit, c, C);
+}
+
+// Exclusive prefix sums of COLS counters over n rows (row-major, in place), one workgroup of 1024 threads: every thread sums a
+// contiguous slice of rows, the slice totals are scanned across the workgroup, then every thread rewrites its slice.  The grand
+// totals go to totals[0 .. COLS) and, for the job build, totals beyond the table capacities (caps.on) raise TH_E_JOB_CAP.
+// n is a few hundred thousand at most: tens of microseconds.
+struct ThScanCaps { int on, v[8]; };
+template <int COLS>
+__global__ void __launch_bounds__(1024)
+th_k_scan_rows(const int *__restrict__ n_ptr, int n_fixed, int *__restrict__ rows, int *__restrict__ totals, ThScanCaps caps, int *__restrict__ err)
+{
+    __shared__ int s_wave[COLS][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = n_ptr ? *n_ptr : n_fixed;
+    const int chunk = (n + 1023) / 1024;
+    const long long lo = (long long)tid * chunk, hi = min((long long)n, lo + chunk);
+    int s[COLS];
+#pragma unroll
+    for (int k = 0; k < COLS; ++k) s[k] = 0;
+    for (long long i = lo; i < hi; ++i)
+#pragma unroll
+        for (int k = 0; k < COLS; ++k) s[k] += rows[i * COLS + k];
+    int ex[COLS];
+#pragma unroll
+    for (int k = 0; k < COLS; ++k) {
+        const int inc = th_wave_incl_sum(s[k]);
+        ex[k] = inc - s[k];
+        if (lane == 63) s_wave[k][wave] = inc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < COLS; ++k) {
+        int before = 0, total = 0;
+        for (int w = 0; w < 16; ++w) { const int v = s_wave[k][w]; if (w < wave) before += v; total += v; }
+        ex[k] += before;
+        if (tid == 0) { totals[k] = total; if (caps.on && total > caps.v[k]) atomicOr(err, TH_E_JOB_CAP); }
+    }
+    for (long long i = lo; i < hi; ++i)
+#pragma unroll
+        for (int k = 0; k < COLS; ++k) { const int v = rows[i * COLS + k]; rows[i * COLS + k] = ex[k]; ex[k] += v; }
+}
+
+// ---- after the POA: alignment item lists (three staging-area classes) and compacted consensus offsets, per job ----
+struct ThAlnItem { int task, which; };   // which >= 0: unit index in the run; -1 left extension; -2 right extension
+#define TH_ALN_SMALL 4096
+#define TH_ALN_MID 7168
+#define TH_ALN_BIG 24576
+// Items whose two sequences fit the small staging area of the anti-diagonal engine (4 KB: 5 waves per SIMD) form the first list; jobs
+// whose unit + consensus fit 7 KB with at most two registers per lane (periods up to ~2500) a second one for the same register budget
+// with a larger area; the rest a third one for the variant with a 24 KB area and up to 6 registers per lane (two waves per SIMD).  The
+// two flank extensions of every job go to the first list.
+__device__ __forceinline__ int th_aln_class(const ThTask &T, int cl, int wdiv, int wadd, int wtol)
+{
+    const long long need2 = (long long)T.max_len + cl + 512 * 2 + 16;
+    const bool two_regs = 2 * (cl / wdiv + wadd - wtol) + 2 + 64 <= 512;     // th_ad_pick would settle for NP <= 2
+    return need2 <= TH_ALN_SMALL ? 0 : (need2 <= TH_ALN_MID && two_regs) ? 1 : 2;
+}
+__global__ void __launch_bounds__(256)
+th_k_items_count(const int *__restrict__ n_tasks, const ThTask *__restrict__ tasks, int *__restrict__ cons_len, const int *__restrict__ status,
+                 int wdiv, int wadd, int wtol, int *__restrict__ rows, ThCnt *C)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *n_tasks) return;
+    const int st = status[t];
+    if (st == 1 || st == 2 || st == 3 || st == 4 || st == 7) atomicAdd(&C->n_retry, 1);
+    else if (st != 0) { atomicAdd(&C->n_failed, 1); cons_len[t] = 0; }
+    const int cl = st ? 0 : cons_len[t];
+    const ThTask T = tasks[t];
+    int c[TH_ITEM_COLS] = { 2, 0, 0, (cl + 3) & ~3 };
+    c[th_aln_class(T, cl, wdiv, wadd, wtol)] += T.pos_n - 1;
+#pragma unroll
+    for (int k = 0; k < TH_ITEM_COLS; ++k) rows[(long long)t * TH_ITEM_COLS + k] = c[k];
+    atomicMax(&C->max_cl, cl);
+}
+__global__ void __launch_bounds__(256)
+th_k_items_emit(const int *__restrict__ n_tasks, const ThTask *__restrict__ tasks, const int *__restrict__ cons_len, const int *__restrict__ status,
+                int wdiv, int wadd, int wtol, const int *__restrict__ rows, const ThCnt *C, ThAlnItem *__restrict__ items, int *__restrict__ cc_off, th_job_t *__restrict__ jobs)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *n_tasks) return;
+    const int st = status[t], cl = st ? 0 : cons_len[t];
+    const ThTask T = tasks[t];
+    const int cls = th_aln_class(T, cl, wdiv, wadd, wtol);
+    const int base[3] = { 0, C->n_item_s, C->n_item_s + C->n_item_m };      // the three lists follow each other in one array
+    int o = base[0] + rows[(long long)t * TH_ITEM_COLS];
+    if (cls == 0) for (int u = 0; u < T.pos_n - 1; ++u) { ThAlnItem it = { t, u }; items[o++] = it; }
+    { ThAlnItem l = { t, -1 }, r = { t, -2 }; items[o++] = l; items[o++] = r; }
+    if (cls) {
+        o = base[cls] + rows[(long long)t * TH_ITEM_COLS + cls];
+        for (int u = 0; u < T.pos_n - 1; ++u) { ThAlnItem it = { t, u }; items[o++] = it; }
+    }
+    const int co = rows[(long long)t * TH_ITEM_COLS + 3];
+    cc_off[t] = co;
+    jobs[t].cons_off = co; jobs[t].cons_len = cl; jobs[t].status = st;
+}
+
+__global__ void th_k_cnt_zero(ThCnt *C) { int *p = (int *)C; for (int i = threadIdx.x; i < (int)(sizeof(ThCnt) / 4); i += blockDim.x) p[i] = 0; }
+// before a rerun of stages 2-3 / the job build: the flags that are being answered, and what the rerun accumulates again
+__global__ void th_k_cnt_rerun(ThCnt *C, int redo_extract, int redo_part)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    C->err &= ~(TH_E_REC_OVERFLOW | TH_E_PART_OVERFLOW | TH_E_JOB_CAP);
+    if (redo_extract) { C->rec = 0; C->q_xw = 0; }
+    if (redo_part) { C->par_top = 0; C->q_part = 0; }
+    C->need_n = 0; C->need_w = 0; C->max_unit = 0; C->max_cons_cap = 0;
+}
+// sets single counters of the block between the segments of a rerun (slow paths only)
+__global__ void th_k_cnt_set(int *p0, int v0, int *p1, int v1, int *p2, int v2, int *p3, int v3)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { if (p0) *p0 = v0; if (p1) *p1 = v1; if (p2) *p2 = v2; if (p3) *p3 = v3; }
+}

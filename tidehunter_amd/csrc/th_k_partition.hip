@@ -13,7 +13,7 @@
 
 // par: chain c writes at par + par_off[c], capacity par_cap[c]; bnd: per-wave scratch, bnd_stride ints each
 __global__ void __launch_bounds__(TH_PART_BLOCK)
-th_k_partition(const ThChainRec *__restrict__ rec, int n_rec, const uint32_t *__restrict__ roff, const uint8_t *__restrict__ bseq,
+th_k_partition(const ThChainRec *__restrict__ rec, const int *__restrict__ n_rec_ptr, const uint32_t *__restrict__ roff, const uint8_t *__restrict__ bseq,
                const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ cells, ThDevPara P,
                int *__restrict__ par, int par_cap, int *__restrict__ par_top, int *__restrict__ par_off, int *__restrict__ par_n,
                int *__restrict__ bnd, long long bnd_stride, int *__restrict__ err, int cap_mul, int *__restrict__ queue)
@@ -22,6 +22,8 @@ th_k_partition(const ThChainRec *__restrict__ rec, int n_rec, const uint32_t *__
     const int wave = blockIdx.x;
     int *mybnd = bnd + (long long)wave * bnd_stride;
     const int k = P.k;
+    if (TH_UNI(*err) & TH_E_REC_OVERFLOW) return;          // the record arena overflowed: the extraction is rerun with a larger one first
+    const int n_rec = TH_UNI(*n_rec_ptr);                 // chain records of the batch (th_k_chain_extract*), read from the counter block
     for (;;) {
         const int c = th_queue_pop(queue);            // chains differ in length and in bridging alignments
         if (c >= n_rec) break;

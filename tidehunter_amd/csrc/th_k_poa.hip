@@ -1115,7 +1115,7 @@ template <int QCAP, typename RT>
 // 6 waves per SIMD: 80 VGPRs (21 dwords of scratch) and 6.5 KB of LDS per wave (query codes packed two per byte); measured per
 // 65536 reads: 4 waves 588 ms, 5 waves 557 ms
 __global__ void __launch_bounds__(TH_POA_BLOCK) TH_WAVES_PER_SIMD(TH_POA_OCC)
-th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict__ units, const uint32_t *__restrict__ roff,
+th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_list, const ThUnit *__restrict__ units, const uint32_t *__restrict__ roff,
          const uint8_t *__restrict__ bseq, ThDevPara P, int *__restrict__ scratch, long long scratch_ints,
          uint8_t *__restrict__ cons, int *__restrict__ cov, int *__restrict__ cons_len, int *__restrict__ status, int *__restrict__ queue, int flags)
 {
@@ -1131,8 +1131,9 @@ th_k_poa(const ThTask *__restrict__ tasks, int n_tasks, const ThUnit *__restrict
     int *my = scratch + (long long)wave * scratch_ints;
     for (;;) {
         // jobs differ a lot in length (units, copies): waves pull the next job from a shared counter
-        const int t = th_queue_pop(queue);
-        if (t >= n_tasks) break;
+        const int qi = th_queue_pop(queue);
+        if (qi >= n_list) break;
+        const int t = list ? TH_UNI(list[qi]) : qi;       // the task list of this kernel variant (th_k_jobs_emit), or every task
         const ThTask T = tasks[t];
         const uint8_t *rb = bseq + roff[T.read];
         const ThUnit *U = units + T.unit_off;

@@ -1,35 +1,13 @@
-// th_rt.h -- the thin runtime layer the pipeline talks to.
+// th_rt.h -- the thin runtime layer the pipeline talks to: HIP runtime calls, kernels launched on a HIP stream.
 //
-// Product build (hipcc, gfx950): HIP runtime calls, kernels launched on a HIP stream.
-// Test-only build (-DTH_CPU_EMUL, tests/cpu_emul/): the same kernel sources run under the lock-step
-// fiber emulation in tests/cpu_emul/hip_emul.h so kernel logic can be unit-tested and sanitised
-// without a GPU.  The emulation is never compiled into libtidehunter_amd.so.
-#pragma once
+// (The test-only CPU build of the kernel sources, tests/cpu_emul/, pre-includes its own version of this layer --
+// tests/cpu_emul/th_rt_emul.h defines TH_RT_H -- so that this product header carries no test code.)
+#ifndef TH_RT_H
+#define TH_RT_H
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-
-#ifdef TH_CPU_EMUL
-#include "hip_emul.h"
-typedef int th_stream_t;
-#define TH_CHECK(x) (x)
-static inline int th_rt_malloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : -1; }
-static inline int th_rt_free(void *p) { free(p); return 0; }
-static inline int th_rt_h2d(void *d, const void *h, size_t n, th_stream_t) { memcpy(d, h, n); return 0; }
-static inline int th_rt_d2h(void *h, const void *d, size_t n, th_stream_t) { memcpy(h, d, n); return 0; }
-static inline int th_rt_memset(void *d, int v, size_t n, th_stream_t) { memset(d, v, n); return 0; }
-static inline int th_rt_sync(th_stream_t) { return 0; }
-static inline int th_rt_host_alloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : -1; }
-static inline int th_rt_host_free(void *p) { free(p); return 0; }
-typedef int th_event_t;
-static inline int th_rt_event_create(th_event_t *e) { *e = 0; return 0; }
-static inline int th_rt_event_record(th_event_t, th_stream_t) { return 0; }
-static inline int th_rt_event_wait(th_event_t) { return 0; }
-static inline int th_rt_event_destroy(th_event_t) { return 0; }
-#define TH_LAUNCH(kernel, grid, block, stream, ...) hipemul::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
-#define TH_LANE() ((int)(threadIdx.x & 63))
-#else
 #include <hip/hip_runtime.h>
 typedef hipStream_t th_stream_t;
 #define TH_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[tidehunter_amd] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
@@ -51,6 +29,20 @@ static inline int th_rt_event_destroy(th_event_t e) { TH_CHECK(hipEventDestroy(e
 #define TH_LAUNCH(kernel, grid, block, stream, ...) do { hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__); \
         const hipError_t le_ = hipGetLastError(); if (le_ != hipSuccess) return th_launch_failed(#kernel, hipGetErrorString(le_)); } while (0)
 #define TH_LANE() ((int)(threadIdx.x & 63))
+static inline int th_rt_device_count(int *n) { return hipGetDeviceCount(n) == hipSuccess ? 0 : -1; }
+static inline int th_rt_set_device(int d) { return hipSetDevice(d) == hipSuccess ? 0 : -1; }
+static inline int th_rt_stream_create(th_stream_t *s) { TH_CHECK(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); return 0; }
+static inline int th_rt_stream_destroy(th_stream_t s) { TH_CHECK(hipStreamDestroy(s)); return 0; }
+static inline int th_rt_stream_wait_event(th_stream_t s, th_event_t e) { TH_CHECK(hipStreamWaitEvent(s, e, 0)); return 0; }
+static inline int th_rt_mem_info(size_t *fr, size_t *tot) { return hipMemGetInfo(fr, tot) == hipSuccess ? 0 : -1; }
+// device time of a stretch of one stream: a pair of timing events recorded around it
+struct th_timer_t { hipEvent_t a, b; };
+static inline void th_rt_timer_begin(th_timer_t *t, th_stream_t s) { hipEventCreate(&t->a); hipEventCreate(&t->b); hipEventRecord(t->a, s); }
+static inline void th_rt_timer_end(th_timer_t *t, th_stream_t s) { hipEventRecord(t->b, s); }
+static inline float th_rt_timer_ms(th_timer_t *t) { float ms = 0; hipEventSynchronize(t->b); hipEventElapsedTime(&ms, t->a, t->b); return ms; }
+static inline void th_rt_timer_destroy(th_timer_t *t) { hipEventDestroy(t->a); hipEventDestroy(t->b); }
+#define TH_ARENA_MIN_BYTES ((size_t)96 << 20)      // batches that need less than this allocate buffer by buffer
+#define TH_PERSISTENT_WAVES(dflt) (dflt)          // size of a persistent grid (the test build shrinks them)
 #endif
 
 // Host arrays that device copies read from or write to live in pinned memory: a copy between HBM and PAGEABLE host memory is staged
