@@ -4,21 +4,23 @@
 One "step" = one pass of the whole hot path (encode -> self-hits -> chain -> partition -> POA ->
 unit/consensus alignments -> host record arithmetic) over one batch of synthetic reads.  Default
 workload: BASELINE.json configs[2], the headline (period 1000 x 10 copies, 10 % error, ~10 kb reads,
-100 000 reads per step per GPU); --config c2 / c4 / c5 select the other shapes of SURVEY.md 8(d).
-The batch is uploaded to HBM before the timed region (inputs resident); every step processes a different batch.
+100 000 reads per step per GPU = the config's whole read set); --config c2 / c4 / c5 select the other shapes of SURVEY.md 8(d).
+The config's read set is generated ONCE per rank (deterministic generator, ~1 GB at the headline shape) and every step processes
+the same batch drawn from it; the batch is uploaded to HBM before the timed region (inputs resident).
 
   python bench.py --gpus N --steps K --warmup W
 For N > 1 the driver launches one rank per GPU with torch.distributed.run (started from here as a child process when
-WORLD_SIZE is not set).  The step's global read set (N x batch reads) is cut into N contiguous blocks balanced by
-CUMULATIVE BASES; the data path has no collective -- RCCL carries the read-length exchange that the
-partition needs, the barrier and the max-over-ranks of the time.  --steal K cuts the set into N*K blocks that ranks
-take from a shared ticket counter (th_ticket_*, POSIX shared memory; the reference's THREAD_READ_I, src/main.c:277-281):
-then uploads happen inside the timed region and the line says so.
+WORLD_SIZE is not set).  The step's global read list (N x batch reads, the set repeated) is cut into N contiguous blocks balanced
+by CUMULATIVE BASES; the data path has no collective -- RCCL carries the barrier and the max / sum of the times and
+counts.  --steal K cuts the list into N*K blocks that ranks take from a shared ticket counter (th_ticket_*, POSIX shared memory;
+the reference's THREAD_READ_I, src/main.c:277-281): then uploads happen inside the timed region and the line says so.
 
 Prints ONE JSON line (rank 0) with `roofline` (the kernel with the largest device time, HIP-event timed on the
 kernel's own stream inside the library), `cpu_baseline` (the CPU oracle -- a scalar C port of the reference's algorithm,
-NOT the reference binary -- on the host cores, N=1 only) and `value_e2e` (the command line on the same workload, first byte
-parsed to last byte written, N=1 only).
+NOT the reference binary -- on the host cores, N=1 only), `value_streamed` (the same steps through th_process_batches(): H2D of
+batch i+1 and the record arithmetic of batch i-1 overlap the kernels of batch i; inputs NOT resident), `value_e2e` (the command
+line on 10 x the read set, first byte parsed to last byte written, every run listed, cold and steady rates apart) and
+`other_shapes` (configs 2 / 4 / 5, three steps each, outside the headline's timed region) -- the last three at N=1 only.
 """
 import argparse
 import hashlib
@@ -87,7 +89,7 @@ def partition_by_bases(lens, parts):
     return cuts
 
 
-def cpu_baseline(lib, make_read, n_reads, cfg):
+def cpu_baseline(read_at, n_reads, cfg):
     """CPU oracle (oracle/tho_oracle, kind 'port') on the first n_reads of the same read set, with one thread and with one
     thread per core; reports the per-core cost both ways so that the thread scaling is visible."""
     cores = effective_cpus()
@@ -98,10 +100,10 @@ def cpu_baseline(lib, make_read, n_reads, cfg):
     n1 = max(8, min(48, n_reads // 16))
     with open(path, "wb") as f:
         for i in range(n_reads):
-            f.write(b">syn_%d\n" % i + make_read(i) + b"\n")
+            f.write(b">syn_%d\n" % i + read_at(i) + b"\n")
     with open(path + ".1", "wb") as f:
         for i in range(n1):
-            f.write(b">syn_%d\n" % i + make_read(i) + b"\n")
+            f.write(b">syn_%d\n" % i + read_at(i) + b"\n")
     extra = cfg.get("cli_opts", [])
 
     def run(threads, fn):
@@ -125,34 +127,61 @@ def cpu_baseline(lib, make_read, n_reads, cfg):
                     "core at this shape WITHOUT abPOA, so an ideal %d-core host runs at most %.0f reads/s before any abPOA time." % (cores, cores * 50.0)}
 
 
-def cli_e2e(lib, make_read, n_reads, cfg, batch_opt):
-    """value_e2e: the command line on one step's reads, wall-clock from the first byte parsed to the last byte written
-    (th_run_file's own clock; process start and HIP initialisation are reported separately as `wall_with_startup_s`)."""
+def cli_e2e(set_reads, copies, cfg, batch_opt, n_runs=2):
+    """value_e2e: the command line on `copies` x the read set (>= 1 000 000 reads at the headline shape), wall-clock from the first byte
+    parsed to the last byte written (th_run_file's own clock; process start and HIP initialisation are reported separately as
+    `wall_with_startup_s`).  Every run is listed: the first is COLD (first GPU process of this bench: HIP initialisation, device
+    allocation, page cache), `steady_reads_per_s` is the rate after the first full-size batch was complete (start-up excluded)."""
     exe = os.path.join(ROOT, "tidehunter_amd", "TideHunter-amd")
     d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
     path, outp = os.path.join(d, "th_bench_e2e_%d.fa" % os.getpid()), os.path.join(d, "th_bench_e2e_%d.out" % os.getpid())
-    nbytes = 0
+    n_reads, nbytes = copies * len(set_reads), copies * sum(len(s) for s in set_reads)
+    runs = []
     try:
         with open(path, "wb") as f:
-            for i in range(n_reads):
-                s = make_read(i)
-                nbytes += len(s)
-                f.write(b">syn_%d\n" % i + s + b"\n")
-        t0 = time.time()
-        err = subprocess.run([exe, *cfg.get("cli_opts", []), "-b", str(batch_opt), "-o", outp, path], check=True, capture_output=True, text=True,
-                             env=dict(os.environ, TH_TRACE="1")).stderr
-        wall = time.time() - t0
-        m = re.search(r"\[th_run_file\] (\d+) reads on \d+ device\(s\): wall ([0-9.]+) s; busy: reader ([0-9.]+) s, device batches ([0-9.]+) s \(summed\), writer ([0-9.]+) s", err)
-        inner = float(m.group(2))
-        md5 = hashlib.md5(open(outp, "rb").read()).hexdigest()
-        return {"value": n_reads / inner, "unit": "reads/s", "reads": n_reads, "seconds_first_byte_to_last_byte": inner, "wall_with_startup_s": wall,
-                "mbases_per_s": nbytes / inner / 1e6, "reader_busy_s": float(m.group(3)), "device_busy_s": float(m.group(4)), "writer_busy_s": float(m.group(5)),
-                "batch_reads": batch_opt, "output_md5": md5,
-                "what": "TideHunter-amd (reader -> H2D -> kernels -> record arithmetic -> writer) on a FASTA of the same reads in %s" % d}
+            for c in range(copies):
+                f.write(b"".join(b">syn_%d\n" % (c * len(set_reads) + i) + s + b"\n" for i, s in enumerate(set_reads)))
+        for _ in range(n_runs):
+            t0 = time.time()
+            err = subprocess.run([exe, *cfg.get("cli_opts", []), "-b", str(batch_opt), "-o", outp, path], check=True, capture_output=True, text=True,
+                                 env=dict(os.environ, TH_TRACE="1")).stderr
+            wall = time.time() - t0
+            m = re.search(r"\[th_run_file\] (\d+) reads on \d+ device pipeline\(s\): wall ([0-9.]+) s; busy: reader ([0-9.]+) s, upload ([0-9.]+) s, device runs ([0-9.]+) s, "
+                          r"record arithmetic ([0-9.]+) s, writer ([0-9.]+) s; steady ([0-9.]+) reads/s over the last ([0-9.]+) s", err)
+            inner = float(m.group(2))
+            assert int(m.group(1)) == n_reads, (m.group(1), n_reads)
+            md5 = hashlib.md5()
+            with open(outp, "rb") as f:
+                for chunk in iter(lambda: f.read(1 << 24), b""):
+                    md5.update(chunk)
+            runs.append({"reads_per_s": n_reads / inner, "seconds_first_byte_to_last_byte": inner, "wall_with_startup_s": wall,
+                         "steady_reads_per_s": float(m.group(8)), "steady_window_s": float(m.group(9)), "startup_s": inner - float(m.group(9)),
+                         "mbases_per_s": nbytes / inner / 1e6, "reader_busy_s": float(m.group(3)), "upload_busy_s": float(m.group(4)), "device_busy_s": float(m.group(5)),
+                         "collect_busy_s": float(m.group(6)), "writer_busy_s": float(m.group(7)), "output_md5": md5.hexdigest()})
+        vals = [r["reads_per_s"] for r in runs]
+        return {"value": sum(vals) / len(vals), "unit": "reads/s", "value_is": "mean of the whole-run rates of all runs (first byte parsed to last byte written), no run dropped",
+                "reads": n_reads, "runs_reads_per_s": vals, "cold_reads_per_s": vals[0], "steady_reads_per_s": [r["steady_reads_per_s"] for r in runs],
+                "runs": runs, "batch_reads": batch_opt,
+                "what": "TideHunter-amd (reader -> H2D -> kernels -> record arithmetic -> writer) on a FASTA of %d x the read set in %s" % (copies, d)}
     finally:
         for p in (path, outp):
             if os.path.exists(p):
                 os.unlink(p)
+
+
+def other_shapes(names, steps=3):
+    """configs 2 / 4 / 5 as three-step child runs of this script (outside the headline's timed region; N=1)"""
+    out = {}
+    for c in names:
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", c, "--steps", str(steps), "--warmup", "1", "--cpu-sample", "0", "--e2e", "0",
+                                "--others", "", "--streamed", "0"], capture_output=True, text=True, timeout=900)
+            j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            out[c] = {"reads_per_s": j["value"], "mbases_per_s": j["mbases_per_s"], "ms_per_step": j["ms_per_step"], "reads_per_step": j["config"]["reads_per_step_per_gpu"],
+                      "kernel_ms_per_step": j["roofline"]["kernel_ms_per_step"], "workload": j["config"]["workload"]}
+        except Exception as e:                                          # a shape that fails is reported, not hidden
+            out[c] = {"error": repr(e)[:300]}
+    return out
 
 
 def spawn_ranks(a):
@@ -172,7 +201,9 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TH_BENCH_BATCH", "0")), help="reads per step per GPU (0: the config's default)")
     ap.add_argument("--steal", type=int, default=0, help="blocks per rank per step taken from a shared ticket counter (0: static partition by bases)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1: auto, 0: skip)")
-    ap.add_argument("--e2e", type=int, default=-1, help="reads for the end-to-end command-line run (-1: one step's batch, 0: skip)")
+    ap.add_argument("--e2e", type=int, default=-1, help="copies of the read set in the end-to-end command-line run (-1: 10 for the headline workload, 0: skip)")
+    ap.add_argument("--streamed", type=int, default=-1, help="also time the steps through th_process_batches(), H2D inside (-1: at N=1, 0: skip)")
+    ap.add_argument("--others", default=None, help="comma-separated configs for `other_shapes` (default: c2,c4,c5 with the headline workload at N=1; '' to skip)")
     ap.add_argument("--digest", action="store_true", help="add an md5 over all records of the timed steps in read order (tests)")
     a = ap.parse_args()
 
@@ -191,6 +222,8 @@ def main():
     os.dup2(2, 1)
     cfg = dict(CONFIGS[a.config])
     B = a.batch if a.batch > 0 else cfg["batch"]
+    # host threads of the record arithmetic: this rank's share of the CPUs the container may use (8 ranks on a 16-CPU quota get 2 each)
+    os.environ.setdefault("TH_HOST_THREADS", str(max(1, min(16, effective_cpus() // world))))
 
     import torch
     dist = None
@@ -219,23 +252,27 @@ def main():
         open(fns[0], "wb").write(b">5p\n" + adapters[0] + b"\n"); open(fns[1], "wb").write(b">3p\n" + adapters[1] + b"\n")
         kw["adapters"] = fns
         cfg["cli_opts"] = ["-5", fns[0], "-3", fns[1]]
-    def make_read(i):
-        i %= cfg["set_size"]
-        if a.config == "c5":
-            return TH.synth_read_c5(lib, cfg["seed"], i, adapters, cfg["err"])
-        return TH.synth_read(lib, cfg["seed"], i, cfg["period"], cfg["copies"], cfg["err"])
 
-    # value_e2e runs FIRST, in a child process, before this process touches the GPU: a process that starts right after another one
-    # released ~100 GB of HBM waits seconds in its first hipMalloc calls while the driver scrubs the freed memory (measured: 3.5-5.9 s),
-    # which would be charged to the command line's first-byte-to-last-byte clock; this way it is the (untimed) warm-up below that waits
+    G = B * world                                   # reads of one step's global list (weak scaling: B per GPU)
+    n_blocks = world * max(1, a.steal)
+    # the config's read set, generated once per rank and shared by every step (<= 1 GB at the headline shape): read i of a step's
+    # global list is read i mod |set|
+    t_gen = time.time()
+    n_set = min(cfg["set_size"], G)
+    if a.config == "c5":
+        set_reads = [TH.synth_read_c5(lib, cfg["seed"], i, adapters, cfg["err"]) for i in range(n_set)]
+    else:
+        set_reads = [TH.synth_read(lib, cfg["seed"], i, cfg["period"], cfg["copies"], cfg["err"]) for i in range(n_set)]
+    t_gen = time.time() - t_gen
+
+    def read_at(i):
+        return set_reads[i % n_set]
+
+    # value_e2e runs FIRST, in child processes, before this process touches the GPU: its first run is then the first GPU process of
+    # the bench (cold), and the HBM it releases is not being scrubbed under this process's own allocations during the timed steps
     e2e = None
     if rank == 0 and world == 1 and a.e2e != 0 and not (a.e2e < 0 and a.config != "c3") and "TH_BENCH_LIB" not in os.environ:      # (by default only for the headline workload)
-        n_e2e = a.e2e if a.e2e > 0 else B
-        # two runs, the better one reported (both listed): the first hipMalloc calls of a process sometimes wait seconds for the driver
-        # to hand out cleared HBM when other processes released a lot of it just before
-        runs = [cli_e2e(lib, make_read, n_e2e, cfg, min(32768, max(1024, n_e2e // 3))) for _ in range(2)]
-        e2e = max(runs, key=lambda r: r["value"])
-        e2e["runs_reads_per_s"] = [r["value"] for r in runs]
+        e2e = cli_e2e(set_reads, a.e2e if a.e2e > 0 else 10, cfg, 32768)
     th = TH.TideHunter(device=local, lib_path=os.environ.get("TH_BENCH_LIB"), **kw)
 
     def sync_all():
@@ -246,33 +283,24 @@ def main():
         if on_gpu:
             torch.cuda.synchronize()
 
+    # block boundaries of a step's global list [0, G), balanced by cumulative bases: every rank holds the whole set, so every rank
+    # computes the same cuts (no exchange); block k is reads cuts[k] .. cuts[k+1]
+    set_lens = [len(s) for s in set_reads]
+    cuts = partition_by_bases([set_lens[i % n_set] for i in range(G)], n_blocks) if n_blocks > 1 else [0, G]
+
+    def block_reads(k):
+        return [read_at(i) for i in range(cuts[k], cuts[k + 1])]            # (references into the set, not copies)
+
     n_batches = a.warmup + a.steps
-    G = B * world                                   # reads of one step's global set (weak scaling: B per GPU)
-    n_blocks = world * max(1, a.steal)
-
-    def step_blocks(b):
-        """block boundaries of step b's global set [b*G, (b+1)*G), balanced by cumulative bases; every rank generates its
-        nominal share, the lengths are exchanged (control-plane metadata only), and each rank fills in what its blocks need"""
-        base = b * G
-        mine = {base + rank * B + i: make_read(base + rank * B + i) for i in range(B)}
-        if world == 1 and n_blocks == 1:
-            return [0, G], mine, base
-        lens = torch.tensor([len(mine[base + rank * B + i]) for i in range(B)], dtype=torch.int32)
-        if dist is not None:
-            if backend == "nccl":
-                lens = lens.cuda()
-            allv = [torch.empty_like(lens) for _ in range(world)]
-            dist.all_gather(allv, lens)
-            lens = torch.cat(allv).cpu()
-        return partition_by_bases(lens.tolist(), n_blocks), mine, base
-
-    def block_reads(cuts, mine, base, k):
-        return [mine[base + i] if base + i in mine else make_read(base + i) for i in range(cuts[k], cuts[k + 1])]
-
-    plans = [step_blocks(b) for b in range(n_batches)]
     ticket = None
     if a.steal > 0:
-        name = ("/th_bench_%s" % os.environ.get("MASTER_PORT", str(os.getppid()))).encode()
+        # one segment per launch: the name carries the launcher's port AND rank 0's pid, and the creator starts from a fresh
+        # segment (a killed run can leave an old one behind with its counters advanced)
+        nonce = torch.tensor([os.getpid()], dtype=torch.int64)
+        if dist is not None:
+            nonce = nonce.cuda() if backend == "nccl" else nonce
+            dist.broadcast(nonce, 0)
+        name = ("/th_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), int(nonce.item()))).encode()
         if rank == 0:
             ticket = lib.th_ticket_open(name, 1)
         if dist is not None:
@@ -282,7 +310,7 @@ def main():
         assert ticket, "th_ticket_open failed"
         if a.steps + a.warmup > 512:
             sys.exit("bench.py: --steal supports at most 512 steps")
-    static_reads = [None if a.steal > 0 else block_reads(*plans[b], rank) for b in range(n_batches)]
+    my_batch = None if a.steal > 0 else block_reads(rank)
 
     for b in range(a.warmup):
         if a.steal > 0:
@@ -290,15 +318,17 @@ def main():
                 k = lib.th_ticket_next(ticket, b)
                 if k >= n_blocks:
                     break
-                th.upload(block_reads(*plans[b], k)); th.run(); th.collect()
+                th.upload(block_reads(k)); th.run(); th.collect()
         else:
-            th.upload(static_reads[b]); th.run(); th.collect()
-    t_total, n_cons, alg_bytes, kms, n_reads_mine, bases_mine, digests, blocks_mine = 0.0, 0, 0, {}, 0, 0, {}, 0
+            th.upload(my_batch); th.run(); th.collect()
+    t_total, n_cons, alg_bytes, kms, n_reads_mine, bases_mine, digests, blocks_mine, n_syncs = 0.0, 0, 0, {}, 0, 0, {}, 0, 0
+
+    def add_timing():
+        for kname, v in th.timing().items():
+            kms[kname] = kms.get(kname, 0.0) + v
 
     def account(batch, recs, first_index):
         nonlocal n_cons, alg_bytes, n_reads_mine, bases_mine
-        for kname, v in th.timing().items():
-            kms[kname] = kms.get(kname, 0.0) + v
         for j, (s, rr) in enumerate(zip(batch, recs)):
             alg_bytes += len(s)                                     # B_alg = L + sum(cons_len + 4*pos_n + 40)
             for r in rr:
@@ -311,7 +341,6 @@ def main():
         bases_mine += sum(len(s) for s in batch)
 
     for b in range(a.warmup, n_batches):
-        cuts, mine, base = plans[b]
         if a.steal > 0:
             # dynamic: blocks from the shared ticket counter; the upload of a block cannot precede the timed region
             sync_all()
@@ -321,19 +350,22 @@ def main():
                 k = lib.th_ticket_next(ticket, b)
                 if k >= n_blocks:
                     break
-                batch = block_reads(cuts, mine, base, k)
+                batch = block_reads(k)
                 th.upload(batch); th.run(); th.collect_native()
-                done.append((k, batch, th.records()))
+                add_timing()
+                done.append((k, batch, th.records() if (a.digest or b == n_batches - 1) else None))
                 blocks_mine += th.launches()
             if on_gpu:
                 torch.cuda.synchronize()
             t_total += time.perf_counter() - t0
             for k, batch, recs in done:
-                account(batch, recs, base + cuts[k])
+                if recs is not None:
+                    account(batch, recs, cuts[k])
+                else:
+                    n_reads_mine += len(batch); bases_mine += sum(len(s) for s in batch)
         else:
             # static: this rank's block is made resident first (upload outside), then run + collect are timed
-            batch = static_reads[b]
-            th.upload(batch)
+            th.upload(my_batch)
             sync_all()
             t0 = time.perf_counter()
             th.run()                 # all kernels + the small D2H of result records
@@ -341,9 +373,17 @@ def main():
             if on_gpu:
                 torch.cuda.synchronize()
             t_total += time.perf_counter() - t0
-            account(batch, th.records(), base + cuts[rank])     # Python dict view for the byte accounting: not part of the path
-            blocks_mine += th.launches()                        # a large batch runs as two concurrent halves: two launches of every kernel
+            n_syncs = th.syncs()
+            add_timing()
+            blocks_mine += th.launches()                        # TH_SUBBATCH > 1: several concurrent parts, that many launches of every kernel
+            if a.digest or b == n_batches - 1:
+                account(my_batch, th.records(), cuts[rank])     # Python dict view for the byte accounting (every step has the same records): not part of the path
+            else:
+                n_reads_mine += len(my_batch); bases_mine += sum(len(s) for s in my_batch)
     sync_all()
+    # the byte accounting ran on the last step (all steps process the same reads): scale it to the timed steps
+    if not a.digest and a.steps > 1:
+        n_cons *= a.steps; alg_bytes *= a.steps
     tot = torch.tensor([float(n_reads_mine), float(bases_mine), float(n_cons), float(alg_bytes)], dtype=torch.float64)
     if dist is not None:
         dev = "cuda" if backend == "nccl" else "cpu"
@@ -367,12 +407,13 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "dtype_note": "integer DP throughout: chain DP and POA fallback rows in int32, packed POA rows and banded alignments in int16 pairs (exact by range proofs)",
         "mbases_per_s": bases / t_total / 1e6,
-        "config": {"workload": cfg["label"] + "; %d reads per step per GPU drawn from the %d-read set (seed %d)" % (B, cfg["set_size"], cfg["seed"]),
+        "config": {"workload": cfg["label"] + "; %d reads per step per GPU drawn from the %d-read set (seed %d), the same batch every step" % (B, cfg["set_size"], cfg["seed"]),
                    "name": a.config, "reads_per_step_per_gpu": B,
                    "sharding": ("contiguous read blocks per rank balanced by cumulative bases, no data-path collective" if a.steal == 0 else
                                 "%d blocks per step (balanced by cumulative bases) taken by the ranks from a shared ticket counter; uploads inside the timed region" % n_blocks),
                    "inputs_resident_before_timing": a.steal == 0},
         "consensus_per_read": n_cons_all / float(reads),
+        "host_syncs_per_step": n_syncs, "read_set_generation_s": t_gen,
     }
     if a.digest:
         h = hashlib.md5()
@@ -383,14 +424,14 @@ def main():
     if rank == 0:
         dom = max(kms, key=kms.get)                      # dominant kernel = largest device time (this rank's launches)
         launches = max(1, blocks_mine)
-        launch_s = kms[dom] / 1000.0 / launches            # one launch of it per block (or per concurrent half of a block)
+        launch_s = kms[dom] / 1000.0 / launches            # one launch of it per block (or per concurrent part of a block)
         per_launch_bytes = alg_bytes / float(launches)
         ach = per_launch_bytes / launch_s / 1e9 if launch_s > 0 else 0.0
         # traffic: HBM bytes of one launch of the dominant kernel from the PMC passes of this same command
-        # (tools/prof_round.sh -> profiles/rNN_hbm_traffic.json); counters cannot be read from inside the process, so
+        # (tools/round3_end.sh -> profiles/rNN_hbm_traffic.json); counters cannot be read from inside the process, so
         # the committed profile is quoted when it was taken at the same workload and batch size, else null
         traffic, traffic_src = None, None
-        for pf in ("r02_hbm_traffic.json",):
+        for pf in ("r03_hbm_traffic.json",):
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", pf)))
                 if prof.get("reads_per_launch") == B * a.steps // launches and prof.get("config", "c3") == a.config and a.steal == 0:
@@ -403,11 +444,21 @@ def main():
                            "frac_of_measured_copy_peak": ach / HBM_COPY_GBS, "measured_copy_peak": HBM_COPY_GBS,
                            "traffic": traffic, "traffic_source": traffic_src, "launch_ms": launch_s * 1000.0,
                            "kernel_ms_per_launch": {k: v / launches for k, v in kms.items()},
+                           "kernel_ms_per_step": {k: v / a.steps for k, v in kms.items()},
                            "algorithmic_bytes_per_launch": per_launch_bytes, "launches_per_step": launches / float(a.steps),
-                           "concurrency_note": "a batch of >= 16384 reads runs as two concurrent halves on two streams; a launch's duration is measured with HIP events "
-                                               "on its own stream while the other half's kernels share the device, so it is longer than the same launch alone",
                            "note": "this path is instruction-issue bound, not bandwidth bound (DESIGN.md section 4): the HBM fraction is reported because "
-                                   "north_star names that roofline; profiles/r02_pmc_instr.json holds the VALU issue fractions"}
+                                   "north_star names that roofline; profiles/r03_pmc_instr.json holds the VALU issue fractions"}
+        # the same steps with the upload INSIDE: th_process_batches() pipelines H2D of batch i+1 and the record arithmetic of batch i-1
+        # under the kernels of batch i (what th_run_file does with batches from the reader)
+        if world == 1 and a.steal == 0 and a.streamed != 0:
+            ks = max(a.steps, 3)
+            t0 = time.perf_counter()
+            th.process_batches([my_batch] * ks)
+            if on_gpu:
+                torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out["value_streamed"] = {"value": ks * len(my_batch) / dt, "unit": "reads/s", "steps": ks, "ms_per_step": 1000.0 * dt / ks, "inputs_resident_before_timing": False,
+                                     "what": "th_process_batches(): %d batches back to back, each uploaded from host memory inside the timed region (pipeline fill and drain included)" % ks}
     th.close()
     if ticket:
         lib.th_ticket_close(ticket, 1 if rank == 0 else 0)
@@ -416,7 +467,10 @@ def main():
             out["value_e2e"] = e2e
         if world == 1 and a.cpu_sample != 0:
             n_cpu = a.cpu_sample if a.cpu_sample > 0 else min(4096, max(64, 24 * effective_cpus()))
-            out["cpu_baseline"] = cpu_baseline(lib, make_read, n_cpu, cfg)
+            out["cpu_baseline"] = cpu_baseline(read_at, n_cpu, cfg)
+        others = a.others if a.others is not None else ("c2,c4,c5" if (a.config == "c3" and world == 1 and "TH_BENCH_LIB" not in os.environ) else "")
+        if others:
+            out["other_shapes"] = other_shapes([c for c in others.split(",") if c])
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if a.config == "c5":

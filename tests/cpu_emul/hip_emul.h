@@ -1,7 +1,7 @@
 // tests/cpu_emul/hip_emul.h -- TEST-ONLY lock-step emulation of the HIP execution model on the CPU.
 //
 // The product (tidehunter_amd/libtidehunter_amd.so) is HIP-only and never includes this file.  The
-// test build (tests/cpu_emul/Makefile, -DTH_CPU_EMUL) compiles the SAME kernel sources with g++ so that
+// test build (tests/cpu_emul/Makefile; it pre-includes th_hw_emul.h / th_rt_emul.h in place of the product's th_hw.h / th_rt.h) compiles the SAME kernel sources with g++ so that
 // `pytest -m "not gpu"` and the sanitizers can exercise kernel logic where no GPU exists.
 //
 // Model: one OS thread; every HIP thread of a block is a ucontext fiber; a wave is 64 consecutive

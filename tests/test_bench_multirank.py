@@ -42,6 +42,21 @@ def test_bench_two_ranks_match_one_rank(tmp_path):
     assert two["config"]["inputs_resident_before_timing"] and not steal["config"]["inputs_resident_before_timing"]
 
 
+def test_bench_eight_ranks_rehearsal(tmp_path):
+    """the launch the driver makes for SCALE (8 ranks under torch.distributed.run), rehearsed on the emulation library: static blocks
+    and stolen blocks give the records of one rank over the same global list, every rank gets a block, one JSON line"""
+    one = _bench(tmp_path, 1, 29551, "--batch", "16")
+    eight = _bench(tmp_path, 8, 29552, "--batch", "2")
+    steal = _bench(tmp_path, 8, 29553, "--batch", "2", "--steal", "2")
+    assert eight["n_gpus"] == 8 and steal["n_gpus"] == 8
+    assert one["records_digest"] == eight["records_digest"] == steal["records_digest"]
+    assert eight["records_digest_reads"] == 16 and steal["records_digest_reads"] == 16
+    sys.path.insert(0, ROOT)
+    import bench
+    lens = [100 + 7 * (i % 5) for i in range(16)]
+    assert all(b > a for a, b in zip(bench.partition_by_bases(lens, 8), bench.partition_by_bases(lens, 8)[1:]))      # no empty block
+
+
 def test_partition_by_bases_balances_bases_not_counts():
     sys.path.insert(0, ROOT)
     import bench

@@ -257,6 +257,47 @@ def test_emul_file_driver_pipeline(emu, tmp_path):
     th.close()
 
 
+def test_emul_pipelined_batches_and_sync_count(emu):
+    """th_process_batches(): five batches (one empty, one repeated) through the upload / kernels / record-arithmetic pipeline give the
+    records of five separate th_process_batch() calls; a run takes exactly three host synchronisations (after the job tables, after
+    the POA, at the end) -- the host builds no table in the middle of the path"""
+    import ctypes as C
+    th = TH.TideHunter(lib_path=emu)
+    a = _reads(th.lib, [(60, 8, 0.10), (120, 5, 0.08), (35, 12, 0.12)])
+    b = _reads(th.lib, [(80, 6, 0.05), (50, 9, 0.1)], seed=12)
+    c = _reads(th.lib, [(70, 7, 0.1), (64, 6, 0.08), (90, 5, 0.1), (45, 10, 0.1)], seed=13)
+    batches = [a, b, [], c, a]
+    want = [th.process(x) if x else [] for x in batches]
+    assert th.syncs() == 3
+    nb = len(batches)
+    pp, ip = C.POINTER(C.c_char_p), C.POINTER(C.c_int)
+    keep = [((C.c_char_p * max(len(x), 1))(*x), (C.c_int * max(len(x), 1))(*[len(s) for s in x])) for x in batches]
+    outs = [th.lib.th_alloc_tandem_seq(max(len(x), 1)) for x in batches]
+    rc = th.lib.th_process_batches(th.h, nb, (pp * nb)(*[C.cast(k[0], pp) for k in keep]), (ip * nb)(*[C.cast(k[1], ip) for k in keep]),
+                                   (C.c_int * nb)(*[len(x) for x in batches]), (C.POINTER(TH.TandemSeq) * nb)(*outs))
+    assert rc == 0
+    for x, o, w in zip(batches, outs, want):
+        th._ts, th._n, saved = o, len(x), th._ts
+        got = th.records()
+        th._ts = saved
+        assert got == w
+        th.lib.th_free_tandem_seq(o, max(len(x), 1))
+    th.close()
+
+
+def test_ticket_segment_starts_from_zero_after_a_killed_run(emu):
+    """a creator that finds a segment of the same name (left by a killed run, counters advanced) must not inherit its values"""
+    lib = TH.load_library(emu)
+    name = b"/th_test_ticket_%d" % os.getpid()
+    t = lib.th_ticket_open(name, 1)
+    assert [lib.th_ticket_next(t, 0) for _ in range(3)] == [0, 1, 2]
+    lib.th_ticket_close(t, 0)                      # (no unlink: what a killed run leaves behind)
+    t = lib.th_ticket_open(name, 1)
+    peer = lib.th_ticket_open(name, 0)
+    assert lib.th_ticket_next(t, 0) == 0 and lib.th_ticket_next(peer, 0) == 1 and lib.th_ticket_next(t, 5) == 0
+    lib.th_ticket_close(peer, 0); lib.th_ticket_close(t, 1)
+
+
 def test_emul_parallel_minimizer_rules(emu, monkeypatch):
     """-w > 1: the wave-parallel selection (per-position rules) against the oracle's restatement of src/tandem_hit.c:97-157 and
     against the sequential replay kept in the kernel (TH_MINIMIZER_SEQ=1); TH_MINIMIZER_STRICT fails the run if any read had to

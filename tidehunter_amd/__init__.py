@@ -174,6 +174,31 @@ class TideHunter:
         """concurrent parts the last uploaded batch runs as (1, or 2 for batches of TH_SUBBATCH_MIN = 16384 reads and more)"""
         return self.lib.th_batch_launches(self.h)
 
+    def syncs(self):
+        """host synchronisations (stream drains) of the last run()"""
+        return self.lib.th_batch_syncs(self.h)
+
+    def process_batches(self, batches):
+        """th_process_batches(): the batches back to back through the upload / kernels / record-arithmetic pipeline; the result slots
+        stay with the library (use process() to look at records) -- this entry exists to time the pipelined seam"""
+        nb = len(batches)
+        uniq = {}
+        for b in batches:                      # (the bench passes the same batch several times: marshal it once)
+            if id(b) not in uniq:
+                n = len(b)
+                uniq[id(b)] = ((C.c_char_p * n)(*b), (C.c_int * n)(*[len(s) for s in b]), n)
+        outs = [self.lib.th_alloc_tandem_seq(max(len(b), 1)) for b in batches]
+        pp, ip = C.POINTER(C.c_char_p), C.POINTER(C.c_int)
+        a_seqs = (pp * nb)(*[C.cast(uniq[id(b)][0], pp) for b in batches])
+        a_lens = (ip * nb)(*[C.cast(uniq[id(b)][1], ip) for b in batches])
+        a_n = (C.c_int * nb)(*[uniq[id(b)][2] for b in batches])
+        a_out = (C.POINTER(TandemSeq) * nb)(*outs)
+        try:
+            self._check(self.lib.th_process_batches(self.h, nb, a_seqs, a_lens, a_n, a_out))
+        finally:
+            for o, b in zip(outs, batches):
+                self.lib.th_free_tandem_seq(o, max(len(b), 1))
+
     def process(self, seqs):
         """tidehunter_core() on every read of the batch; returns a list (per read) of record dicts."""
         self.upload(seqs)

@@ -1267,12 +1267,16 @@ int th_synth_read_c5(uint64_t seed, uint64_t read_index, const char *five, int f
 struct th_ticket { long long *c; char name[128]; };
 th_ticket_t *th_ticket_open(const char *name, int create)
 {
-    int fd = shm_open(name, create ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
+    /* the creator starts from a fresh, zero-filled segment: a run that was killed may have left one of this name behind with its
+     * counters advanced (reopening it made the next run skip blocks) */
+    if (create) shm_unlink(name);
+    int fd = shm_open(name, create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDWR, 0600);
     if (fd < 0) { host_fail("shm_open failed for the ticket counters"); return NULL; }
     if (create && ftruncate(fd, TH_TICKET_N * (off_t)sizeof(long long)) != 0) { close(fd); host_fail("ftruncate failed for the ticket counters"); return NULL; }
     void *m = mmap(NULL, TH_TICKET_N * sizeof(long long), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (m == MAP_FAILED) { host_fail("mmap failed for the ticket counters"); return NULL; }
+    if (create) memset(m, 0, TH_TICKET_N * sizeof(long long));
     th_ticket_t *t = (th_ticket_t *)calloc(1, sizeof(*t));
     t->c = (long long *)m; snprintf(t->name, sizeof(t->name), "%s", name);
     return t;

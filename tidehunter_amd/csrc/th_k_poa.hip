@@ -319,36 +319,23 @@ __device__ __forceinline__ int th_poa_rows_body(const ThPoaG &g)
 // The phase as a function of its own (not inlined on the device): its registers -- three chunks in flight -- are allocated apart
 // from the DP row loop's, which loses its loop-invariant registers to scratch otherwise.  The graph descriptor is rebuilt from the
 // wave's scratch base and the job's capacities (a by-reference descriptor would have to live in memory).
-#if defined(TH_CPU_EMUL) || defined(TH_POA_ROWS_INLINE)
-#define TH_NOINLINE
+#ifdef TH_POA_ROWS_INLINE      // (measurement only: the phase inlined into the job loop)
+#define TH_POA_ROWS_ATTR
 #else
-#define TH_NOINLINE __attribute__((noinline))
+#define TH_POA_ROWS_ATTR TH_NOINLINE
 #endif
-__device__ TH_NOINLINE int th_poa_rows(int *my, int cap, int ocap, int opn, int n_node, int order_swapped)
+__device__ TH_POA_ROWS_ATTR int th_poa_rows(int *my, int cap, int ocap, int opn, int n_node, int order_swapped)
 {
-#ifndef TH_CPU_EMUL
-    my = (int *)(((unsigned long long)(uint32_t)TH_UNI((int)((unsigned long long)my >> 32)) << 32) | (uint32_t)TH_UNI((int)(unsigned long long)my));
-#endif
+    my = TH_UNI_PTR(int, my);
     ThPoaG g;
     th_poa_carve(g, my, TH_UNI(cap), TH_UNI(ocap), TH_UNI(opn));
     g.cap = TH_UNI(cap); g.n_node = TH_UNI(n_node);
     if (TH_UNI(order_swapped)) { int *t = g.order; g.order = g.order2; g.order2 = t; }     // th_poa_merge swaps the two order arrays after every alignment
     const int r_ = th_poa_rows_body(g);
-#if defined(TH_CPU_EMUL) && defined(TH_ROWS_DEBUG)
-    if (TH_LANE() == 0) {
-        const int n = g.n_node; static thread_local int ref[1 << 20];
-        for (int i = n - 1; i >= 0; --i) {
-            const int u = g.order[i]; int best = u == 1 ? -1 : -TH_BIG;
-            for (int o = 0; o < g.outn[u]; ++o) { const int sx = g.pos[th_poa_out(g, u, o)]; best = max(best, ref[sx] + 1); }
-            ref[i] = best;
-            if (g.r_rem[i] != best) { fprintf(stderr, "[rows debug] n %d row %d: remain %d, reference %d (outn %d)\n", n, i, g.r_rem[i], best, g.outn[u]); break; }
-        }
-    }
-#endif
     return r_;
 }
 
-#if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
+#if defined(TH_POA_PROF)
 __device__ unsigned long long th_poa_prof[20];    // 0..3 phase cycles; 4..7 traceback events (tiles loaded, run trips, run steps, single steps); 8..13 rows per category, 14..19 their cycles
 #define TH_PROF_CNT(k, v) do { if (TH_LANE() == 0) atomicAdd(&th_poa_prof[k], (unsigned long long)(v)); } while (0)
 #define TH_PROF_T0() unsigned long long pt_ = __builtin_amdgcn_s_memtime()
@@ -410,11 +397,7 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
         const bool lo_ok = j0 >= b && j0 <= e, hi_ok = j0 + 1 <= e;
         const uint32_t IM = (lo_ok ? 0xffffu : 0u) | (hi_ok ? 0xffff0000u : 0u);
         // substitution scores of the two columns from the row's table
-#ifdef TH_CPU_EMUL
-        const uint32_t qx = s_qs[min(j0, QCAP) >> 1];                        // the pair's two 4-bit query codes
-#else
-        const uint32_t qx = s_qs[j0 >> 1];      // columns beyond e may read past the staged codes (still inside the workgroup's LDS): they are masked out below
-#endif
+        const uint32_t qx = s_qs[TH_LDS_SLACK_INDEX(j0, QCAP) >> 1];      // the pair's two 4-bit query codes; columns beyond e may read past the staged codes (still inside the workgroup's LDS): they are masked out below
         // T: the four biased scores of this row's node base against A, C, G, T, one per byte; code 4 (N, and the column 0 / beyond-the-
         // query filler) selects byte 0 of the other source, the bias itself.  One byte permute looks both columns up.
         const uint32_t SC = th_pk_sub(th_perm(32u, T, (((qx << 12) | qx) & 0x000f000fu) | 0x0c000c00u), 0x00200020u);
@@ -511,7 +494,7 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
 
 // end of a packed row taken by one of the two straight-line paths of the row loop: the row becomes "the previous row", its band /
 // maximum columns / direction-word offset go into lane (row & 63) of the chunk registers, a complete chunk goes to the row tables
-#if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
+#if defined(TH_POA_PROF)
 #define TH_POA_PK_PROF(cat) { pf_n[cat] += 1; pf_t[cat] += __builtin_amdgcn_s_memtime() - row_t0; }
 #else
 #define TH_POA_PK_PROF(cat)
@@ -534,12 +517,10 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
 {
     constexpr bool LQ = QCAP > 0, WIDE = sizeof(RT) == 4;
     int lane = TH_LANE();
-#ifndef TH_CPU_EMUL
     // the per-lane constants of the row loop (column offsets times the gap extensions, ring addresses ...) are derived from this copy:
     // they are rebuilt at every call instead of being hoisted out of the job's alignment loop, where they would stay live -- and
     // get spilled to scratch, to be reloaded INSIDE the row loop -- across the other phases
-    asm volatile("" : "+v"(lane));
-#endif
+    TH_OPAQUE_V(lane);
     const int M = P.match, X = P.mismatch, O1 = P.go1, E1 = P.ge1, O2 = P.go2, E2 = P.ge2;
     qlen = TH_UNI(qlen);
     // noband (the rerun of a job whose adaptive band failed): a half-width beyond any column makes every row span 0..qlen through
@@ -557,11 +538,9 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     const int neg_thr = -(int)real_b - 1;
     // packed constants
     uint32_t O1P = TH_PK_DUP(O1), O2P = TH_PK_DUP(O2), E1P = TH_PK_DUP(E1), E2P = TH_PK_DUP(E2);
-#ifndef TH_CPU_EMUL
     // the scalar register file of this kernel is full (the graph descriptor alone is ~35 pointer pairs), and a spilled scalar costs a
     // v_readlane -- a vector instruction -- at every use: the four constants every packed row uses several times live in VGPRs instead
-    asm volatile("" : "+v"(O1P), "+v"(O2P), "+v"(E1P), "+v"(E2P));
-#endif
+    TH_OPAQUE_V(O1P); TH_OPAQUE_V(O2P); TH_OPAQUE_V(E1P); TH_OPAQUE_V(E2P);
     const uint32_t TXB = (uint32_t)(32 - X) * 0x01010101u;           // score table of a packed row: one byte per query code A, C, G, T, biased by 32 ...
     // ... and with the match score in place for each node base: lane nb (0..4; 4 = N scores 0 against everything) of one register,
     // a row fetches its table with one v_readlane
@@ -578,7 +557,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     int tail_dirty = (1 << TH_POA_RING) - 1;      // ring slots whose columns beyond the first 128 are not known to hold minus infinity (see th_poa_pk_row)
     for (int x = lane; x < TH_POA_RING * 3 * TH_POA_PAD; x += TH_WAVE) s_ring[x / (3 * TH_POA_PAD)][(x / TH_POA_PAD) % 3][x % TH_POA_PAD] = (RT)(WIDE ? TH_NEG : -32768);
     TH_WAVE_FENCE();
-#if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
+#if defined(TH_POA_PROF)
     unsigned long long pf_n[6] = { 0, 0, 0, 0, 0, 0 }, pf_t[6] = { 0, 0, 0, 0, 0, 0 };
 #endif
     for (int i = 0; i + 1 < n; ++i) {
@@ -590,7 +569,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             }
             TH_VM_WAIT0();      // here, once per 64 rows -- not at the first use below, where it would drain every row's stores
         }
-#if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
+#if defined(TH_POA_PROF)
         const unsigned long long row_t0 = __builtin_amdgcn_s_memtime();
 #endif
         const int sl = i & 63;
@@ -848,7 +827,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         }
         const int cstate = cache_me ? 3 : 0;
         L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = cstate;
-#if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
+#if defined(TH_POA_PROF)
         { const unsigned long long dt = __builtin_amdgcn_s_memtime() - row_t0;
           const int cat = pk ? 1 : inn != 1 ? 2 : p0 != i - 1 ? 3 : needfull ? 4 : 5;     // (0: common packed row) / other packed / several predecessors / one far predecessor / stores full cells / other
           pf_n[cat] += 1; pf_t[cat] += dt; }
@@ -860,7 +839,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         }
         TH_WAVE_FENCE();
     }
-#if defined(TH_POA_PROF) && !defined(TH_CPU_EMUL)
+#if defined(TH_POA_PROF)
     if (lane == 0) for (int c = 0; c < 6; ++c) { atomicAdd(&th_poa_prof[8 + c], pf_n[c]); atomicAdd(&th_poa_prof[14 + c], pf_t[c]); }
 #endif
     // global end: best predecessor row of the sink (row n-1) at column qlen, first in edge order
@@ -911,9 +890,7 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
                 // for the whole chain at every tile: it was four round trips long)
                 const int rb = g.r_beg[row], re = g.r_end[row], meta = g.r_meta[row], roff = g.r_off[row], rfoff = g.r_foff[row];
                 t_p0 = g.r_p[row * 4]; t_p1 = g.r_p[row * 4 + 1]; t_p2 = g.r_p[row * 4 + 2]; t_p3 = g.r_p[row * 4 + 3];
-#ifndef TH_CPU_EMUL
-                asm volatile("" : : "v"(rb), "v"(re), "v"(meta), "v"(roff), "v"(rfoff));     // (all five in flight together: the compiler would sink each load behind the test that needs it)
-#endif
+                TH_KEEP_V(rb); TH_KEEP_V(re); TH_KEEP_V(meta); TH_KEEP_V(roff); TH_KEEP_V(rfoff);     // (all five in flight together: the compiler would sink each load behind the test that needs it)
                 if (col >= rb && col <= re) {
                     t_d = ((meta >> 8) & 0xff) > TH_D16_WIDE_DEG ? g.cell[rfoff + (col - rb)].w : (int)th_d16_expand(g.dcell[roff + (col - rb)]);
                     t_ok = 1;
