@@ -573,7 +573,7 @@ static th_handle_t *th_init_sub(const th_para_t *p, int device, int n_sub_max)
 }
 th_handle_t *th_init(const th_para_t *p, int device)
 {
-    int ns = 2;
+    int ns = 1;          /* one pipeline, one stream (TH_SUBBATCH=2: a large batch as two concurrent halves, round 2's default) */
     const char *e = getenv("TH_SUBBATCH");
     if (e && atoi(e) >= 1) ns = atoi(e);
     return th_init_sub(p, device, ns);
@@ -1001,10 +1001,11 @@ typedef struct {
     int next_batch;              /* ticket counter of the device pipelines (the reference's THREAD_READ_I, src/main.c:277-281, at batch granularity) */
     double t_read, t_write;      /* busy seconds of the two side threads (TH_TRACE=1 prints them) */
     double t_start; int trace;
-    /* steady-state bookkeeping: when the first full-size batch was complete and how many reads were complete by then */
-    double t_first_full; long long reads_done, reads_at_first_full;
 } th_pipe_t;
-typedef struct { th_pipe_t *q; int dev_index, device; int rc, total, batches; th_stage3_t st; } th_dev_worker_t;
+/* steady-state bookkeeping per pipeline: when its first full-size batch was complete, how many of its reads were complete by then, and
+ * when its last batch was complete -- the rate over that window excludes start-up (HIP initialisation, device allocation, the ramp) and,
+ * taken per pipeline, is not inflated by another pipeline's batch that happens to complete just after the window opens */
+typedef struct { th_pipe_t *q; int dev_index, device; int rc, total, batches; th_stage3_t st; double t_first_full, t_last; long long reads_done, reads_at_first_full; } th_dev_worker_t;
 
 /* waits until the slot holds batch `batch` in state `state` (batch < 0: any occupant -- the reader waiting for a free slot);
  * returns 0 if that batch lies beyond the end of the input instead */
@@ -1067,10 +1068,8 @@ static void pipe_batch_done(th_stage3_t *st, int k, void *tag)
     (void)k;
     if (st->failed) { w->rc = -1; q->stop = 1; } else w->total += s->n;     /* never partial output: a failed batch and everything after it are dropped */
     const double t = now_s();
-    pthread_mutex_lock(&q->mu);
-    q->reads_done += s->n;
-    if (q->t_first_full == 0 && s->n >= q->batch_reads) { q->t_first_full = t; q->reads_at_first_full = q->reads_done; }
-    pthread_mutex_unlock(&q->mu);
+    w->reads_done += s->n; if (s->n > 0) w->t_last = t;
+    if (w->t_first_full == 0 && s->n >= q->batch_reads) { w->t_first_full = t; w->reads_at_first_full = w->reads_done; }
     if (q->trace) fprintf(stderr, "[th_run_file]   pipeline %d: batch %d (%d reads) complete at %.3f s\n", w->dev_index, s->batch, s->n, t - q->t_start);
     slot_set(q, s, SLOT_DONE);
 }
@@ -1116,7 +1115,7 @@ static void *pipe_device(void *arg)
 int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *devices_in, int n_dev_in, int batch_reads)
 {
     if (n_dev_in < 1 || n_dev_in > TH_MAX_DEV) return host_fail("between 1 and 16 devices");
-    if (batch_reads <= 0) batch_reads = 32768;
+    if (batch_reads <= 0) batch_reads = 65536;      /* per-position arrays + POA scratch of one pipeline: ~70 GB of HBM at 10 kb reads */
     /* One pipeline (handle + upload / run / collect threads) per listed device.  TH_WORKERS_PER_DEV=2 puts two of them on each
      * device (round 2's design: two handles whose kernels interleave on the device; kept for A/B measurements). */
     int wpd = 1;
@@ -1146,11 +1145,16 @@ int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *d
     pthread_join(t_rd, NULL); pthread_join(t_wr, NULL);
     if (getenv("TH_TRACE")) {
         const double t_end = now_s();
-        /* steady: the reads completed after the first full-size batch over the time since then (start-up -- HIP initialisation,
-         * device allocation, the ramp -- excluded); 0 when the input is too short to have one */
-        const double steady = (q->t_first_full > 0 && t_end > q->t_first_full && q->reads_done > q->reads_at_first_full) ? (q->reads_done - q->reads_at_first_full) / (t_end - q->t_first_full) : 0;
+        /* steady: per pipeline, the reads completed after its first full-size batch over the time from then to its last batch; the
+         * pipelines' rates add up.  0 when the input is too short for a window. */
+        double steady = 0, window = 0;
+        for (int d = 0; d < n_dev; ++d)
+            if (w[d].t_first_full > 0 && w[d].t_last > w[d].t_first_full && w[d].reads_done > w[d].reads_at_first_full) {
+                steady += (w[d].reads_done - w[d].reads_at_first_full) / (w[d].t_last - w[d].t_first_full);
+                if (w[d].t_last - w[d].t_first_full > window) window = w[d].t_last - w[d].t_first_full;
+            }
         fprintf(stderr, "[th_run_file] %d reads on %d device pipeline(s): wall %.3f s; busy: reader %.3f s, upload %.3f s, device runs %.3f s, record arithmetic %.3f s, writer %.3f s; steady %.1f reads/s over the last %.3f s\n",
-                total, n_dev, t_end - t_start, q->t_read, busy_up, busy_run, busy_col, q->t_write, steady, q->t_first_full > 0 ? t_end - q->t_first_full : 0.0);
+                total, n_dev, t_end - t_start, q->t_read, busy_up, busy_run, busy_col, q->t_write, steady, window);
         if (n_dev > 1) for (int d = 0; d < n_dev; ++d) fprintf(stderr, "[th_run_file]   pipeline %d (device %d): %d batches, %d reads, device busy %.3f s\n", d, devices[d], w[d].batches, w[d].total, w[d].st.busy_run);
     }
     for (int d = 0; d < n_dev; ++d) st3_destroy(&w[d].st);

@@ -55,7 +55,7 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
     __shared__ unsigned long long s_ring[RING ? TH_CHAIN_BLOCK / TH_WAVE : 1][RING ? RING : 1];
     unsigned long long *ring = s_ring[RING ? (threadIdx.x >> 6) : 0];
     constexpr bool RP2 = RING == 0 || (RING & (RING - 1)) == 0;         // power of two: the slot is a mask; else the wave keeps cur mod RING in a scalar
-    int cur_slot = RP2 ? 0 : 1 % (RING ? RING : 1);                     // cur mod RING (cur starts at 1)
+    int cur_slot = 0;                                                   // cb mod RING (rings whose size is not a power of two)
     // init_dp (src/tandem_chain.c:113-126): score = k + min(k, period), no predecessor
     for (int i = lane; i < n; i += TH_WAVE) {
         const int e = E[i], p = Pd[i], s0 = k + min(k, p);
@@ -67,23 +67,60 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
     // end / period of the 64 hits of cur's chunk, one per lane: the current hit's pair is a v_readlane away -- a load per hit
     // (two dependent round trips to L2 before the first trip could start) was a quarter of the kernel's time
     int c_e = lane < n ? E[lane] : 0, c_p = lane < n ? Pd[lane] : 1;
-    for (int cur = 1; cur < n; ++cur) {
-        if ((cur & 63) == 0) {
-            if (RING) {                                                // the chunk cur .. cur+63 enters the ring (its scores are still the initial ones)
-                if (cur + lane < n) ring[RP2 ? ((cur + lane) & (RING - 1)) : (int)min((uint32_t)(cur_slot + lane), (uint32_t)(cur_slot + lane - RING))] = R[cur + lane];
+    // FOLLOWERS.  A hit whose immediate predecessor has the same period and ends fewer than k bases before it -- the next k-mer of a
+    // run of matching k-mers, ~80 % of the hits of a tandem repeat at 10 % error -- needs no scan: that predecessor is a connection
+    // of type OVL (:151-166: same period, matched = 2 d < 2 k), an OVL connection ends the scan whether it improves or not
+    // (:342-346), and it always improves, because its score is the predecessor's (>= the common initial score k + min(k, period))
+    // plus matched - gap = 2 d - ilog2(2 d) / 2 >= 2.  So score = predecessor's score + that constant and from = the predecessor:
+    // along a run the scores are a prefix sum over the distances, taken 64 hits at a time, and only the HEADS of runs are scanned.
+    // (What the sequential scan of such a hit did: one trip of 64 lanes, of which lane 0 decided.)
+    int prev_e = 0, prev_p = 0, carry_sc = 0;         // the hit before the chunk: end, period, final score
+    for (int cb = 0; cb < n; cb += TH_WAVE) {
+        if (cb) {
+            if (RING) {                                                // the chunk cb .. cb+63 enters the ring (its scores are still the initial ones)
+                if (cb + lane < n) ring[RP2 ? ((cb + lane) & (RING - 1)) : (int)min((uint32_t)(cur_slot + lane), (uint32_t)(cur_slot + lane - RING))] = R[cb + lane];
                 TH_WAVE_FENCE();
             }
-            if (cur + lane < n) { c_e = E[cur + lane]; c_p = Pd[cur + lane]; }
+            if (cb + lane < n) { c_e = E[cb + lane]; c_p = Pd[cb + lane]; }
         }
-        const int ring_lo = RING ? (cur | 63) + 1 - RING : 0;      // oldest hit index the ring still holds
-        const int ce = TH_READLANE(c_e, cur & 63), cp = TH_READLANE(c_p, cur & 63), cs = ce - cp;       // the same in every lane: scalar registers
-        const int init = k + min(k, cp);
-        int best = init + 15, bi = -1, iter = 0;       // best and the candidates are kept 15 above their value inside the scan (the constant of the logarithm term)
+        const int ring_lo = RING ? cb + TH_WAVE - RING : 0;      // oldest hit index the ring still holds
+        const bool okl = cb + lane < n;
+        const int q_e = th_shr1(c_e, prev_e), q_p = th_shr1(c_p, prev_p);      // the hit before this lane's
+        const int d = c_e - q_e;
+        const bool fol = okl && (cb + lane) >= 1 && c_p == q_p && d >= 1 && d < k && d <= c_p;
+        const unsigned long long follm = TH_BALLOT(fol), okm = TH_BALLOT(okl);
+        const int fcon = fol ? 2 * d - ((31 - TH_CLZ_NZ(2 * d)) >> 1) : 0;
+        const int ps = th_wave_incl_sum(fcon);                  // followers: score = score of the run's head + ps - ps[head]
+        int seg_sc = carry_sc, seg_ps = 0, seg_lo = 0;          // the segment before the chunk's first head continues the previous chunk's last run
+        unsigned long long todo = okm & ~follm;                 // heads of the chunk, in order
+        int fin = 0;                                            // final score of this lane's hit
+        for (;;) {
+            const int h = todo ? th_ctz64nz(todo) : TH_WAVE;    // next head (64: none left)
+            // followers between the previous head and this one
+            const unsigned long long segm = seg_lo >= TH_WAVE ? 0ull : follm & (h >= TH_WAVE ? ~0ull : ((1ull << h) - 1)) & (~0ull << seg_lo);
+            if (segm) {
+                if (TH_LANE_OF_MASK(segm, lane)) {
+                    const int sc = seg_sc + ps - seg_ps, x = cb + lane;
+                    fin = sc;
+                    S[x] = sc; F[x] = x - 1;
+                    if (PK) ((int *)(R + x))[1] = sc;
+                    if (RING) ((int *)(ring + (RP2 ? (x & (RING - 1)) : (int)min((uint32_t)(cur_slot + lane), (uint32_t)(cur_slot + lane - RING)))))[1] = sc;
+                }
+                TH_WAVE_FENCE();
+            }
+            if (!todo) break;
+            todo &= todo - 1;
+            const int cur = cb + h;
+            const int ce = TH_READLANE(c_e, h), cp = TH_READLANE(c_p, h), cs = ce - cp;       // the same in every lane: scalar registers
+            const int init = k + min(k, cp);
+            int best = init + 15, bi = -1, iter = 0;       // best and the candidates are kept 15 above their value inside the scan (the constant of the logarithm term)
+            if (cur >= 1) {
         const int max_h = cp;
         // the two period-ratio tests below as one range test on the predecessor's period: 5 cp >= 9 pp <=> pp <= (5 cp) / 9 and
         // 5 pp >= 9 cp <=> pp >= ceil(9 cp / 5), so a connection needs plo < pp < phi
         const uint32_t plo = (5u * (uint32_t)cp) / 9u, phi = (9u * (uint32_t)cp + 4u) / 5u;
-        int bslot = RP2 ? 0 : (cur_slot == 0 ? RING - 1 : cur_slot - 1);      // (cur - 1) mod RING
+        const int hslot = RP2 ? 0 : (cur_slot + h >= RING ? cur_slot + h - RING : cur_slot + h);        // cur mod RING
+        int bslot = RP2 ? 0 : (hslot == 0 ? RING - 1 : hslot - 1);      // (cur - 1) mod RING
         // The packed records of a trip: 64 hits base, base-1, ... -- from the ring when the whole trip lies inside it, else from HBM (two
         // different loads under a wave-uniform branch: a select between the two POINTERS would become one flat load, which waits for the
         // wave's outstanding global stores -- the previous hit's results -- before every trip).  Lanes before the first hit read some
@@ -155,10 +192,17 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
         if (lane == 0 && best > init) {                                                                 // :352-354
             S[cur] = best; F[cur] = bi;
             if (PK) ((int *)(R + cur))[1] = best;
-            if (RING) ((int *)(ring + (RP2 ? (cur & (RING - 1)) : cur_slot)))[1] = best;
+            if (RING) ((int *)(ring + (RP2 ? (cur & (RING - 1)) : hslot)))[1] = best;
         }
-        if (!RP2 && ++cur_slot == RING) cur_slot = 0;
         TH_WAVE_FENCE();
+            } else best -= 15;
+            seg_sc = max(best, init); seg_ps = TH_READLANE(ps, h); seg_lo = h + 1;
+            if (lane == h) fin = seg_sc;
+        }
+        // the chunk's last hit is what the next chunk's first one looks back at
+        const int last = min(TH_WAVE, n - cb) - 1;
+        prev_e = TH_READLANE(c_e, last); prev_p = TH_READLANE(c_p, last); carry_sc = TH_READLANE(fin, last);
+        if (!RP2) { cur_slot += TH_WAVE; if (cur_slot >= RING) cur_slot -= RING; }
     }
 }
 
