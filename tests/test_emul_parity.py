@@ -222,8 +222,8 @@ def test_emul_poa_band_failure_is_rerun_without_a_band(emu, monkeypatch):
 
 
 def test_emul_file_driver_pipeline(emu, tmp_path):
-    """th_run_file_multi on the emulation library: reader -> device workers (two per device, batches taken from the shared ticket
-    counter, ramped batch sizes) -> writer; several batches, output order = input order, bytes equal to the oracle's command line"""
+    """th_run_file_multi on the emulation library: reader -> device pipelines (upload / run / collect threads each; one or two per
+    device, batches taken from the shared ticket counter, ramped batch sizes) -> writer; several batches, output order = input order, bytes equal to the oracle's command line"""
     import ctypes as C
     import subprocess
     th = TH.TideHunter(lib_path=emu, out_fmt=2)
@@ -239,7 +239,7 @@ def test_emul_file_driver_pipeline(emu, tmp_path):
     with gzip.open(gz, "wb") as f:
         f.write(fa.read_bytes())
     U.write_bgzf(bgz, fa.read_bytes(), block=300)
-    for devs, batch, env, src in (([0], 2, {}, fa), ([0, 0], 3, {}, fa), ([0], 100, {"TH_RAMP0": "1"}, fa), ([0], 2, {"TH_WORKERS_PER_DEV": "1"}, fa),
+    for devs, batch, env, src in (([0], 2, {}, fa), ([0, 0], 3, {}, fa), ([0], 100, {"TH_RAMP0": "1"}, fa), ([0], 2, {"TH_WORKERS_PER_DEV": "2"}, fa),
                                   ([0], 3, {}, gz), ([0], 3, {}, bgz)):
         for k, v in env.items():
             os.environ[k] = v

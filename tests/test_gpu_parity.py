@@ -250,10 +250,12 @@ def test_gpu_alignment_engines(monkeypatch, env):
 
 
 def test_gpu_two_concurrent_halves_match_one_pipeline(monkeypatch):
-    """a batch of 16384 reads or more runs as two concurrent halves (two streams, two sets of buffers) and is merged by read index:
-    same records as one pipeline, and as the oracle on a sample; mixed read lengths so that the halves are cut by bases, not by count"""
+    """TH_SUBBATCH=2: a batch of 16384 reads or more runs as two concurrent halves (two streams, two sets of buffers) and is merged by
+    read index: same records as one pipeline (the default), and as the oracle on a sample; mixed read lengths so that the halves are cut
+    by bases, not by count"""
     lib = TH.load_library()
     seqs = [TH.synth_read(lib, 41, i, (150, 300, 90)[i % 3], (6, 5, 10)[i % 3], 0.08) for i in range(18000)]
+    monkeypatch.setenv("TH_SUBBATCH", "2")
     t2 = TH.TideHunter(device=0)
     a = t2.process(seqs)
     assert t2.launches() == 2

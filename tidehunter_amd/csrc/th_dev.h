@@ -55,7 +55,9 @@ struct ThCnt {
     unsigned long long need_n, need_w;       // POA scratch ints per wave the largest job of either variant asks for
     // item build
     int n_item_s, n_item_m, n_item_b, cc_total, max_cl, pad1[3];
-    int pad2[28];
+    int n_defer, q_aln_d;    // unit alignments deferred to the full-matrix launch, and that launch's queue head
+    int aln_wide[2];         // wide first bands (three registers per lane and more) tried / failed in the big-area alignment launch
+    int pad2[24];
 };
 static_assert(sizeof(ThCnt) == 256, "counter block");
 #define TH_E_REC_OVERFLOW 1       // chain record arena too small (rerun the extraction with a larger one)

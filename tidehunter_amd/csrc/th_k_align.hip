@@ -78,14 +78,20 @@ __device__ __forceinline__ bool th_adx_align(int np, const uint8_t *__restrict__
     return ok;
 }
 
-// mode: 0 strip engine only (th_ksw_global_band_wave), 1 anti-diagonal engine first (default), 2 both and compare (err bit 64 on a difference)
+// mode: 0 strip engine only (th_ksw_global_band_wave), 1 anti-diagonal engine first (default), 2 both and compare (err bit 64 on a
+// difference), 3 full matrix at once (the deferred items of the launch before, see `defer`).
+// n_items_ptr: the item count when it only exists on the device (the deferred list).
+// defer / defer_n: a unit alignment that ends up needing the FULL matrix is not computed here but appended to this list, which a
+// second launch of the small-staging-area variant takes in mode 3: the full matrix runs on the strip engine, which needs 4 KB of LDS,
+// and at this variant's 24 KB it would run at one or two waves per SIMD (config 4: 5000 x 5000 matrices at 15 % error, which no band
+// can certify, were 470 of the 849 ms of a step that way).
 template <int LDSB, int NPMAX>
 __global__ void __launch_bounds__(TH_ALN_BLOCK) TH_ALN_OCC
 th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__restrict__ tasks, const int *__restrict__ pos,
            const uint32_t *__restrict__ roff, const uint8_t *__restrict__ bseq,
            const uint8_t *__restrict__ cons, const int *__restrict__ cons_len,
            int *__restrict__ bnd, long long bnd_stride, int *__restrict__ iden, int *__restrict__ ext, int *__restrict__ err, int *__restrict__ queue,
-           int wdiv, int wadd, int wtol, int mode, int xpct)
+           int wdiv, int wadd, int wtol, int mode, int xpct, const int *__restrict__ n_items_ptr, ThAlnItem *__restrict__ defer, int *__restrict__ defer_n, int *__restrict__ wide_stat)
 {
     // one LDS area, used either as the left-border inbox of the strip sweep (two 64-row blocks, 4 KB) or as the staged bases
     // of the anti-diagonal engine (never both at once)
@@ -95,6 +101,7 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
     const int lane = TH_LANE();
     const int wave = blockIdx.x;
     int *mybnd = bnd + (long long)wave * bnd_stride;
+    if (n_items_ptr) n_items = TH_UNI(*n_items_ptr);
     for (;;) {
         const int it = th_queue_pop(queue);   // dynamic work queue: items range from a short extension to a full matrix
         if (it >= n_items) break;
@@ -120,10 +127,22 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                     v = -1;
                     int s1 = 0; bool have_s1 = false;
                     // anti-diagonal engine: its band is as wide as its registers (>= W - wtol), so it also serves matrices narrower than the band
-                    int np = mode ? th_ad_pick(len, cl, max(W - wtol, 0), LDSB, NPMAX) : 0;
+                    int np = (mode == 1 || mode == 2) ? th_ad_pick(len, cl, max(W - wtol, 0), LDSB, NPMAX) : 0;
+                    // A first band of three registers per lane or more (units of several thousand bases) that keeps failing its certificate in
+                    // this launch -- pairs as divergent as config 4's, 15 % error: no band short of the matrix can be certified -- is probed
+                    // with ONE register first: the probe's banded score sizes the band that could be certified, and the pair goes on to the
+                    // full matrix for a sixth of the wide pass it would have wasted.  The launch counts its wide first bands and their
+                    // failures (wide_stat[0], [1]); which engine computes an alignment never changes its result.
+                    const bool wide_first = np >= 3 && wide_stat != nullptr;
+                    if (wide_first) {
+                        const int tries = TH_LOAD_L2(&wide_stat[0]), fails = TH_LOAD_L2(&wide_stat[1]);
+                        if (TH_UNI(tries) >= 8 && 2 * TH_UNI(fails) > TH_UNI(tries) && th_ad_pick(len, cl, 0, LDSB, NPMAX) == 1) np = 1;
+                    }
+                    const int np_first = np;
                     const bool ad_first = np != 0;
                     while (np) {
                         v = th_ad_align<NPMAX>(np, qp, len, cs, cl, s_seq, &s1); have_s1 = true;
+                        if (wide_first && np == np_first && np >= 3 && lane == 0) { atomicAdd(&wide_stat[0], 1); if (v < 0) atomicAdd(&wide_stat[1], 1); }
                         if (v >= 0) break;
                         // not certified: the banded score s1 bounds the optimum from below, and a band whose Gmin exceeds
                         // (m + n - 2 s1 - 4q) / (1 + 2e) is certified for any optimum >= s1
@@ -132,12 +151,18 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                         const int np2 = W2 < 4096 ? th_ad_pick(len, cl, (int)W2, LDSB, NPMAX) : 0;
                         np = np2 > np ? np2 : 0;
                     }
-                    if (!ad_first && 64 + 2 * W + aD < (cl * 3) / 4) { v = th_ksw_global_band_wave(qp, len, cs, cl, W, mybnd, s_in, &s1); have_s1 = true; }
+                    if (!ad_first && mode != 3 && 64 + 2 * W + aD < (cl * 3) / 4) { v = th_ksw_global_band_wave(qp, len, cs, cl, W, mybnd, s_in, &s1); have_s1 = true; }
                     if (v < 0 && have_s1) {
                         // strip engine for the second, wider certified band (more divergent than ~12 %) if it is still clearly narrower than the matrix
                         const long long g2 = ((long long)len + cl - 2LL * s1 - 4 * TH_KQ) / (1 + 2 * TH_KE) + 2;
                         const long long W2 = (g2 - 2 - aD + 1) / 2 + 8;
                         if (W2 > W && 64 + 2 * W2 + aD < (cl * 3) / 4) v = th_ksw_global_band_wave(qp, len, cs, cl, (int)W2, mybnd, s_in, &s1);
+                    }
+                    if (v < 0 && defer && mode == 1) {          // the full matrix: on the strip engine's own launch (mode 3)
+                        int slot = 0;
+                        if (lane == 0) slot = atomicAdd(defer_n, 1);
+                        if (lane == 0) defer[slot] = I;
+                        continue;
                     }
                     if (v < 0) v = th_ksw_global_wave<false>(qp, len, cs, cl, 0, mybnd, nullptr);
                     if (mode == 2) {
