@@ -79,19 +79,21 @@ __device__ __forceinline__ bool th_adx_align(int np, const uint8_t *__restrict__
 }
 
 // mode: 0 strip engine only (th_ksw_global_band_wave), 1 anti-diagonal engine first (default), 2 both and compare (err bit 64 on a
-// difference), 3 full matrix at once (the deferred items of the launch before, see `defer`).
+// difference), 3 strip engine for the deferred items of the launch before (see `defer`; item_s1: their banded scores).
 // n_items_ptr: the item count when it only exists on the device (the deferred list).
-// defer / defer_n: a unit alignment that ends up needing the FULL matrix is not computed here but appended to this list, which a
-// second launch of the small-staging-area variant takes in mode 3: the full matrix runs on the strip engine, which needs 4 KB of LDS,
-// and at this variant's 24 KB it would run at one or two waves per SIMD (config 4: 5000 x 5000 matrices at 15 % error, which no band
-// can certify, were 470 of the 849 ms of a step that way).
+// defer / defer_n / defer_s1: a unit alignment that the anti-diagonal engine could not certify is not finished here but appended to this
+// list with its banded score, and a second launch of the small-staging-area variant takes it in mode 3: what is left -- a wider certified
+// band or the full matrix -- runs on the strip engine, which needs 4 KB of LDS, and at this variant's 24 KB and 250 registers it would
+// run at one or two waves per SIMD (config 4: 5000 x 5000 pairs at 15 % error were 470 of the 849 ms of a step that way).
+#define TH_ALN_NO_S1 (-0x40000000)
 template <int LDSB, int NPMAX>
 __global__ void __launch_bounds__(TH_ALN_BLOCK) TH_ALN_OCC
 th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__restrict__ tasks, const int *__restrict__ pos,
            const uint32_t *__restrict__ roff, const uint8_t *__restrict__ bseq,
            const uint8_t *__restrict__ cons, const int *__restrict__ cons_len,
            int *__restrict__ bnd, long long bnd_stride, int *__restrict__ iden, int *__restrict__ ext, int *__restrict__ err, int *__restrict__ queue,
-           int wdiv, int wadd, int wtol, int mode, int xpct, const int *__restrict__ n_items_ptr, ThAlnItem *__restrict__ defer, int *__restrict__ defer_n, int *__restrict__ wide_stat)
+           int wdiv, int wadd, int wtol, int mode, int xpct, const int *__restrict__ n_items_ptr, ThAlnItem *__restrict__ defer, int *__restrict__ defer_n, int *__restrict__ wide_stat,
+           const int *__restrict__ item_s1, int *__restrict__ defer_s1)
 {
     // one LDS area, used either as the left-border inbox of the strip sweep (two 64-row blocks, 4 KB) or as the staged bases
     // of the anti-diagonal engine (never both at once)
@@ -152,17 +154,17 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                         np = np2 > np ? np2 : 0;
                     }
                     if (!ad_first && mode != 3 && 64 + 2 * W + aD < (cl * 3) / 4) { v = th_ksw_global_band_wave(qp, len, cs, cl, W, mybnd, s_in, &s1); have_s1 = true; }
+                    if (mode == 3) { s1 = item_s1[it]; have_s1 = s1 != TH_ALN_NO_S1; }       // deferred by the launch before, with its banded score
+                    if (v < 0 && defer && mode == 1) {          // what is left is strip-engine work (a wider certified band, the full matrix): on that engine's own launch
+                        int slot = 0;
+                        if (lane == 0) { slot = atomicAdd(defer_n, 1); defer[slot] = I; defer_s1[slot] = have_s1 ? s1 : TH_ALN_NO_S1; }
+                        continue;
+                    }
                     if (v < 0 && have_s1) {
                         // strip engine for the second, wider certified band (more divergent than ~12 %) if it is still clearly narrower than the matrix
                         const long long g2 = ((long long)len + cl - 2LL * s1 - 4 * TH_KQ) / (1 + 2 * TH_KE) + 2;
                         const long long W2 = (g2 - 2 - aD + 1) / 2 + 8;
                         if (W2 > W && 64 + 2 * W2 + aD < (cl * 3) / 4) v = th_ksw_global_band_wave(qp, len, cs, cl, (int)W2, mybnd, s_in, &s1);
-                    }
-                    if (v < 0 && defer && mode == 1) {          // the full matrix: on the strip engine's own launch (mode 3)
-                        int slot = 0;
-                        if (lane == 0) slot = atomicAdd(defer_n, 1);
-                        if (lane == 0) defer[slot] = I;
-                        continue;
                     }
                     if (v < 0) v = th_ksw_global_wave<false>(qp, len, cs, cl, 0, mybnd, nullptr);
                     if (mode == 2) {

@@ -96,7 +96,7 @@ struct th_gpu {
     DBuf<ThChainRec> d_rec;
     DBuf<int> d_par, d_par_off, d_par_n, d_par_dst, d_parc, d_bnd, d_scratch, d_cov, d_cons_len, d_status, d_iden, d_ext;
     DBuf<int> d_rows, d_list_n, d_list_w, d_sublist;      // per-read / per-job counters of the table builds, POA task lists
-    DBuf<ThTask> d_tasks; DBuf<ThUnit> d_units; DBuf<ThAlnItem> d_items, d_defer; DBuf<th_job_t> d_jobs;
+    DBuf<ThTask> d_tasks; DBuf<ThUnit> d_units; DBuf<ThAlnItem> d_items, d_defer; DBuf<int> d_defer_s1; DBuf<th_job_t> d_jobs;
     int reserve_n = 0; Arena arena;
     int task_cap = 0, unit_cap = 0, parc_cap = 0;          // table capacities (grown when a batch overflows them)
     bool ad_on = false; int ad_min_cons = 0; ThAdPara h_ad; DBuf<ThAdPara> d_adp; DBuf<int> d_ad; bool adp_up = false;
@@ -160,7 +160,7 @@ extern "C" void th_gpu_destroy(th_gpu_t *g)
     g->d_par.release(); g->d_par_off.release(); g->d_par_n.release(); g->d_par_dst.release(); g->d_parc.release(); g->d_bnd.release(); g->d_scratch.release();
     g->d_cov.release(); g->d_cons_len.release(); g->d_status.release(); g->d_iden.release(); g->d_ext.release();
     g->d_rows.release(); g->d_list_n.release(); g->d_list_w.release(); g->d_sublist.release();
-    g->d_tasks.release(); g->d_units.release(); g->d_items.release(); g->d_defer.release(); g->d_jobs.release(); g->d_adp.release(); g->d_ad.release();
+    g->d_tasks.release(); g->d_units.release(); g->d_items.release(); g->d_defer.release(); g->d_defer_s1.release(); g->d_jobs.release(); g->d_adp.release(); g->d_ad.release();
     if (g->stage_ok) for (int b = 0; b < 2; ++b) { th_rt_host_free(g->h_stage[b]); th_rt_event_destroy(g->stage_ev[b]); }
     if (g->arena.base) th_rt_free(g->arena.base);
     th_rt_stream_destroy(g->stream); th_rt_stream_destroy(g->cstream);
@@ -611,17 +611,17 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
                   g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, &dc->err, (q), g->aln_wdiv, g->aln_wadd, g->aln_wtol
             // (a second list of fewer than 512 items -- the odd long unit of a short-period batch -- rides with the third: one launch fewer)
             const int mid_first = ns, mid_n = (nm - ns >= 512 || ni == nm) ? nm - ns : 0, big_first = mid_n ? nm : ns, big_n = ni - big_first;
-            const int *no_n = nullptr; ThAlnItem *no_defer = nullptr; int *no_dn = nullptr, *no_ws = nullptr;
-            if (ns) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(0, ns, &dc->q_aln_s), g->aln_mode, g->aln_xpct, no_n, no_defer, no_dn, no_ws);
-            if (mid_n) TH_LAUNCH((th_k_align<TH_ALN_MID, 2>), std::min(mid_n, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(mid_first, mid_n, &dc->q_aln_m), g->aln_mode, g->aln_xpct, no_n, no_defer, no_dn, no_ws);
+            const int *no_n = nullptr, *no_s1 = nullptr; ThAlnItem *no_defer = nullptr; int *no_dn = nullptr, *no_ws = nullptr, *no_ds1 = nullptr;
+            if (ns) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(0, ns, &dc->q_aln_s), g->aln_mode, g->aln_xpct, no_n, no_defer, no_dn, no_ws, no_s1, no_ds1);
+            if (mid_n) TH_LAUNCH((th_k_align<TH_ALN_MID, 2>), std::min(mid_n, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(mid_first, mid_n, &dc->q_aln_m), g->aln_mode, g->aln_xpct, no_n, no_defer, no_dn, no_ws, no_s1, no_ds1);
             if (big_n && big_first < ni) {
-                // the big-area variant hands the alignments that need the full matrix on to a second launch of the small-area one (mode 3):
-                // same results, but the strip engine then runs at five waves per SIMD instead of one or two
-                TRY(g->d_defer.ensure((size_t)big_n));
-                TH_LAUNCH((th_k_align<TH_ALN_BIG, 6>), std::min(big_n, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(big_first, big_n, &dc->q_aln_b), g->aln_mode, g->aln_xpct, no_n, g->d_defer.p, &dc->n_defer, dc->aln_wide);
+                // the big-area variant hands the alignments its anti-diagonal engine could not certify on to a second launch of the small-area one
+                // (mode 3): same results, but their strip-engine work then runs at three waves per SIMD instead of one or two
+                TRY(g->d_defer.ensure((size_t)big_n)); TRY(g->d_defer_s1.ensure((size_t)big_n));
+                TH_LAUNCH((th_k_align<TH_ALN_BIG, 6>), std::min(big_n, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(big_first, big_n, &dc->q_aln_b), g->aln_mode, g->aln_xpct, no_n, g->d_defer.p, &dc->n_defer, dc->aln_wide, no_s1, g->d_defer_s1.p);
                 if (g->aln_mode == 1) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(big_n, wa), TH_ALN_BLOCK, g->stream, (const ThAlnItem *)g->d_defer.p, 0, (const ThTask *)g->d_tasks.p, (const int *)g->d_parc.p,
                               (const uint32_t *)in.d_roff.p, (const uint8_t *)g->d_bseq.p, (const uint8_t *)g->d_cons.p, (const int *)g->d_cons_len.p,
-                              g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, &dc->err, &dc->q_aln_d, g->aln_wdiv, g->aln_wadd, g->aln_wtol, 3, g->aln_xpct, (const int *)&dc->n_defer, no_defer, no_dn, no_ws);
+                              g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, &dc->err, &dc->q_aln_d, g->aln_wdiv, g->aln_wadd, g->aln_wtol, 3, g->aln_xpct, (const int *)&dc->n_defer, no_defer, no_dn, no_ws, (const int *)g->d_defer_s1.p, no_ds1);
             }
 #undef TH_ALN_ARGS
         }
