@@ -122,7 +122,7 @@ int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *d
 /* The FASTA/FASTQ reader alone (kseq grammar, src/kseq.h:176-215; the reader of mini_tandem_read_seq, src/main.c:173-182), no device
  * involved: an uncompressed file is mmap'ed and parsed in place (single-line sequences are never copied), a bgzip file is inflated by
  * a pool of threads, plain gzip / stdin stream through zlib on a producer thread.  Returns the number of records, -1 if the file
- * cannot be opened; *n_bases and *digest (FNV-1a over names and sequences) are optional. */
+ * cannot be opened, -2 if it is corrupt or truncated (th_run_file then fails too instead of returning a shortened output); *n_bases and *digest (FNV-1a over names and sequences) are optional. */
 long long th_parse_file(const char *read_fn, long long *n_bases, unsigned long long *digest);
 
 /* deterministic synthetic tandem-repeat reads; returns read length, writes at most cap bases */

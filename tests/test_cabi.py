@@ -48,3 +48,21 @@ def test_synth_reads_are_deterministic(lib):
     l = TH.load_library()
     a = TH.synth_read(l, 1, 5, 1000, 10, 0.1); b = TH.synth_read(l, 1, 5, 1000, 10, 0.1); c = TH.synth_read(l, 1, 6, 1000, 10, 0.1)
     assert a == b and a != c and 9000 < len(a) < 11000 and set(a) <= set(b"ACGT")
+
+
+def test_isa_untracked_lds_read_is_not_touched_before_its_wait(tmp_path):
+    """th_k_chain_dp requests its next trip's records with an LDS read the compiler does not track (th_hw.h: TH_LDS_READ64_ASYNC /
+    TH_LDS_ASYNC_WAIT); tools/isa_check_async_lds.py looks at the gfx950 assembly of the product build for any instruction that touches
+    the destination registers between the read and its wait"""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "tidehunter_amd", "csrc")
+    out = tmp_path / "th_pipeline.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-value", "-Wno-pass-failed", "-w", "-I" + src, "-I" + os.path.join(ROOT, "include"),
+                    "--cuda-device-only", "-S", os.path.join(src, "th_pipeline.hip"), "-o", str(out)], check=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_check_async_lds.py"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

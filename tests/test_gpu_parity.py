@@ -268,3 +268,19 @@ def test_gpu_two_concurrent_halves_match_one_pipeline(monkeypatch):
     assert a == b
     sample = list(range(0, len(seqs), 150))
     assert U.assert_records_equal([seqs[i] for i in sample], [a[i] for i in sample], O.default_para(), "two halves") >= 100
+
+
+@pytest.mark.gpu
+def test_gpu_chain_dp_ring_variants_agree(monkeypatch):
+    """th_k_chain_dp with its LDS ring of 512 records (the default: next trip's records requested by an LDS read the compiler does not
+    track), without a ring (every trip from HBM) and with the 768 / 1024-entry rings: identical hits, scores, predecessors, chains and
+    par_pos on reads whose windows are longer than the ring, all against the oracle's stage dumps"""
+    lib = TH.load_library()
+    seqs = [TH.synth_read(lib, 9, i, (1000, 300, 2000)[i % 3], (10, 30, 5)[i % 3], 0.10) for i in range(96)]
+    para = O.default_para(only_unit=1)
+    for ring in ("512", "0", "768", "1024"):
+        monkeypatch.setenv("TH_CHAIN_RING", ring)
+        t = TH.TideHunter(device=0, only_unit=1)
+        t.process(seqs)
+        U.stage_compare(t, seqs, para)
+        t.close()

@@ -61,6 +61,23 @@ def test_reader_paths_agree_on_awkward_input(tmp_path):
     assert _parse(lib, tmp_path / "empty.fa")[:2] == (0, 0)
 
 
+def test_bgzf_group_boundary_and_damage(tmp_path):
+    """exactly 512 data members (one reader group) followed by the empty end-of-file member: the second group holds only that member
+    and must not be reported as corrupt; a truncated file IS reported (-2), not parsed as if it were complete"""
+    lib = U.synth_lib()
+    seqs = [U.synth_read(lib, 6, i, 50, 4, 0.05) for i in range(300)]
+    raw = b"".join(b">r%d\n" % i + s + b"\n" for i, s in enumerate(seqs))
+    block = -(-len(raw) // 512)
+    assert -(-len(raw) // block) == 512
+    bgz = tmp_path / "g512.fa.bgz"
+    U.write_bgzf(bgz, raw, block=block)
+    n, nb, _, _ = _parse(lib, bgz)
+    assert (n, nb) == (len(seqs), sum(len(s) for s in seqs))
+    cut = tmp_path / "cut.fa.bgz"
+    cut.write_bytes(bgz.read_bytes()[: os.path.getsize(bgz) // 2 + 7])        # (mid-member)
+    assert _parse(lib, cut)[0] == -2
+
+
 def test_mmap_reader_rate(tmp_path):
     """single-line 10 kb reads (the headline shape) from the page cache: several GB/s on one thread (7 GB/s measured on the build
     container, where the zlib stream path reaches 2.3 GB/s on the same file) -- the bar of SURVEY 8(f).2 is ~7 GB/s for 8 GPUs"""

@@ -97,6 +97,7 @@ enum { RD_STREAM = 0, RD_MEM = 1, RD_BGZF = 2 };
 typedef struct { const unsigned char *src; uint32_t clen, isize; size_t out_off; } bgzf_blk_t;
 typedef struct th_reader {
     int mode, last, eof;
+    int failed;                  /* corrupt or truncated input: what was parsed so far is NOT the whole file (th_run_file reports it) */
     /* the window the grammar reads from */
     const unsigned char *buf; size_t beg, end;
     /* STREAM: zlib on a producer thread, two buffers */
@@ -119,7 +120,7 @@ static void *stream_producer(void *arg)
         if (quit) return NULL;
         const long n = gzread(r->fp, r->sbuf[b], RD_CHUNK);
         pthread_mutex_lock(&r->smu);
-        if (n < 0) { int en = 0; fprintf(stderr, "[tidehunter_amd] read error: %s\n", gzerror(r->fp, &en)); }
+        if (n < 0) { int en = 0; fprintf(stderr, "[tidehunter_amd] read error: %s\n", gzerror(r->fp, &en)); r->failed = 1; }
         r->slen[b] = n > 0 ? n : 0; r->sfull[b] = 1; if (n <= 0) r->sdone = 1;
         pthread_cond_broadcast(&r->scv); pthread_mutex_unlock(&r->smu);
         if (n <= 0) return NULL;
@@ -134,7 +135,7 @@ static size_t bgzf_member(const unsigned char *p, size_t avail, uint32_t *clen, 
     unsigned bsize = 0, off = 12;
     while (off + 4 <= 12 + xlen) {
         const unsigned slen = p[off + 2] | p[off + 3] << 8;
-        if (p[off] == 'B' && p[off + 1] == 'C' && slen == 2) bsize = (p[off + 4] | p[off + 5] << 8) + 1u;
+        if (p[off] == 'B' && p[off + 1] == 'C' && slen == 2 && off + 6 <= 12 + xlen) bsize = (p[off + 4] | p[off + 5] << 8) + 1u;
         off += 4 + slen;
     }
     if (!bsize || bsize > avail || bsize < 12 + xlen + 8) return 0;
@@ -158,6 +159,7 @@ static void *bgzf_worker(void *arg)
             const int i = __atomic_fetch_add(&r->next_blk, 1, __ATOMIC_RELAXED);
             if (i >= r->nblk) break;
             const bgzf_blk_t *b = &r->blk[i];
+            if (b->isize == 0) continue;                 /* the empty end-of-file member */
             memset(&z, 0, sizeof(z));
             if (inflateInit2(&z, -15) != Z_OK) { r->zerr = 1; continue; }
             z.next_in = (unsigned char *)b->src; z.avail_in = b->clen; z.next_out = out + b->out_off; z.avail_out = b->isize;
@@ -182,7 +184,7 @@ static int bgzf_start_group(th_reader_t *r, int which)
         out += isize; r->zpos += sz; ++n;
     }
     if (n == 0) return 0;
-    if (out > r->gcap[which]) { free(r->gbuf[which]); r->gcap[which] = out + (out >> 3) + 65536; r->gbuf[which] = (unsigned char *)malloc(r->gcap[which]); }
+    if (out > r->gcap[which] || !r->gbuf[which]) { free(r->gbuf[which]); r->gcap[which] = out + (out >> 3) + 65536; r->gbuf[which] = (unsigned char *)malloc(r->gcap[which]); }    /* (never NULL: a group may hold only the empty end-of-file member, and inflate() rejects a NULL output) */
     r->glen[which] = out; r->nblk = n; r->next_blk = 0; r->gpending = which; r->zbusy = 1;
     pthread_mutex_lock(&r->zmu); r->zdone = 0; ++r->zgo; pthread_cond_broadcast(&r->zcv); pthread_mutex_unlock(&r->zmu);
     return 1;
@@ -215,10 +217,10 @@ static int rd_fill(th_reader_t *r)
     }
     /* BGZF: the group started earlier is (being) inflated; wait for it, expose it, start the one after it */
     for (;;) {
-        if (r->zfinished) { r->eof = 1; return 0; }
-        if (!r->zbusy && !bgzf_start_group(r, 0)) { r->eof = 1; return 0; }
+        if (r->zfinished) { if (r->zerr) { fprintf(stderr, "[tidehunter_amd] corrupt or truncated BGZF input\n"); r->failed = 1; } r->eof = 1; return 0; }
+        if (!r->zbusy && !bgzf_start_group(r, 0)) { if (r->zerr) r->failed = 1; r->eof = 1; return 0; }
         bgzf_wait_group(r);
-        if (r->zerr) { fprintf(stderr, "[tidehunter_amd] corrupt BGZF input\n"); r->eof = 1; return 0; }
+        if (r->zerr) { fprintf(stderr, "[tidehunter_amd] corrupt BGZF input\n"); r->failed = 1; r->eof = 1; return 0; }
         const int ready = r->gpending;
         r->buf = r->gbuf[ready]; r->beg = 0; r->end = r->glen[ready]; r->gcur = ready;
         if (!bgzf_start_group(r, ready ^ 1)) r->zfinished = 1;
@@ -1160,6 +1162,7 @@ int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *d
     for (int d = 0; d < n_dev; ++d) st3_destroy(&w[d].st);
     for (int i = 0; i < q->n_slot; ++i) { th_free_tandem_seq(q->slot[i].ts, batch_reads); free(q->slot[i].names); free(q->slot[i].seqs); free(q->slot[i].lens); free(q->slot[i].noff); free(q->slot[i].soff); free(q->slot[i].arena.s); }
     pthread_mutex_destroy(&q->mu); pthread_cond_destroy(&q->cv);
+    if (r->failed && !rc) { rc = -1; host_fail("the input is corrupt or truncated: the output holds only the reads before the damage"); }
     free(q); free(w); rd_close(r);
     return rc ? -1 : total;
 }
@@ -1195,7 +1198,9 @@ long long th_parse_file(const char *read_fn, long long *n_bases, unsigned long l
         n += k;
         if (k < 4096) break;
     }
+    const int damaged = r->failed;
     free(a.s); rd_close(r);
+    if (damaged) return -2;                       /* corrupt or truncated input */
     if (n_bases) *n_bases = bases;
     if (digest) *digest = h;
     return n;

@@ -74,16 +74,12 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
     // plus matched - gap = 2 d - ilog2(2 d) / 2 >= 2.  So score = predecessor's score + that constant and from = the predecessor:
     // along a run the scores are a prefix sum over the distances, taken 64 hits at a time, and only the HEADS of runs are scanned.
     // (What the sequential scan of such a hit did: one trip of 64 lanes, of which lane 0 decided.)
-    // BLOCK BOUNDS.  A head's scan is long when no predecessor stops it -- a head after an indel has a period no neighbour shares, so
-    // every connection is of type REG and the scan runs to the end of the window, ~830 hits (13 trips) on average at the headline
-    // shape.  But scores grow along a chain, so after the first trip or two the running best is far above anything older hits could
-    // offer: a trip whose hits all lie in completed 64-hit blocks is SKIPPED when the blocks' largest final score + 2k (the largest
-    // connection score: matched <= 2k, gap >= 0) cannot exceed the running best.  Exact: nothing in such a trip improves, so none of
-    // its hits can be an improving SAME/OVL stop; a non-improving OVL stop needs a hit within k bases of the current one, which sits in
-    // the first trip (never skippable: the initial best is below every block maximum + 2k); the window's end (:331) is recognised from
-    // the block's last end; and where the max_h rule (:349) would stop inside a skipped trip the result is the same as stopping after it.
+    // (Tried on top of this and dropped: skipping whole trips whose 64-hit blocks cannot beat the running best -- block maxima of the final
+    // scores in lane registers, + 2k as the largest connection score.  A third of a tandem repeat's hits have periods of two, three, ...
+    // unit lengths (their copy one period back was hit by an error); their running best stays low while every block's maximum comes
+    // from the main chain, so the bound skips 12 % of the trips, 24 % with maxima per period class (ratio 1.8), 44 % with an exact
+    // per-trip filter -- and the bookkeeping per trip cost more than that: 125 -> 234 ms per 100 000 reads.)
     int prev_e = 0, prev_p = 0, carry_sc = 0;         // the hit before the chunk: end, period, final score
-    int v_bmax = 0, v_bend = 0;                        // lane (block & 63): largest final score / last end of the completed 64-hit block
     for (int cb = 0; cb < n; cb += TH_WAVE) {
         if (cb) {
             if (RING) {                                                // the chunk cb .. cb+63 enters the ring (its scores are still the initial ones)
@@ -144,36 +140,15 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
         // The next trip's records are requested before this trip is resolved (seven scans in eight go on): the trip is a chain of
         // dependent steps -- load, score, prefix maximum, masks, branch -- and the wave has nothing else to overlap the load with.
         const int base0 = cur - 1;
-        const int cblk = cb >> 6;                     // blocks below this one are complete; v_bmax / v_bend hold the last 64 of them
-        // can the trip over hits base, base-1, ... base-63 be skipped?  0 no, 1 yes, 2 yes and the window ends inside or before it
-        auto skippable = [&](int base_) -> int {
-            if (base_ >= cb || base_ < 0) return 0;
-            const int bA = base_ >> 6, bB = max(base_ - (TH_WAVE - 1), 0) >> 6;
-            if (cblk - bB > 64) return 0;
-            const int m = max(TH_READLANE(v_bmax, bA & 63), TH_READLANE(v_bmax, bB & 63));
-            if (m + 2 * k + 15 > best) return 0;
-            return TH_READLANE(v_bend, bA & 63) < cs ? 2 : 1;
-        };
-        int have = -1;                                // the trip (its base) whose records rec_next holds or has requested
-        unsigned long long rec_next = 0ull;
-        if (PK && base0 >= 0) { rec_next = fetch(base0, bslot); have = base0; }
+        unsigned long long rec_next = (PK && base0 >= 0) ? fetch(base0, bslot) : 0ull;
         TH_LDS_ASYNC_WAIT(rec_next);
         for (int base = base0; base >= 0; base -= TH_WAVE, bslot = RP2 ? 0 : (bslot >= TH_WAVE ? bslot - TH_WAVE : bslot - TH_WAVE + RING)) {
-            {   // (asked again even if the records were requested: the trip before may have raised the best)
-                const int sk = skippable(base);
-                if (sk == 2) break;
-                if (sk == 1) { iter += min(base + 1, TH_WAVE); if (iter >= max_h) break; continue; }
-            }
-            if (have != base) {                       // no records were requested for this trip: it looked skippable when the trip before it started
-                if (PK) { rec_next = fetch(base, bslot); TH_LDS_ASYNC_WAIT(rec_next); }
-                have = base;
-            }
             const int idx = base - lane;
             const bool valid = idx >= 0;
             int pe, pp, psc;
             if (PK) {
                 const unsigned long long rec = rec_next;
-                if (base >= TH_WAVE && !skippable(base - TH_WAVE)) { rec_next = fetch(base - TH_WAVE, RP2 ? 0 : (bslot >= TH_WAVE ? bslot - TH_WAVE : bslot - TH_WAVE + RING)); have = base - TH_WAVE; }
+                if (base >= TH_WAVE) rec_next = fetch(base - TH_WAVE, RP2 ? 0 : (bslot >= TH_WAVE ? bslot - TH_WAVE : bslot - TH_WAVE + RING));
                 pe = (int)((uint32_t)rec >> 16); pp = (int)((uint32_t)rec & 0xffffu); psc = (int)(rec >> 32);
             } else { pe = valid ? E[idx] : 0; pp = valid ? Pd[idx] : 1; psc = valid ? S[idx] : 0; }
             const int ps = pe - pp;
@@ -232,8 +207,6 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
         // the chunk's last hit is what the next chunk's first one looks back at
         const int last = min(TH_WAVE, n - cb) - 1;
         prev_e = TH_READLANE(c_e, last); prev_p = TH_READLANE(c_p, last); carry_sc = TH_READLANE(fin, last);
-        const int blk_max = th_wave_max(okl ? fin : TH_INT_MIN);
-        v_bmax = TH_WRITELANE(v_bmax, blk_max, (cb >> 6) & 63); v_bend = TH_WRITELANE(v_bend, prev_e, (cb >> 6) & 63);
         if (!RP2) { cur_slot += TH_WAVE; if (cur_slot >= RING) cur_slot -= RING; }
     }
 }

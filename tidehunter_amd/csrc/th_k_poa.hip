@@ -64,7 +64,9 @@ __device__ __forceinline__ uint32_t th_d16_expand(uint32_t w)
 #define TH_POA_GAP_WINS_TIE 0
 #define TH_POA_INL 4
 #define TH_POA_RING 4      // recent rows kept in LDS (a row can read the three before it)
+#ifndef TH_POA_RW
 #define TH_POA_RW 192      // widest cached band
+#endif
 #define TH_POA_PAD 4       // minus-infinity shorts in front of every ring row (columns left of the band; clamp target)
 #define TH_POA_RS (TH_POA_PAD + TH_POA_RW + 4)   // shorts per ring array: pad + band (from its even base) + the odd-edge pair
 #define TH_BIG 0x3fffffff
