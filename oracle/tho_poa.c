@@ -65,6 +65,8 @@
  * the ONE line to pin (the HIP kernel has the same constant, TH_POA_GAP_WINS_TIE in th_k_poa.hip).
  * THO_POA_OPT_BAND = 0 disables the adaptive band (every row spans 0..qlen): used by the cross-check tests only. */
 static int g_gap_wins_tie = THO_POA_GAP_WINS_TIE, g_band = 1;
+static long *g_band_hist = NULL;     /* measurement hook (tools): histogram of band widths in bins of 16 columns */
+void tho_poa_band_hist(long *h) { g_band_hist = h; }
 void tho_poa_set_opt(int what, int value)
 {
     if (what == THO_POA_OPT_GAP_TIE) g_gap_wins_tie = value ? 1 : 0;
@@ -176,6 +178,7 @@ static int align_to_graph(graph_t *g, const uint8_t *q, int qlen, const tho_para
         if (!band) { b = 0; e = qlen; }
         if (b > e) { free(beg); free(roff); return -1; }
         beg[i] = b; end[i] = e; roff[i] = ncell; ncell += (size_t)(e - b + 1);
+        if (g_band_hist) { int wdt = (e - b + 1) / 16; __atomic_fetch_add(&g_band_hist[wdt > 63 ? 63 : wdt], 1L, __ATOMIC_RELAXED); }
         if (ncell > mcell) {
             while (ncell > mcell) mcell *= 2;
             H = tl_H = (int *)realloc(H, sizeof(int) * mcell); N1 = tl_N1 = (int *)realloc(N1, sizeof(int) * mcell);

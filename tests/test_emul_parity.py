@@ -394,3 +394,23 @@ def test_emul_batch_runs_as_two_concurrent_halves(emu, monkeypatch):
         U.assert_records_equal(seqs, got, para, "two halves %r" % (kw,))
         assert th.process(seqs[:2]) == got[:2] and th.launches() == 1
         th.close()
+
+
+def test_emul_poa_relative_score_variant(monkeypatch):
+    """thpoa_l, the long-unit POA configuration (int16 scores relative to a running base, ring rows of up to 384 columns in three trips):
+    forced on short units (TH_POA_FORCE_LONG) in a build whose rebasing threshold is 40 instead of 8000, so that the ring is rebased every
+    few rows, upwards and downwards -- records equal the oracle's, including far rows (full cells in absolute scores) and bubbles"""
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(U.ROOT, "tests", "cpu_emul"), "libth_emul_rel.so"], check=True, stdout=subprocess.DEVNULL)
+    lib = os.path.join(U.ROOT, "tests", "cpu_emul", "libth_emul_rel.so")
+    monkeypatch.setenv("TH_POA_FORCE_LONG", "1")
+    th = TH.TideHunter(lib_path=lib)
+    seqs = _reads(th.lib, [(60, 8, 0.10), (120, 5, 0.08), (35, 12, 0.12), (200, 4, 0.15), (90, 6, 0.0), (150, 7, 0.2), (300, 4, 0.1)])
+    got = th.process(seqs)
+    assert U.assert_records_equal(seqs, got, O.default_para(), "relative-score POA") >= 6
+    th.close()
+    # unusual scoring: larger steps, more rebases
+    th = TH.TideHunter(lib_path=lib, match=5, mismatch=9, gap_open1=8, gap_ext1=4, gap_open2=30, gap_ext2=2)
+    got = th.process(seqs)
+    assert U.assert_records_equal(seqs, got, O.default_para(match=5, mismatch=9, gap_open1=8, gap_ext1=4, gap_open2=30, gap_ext2=2), "relative-score POA, other scoring") >= 6
+    th.close()

@@ -48,16 +48,17 @@ struct ThCnt {
     int q_aln_m, q_aln_b;    // ... alignment items, mid / big staging area
     int n_retry;             // jobs the POA gave back (status 1-4, 7): the host takes the slow path when this is not 0
     int n_failed;            // jobs that stay without a consensus (status 5, 6)
-    int pad0[3];
-    // job build (the first six in the column order of th_k_jobs_count: the scan writes them in one go)
-    int par_total, n_task, n_unit, cons_total, aln_total, n_task_n;
-    int max_unit, max_cons_cap;
-    unsigned long long need_n, need_w;       // POA scratch ints per wave the largest job of either variant asks for
+    int q_poa_l;             // ... POA relative-int16 variant (long units)
+    int pad0[2];
+    // job build (the first seven in the column order of th_k_jobs_count: the scan writes them in one go)
+    int par_total, n_task, n_unit, cons_total, aln_total, n_task_n, n_task_l;
+    int max_unit, max_cons_cap, pad1;
+    unsigned long long need_n, need_w, need_l;       // POA scratch ints per wave the largest job of each variant asks for
     // item build
-    int n_item_s, n_item_m, n_item_b, cc_total, max_cl, pad1[3];
-    int n_defer, q_aln_d;    // unit alignments deferred to the full-matrix launch, and that launch's queue head
+    int n_item_s, n_item_m, n_item_b, cc_total, max_cl, pad2[3];
+    int n_defer, q_aln_d;    // unit alignments deferred to the strip-engine launch, and that launch's queue head
     int aln_wide[2];         // wide first bands (three registers per lane and more) tried / failed in the big-area alignment launch
-    int pad2[24];
+    int pad3[20];
 };
 static_assert(sizeof(ThCnt) == 256, "counter block");
 #define TH_E_REC_OVERFLOW 1       // chain record arena too small (rerun the extraction with a larger one)

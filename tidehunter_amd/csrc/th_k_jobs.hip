@@ -13,7 +13,7 @@
 // (th_k_items_count / th_k_scan_rows / th_k_items_emit).  The host only reads the 256-byte counter block.
 #include "th_dev.h"
 
-#define TH_JOB_COLS 6             // per-read counters: par_pos entries, jobs, units, consensus bytes, alignment slots, jobs of the int16 POA variant
+#define TH_JOB_COLS 7             // per-read counters: par_pos entries, jobs, units, consensus bytes, alignment slots, jobs of the int16 / of the relative-int16 POA variant
 #define TH_ITEM_COLS 4            // per-job counters: small / mid / big alignment items, compacted consensus bytes
 
 // Scratch of one POA wave for a job, in ints.  Mirrors the carve in th_k_poa: 39 node / row arrays of `cap`, the overflow pool,
@@ -22,7 +22,7 @@
 // variant on long units: measured band ~ 2w + 1 + len / 30 at 15 % error).  Graph rows grow by ~9 % of the unit length per unit
 // (measured: 1.27 x at 4 units of 5000, ~1.5 x at 9 units of 1000, ~2.6 x at 20 units of 200).  cell_factor is the attempt's
 // safety factor (1.5 at first, doubled for the jobs that come back with "scratch too small").
-__host__ __device__ static inline long long th_poa_need_ints(int n_units, int sum_len, int max_len, double cell_factor, bool noband, bool wide)
+__host__ __device__ static inline long long th_poa_need_ints(int n_units, int sum_len, int max_len, double cell_factor, bool noband, bool wide /* class 0: rows wider than the ring store full cells */)
 {
     if (n_units <= 2) return 0;
     const long long cap = sum_len + 2, ocap = 2LL * (sum_len + n_units + 8), opn = cap + max_len + 2;
@@ -32,35 +32,44 @@ __host__ __device__ static inline long long th_poa_need_ints(int n_units, int su
     const long long span = 2 * w + 1 + 48 + max_len / 30;
     long long rows = (long long)(max_len * (1.0 + 0.09 * (n_units - 1))) + 64;
     if (rows > cap) rows = cap;
-    const bool all_full = wide && span + 16 >= TH_POA_RW;
+    const bool all_full = wide && span + 16 >= TH_POA_RW_N;
     return (graph + (long long)(rows * span * cell_factor * (all_full ? 4.5 : 1.5)) + 63) & ~63LL;
 }
 // Which POA variant a job starts on.  The int16 variant gives a job back (status 7) when an alignment's scores may not fit
 // (th_poa_dp: cache16_ok, evaluated with the graph's row count at that alignment); with the row estimate above the same test
 // tells beforehand, for nearly every job, that it would -- those start on the 32-bit variant (both are exact: same results).
-__host__ __device__ static inline bool th_poa_job_is_narrow(int n_units, int max_len, const ThDevPara &P)
+// Returns the job's class: 1 narrow (thpoa_n int16, absolute scores), 2 long (thpoa_l: relative int16 scores, rows of up to 384 columns,
+// units of up to TH_POA_QCAP_LONG bases), 0 wide (32-bit rows).
+__host__ __device__ static inline int th_poa_job_class(int n_units, int max_len, const ThDevPara &P)
 {
-    if (max_len > TH_POA_QCAP) return false;
     const int M = P.match, X = P.mismatch, maxE = P.ge1 > P.ge2 ? P.ge1 : P.ge2;
     const int g1 = P.go1 + P.ge1, g2 = P.go2 + P.ge2, gap1 = g1 < g2 ? g1 : g2;
     const int mx = M > X ? (M > gap1 ? M : gap1) : (X > gap1 ? X : gap1);
-    const long long rows = (long long)(max_len * (1.0 + 0.09 * (n_units - 1))) + 64;
-    const long long real_b = (long long)mx * (max_len + rows) + P.go1 + P.go2 + 2 * maxE;
-    return M <= 31 && X <= 31 && real_b + (long long)M * rows + 2LL * (TH_POA_RW + 64) * maxE < 32000;
+    if (M > 31 || X > 31) return 0;
+    if (max_len <= TH_POA_QCAP) {
+        const long long rows = (long long)(max_len * (1.0 + 0.09 * (n_units - 1))) + 64;
+        const long long real_b = (long long)mx * (max_len + rows) + P.go1 + P.go2 + 2 * maxE;
+        if (real_b + (long long)M * rows + 2LL * (TH_POA_RW_N + 64) * maxE < 32000) return 1;
+    }
+    // (the range test of th_poa_dp's relative mode: it depends on the scoring only)
+    if (max_len <= TH_POA_QCAP_LONG &&
+        (long long)mx * 3 * (TH_POA_RW_L + 64) + 2LL * (TH_POA_RW_L + 64) * maxE + P.go1 + P.go2 < -TH_POA_REL_THR - TH_POA_REL_HI) return 2;
+    return 0;
 }
 
 struct ThJobTables {
     const uint32_t *roff; const int *read_ch_base, *read_ch_n;
     const int *par, *par_off, *par_n;                // the partition's arena and each chain's region in it
     int *par_dst, *parc;                             // compact copy: chain c's boundaries at parc[par_dst[c] ..]
-    ThTask *tasks; ThUnit *units; th_job_t *jobs; int *list_n, *list_w;
-    int task_cap, unit_cap, parc_cap;
+    ThTask *tasks; ThUnit *units; th_job_t *jobs; int *list_n, *list_w, *list_l;
+    int task_cap, unit_cap, parc_cap, cls_mask;
 };
 
 // the walk over one read's chains; EMIT = false counts into c[], EMIT = true writes at the offsets in c[] (advancing them)
 template <bool EMIT>
 __device__ __forceinline__ void th_jobs_walk(const ThJobTables &J, const ThDevPara &P, int r, int only_unit, int *c, ThCnt *C)
 {
+    const int cls_mask = J.cls_mask;
     const int L = (int)(J.roff[r + 1] - J.roff[r]);
     const int min_copy = P.min_copy;
     const int cb = J.read_ch_base[r], cn = J.read_ch_n[r];
@@ -85,22 +94,23 @@ __device__ __forceinline__ void th_jobs_walk(const ThJobTables &J, const ThDevPa
                     ++n_units; sum_len += len; max_len = max(max_len, len);
                 }
                 const int cons_cap = n_units <= 2 ? first_len : min(sum_len, 3 * max_len + 64);
-                const bool narrow = th_poa_job_is_narrow(n_units, max_len, P);
+                int cls = th_poa_job_class(n_units, max_len, P) & cls_mask;       // (cls_mask 1: no long class -- TH_POA_LONG=0)
+                if ((J.cls_mask & 4) && cls == 1) cls = 2;                        // (TH_POA_FORCE_LONG=1, tests: short units on the long-unit variant)
                 if (EMIT) {
                     const int t = c[1];
                     ThTask T; T.read = r; T.pos_off = dst + i; T.pos_n = j - i; T.unit_off = c[2]; T.n_units = n_units; T.sum_len = sum_len; T.max_len = max_len;
-                    T.cons_off = c[3]; T.cons_cap = cons_cap; T.aln_off = c[4]; T.narrow = narrow ? 1 : 0; T.noband = 0;
+                    T.cons_off = c[3]; T.cons_cap = cons_cap; T.aln_off = c[4]; T.narrow = cls; T.noband = 0;
                     J.tasks[t] = T;
                     th_job_t jb; jb.read = r; jb.pos_off = T.pos_off; jb.pos_n = T.pos_n; jb.n_seqs = n_units; jb.cons_off = 0; jb.cons_len = 0; jb.aln_off = T.aln_off; jb.status = 0;
                     J.jobs[t] = jb;
-                    if (narrow) J.list_n[c[5]] = t; else J.list_w[t - c[5]] = t;
+                    if (cls == 1) J.list_n[c[5]] = t; else if (cls == 2) J.list_l[c[6]] = t; else J.list_w[t - c[5] - c[6]] = t;
                     if (!only_unit) {
                         if (n_units <= 1) atomicOr(&C->err, TH_E_MSA_UNITS);
-                        atomicMax(narrow ? &C->need_n : &C->need_w, (unsigned long long)th_poa_need_ints(n_units, sum_len, max_len, 1.5, false, !narrow));
+                        atomicMax(cls == 1 ? &C->need_n : cls == 2 ? &C->need_l : &C->need_w, (unsigned long long)th_poa_need_ints(n_units, sum_len, max_len, 1.5, false, cls == 0));
                         atomicMax(&C->max_unit, max_len); atomicMax(&C->max_cons_cap, cons_cap);
                     }
                 }
-                c[1] += 1; c[2] += n_units; c[3] += (cons_cap + 15) & ~15; c[4] += j - i - 1; c[5] += narrow ? 1 : 0;
+                c[1] += 1; c[2] += n_units; c[3] += (cons_cap + 15) & ~15; c[4] += j - i - 1; c[5] += cls == 1 ? 1 : 0; c[6] += cls == 2 ? 1 : 0;
             }
             i = j + 1;
         }
@@ -112,7 +122,7 @@ th_k_jobs_count(int n_reads, ThJobTables J, ThDevPara P, int only_unit, int *__r
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
-    int c[TH_JOB_COLS] = { 0, 0, 0, 0, 0, 0 };
+    int c[TH_JOB_COLS] = { 0, 0, 0, 0, 0, 0, 0 };
     th_jobs_walk<false>(J, P, r, only_unit, c, C);
 #pragma unroll
     for (int k = 0; k < TH_JOB_COLS; ++k) rows[(long long)r * TH_JOB_COLS + k] = c[k];
@@ -232,7 +242,7 @@ __global__ void th_k_cnt_rerun(ThCnt *C, int redo_extract, int redo_part)
     C->err &= ~(TH_E_REC_OVERFLOW | TH_E_PART_OVERFLOW | TH_E_JOB_CAP);
     if (redo_extract) { C->rec = 0; C->q_xw = 0; }
     if (redo_part) { C->par_top = 0; C->q_part = 0; }
-    C->need_n = 0; C->need_w = 0; C->max_unit = 0; C->max_cons_cap = 0;
+    C->need_n = 0; C->need_w = 0; C->need_l = 0; C->max_unit = 0; C->max_cons_cap = 0;
 }
 // sets single counters of the block between the segments of a rerun (slow paths only)
 __global__ void th_k_cnt_set(int *p0, int v0, int *p1, int v1, int *p2, int v2, int *p3, int v3)

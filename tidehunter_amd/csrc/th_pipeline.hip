@@ -95,7 +95,7 @@ struct th_gpu {
     DBuf<ThCnt> d_cnt; th_pvec<ThCnt> h_cnt;
     DBuf<ThChainRec> d_rec;
     DBuf<int> d_par, d_par_off, d_par_n, d_par_dst, d_parc, d_bnd, d_scratch, d_cov, d_cons_len, d_status, d_iden, d_ext;
-    DBuf<int> d_rows, d_list_n, d_list_w, d_sublist;      // per-read / per-job counters of the table builds, POA task lists
+    DBuf<int> d_rows, d_list_n, d_list_w, d_list_l, d_sublist;      // per-read / per-job counters of the table builds, POA task lists
     DBuf<ThTask> d_tasks; DBuf<ThUnit> d_units; DBuf<ThAlnItem> d_items, d_defer; DBuf<int> d_defer_s1; DBuf<th_job_t> d_jobs;
     int reserve_n = 0; Arena arena;
     int task_cap = 0, unit_cap = 0, parc_cap = 0;          // table capacities (grown when a batch overflows them)
@@ -159,7 +159,7 @@ extern "C" void th_gpu_destroy(th_gpu_t *g)
     g->d_read_ch_base.release(); g->d_read_ch_n.release(); g->d_gsort.release(); g->d_eps.release(); g->d_cnt.release(); g->d_rec.release();
     g->d_par.release(); g->d_par_off.release(); g->d_par_n.release(); g->d_par_dst.release(); g->d_parc.release(); g->d_bnd.release(); g->d_scratch.release();
     g->d_cov.release(); g->d_cons_len.release(); g->d_status.release(); g->d_iden.release(); g->d_ext.release();
-    g->d_rows.release(); g->d_list_n.release(); g->d_list_w.release(); g->d_sublist.release();
+    g->d_rows.release(); g->d_list_n.release(); g->d_list_w.release(); g->d_list_l.release(); g->d_sublist.release();
     g->d_tasks.release(); g->d_units.release(); g->d_items.release(); g->d_defer.release(); g->d_defer_s1.release(); g->d_jobs.release(); g->d_adp.release(); g->d_ad.release();
     if (g->stage_ok) for (int b = 0; b < 2; ++b) { th_rt_host_free(g->h_stage[b]); th_rt_event_destroy(g->stage_ev[b]); }
     if (g->arena.base) th_rt_free(g->arena.base);
@@ -324,15 +324,16 @@ static int th_fetch_cnt(th_gpu *g, ThCnt **out)
 extern "C" int th_gpu_syncs(th_gpu_t *g) { return g->n_sync; }
 
 // one launch of the POA kernel over a task list (both variants write consensus / length / status at the task's own index)
-static int th_poa_launch(th_gpu *g, KTimer &kt, const ThIn &in, const int *list, int n_list, bool wide, int max_unit, long long need, int wv, int *queue, int poa_flags)
+static int th_poa_launch(th_gpu *g, KTimer &kt, const ThIn &in, const int *list, int n_list, int cls /* 1 int16, 2 relative int16 (long units), 0 32-bit */, int max_unit, long long need, int wv, int *queue, int poa_flags)
 {
     if (n_list <= 0) return 0;
     KT_BEGIN(TK_POA);
-#define POA_LAUNCH(QC, RT) TH_LAUNCH((th_k_poa<QC, RT>), wv, TH_POA_BLOCK, g->stream, (const ThTask *)g->d_tasks.p, list, n_list, (const ThUnit *)g->d_units.p, (const uint32_t *)in.d_roff.p, \
+#define POA_LAUNCH(NS, QC, RT) TH_LAUNCH((NS::th_k_poa<QC, RT>), wv, TH_POA_BLOCK, g->stream, (const ThTask *)g->d_tasks.p, list, n_list, (const ThUnit *)g->d_units.p, (const uint32_t *)in.d_roff.p, \
                           (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, g->d_cons_len.p, g->d_status.p, queue, poa_flags)
-    if (!wide) POA_LAUNCH(TH_POA_QCAP, short);
-    else if (max_unit <= TH_POA_QCAP_WIDE) POA_LAUNCH(TH_POA_QCAP_WIDE, int);
-    else POA_LAUNCH(0, int);
+    if (cls == 1) POA_LAUNCH(thpoa_n, TH_POA_QCAP, short);
+    else if (cls == 2) POA_LAUNCH(thpoa_l, TH_POA_QCAP_LONG, short);
+    else if (max_unit <= TH_POA_QCAP_WIDE) POA_LAUNCH(thpoa_n, TH_POA_QCAP_WIDE, int);
+    else POA_LAUNCH(thpoa_n, 0, int);
 #undef POA_LAUNCH
     KT_END(TK_POA);
     return 0;
@@ -350,7 +351,8 @@ static int th_poa_retries(th_gpu *g, KTimer &kt, const ThIn &in, int nt, int poa
     TRY(th_rt_d2h(g->h_tasks.data(), g->d_tasks.p, (size_t)nt * sizeof(ThTask), g->stream));
     TRY(th_rt_d2h(g->h_status.data(), g->d_status.p, (size_t)nt * 4, g->stream));
     TRY(th_rt_sync(g->stream));
-    auto run_list = [&](const std::vector<int> &grp, bool wide, bool noband, double factor, bool *ran) -> int {
+    auto run_list = [&](const std::vector<int> &grp, int cls, bool noband, double factor, bool *ran) -> int {
+        const bool wide = cls == 0;
         *ran = false;
         if (grp.empty()) return 0;
         long long need = 1024; int max_unit = 0;
@@ -362,7 +364,7 @@ static int th_poa_retries(th_gpu *g, KTimer &kt, const ThIn &in, int nt, int poa
         TRY(g->d_sublist.ensure(grp.size()));
         TRY(th_rt_h2d(g->d_sublist.p, g->h_sublist.data(), grp.size() * 4, g->stream));
         TH_LAUNCH(th_k_cnt_set, 1, 64, g->stream, &g->d_cnt.p->q_poa_w, 0, (int *)nullptr, 0, (int *)nullptr, 0, (int *)nullptr, 0);
-        TRY(th_poa_launch(g, kt, in, g->d_sublist.p, (int)grp.size(), wide, max_unit, need, wv, &g->d_cnt.p->q_poa_w, (noband ? 1 : 0) | poa_test_fail << 8));
+        TRY(th_poa_launch(g, kt, in, g->d_sublist.p, (int)grp.size(), cls, max_unit, need, wv, &g->d_cnt.p->q_poa_w, (noband ? 1 : 0) | poa_test_fail << 8));
         TRY(th_rt_d2h(g->h_status.data(), g->d_status.p, (size_t)nt * 4, g->stream));
         TRY(th_rt_sync(g->stream));
         *ran = true;
@@ -370,19 +372,20 @@ static int th_poa_retries(th_gpu *g, KTimer &kt, const ThIn &in, int nt, int poa
     };
     double factor = 1.5;
     for (int attempt = 0; attempt < 8; ++attempt, factor *= 2) {
-        std::vector<int> narrow, wide;
+        std::vector<int> narrow, wide, lng;
         for (int t = 0; t < nt; ++t) {
             const int st = g->h_status[t];
             if (st == 7) wide.push_back(t);                                             // (has not run on this variant yet: same factor)
-            else if ((st == 1 || st == 2) && attempt > 0) (g->h_tasks[t].narrow ? narrow : wide).push_back(t);
+            else if ((st == 1 || st == 2) && attempt > 0) (g->h_tasks[t].narrow == 1 ? narrow : g->h_tasks[t].narrow == 2 ? lng : wide).push_back(t);
         }
         if (attempt == 0 && wide.empty()) continue;
-        if (narrow.empty() && wide.empty()) break;
-        bool ran_n = false, ran_w = false;
+        if (narrow.empty() && wide.empty() && lng.empty()) break;
+        bool ran_n = false, ran_w = false, ran_l = false;
         for (int t : wide) if (g->h_status[t] == 7) g->h_tasks[t].narrow = 0;             // from now on a 32-bit job
-        TRY(run_list(narrow, false, false, factor, &ran_n));
-        TRY(run_list(wide, true, false, factor, &ran_w));
-        if (!ran_n && !ran_w) break;
+        TRY(run_list(narrow, 1, false, factor, &ran_n));
+        TRY(run_list(lng, 2, false, factor, &ran_l));
+        TRY(run_list(wide, 0, false, factor, &ran_w));
+        if (!ran_n && !ran_w && !ran_l) break;
     }
     {   // jobs whose adaptive band failed: one wave at a time if that is what the scratch allows
         factor = 1.0;
@@ -392,7 +395,7 @@ static int th_poa_retries(th_gpu *g, KTimer &kt, const ThIn &in, int nt, int poa
             if (nb.empty()) break;
             for (int t : nb) g->h_tasks[t].noband = 1;                                    // (marks the jobs of the no-band rerun)
             bool ran = false;
-            TRY(run_list(nb, true, true, factor, &ran));
+            TRY(run_list(nb, 0, true, factor, &ran));
             if (!ran) break;
         }
     }
@@ -496,11 +499,11 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
             KT_END(TK_PART);
         }
         {
-            TRY(g->d_tasks.ensure(g->task_cap)); TRY(g->d_jobs.ensure(g->task_cap)); TRY(g->d_list_n.ensure(g->task_cap)); TRY(g->d_list_w.ensure(g->task_cap));
+            TRY(g->d_tasks.ensure(g->task_cap)); TRY(g->d_jobs.ensure(g->task_cap)); TRY(g->d_list_n.ensure(g->task_cap)); TRY(g->d_list_w.ensure(g->task_cap)); TRY(g->d_list_l.ensure(g->task_cap));
             TRY(g->d_units.ensure((size_t)g->unit_cap + 1)); TRY(g->d_parc.ensure((size_t)g->parc_cap + 1));
             ThJobTables J; J.roff = in.d_roff.p; J.read_ch_base = g->d_read_ch_base.p; J.read_ch_n = g->d_read_ch_n.p;
             J.par = g->d_par.p; J.par_off = g->d_par_off.p; J.par_n = g->d_par_n.p; J.par_dst = g->d_par_dst.p; J.parc = g->d_parc.p;
-            J.tasks = g->d_tasks.p; J.units = g->d_units.p; J.jobs = g->d_jobs.p; J.list_n = g->d_list_n.p; J.list_w = g->d_list_w.p;
+            J.tasks = g->d_tasks.p; J.units = g->d_units.p; J.jobs = g->d_jobs.p; J.list_n = g->d_list_n.p; J.list_w = g->d_list_w.p; J.list_l = g->d_list_l.p; J.cls_mask = (env_int("TH_POA_LONG", 1) ? 3 : 1) | (env_int("TH_POA_FORCE_LONG", 0) ? 4 : 0);
             J.task_cap = g->task_cap; J.unit_cap = g->unit_cap; J.parc_cap = g->parc_cap;
             ThScanCaps caps; caps.on = 1; for (int k = 0; k < 8; ++k) caps.v[k] = 0x7fffffff;
             caps.v[0] = g->parc_cap; caps.v[1] = g->task_cap; caps.v[2] = g->unit_cap;
@@ -547,7 +550,7 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
     }
     if (cnt->err & TH_E_MSA_UNITS) return th_fail("Not enough sequences to perform msa.");        // src/abpoa_cons.c:61
     if (cnt->err) return th_fail("stage 1-3 kernels reported error flags " + std::to_string(cnt->err));
-    const int n_rec = cnt->rec, nt = cnt->n_task, par_total = cnt->par_total, n_task_n = cnt->n_task_n, n_task_w = nt - n_task_n;
+    const int n_rec = cnt->rec, nt = cnt->n_task, par_total = cnt->par_total, n_task_n = cnt->n_task_n, n_task_l = cnt->n_task_l, n_task_w = nt - n_task_n - n_task_l;
     const long long cons_total = (long long)cnt->cons_total + 16; const int aln_total = cnt->aln_total;
     if (trace) fprintf(stderr, "[th] %.3f s: stages 1-3 and job tables done, %d chains, %d jobs (device malloc %.3f s for %.2f GB in %d calls, free %.3f s so far)\n", th_wall_s() - t_run0, n_rec, nt, g_alloc_s, g_alloc_bytes / 1e9, g_alloc_n, g_free_s);
 
@@ -563,14 +566,16 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
         // recent rows as int16 in LDS (packed rows, 6 waves per SIMD); jobs whose scores may not fit int16 (long units, unusual scoring)
         // or whose units exceed its query staging buffer run on the 32-bit-ring variant.
         const int poa_test_fail = std::max(0, env_int("TH_POA_TEST_FAIL", 0));   // test knob, see th_k_poa
-        const long long need_n = std::max<long long>(1024, (long long)cnt->need_n), need_w = std::max<long long>(1024, (long long)cnt->need_w);
+        const long long need_n = std::max<long long>(1024, (long long)cnt->need_n), need_w = std::max<long long>(1024, (long long)cnt->need_w), need_l = std::max<long long>(1024, (long long)cnt->need_l);
         const int wv_n = n_task_n ? th_poa_waves(g, n_task_n, need_n) : 0, wv_w = n_task_w ? th_poa_waves(g, n_task_w, need_w) : 0;
+        const int wv_l = n_task_l ? std::min(th_poa_waves(g, n_task_l, need_l), g->waves_poa / 2) : 0;       // (three waves per SIMD)
         // a handle reserved for larger batches takes the scratch of the full persistent grid at once (with slack for longer units)
         const long long wv_alloc = g->reserve_n > n ? th_poa_waves(g, std::max(g->reserve_n, n_task_n), need_n) : wv_n;
-        TRY(g->d_scratch.ensure((size_t)std::max<long long>(std::max<long long>(need_n * std::max<long long>(wv_n, wv_alloc), need_w * wv_w), 1024)));
-        TRY(th_poa_launch(g, kt, in, g->d_list_n.p, n_task_n, false, cnt->max_unit, need_n, wv_n, &dc->q_poa_n, poa_test_fail << 8));
-        TRY(th_poa_launch(g, kt, in, g->d_list_w.p, n_task_w, true, cnt->max_unit, need_w, wv_w, &dc->q_poa_w, poa_test_fail << 8));
-        if (trace) { th_rt_sync(g->stream); fprintf(stderr, "[th] %.3f s: poa done (%d + %d jobs, %d / %d waves, %lld MB scratch)\n", th_wall_s() - t_run0, n_task_n, n_task_w, wv_n, wv_w, (long long)(std::max(need_n * wv_n, need_w * wv_w) * 4 >> 20)); }
+        TRY(g->d_scratch.ensure((size_t)std::max<long long>(std::max<long long>(std::max<long long>(need_n * std::max<long long>(wv_n, wv_alloc), need_w * wv_w), need_l * wv_l), 1024)));
+        TRY(th_poa_launch(g, kt, in, g->d_list_l.p, n_task_l, 2, cnt->max_unit, need_l, wv_l, &dc->q_poa_l, poa_test_fail << 8));       // (the long jobs first: the short ones fill the tail)
+        TRY(th_poa_launch(g, kt, in, g->d_list_n.p, n_task_n, 1, cnt->max_unit, need_n, wv_n, &dc->q_poa_n, poa_test_fail << 8));
+        TRY(th_poa_launch(g, kt, in, g->d_list_w.p, n_task_w, 0, cnt->max_unit, need_w, wv_w, &dc->q_poa_w, poa_test_fail << 8));
+        if (trace) { th_rt_sync(g->stream); fprintf(stderr, "[th] %.3f s: poa done (%d + %d + %d jobs, %d / %d / %d waves, %lld MB scratch)\n", th_wall_s() - t_run0, n_task_n, n_task_l, n_task_w, wv_n, wv_l, wv_w, (long long)(std::max(std::max(need_n * wv_n, need_w * wv_w), need_l * wv_l) * 4 >> 20)); }
         for (int pass = 0;; ++pass) {
             // ---- item lists of the alignment kernels and the compacted consensus offsets, per job, on the device ----
             KT_BEGIN(TK_ALIGN);
@@ -591,12 +596,12 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
         }
         if (cnt->n_failed) fprintf(stderr, "[tidehunter_amd] warning: %d consensus job(s) could not be aligned (POA status 3-6, or no scratch for them) and are reported without a consensus\n", cnt->n_failed);
 #if defined(TH_POA_PROF)
-        { unsigned long long pr[20]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(th_poa_prof), sizeof(pr));
+        { unsigned long long pr[20]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(thpoa_n::th_poa_prof), sizeof(pr));
           fprintf(stderr, "[poa_prof] rows %llu dp %llu traceback %llu merge %llu (cycles summed over waves)\n", pr[0], pr[1], pr[2], pr[3]);
           fprintf(stderr, "[poa_prof]   traceback: %llu tiles loaded, %llu run trips emitting %llu steps, %llu single steps\n", pr[4], pr[5], pr[6], pr[7]);
           const char *cat[6] = { "common packed", "other packed", "several predecessors", "one far predecessor", "stores full cells", "other" };
           for (int c = 0; c < 6; ++c) fprintf(stderr, "[poa_prof]   %-22s rows %12llu cycles %16llu (%.0f per row)\n", cat[c], pr[8 + c], pr[14 + c], pr[8 + c] ? (double)pr[14 + c] / pr[8 + c] : 0.0);
-          unsigned long long z[20] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(th_poa_prof), z, sizeof(z)); }
+          unsigned long long z[20] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(thpoa_n::th_poa_prof), z, sizeof(z)); }
 #endif
         // ---- unit-vs-consensus alignments and flank extensions: three item lists in one array, one kernel variant each ----
         const int ns = cnt->n_item_s, nm = ns + cnt->n_item_m, ni = nm + cnt->n_item_b, max_cl = cnt->max_cl;
