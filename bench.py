@@ -214,7 +214,10 @@ def main():
     ap.add_argument("--streamed", type=int, default=-1, help="also time the steps through th_process_batches(), H2D inside (-1: at N=1, 0: skip)")
     ap.add_argument("--others", default=None, help="comma-separated configs for `other_shapes` (default: c2,c4,c5 with the headline workload at N=1; '' to skip)")
     ap.add_argument("--digest", action="store_true", help="add an md5 over all records of the timed steps in read order (tests)")
+    ap.add_argument("--quick", action="store_true", help="the timed steps only: no CPU baseline, end-to-end run, streamed run or other shapes (profiler passes)")
     a = ap.parse_args()
+    if a.quick:
+        a.cpu_sample, a.e2e, a.streamed, a.others = 0, 0, 0, ""
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:

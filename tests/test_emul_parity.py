@@ -414,3 +414,14 @@ def test_emul_poa_relative_score_variant(monkeypatch):
     got = th.process(seqs)
     assert U.assert_records_equal(seqs, got, O.default_para(match=5, mismatch=9, gap_open1=8, gap_ext1=4, gap_open2=30, gap_ext2=2), "relative-score POA, other scoring") >= 6
     th.close()
+
+
+def test_emul_poa_long_variant_three_trip_rows(emu):
+    """a read of 2100-base units (9 copies): its POA runs on thpoa_l with bands of more than 256 columns, i.e. three 128-column trips per
+    row, some starting at an odd column with the ring's full width (the case a ring of 3 x 128 columns got wrong: a band of RW columns
+    from an odd start needs RW + 2 slots); records equal the oracle's"""
+    seq = U.read_fastx(os.path.join(U.DATA, "long_unit_2100x9.fa"))[0][1]
+    th = TH.TideHunter(lib_path=emu)
+    got = th.process([seq])
+    assert U.assert_records_equal([seq], got, O.default_para(), "2100 x 9") == 1
+    th.close()

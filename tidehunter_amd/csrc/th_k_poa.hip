@@ -68,7 +68,7 @@ __device__ __forceinline__ uint32_t th_d16_expand(uint32_t w)
 //   thpoa_n  ring rows of up to 192 columns (two trips of 128), absolute int16 scores: units of up to ~1500 bases (TH_POA_QCAP staged
 //            bases; longer ones whose scores may leave int16 are given back with status 7), 6 waves per SIMD -- and the 32-bit-ring
 //            variants <8192, int> / <0, int> for everything else;
-//   thpoa_l  ring rows of up to 384 columns (three trips), int16 scores RELATIVE to a running base that follows the row maxima: units
+//   thpoa_l  ring rows of up to 382 columns (three trips), int16 scores RELATIVE to a running base that follows the row maxima: units
 //            of up to TH_POA_QCAP_LONG bases (configs 4 and 5: periods of 2000 and 5000) on the packed path instead of one column per
 //            lane in 32 bits, 3 waves per SIMD.
 #ifndef TH_POA_OCC
@@ -78,7 +78,12 @@ __device__ __forceinline__ uint32_t th_d16_expand(uint32_t w)
 #define TH_POA_RW_N 192         // widest cached band, thpoa_n
 #endif
 #define TH_POA_QCAP_LONG 6144   // query bases staged in LDS by thpoa_l
-#define TH_POA_RW_L 384         // widest cached band, thpoa_l
+#ifndef TH_POA_RW_L
+#define TH_POA_RW_L 382         // widest cached band, thpoa_l (a band of RW columns may start at an odd column: RW + 2 <= 128 x trips)
+#endif
+#ifndef TH_POA_TRIPS_L
+#define TH_POA_TRIPS_L 3
+#endif
 #ifndef TH_POA_REL_THR
 #define TH_POA_REL_THR (-24000) // relative scores below this are minus infinity
 #endif
@@ -101,7 +106,7 @@ __device__ __forceinline__ uint32_t th_d16_expand(uint32_t w)
 
 #define TH_POA_NS thpoa_l
 #define TH_POA_RW TH_POA_RW_L
-#define TH_POA_TRIPS 3
+#define TH_POA_TRIPS TH_POA_TRIPS_L
 #define TH_POA_REL 1
 #define TH_POA_OCC_NS 3
 #include "th_k_poa_body.h"

@@ -1,6 +1,7 @@
 // th_k_poa_body.h -- the POA kernels, compiled once per configuration (th_k_poa.hip sets TH_POA_NS, TH_POA_RW, TH_POA_TRIPS, TH_POA_REL,
 // TH_POA_OCC_NS and includes this file; no include guard on purpose).
 namespace TH_POA_NS {
+static_assert(TH_POA_RW + 2 <= 128 * TH_POA_TRIPS && (TH_POA_RW & 1) == 0, "a packed row covers its band from the even column at or below its start");
 struct ThPoaG {
     int cap, n_node;
     // by node id
@@ -301,9 +302,11 @@ __device__ unsigned long long th_poa_prof[20];    // 0..3 phase cycles; 4..7 tra
 // reached from the path's cell of its column by a vertical gap, from the row maximum's cell by a horizontal one), far above
 // TH_POA_REL_THR; anything below that threshold is minus infinity and is stored as exactly -32768 (it cannot drift upwards).
 #if TH_POA_REL
+#define TH_POA_SET_RMAX(v) (L_rmax = TH_UNI(v))
 #define TH_RING_LD(x) ((int)(x) < TH_POA_REL_THR ? TH_NEG : (int)(x) + base)
 #define TH_RING_ST(v) ((RT)((v) - base < TH_POA_REL_THR ? -32768 : (v) - base))
 #else
+#define TH_POA_SET_RMAX(v) ((void)0)
 #define TH_RING_LD(x) (WIDE ? (int)(x) : ((int)(x) < neg_thr ? TH_NEG : (int)(x)))
 #define TH_RING_ST(v) ((RT)(WIDE ? (v) : max((v), -32768)))
 #endif
@@ -333,6 +336,16 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
     for (int t0 = 0; t0 < TH_POA_TRIPS * 128; t0 += 128) {
         const int jr = t0 + 2 * lane, j0 = B0 + jr;
         const int wi = (jr + TH_POA_PAD) >> 1;              // this lane's pair in the row being written
+#if TH_POA_TRIPS == 2
+        if (t0 && B0 + t0 > e) {                             // one trip was enough: clear the rest of the slot, unless it is clean already
+            if (tail_dirty & (1 << myslot)) {                // (bit s of tail_dirty: slot s may hold values beyond its first 128 columns)
+                if (wi < TH_POA_RS / 2) { wH[wi] = TH_PK_NEG; wE1[wi] = TH_PK_NEG; wE2[wi] = TH_PK_NEG; }
+                tail_dirty &= ~(1 << myslot);
+            }
+            break;
+        }
+        if (t0) tail_dirty |= 1 << myslot;
+#else
         if (t0 && B0 + t0 > e) {                             // the trips so far were enough: clear the rest of the slot, unless it is clean already
             const int tdone = t0 >> 7, told = TH_TD_GET(tail_dirty, myslot);      // trips 0 .. tdone - 1 written now; trips 1 .. told held values before
             for (int tt = tdone; tt <= told; ++tt) {
@@ -343,6 +356,7 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
             break;
         }
         if (t0 && (t0 >> 7) > TH_TD_GET(tail_dirty, myslot)) TH_TD_SET(tail_dirty, myslot, t0 >> 7);
+#endif
         const bool lo_ok = j0 >= b && j0 <= e, hi_ok = j0 + 1 <= e;
         const uint32_t IM = (lo_ok ? 0xffffu : 0u) | (hi_ok ? 0xffff0000u : 0u);
         // substitution scores of the two columns from the row's table
@@ -458,7 +472,7 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
 #define TH_POA_PK_PROF(cat)
 #endif
 #define TH_POA_PK_ROW_DONE(cat, FOFF) do { \
-        L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = 3; L_rmax = TH_UNI(rmax); \
+        L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = 3; TH_POA_SET_RMAX(rmax); \
         TH_POA_PK_PROF(cat) \
         th_writelane6(m_beg, m_end, m_left, m_right, m_off, m_foff, b, e, L_l, L_r, my_off, (FOFF), sl); \
         if (sl == 63 || i + 2 >= n) { \
@@ -521,7 +535,11 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     // (one v_writelane each per row); they go to the row tables in HBM 64 rows at a time, so the common row issues no
     // metadata store at all.  A predecessor inside the chunk is read back with v_readlane, an older one from the tables.
     int m_beg = 0, m_end = 0, m_left = 0, m_right = 0, m_off = 0, m_foff = 0;
-    int tail_dirty = (1 << (2 * TH_POA_RING)) - 1;      // per ring slot (2 bits): the last trip whose columns are not known to hold minus infinity (see th_poa_pk_row); all of them at first
+#if TH_POA_TRIPS == 2
+    int tail_dirty = (1 << TH_POA_RING) - 1;      // ring slots whose columns beyond the first 128 are not known to hold minus infinity (see th_poa_pk_row)
+#else
+    int tail_dirty = (1 << (2 * TH_POA_RING)) - 1;      // per ring slot (2 bits): the last trip whose columns are not known to hold minus infinity; all of them at first
+#endif
     for (int x = lane; x < TH_POA_RING * 3 * TH_POA_PAD; x += TH_WAVE) s_ring[x / (3 * TH_POA_PAD)][(x / TH_POA_PAD) % 3][x % TH_POA_PAD] = (RT)(WIDE ? TH_NEG : -32768);
     TH_WAVE_FENCE();
 #if defined(TH_POA_PROF)
@@ -727,7 +745,11 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             uint32_t *wH = (uint32_t *)s_ring[myslot][0], *wE1 = (uint32_t *)s_ring[myslot][1], *wE2 = (uint32_t *)s_ring[myslot][2];
             for (int x = TH_POA_PAD / 2 + lane; x < TH_POA_RS / 2; x += TH_WAVE) { wH[x] = TH_PK_NEG; wE1[x] = TH_PK_NEG; wE2[x] = TH_PK_NEG; }
             TH_WAVE_FENCE();
-            TH_TD_SET(tail_dirty, myslot, TH_POA_TRIPS - 1);            // the cells written below may reach beyond the slot's first 128 columns
+#if TH_POA_TRIPS == 2
+            tail_dirty |= 1 << myslot;            // the cells written below may reach beyond the slot's first 128 columns
+#else
+            TH_TD_SET(tail_dirty, myslot, TH_POA_TRIPS - 1);
+#endif
         }
         int carry1 = TH_NEG + b * E1, carry2 = TH_NEG + b * E2;
         for (int c0 = b; c0 <= e; c0 += TH_WAVE) {
@@ -808,7 +830,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         }
         const int cstate = cache_me ? 3 : 0;
         L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = cstate;
-        L_rmax = TH_UNI(pk ? rmax : rmax - base);      // (the 32-bit path works with absolute scores)
+        TH_POA_SET_RMAX(pk ? rmax : rmax - base);      // (the 32-bit path works with absolute scores)
 #if defined(TH_POA_PROF)
         { const unsigned long long dt = __builtin_amdgcn_s_memtime() - row_t0;
           const int cat = pk ? 1 : inn != 1 ? 2 : p0 != i - 1 ? 3 : needfull ? 4 : 5;     // (0: common packed row) / other packed / several predecessors / one far predecessor / stores full cells / other
@@ -1153,3 +1175,6 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
     }
 }
 }  // namespace TH_POA_NS
+#undef TH_RING_LD
+#undef TH_RING_ST
+#undef TH_POA_SET_RMAX

@@ -12,7 +12,7 @@ S=$(ls $W/*gfx950*.s | head -1)
 python3 - "$S" <<'PY'
 import re, sys
 txt = open(sys.argv[1]).read()
-m = re.search(r'^(_Z8th_k_poaILi3072Es[^:\n]*):\s.*?^\s*\.amdhsa_kernel \1(.*?)\.end_amdhsa_kernel', txt, re.S | re.M)
+m = re.search(r'^(_ZN7thpoa_n8th_k_poaILi3072Es[^:\n]*):\s.*?^\s*\.amdhsa_kernel \1(.*?)\.end_amdhsa_kernel', txt, re.S | re.M)
 body = m.group(0)
 ins = [l.split()[0] for l in body.splitlines() if l.startswith('\t') and not l.strip().startswith((';', '.'))]
 v = sum(i.startswith('v_') for i in ins); s = sum(i.startswith('s_') for i in ins)

@@ -6,7 +6,7 @@ B=${TH_BENCH_BATCH:-32768}; export TH_BENCH_BATCH=$B
 rocprofv3 -L > $O/counters_avail.txt 2>&1
 pass() { # tag, counters...
   tag=$1; shift
-  timeout 900 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$tag -o run -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --e2e 0 > $O/$tag.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$tag -o run -- python3 $R/bench.py --steps 1 --warmup 0 --quick > $O/$tag.log 2>&1
 }
 pass p1 SQ_INSTS_LDS SQ_INSTS_VALU
 pass p2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
