@@ -58,7 +58,8 @@ struct ThCnt {
     int n_item_s, n_item_m, n_item_b, cc_total, max_cl, pad2[3];
     int n_defer, q_aln_d;    // unit alignments deferred to the strip-engine launch, and that launch's queue head
     int aln_wide[2];         // wide first bands (three registers per lane and more) tried / failed in the big-area alignment launch
-    int pad3[20];
+    int max_need_big;        // bytes of staging area the largest item of the third alignment list could ask for
+    int pad3[19];
 };
 static_assert(sizeof(ThCnt) == 256, "counter block");
 #define TH_E_REC_OVERFLOW 1       // chain record arena too small (rerun the extraction with a larger one)

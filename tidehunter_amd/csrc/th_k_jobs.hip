@@ -184,6 +184,7 @@ th_k_scan_rows(const int *__restrict__ n_ptr, int n_fixed, int *__restrict__ row
 struct ThAlnItem { int task, which; };   // which >= 0: unit index in the run; -1 left extension; -2 right extension
 #define TH_ALN_SMALL 4096
 #define TH_ALN_MID 7168
+#define TH_ALN_BIG16 16384
 #define TH_ALN_BIG 24576
 // Items whose two sequences fit the small staging area of the anti-diagonal engine (4 KB: 5 waves per SIMD) form the first list; jobs
 // whose unit + consensus fit 7 KB with at most two registers per lane (periods up to ~2500) a second one for the same register budget
@@ -207,7 +208,9 @@ th_k_items_count(const int *__restrict__ n_tasks, const ThTask *__restrict__ tas
     const int cl = st ? 0 : cons_len[t];
     const ThTask T = tasks[t];
     int c[TH_ITEM_COLS] = { 2, 0, 0, (cl + 3) & ~3 };
-    c[th_aln_class(T, cl, wdiv, wadd, wtol)] += T.pos_n - 1;
+    const int cls = th_aln_class(T, cl, wdiv, wadd, wtol);
+    c[cls] += T.pos_n - 1;
+    if (cls == 2) atomicMax(&C->max_need_big, T.max_len + cl + 512 * 6 + 16);      // staging area the largest third-list item could ask for
 #pragma unroll
     for (int k = 0; k < TH_ITEM_COLS; ++k) rows[(long long)t * TH_ITEM_COLS + k] = c[k];
     atomicMax(&C->max_cl, cl);

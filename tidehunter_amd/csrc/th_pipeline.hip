@@ -589,7 +589,7 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
             TRY(th_fetch_cnt(g, &cnt));                                                 // ---- host synchronisation 2 of 3 ----
             if (pass == 0 && cnt->n_retry) {
                 TRY(th_poa_retries(g, kt, in, nt, poa_test_fail));
-                TH_LAUNCH(th_k_cnt_set, 1, 64, g->stream, &dc->n_retry, 0, &dc->n_failed, 0, &dc->max_cl, 0, (int *)nullptr, 0);
+                TH_LAUNCH(th_k_cnt_set, 1, 64, g->stream, &dc->n_retry, 0, &dc->n_failed, 0, &dc->max_cl, 0, &dc->max_need_big, 0);
                 continue;
             }
             break;
@@ -623,7 +623,11 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
                 // the big-area variant hands the alignments its anti-diagonal engine could not certify on to a second launch of the small-area one
                 // (mode 3): same results, but their strip-engine work then runs at three waves per SIMD instead of one or two
                 TRY(g->d_defer.ensure((size_t)big_n)); TRY(g->d_defer_s1.ensure((size_t)big_n));
-                TH_LAUNCH((th_k_align<TH_ALN_BIG, 6>), std::min(big_n, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(big_first, big_n, &dc->q_aln_b), g->aln_mode, g->aln_xpct, no_n, g->d_defer.p, &dc->n_defer, dc->aln_wide, no_s1, g->d_defer_s1.p);
+                // (16 KB of staging area when every item fits it -- units of up to ~6000 bases: eight waves per CU instead of six)
+                if (cnt->max_need_big <= TH_ALN_BIG16)
+                    TH_LAUNCH((th_k_align<TH_ALN_BIG16, 6>), std::min(big_n, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(big_first, big_n, &dc->q_aln_b), g->aln_mode, g->aln_xpct, no_n, g->d_defer.p, &dc->n_defer, dc->aln_wide, no_s1, g->d_defer_s1.p);
+                else
+                    TH_LAUNCH((th_k_align<TH_ALN_BIG, 6>), std::min(big_n, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(big_first, big_n, &dc->q_aln_b), g->aln_mode, g->aln_xpct, no_n, g->d_defer.p, &dc->n_defer, dc->aln_wide, no_s1, g->d_defer_s1.p);
                 if (g->aln_mode == 1) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(big_n, wa), TH_ALN_BLOCK, g->stream, (const ThAlnItem *)g->d_defer.p, 0, (const ThTask *)g->d_tasks.p, (const int *)g->d_parc.p,
                               (const uint32_t *)in.d_roff.p, (const uint8_t *)g->d_bseq.p, (const uint8_t *)g->d_cons.p, (const int *)g->d_cons_len.p,
                               g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, &dc->err, &dc->q_aln_d, g->aln_wdiv, g->aln_wadd, g->aln_wtol, 3, g->aln_xpct, (const int *)&dc->n_defer, no_defer, no_dn, no_ws, (const int *)g->d_defer_s1.p, no_ds1);
