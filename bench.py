@@ -6,7 +6,8 @@ unit/consensus alignments -> host record arithmetic) over one batch of synthetic
 workload: BASELINE.json configs[2], the headline (period 1000 x 10 copies, 10 % error, ~10 kb reads,
 100 000 reads per step per GPU = the config's whole read set); --config c2 / c4 / c5 select the other shapes of SURVEY.md 8(d).
 The config's read set is generated ONCE per rank (deterministic generator, ~1 GB at the headline shape) and every step processes
-the same batch drawn from it; the batch is uploaded to HBM before the timed region (inputs resident).
+the same batch drawn from it; the batch is uploaded to HBM before the timed region (inputs resident), and the K timed passes run back to back in ONE region
+(th_batch_run_steps: the host-side record arithmetic of pass k overlaps the kernels of pass k+1, the last pass's ends inside the region).
 
   python bench.py --gpus N --steps K --warmup W
 For N > 1 the driver launches one rank per GPU with torch.distributed.run (started from here as a child process when
@@ -352,8 +353,8 @@ def main():
         n_reads_mine += len(batch)
         bases_mine += sum(len(s) for s in batch)
 
-    for b in range(a.warmup, n_batches):
-        if a.steal > 0:
+    if a.steal > 0:
+        for b in range(a.warmup, n_batches):
             # dynamic: blocks from the shared ticket counter; the upload of a block cannot precede the timed region
             sync_all()
             t0 = time.perf_counter()
@@ -375,26 +376,26 @@ def main():
                     account(batch, recs, cuts[k])
                 else:
                     n_reads_mine += len(batch); bases_mine += sum(len(s) for s in batch)
-        else:
-            # static: this rank's block is made resident first (upload outside), then run + collect are timed
-            th.upload(my_batch)
-            sync_all()
-            t0 = time.perf_counter()
-            th.run()                 # all kernels + the small D2H of result records
-            th.collect_native()      # host-side record arithmetic in C (src/gen_cons.c:208-301)
-            if on_gpu:
-                torch.cuda.synchronize()
-            t_total += time.perf_counter() - t0
-            n_syncs = th.syncs()
-            add_timing()
-            blocks_mine += th.launches()                        # TH_SUBBATCH > 1: several concurrent parts, that many launches of every kernel
-            if a.digest or b == n_batches - 1:
-                account(my_batch, th.records(), cuts[rank])     # Python dict view for the byte accounting (every step has the same records): not part of the path
-            else:
-                n_reads_mine += len(my_batch); bases_mine += sum(len(s) for s in my_batch)
+    else:
+        # static: this rank's block is made resident first (upload outside), then EXACTLY K passes are timed in one region:
+        # th_batch_run_steps() runs all kernels + the small D2H of result records of pass k+1 while the host-side record arithmetic
+        # (src/gen_cons.c:208-301, in C) of pass k fills the tandem_seq_t slots -- the last pass's arithmetic ends inside the region
+        th.upload(my_batch)
+        sync_all()
+        t0 = time.perf_counter()
+        kstep = th.run_steps(a.steps)
+        if on_gpu:
+            torch.cuda.synchronize()
+        t_total += time.perf_counter() - t0
+        n_syncs = th.syncs()
+        for kname, v in kstep.items():
+            kms[kname] = kms.get(kname, 0.0) + v
+        blocks_mine += th.launches() * a.steps              # TH_SUBBATCH > 1: several concurrent parts, that many launches of every kernel
+        account(my_batch, th.records(), cuts[rank])         # Python dict view for the byte accounting (every pass has the same records): not part of the path
+        n_reads_mine += len(my_batch) * (a.steps - 1); bases_mine += sum(len(s) for s in my_batch) * (a.steps - 1)
     sync_all()
     # the byte accounting ran on the last step (all steps process the same reads): scale it to the timed steps
-    if not a.digest and a.steps > 1:
+    if (a.steal == 0 or not a.digest) and a.steps > 1:
         n_cons *= a.steps; alg_bytes *= a.steps
     tot = torch.tensor([float(n_reads_mine), float(bases_mine), float(n_cons), float(alg_bytes)], dtype=torch.float64)
     if dist is not None:
@@ -478,7 +479,7 @@ def main():
         if e2e is not None:
             out["value_e2e"] = e2e
         if world == 1 and a.cpu_sample != 0:
-            n_cpu = a.cpu_sample if a.cpu_sample > 0 else min(4096, max(64, 24 * effective_cpus()))
+            n_cpu = a.cpu_sample if a.cpu_sample > 0 else min(8192, max(256, 400 * effective_cpus()))      # ~15 s of oracle time at ~28 reads/s per core
             out["cpu_baseline"] = cpu_baseline(read_at, n_cpu, cfg)
         others = a.others if a.others is not None else ("c2,c4,c5" if (a.config == "c3" and world == 1 and "TH_BENCH_LIB" not in os.environ) else "")
         if others:

@@ -107,6 +107,9 @@ int th_batch_syncs(th_handle_t *h);
  * n_batches calls of th_process_batch(); this is the loop body of mini_tandem() (src/main.c:396-432) with its three phases
  * overlapped.  th_run_file() drives the same pipeline from the reader. */
 int th_process_batches(th_handle_t *h, int n_batches, const char *const *const *seqs, const int *const *lens, const int *n, th_tandem_seq_t *const *out);
+/* the resident batch (th_batch_upload) run `steps` times, the record arithmetic of pass k under the kernels of pass k+1; ms_kernel
+ * (8 doubles, may be NULL): device milliseconds per kernel summed over the passes -- bench.py's timed region */
+int th_batch_run_steps(th_handle_t *h, int steps, th_tandem_seq_t *out, double *ms_kernel);
 
 /* mini_tandem_output(), src/main.c:214-271 (resets the slots after printing, as the reference does) */
 void th_output(FILE *fp, int n, const char *const *names, const char *const *seqs, const int *lens,

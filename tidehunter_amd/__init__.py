@@ -70,6 +70,7 @@ def load_library(path=None):
     lib.th_batch_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     lib.th_batch_launches.argtypes = [C.c_void_p]
     lib.th_batch_syncs.argtypes = [C.c_void_p]
+    lib.th_batch_run_steps.argtypes = [C.c_void_p, C.c_int, C.POINTER(TandemSeq), C.POINTER(C.c_double)]
     lib.th_process_batches.argtypes = [C.c_void_p, C.c_int, C.POINTER(pp), C.POINTER(ip), ip, C.POINTER(C.POINTER(TandemSeq))]
     lib.th_run_file.argtypes = [C.c_char_p, C.POINTER(Para), C.c_void_p, C.c_int, C.c_int]
     lib.th_synth_read.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_char_p, C.c_int]
@@ -173,6 +174,13 @@ class TideHunter:
     def launches(self):
         """concurrent parts the last uploaded batch runs as (1, or 2 for batches of TH_SUBBATCH_MIN = 16384 reads and more)"""
         return self.lib.th_batch_launches(self.h)
+
+    def run_steps(self, steps):
+        """th_batch_run_steps(): the resident batch `steps` times, record arithmetic of pass k under the kernels of pass k+1; the slots hold
+        the last pass's records afterwards (records()).  Returns the device ms per kernel summed over the passes."""
+        a = (C.c_double * 8)()
+        self._check(self.lib.th_batch_run_steps(self.h, steps, self._ts, a))
+        return {self.KERNELS[i]: a[i] for i in range(6)}
 
     def syncs(self):
         """host synchronisations (stream drains) of the last run()"""

@@ -916,6 +916,8 @@ typedef struct th_stage3 {
     pthread_mutex_t mu; pthread_cond_t cv;
     int up_done, run_done, col_done, n_total;       /* batches past each stage; n_total: how many there will be (-1: not known yet) */
     int failed;
+    int resident;                /* th_batch_run_steps(): every step runs the batch that sits in input set 0 (nothing is uploaded) */
+    double ms_kernel[8];         /* device milliseconds per kernel, summed over the runs */
     /* batch k of this pipeline: reads and result slots (ring of 8: at most 4 batches are in flight) */
     struct { const char *const *seqs; const int *lens; int n; th_tandem_seq_t *out; void *tag; } b[8];
     void (*on_done)(struct th_stage3 *, int k, void *tag);      /* called by the collecting thread when batch k is complete */
@@ -952,7 +954,9 @@ static void *st3_runner(void *arg)
         if (!st3_wait(p, &p->up_done, k)) return NULL;
         if (k >= 2) st3_wait(p, &p->col_done, k - 2);            /* result set k & 1 is free once batch k-2 has been collected */
         const double t0 = now_s();
-        if (!p->failed && p->b[k & 7].n > 0 && batch_run_s(p->h, k, k)) p->failed = 1;
+        if (!p->failed && p->b[k & 7].n > 0 && batch_run_s(p->h, p->resident ? 0 : k, k)) p->failed = 1;
+        if (!p->failed && p->b[k & 7].n > 0)
+            for (int s = 0; s < p->h->res[k & 1].n_sub; ++s) { th_gpu_out_t o; th_gpu_get(p->h->gpu[s], k, &o); for (int i = 0; i < 8; ++i) p->ms_kernel[i] += o.ms_kernel[i]; }
         p->busy_run += now_s() - t0;
         st3_bump(p, &p->run_done);
     }
@@ -982,6 +986,29 @@ int th_process_batches(th_handle_t *h, int n_batches, const char *const *const *
     if (getenv("TH_TRACE")) fprintf(stderr, "[th_process_batches] %d batches: busy upload %.3f s, run %.3f s, collect %.3f s\n", n_batches, p.busy_up, p.busy_run, p.busy_col);
     st3_destroy(&p);
     if (bad && !g_err[0]) snprintf(g_err, sizeof(g_err), "a batch failed on the device (see stderr)");
+    return bad ? -1 : 0;
+}
+
+/* The resident batch (th_batch_upload) run `steps` times: the kernels of pass k+1 overlap the record arithmetic of pass k (second
+ * result set), as in the file driver; every pass fills out[0..n).  ms_kernel (8 doubles, optional) receives the device milliseconds
+ * per kernel summed over the passes.  This is bench.py's timed region: inputs resident, K passes, nothing else inside. */
+int th_batch_run_steps(th_handle_t *h, int steps, th_tandem_seq_t *out, double *ms_kernel)
+{
+    th_stage3_t p; st3_init(&p, h); p.resident = 1;
+    pthread_t t_run, t_col;
+    if (pthread_create(&t_run, NULL, st3_runner, &p) != 0) { st3_destroy(&p); return host_fail("pthread_create failed"); }
+    if (pthread_create(&t_col, NULL, st3_collector, &p) != 0) { st3_finish(&p, 0); pthread_join(t_run, NULL); st3_destroy(&p); return host_fail("pthread_create failed"); }
+    for (int k = 0; k < steps; ++k) {
+        if (k >= 2) st3_wait(&p, &p.run_done, k - 2);
+        p.b[k & 7].seqs = h->up[0].seqs; p.b[k & 7].lens = h->up[0].lens; p.b[k & 7].n = h->up[0].n; p.b[k & 7].out = out; p.b[k & 7].tag = NULL;
+        st3_bump(&p, &p.up_done);
+    }
+    st3_finish(&p, steps);
+    pthread_join(t_run, NULL); pthread_join(t_col, NULL);
+    const int bad = p.failed;
+    if (ms_kernel) for (int i = 0; i < 8; ++i) ms_kernel[i] = p.ms_kernel[i];
+    st3_destroy(&p);
+    if (bad && !g_err[0]) snprintf(g_err, sizeof(g_err), "a pass failed on the device (see stderr)");
     return bad ? -1 : 0;
 }
 
