@@ -142,14 +142,15 @@ def cli_e2e(set_reads, copies, cfg, batch_opt, n_runs=2):
         with open(path, "wb") as f:
             for c in range(copies):
                 f.write(b"".join(b">syn_%d\n" % (c * len(set_reads) + i) + s + b"\n" for i, s in enumerate(set_reads)))
-        # the first GPU process on a machine pays for things that are not this program's (driver and runtime start-up, code-object
-        # caches, clocks): a 2000-read run takes them, listed apart and not part of `value`
-        wpath = path + ".warm"
+        # the first GPU process on a machine pays for things that are not this program's (driver and runtime start-up -- seen: 4 s until the
+        # first handle is ready -- and the first large device allocation on untouched HBM -- seen: 3.5 s): a run over one small and one full
+        # batch takes them, listed apart with its own rate and not part of `value`
+        wpath, n_warm = path + ".warm", min(len(set_reads), batch_opt + batch_opt // 4)
         with open(wpath, "wb") as f:
-            f.write(b"".join(b">w_%d\n" % i + s + b"\n" for i, s in enumerate(set_reads[:2000])))
+            f.write(b"".join(b">w_%d\n" % i + s + b"\n" for i, s in enumerate(set_reads[:n_warm])))
         t0 = time.time()
-        subprocess.run([exe, *cfg.get("cli_opts", []), "-o", outp, wpath], check=True, capture_output=True)
-        machine_warmup = {"reads": min(2000, len(set_reads)), "wall_s": time.time() - t0}
+        subprocess.run([exe, *cfg.get("cli_opts", []), "-b", str(batch_opt), "-o", outp, wpath], check=True, capture_output=True)
+        machine_warmup = {"reads": n_warm, "wall_s": time.time() - t0, "reads_per_s_with_process_startup": n_warm / (time.time() - t0)}
         os.unlink(wpath)
         for _ in range(n_runs):
             t0 = time.time()
@@ -449,7 +450,7 @@ def main():
                 prof = json.load(open(os.path.join(ROOT, "profiles", pf)))
                 if prof.get("reads_per_launch") == B * a.steps // launches and prof.get("config", "c3") == a.config and a.steal == 0:
                     for kname, v in prof["kernels"].items():
-                        if kname.replace("void ", "").split("<")[0] == dom:
+                        if kname.replace("void ", "").split("<")[0].split("::")[-1] == dom:
                             traffic, traffic_src = v["hbm_bytes_per_launch_corrected"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % pf
             except (OSError, ValueError, KeyError):
                 pass
