@@ -425,3 +425,32 @@ def test_emul_poa_long_variant_three_trip_rows(emu):
     got = th.process([seq])
     assert U.assert_records_equal([seq], got, O.default_para(), "2100 x 9") == 1
     th.close()
+
+
+def test_emul_single_copy_reads_searched_on_the_device():
+    """-F -s (src/gen_cons.c:128-171): reads that carry the adapters once -- sense, antisense, with errors, adapters twice, lower case --
+    get their full-length record from th_k_adapter_reads (whole-read Myers searches over the uploaded bytes, up to three per query as
+    collect_ed_res does); records equal the oracle's"""
+    rng = np.random.default_rng(5)
+    rnd = lambda n: bytes(b"ACGT"[i] for i in rng.integers(0, 4, n))
+    comp = bytes.maketrans(b"ACGTacgtN", b"TGCAtgcaN")
+    rc = lambda s: s.translate(comp)[::-1]
+    ad = (os.path.join(U.DATA, "5prime.fa"), os.path.join(U.DATA, "3prime.fa"))
+    five, three = U.read_fastx(ad[0])[0][1], U.read_fastx(ad[1])[0][1]
+    def mut(s, n):
+        s = bytearray(s)
+        for _ in range(n):
+            s[int(rng.integers(0, len(s)))] = b"ACGT"[int(rng.integers(0, 4))]
+        return bytes(s)
+    unit = five + rnd(300) + rc(three)
+    seqs = [rnd(40) + unit + rnd(25), rc(rnd(10) + unit + rnd(70)), rnd(5) + mut(five, 3) + rnd(250) + rc(mut(three, 1)) + rnd(5),
+            rnd(30) + unit + rnd(90) + unit + rnd(12), (rnd(20) + unit + rnd(20)).lower(), rnd(400), five + rnd(20) + rc(three), b"ACGT" * 2]
+    kw = dict(only_full_length=1, single_copy=1)
+    for extra in (dict(), dict(out_fmt=4), dict(ada_match_rat=0.7)):
+        th = TH.TideHunter(lib_path=U.emul_lib_path(), adapters=ad, **kw, **extra)
+        got = th.process(seqs)
+        para = O.default_para(**kw, **extra)
+        O.load().tho_para_load_adapters(para, ad[0].encode(), ad[1].encode())
+        n = U.assert_records_equal(seqs, got, para, "single copy %r" % (extra,))
+        assert n >= 4, n
+        th.close()

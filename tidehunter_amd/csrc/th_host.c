@@ -557,6 +557,7 @@ static th_handle_t *th_init_sub(const th_para_t *p, int device, int n_sub_max)
     gp.k = (int)p->k; gp.w = (int)p->w; gp.hpc = p->hpc ? 1 : 0; gp.min_p = (uint32_t)p->min_p; gp.max_p = (uint32_t)p->max_p; gp.one_minus_div = 1 - p->max_div; gp.min_copy = p->min_copy;
     gp.match = p->match; gp.mismatch = p->mismatch; gp.go1 = p->gap_open1; gp.ge1 = p->gap_ext1; gp.go2 = p->gap_open2; gp.ge2 = p->gap_ext2;
     gp.only_unit = p->only_unit;
+    gp.single_copy = (p->single_copy == 1 && p->only_full_length) ? 1 : 0;
     gp.want_cov = (p->min_cov > 0 || p->min_frac > 0.0 || p->out_fmt == TH_FASTQ_FMT || p->out_fmt == TH_TAB_QUAL_FMT) ? 1 : 0;
     if (p->five_seq != NULL && p->three_seq != NULL && p->five_rc_seq != NULL && p->three_rc_seq != NULL) {   /* src/gen_cons.c:226,238-263 */
         gp.ad_seq[0] = p->five_seq; gp.ad_seq[1] = p->three_rc_seq; gp.ad_seq[2] = p->five_rc_seq; gp.ad_seq[3] = p->three_seq;
@@ -664,15 +665,25 @@ static int full_len_pick(const th_para_t *p, int ln, const ed_res_t *l, int rn, 
         if (r[j].start - l[i].end - 1 >= p->min_len && tot > l[i].ed + r[j].ed) { tot = l[i].ed + r[j].ed; *ts = l[i].end + 1; *te = r[j].start - 1; }
     return tot;
 }
-static void single_copy(int seq_len, const char *seq, th_tandem_seq_t *t, const th_para_t *p)   /* :128-171 */
+/* dev: the searches as the device ran them (th_k_adapter_reads: 10 ints per query -- 5', rc(3'), rc(5'), 3' -- hit count and up to three
+ * (ed, start, end)), or NULL: then the host searches (adapters of more than 256 symbols) */
+static int dev_ed(const int *dev, int query, ed_res_t *r)
+{
+    const int *o = dev + 10 * query; const int n = o[0];
+    for (int i = 0; i < n; ++i) { r[i].ed = o[1 + 3 * i]; r[i].start = o[2 + 3 * i]; r[i].end = o[3 + 3 * i]; }
+    return n;
+}
+static void single_copy(int seq_len, const char *seq, th_tandem_seq_t *t, const th_para_t *p, const int *dev)   /* :128-171 */
 {
     int cons_len = 0, full_length = 0, ts = -1, te = -1, tot, pos[2] = { 0, 0 };
     ed_res_t r5[3], r3[3];
-    int n5 = collect_ed(p, p->five_seq, p->five_len, seq, seq_len, r5), n3 = collect_ed(p, p->three_rc_seq, p->three_len, seq, seq_len, r3);
+    int n5 = dev ? dev_ed(dev, 0, r5) : collect_ed(p, p->five_seq, p->five_len, seq, seq_len, r5);
+    int n3 = dev ? dev_ed(dev, 1, r3) : collect_ed(p, p->three_rc_seq, p->three_len, seq, seq_len, r3);
     tot = full_len_pick(p, n5, r5, n3, r3, &ts, &te);
     if (tot != INT_MAX) { pos[0] = ts; pos[1] = te; cons_len = te - ts + 1; full_length = 1; }
     if (tot > 0) {
-        n5 = collect_ed(p, p->five_rc_seq, p->five_len, seq, seq_len, r5); n3 = collect_ed(p, p->three_seq, p->three_len, seq, seq_len, r3);
+        n5 = dev ? dev_ed(dev, 2, r5) : collect_ed(p, p->five_rc_seq, p->five_len, seq, seq_len, r5);
+        n3 = dev ? dev_ed(dev, 3, r3) : collect_ed(p, p->three_seq, p->three_len, seq, seq_len, r3);
         if (full_len_pick(p, n3, r3, n5, r5, &ts, &te) < tot) { pos[0] = ts; pos[1] = te; cons_len = te - ts + 1; full_length = 2; }
     }
     if (full_length > 0) {
@@ -797,7 +808,7 @@ static void *collect_range(void *arg)
         t->cons_n = 0; t->cons_seq->seq.l = 0; t->cons_seq->qual.l = 0;
         while (ji < o->n_jobs && o->jobs[ji].read == r) { finish_job(h, B, o, &o->jobs[ji], t, a->rb); ++ji; }
         if (B->lens[a->rb + r] >= p->k && p->single_copy == 1 && p->only_full_length && p->five_seq != NULL && p->three_seq != NULL)
-            single_copy(B->lens[a->rb + r], B->seqs[a->rb + r], t, p);   /* src/tidehunter.c:24,49-51 */
+            single_copy(B->lens[a->rb + r], B->seqs[a->rb + r], t, p, o->single ? o->single + 40 * r : NULL);   /* src/tidehunter.c:24,49-51 */
     }
     return NULL;
 }

@@ -16,6 +16,7 @@ typedef struct {
     /* adapter search on the device (src/gen_cons.c:226-291): the four queries in the order 5', rc(3'), rc(5'), 3' with their
      * lengths and edlib thresholds k = (int)(len * (1 - ada_match_rat)) (float arithmetic, done by the host); NULL = no adapters */
     const char *ad_seq[4]; int ad_len[4], ad_k[4];
+    int single_copy;        /* -s with -F and adapters: the four queries are also searched in every whole read (src/gen_cons.c:128-171) */
 } th_gpu_para_t;
 
 /* one consensus job as the host sees it after the device run */
@@ -33,6 +34,8 @@ typedef struct {
     const int *par;         /* compact par_pos values */
     const uint8_t *cons; const int *cov; const int *iden;   /* cov is NULL unless want_cov */
     const int *ext;         /* 4 ints per job: max_q_l, max_t_l, max_q_r, max_t_r of the ksw2 extensions (src/gen_cons.c:218-223) */
+    const int *single;      /* -s: 40 ints per read -- per query (5', rc(3'), rc(5'), 3') the hit count and up to three (ed, start, end), as collect_ed_res
+                             * leaves them (src/gen_cons.c:89-110); NULL when the device did not search (no -s, or an adapter longer than 256 symbols) */
     const int *adapt;       /* 12 ints per job: (ed, start, end) of the four adapter searches on consensus + consensus; NULL when the
                              * device did not run them (no adapters, or an adapter longer than 256 symbols: the host searches) */
     double ms_kernels;      /* device time of the last run (HIP events), all kernels */

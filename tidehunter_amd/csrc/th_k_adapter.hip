@@ -80,3 +80,65 @@ th_k_adapter(const ThTask *__restrict__ tasks, int n_tasks, const uint8_t *__res
     }
     o[0] = best; o[1] = be - last_p; o[2] = be;
 }
+
+// ---- `-s`: adapters searched in the WHOLE read (single_copy_full_len_seq / collect_ed_res, src/gen_cons.c:89-171) ----
+// One lane per (read, query): edlib_align_HW over the read, then -- as collect_ed_res does -- once more over the part before the hit
+// (if it starts at or beyond the query's length) and over the part from its end on (if that leaves room for the query).  The text is the
+// read as it was uploaded (raw bytes), the equality tables cover all 256 byte values with the reference's rule (byte equality, a/A c/C
+// g/G t/T n/N: src/edlib_align.c:21-27), built by the host.
+struct ThAdRead { unsigned long long peq[4][2][256][TH_AD_MAXB]; };     // [query][0 forward / 1 reversed query][text byte][block]
+
+__device__ __forceinline__ int th_edlib_hw_bytes(const unsigned long long (*pf)[TH_AD_MAXB], const unsigned long long (*pr)[TH_AD_MAXB], int nb, int qlen, int k,
+                                                 const uint8_t *__restrict__ t, int tlen, int *start, int *end)
+{
+    if (qlen <= 0 || tlen <= 0) return -1;
+    const int lastbit = (qlen - 1) & 63;
+    unsigned long long Pv[TH_AD_MAXB], Mv[TH_AD_MAXB];
+#pragma unroll
+    for (int b = 0; b < TH_AD_MAXB; ++b) { Pv[b] = ~0ull; Mv[b] = 0ull; }
+    int score = qlen, best = 0x7fffffff, be = 0;
+    for (int c = 0; c < tlen; ++c) {
+        score = th_myers_step<true>(pf[t[c]], nb, lastbit, Pv, Mv, score);
+        if (score < best) { best = score; be = c; }
+    }
+    if (k >= 0 && best > min(k, qlen)) return -1;
+    if (best >= qlen && (64 - qlen % 64) % 64 > 0) { *start = 0; *end = -1; return qlen; }     // edlib's "position -1"
+#pragma unroll
+    for (int b = 0; b < TH_AD_MAXB; ++b) { Pv[b] = ~0ull; Mv[b] = 0ull; }
+    score = qlen;
+    int last_p = -1;
+    for (int c = 0; c <= be; ++c) {
+        score = th_myers_step<false>(pr[t[be - c]], nb, lastbit, Pv, Mv, score);
+        if (score == best) last_p = c;
+    }
+    *end = be; *start = be - last_p;
+    return best;
+}
+
+// out[40 * read + 10 * query + 0] = number of hits (0..3), then (ed, start, end) of each -- what collect_ed_res leaves in its array
+__global__ void __launch_bounds__(64)
+th_k_adapter_reads(int n_reads, const uint32_t *__restrict__ roff, const uint8_t *__restrict__ seq, const ThAdPara *__restrict__ AP, const ThAdRead *__restrict__ AR, int *__restrict__ out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = x >> 2, sr = x & 3;
+    if (r >= n_reads) return;
+    int *o = out + 40 * r + 10 * sr;
+    const uint8_t *t = seq + roff[r]; const int len = (int)(roff[r + 1] - roff[r]);
+    const int qlen = AP->len[sr], k = AP->k[sr], nb = AP->nb[sr];
+    const unsigned long long (*pf)[TH_AD_MAXB] = AR->peq[sr][0], (*pr)[TH_AD_MAXB] = AR->peq[sr][1];
+    int n = 0, s = 0, e = 0;
+    int ed = th_edlib_hw_bytes(pf, pr, nb, qlen, k, t, len, &s, &e);
+    if (ed != -1) {
+        o[1] = ed; o[2] = s; o[3] = e; n = 1;
+        const int s0 = s, e0 = e;
+        if (s0 >= qlen) {
+            ed = th_edlib_hw_bytes(pf, pr, nb, qlen, k, t, s0, &s, &e);
+            if (ed != -1) { o[1 + 3 * n] = ed; o[2 + 3 * n] = s; o[3 + 3 * n] = e; ++n; }
+        }
+        if (e0 <= len - qlen) {
+            ed = th_edlib_hw_bytes(pf, pr, nb, qlen, k, t + e0, len - e0, &s, &e);
+            if (ed != -1) { o[1 + 3 * n] = ed; o[2 + 3 * n] = e0 + s; o[3 + 3 * n] = e0 + e; ++n; }
+        }
+    }
+    o[0] = n;
+}

@@ -77,8 +77,8 @@ struct ThIn {
 };
 // the small result records of one run, on the host (pinned: the D2H copies go through the DMA engines)
 struct ThOut {
-    th_pvec<th_job_t> jobs; th_pvec<int> parc, iden, ext, cov, ad; th_pvec<uint8_t> cons;
-    int n_jobs = 0; bool ad_valid = false;
+    th_pvec<th_job_t> jobs; th_pvec<int> parc, iden, ext, cov, ad, single; th_pvec<uint8_t> cons;
+    int n_jobs = 0; bool ad_valid = false, single_valid = false;
     double ms_kernels = 0, ms_dominant = 0, ms_k[8] = { 0 };
 };
 
@@ -100,6 +100,7 @@ struct th_gpu {
     int reserve_n = 0; Arena arena;
     int task_cap = 0, unit_cap = 0, parc_cap = 0;          // table capacities (grown when a batch overflows them)
     bool ad_on = false; int ad_min_cons = 0; ThAdPara h_ad; DBuf<ThAdPara> d_adp; DBuf<int> d_ad; bool adp_up = false;
+    bool sc_on = false; ThAdRead *h_adr = nullptr; DBuf<ThAdRead> d_adr; DBuf<int> d_single; bool adr_up = false;     // -s: whole-read adapter searches
     th_pvec<ThTask> h_tasks; th_pvec<int> h_cons_len, h_status, h_sublist;     // slow paths only
     int n_sync = 0;
     int aln_wdiv = 10, aln_wadd = 24;     // first certified band of the unit alignments: half-width cons_len / wdiv + wadd
@@ -132,6 +133,17 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
                 }
         }
         g->ad_min_cons = p->ad_len[0] + p->ad_len[3];
+        if (g->ad_on && p->single_copy) {          // -s: tables over all 256 byte values of a read
+            g->sc_on = true; g->h_adr = new ThAdRead(); memset(g->h_adr, 0, sizeof(ThAdRead));
+            for (int sr = 0; sr < 4; ++sr) {
+                const int m = p->ad_len[sr];
+                for (int c = 0; c < 256; ++c)
+                    for (int i = 0; i < m; ++i) {
+                        if (eq(p->ad_seq[sr][i], (char)c)) g->h_adr->peq[sr][0][c][i / 64] |= 1ull << (i & 63);
+                        if (eq(p->ad_seq[sr][m - 1 - i], (char)c)) g->h_adr->peq[sr][1][c][i / 64] |= 1ull << (i & 63);
+                    }
+            }
+        }
     }
     g->para.ad_seq[0] = g->para.ad_seq[1] = g->para.ad_seq[2] = g->para.ad_seq[3] = nullptr;     // (borrowed strings: not kept)
     int ndev = 0;
@@ -160,7 +172,7 @@ extern "C" void th_gpu_destroy(th_gpu_t *g)
     g->d_par.release(); g->d_par_off.release(); g->d_par_n.release(); g->d_par_dst.release(); g->d_parc.release(); g->d_bnd.release(); g->d_scratch.release();
     g->d_cov.release(); g->d_cons_len.release(); g->d_status.release(); g->d_iden.release(); g->d_ext.release();
     g->d_rows.release(); g->d_list_n.release(); g->d_list_w.release(); g->d_list_l.release(); g->d_sublist.release();
-    g->d_tasks.release(); g->d_units.release(); g->d_items.release(); g->d_defer.release(); g->d_defer_s1.release(); g->d_jobs.release(); g->d_adp.release(); g->d_ad.release();
+    g->d_tasks.release(); g->d_units.release(); g->d_items.release(); g->d_defer.release(); g->d_defer_s1.release(); g->d_jobs.release(); g->d_adp.release(); g->d_ad.release(); g->d_adr.release(); g->d_single.release(); delete g->h_adr;
     if (g->stage_ok) for (int b = 0; b < 2; ++b) { th_rt_host_free(g->h_stage[b]); th_rt_event_destroy(g->stage_ev[b]); }
     if (g->arena.base) th_rt_free(g->arena.base);
     th_rt_stream_destroy(g->stream); th_rt_stream_destroy(g->cstream);
@@ -418,7 +430,7 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
     const int n = in.n; const long long T = in.T; const size_t padT = (size_t)((T + 15) & ~15LL);
     const double t_run0 = th_wall_s();
     const bool trace = getenv("TH_TRACE") != nullptr;
-    out.n_jobs = 0; out.ad_valid = false; out.ms_kernels = out.ms_dominant = 0; g->n_sync = 0;
+    out.n_jobs = 0; out.ad_valid = false; out.single_valid = false; out.ms_kernels = out.ms_dominant = 0; g->n_sync = 0;
     for (int k = 0; k < 8; ++k) out.ms_k[k] = 0;
     out.jobs.clear(); out.parc.clear();
     if (n == 0) return 0;
@@ -459,6 +471,17 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
               (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, (const int *)g->d_score.p,
               g->d_xorder.p, g->d_xstart.p, g->d_xend.p);
     KT_END(TK_CHAIN_X);
+    if (g->sc_on) {      // -s: the adapters in every whole read (independent of everything else: it only needs the uploaded bytes)
+        TRY(g->d_adp.ensure(1)); TRY(g->d_adr.ensure(1)); TRY(g->d_single.ensure((size_t)n * 40));
+        if (!g->adp_up) { TRY(th_rt_h2d(g->d_adp.p, &g->h_ad, sizeof(ThAdPara), g->stream)); g->adp_up = true; }
+        if (!g->adr_up) { TRY(th_rt_h2d(g->d_adr.p, g->h_adr, sizeof(ThAdRead), g->stream)); g->adr_up = true; }
+        KT_BEGIN(TK_ALIGN);
+        TH_LAUNCH(th_k_adapter_reads, (n * 4 + 63) / 64, 64, g->stream, n, (const uint32_t *)in.d_roff.p, (const uint8_t *)in.d_seq.p, (const ThAdPara *)g->d_adp.p, (const ThAdRead *)g->d_adr.p, g->d_single.p);
+        KT_END(TK_ALIGN);
+        th_room(out.single, (size_t)n * 40); out.single.resize((size_t)n * 40);
+        TRY(th_rt_d2h(out.single.data(), g->d_single.p, (size_t)n * 160, g->stream));
+        out.single_valid = true;
+    }
 
     // ---- stages 2-3 and the job tables, enqueued in one go; the counter block tells afterwards whether an arena was too small.
     // Chain extraction fills an arena of chain records with one atomic per read (8 records per read on average is plenty); the
@@ -678,6 +701,7 @@ extern "C" int th_gpu_get(th_gpu_t *g, int out_slot, th_gpu_out_t *o)
     o->n_jobs = out.n_jobs; o->jobs = out.jobs.data(); o->par = out.parc.data();
     o->cons = out.cons.data(); o->cov = g->para.want_cov ? out.cov.data() : nullptr; o->iden = out.iden.data(); o->ext = out.ext.data();
     o->adapt = out.ad_valid ? out.ad.data() : nullptr;
+    o->single = out.single_valid ? out.single.data() : nullptr;
     o->ms_kernels = out.ms_kernels; o->ms_dominant = out.ms_dominant;
     for (int k = 0; k < 8; ++k) o->ms_kernel[k] = out.ms_k[k];
     return 0;
