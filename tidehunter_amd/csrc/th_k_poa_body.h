@@ -269,7 +269,7 @@ __device__ TH_POA_ROWS_ATTR int th_poa_rows(int *my, int cap, int ocap, int opn,
 }
 
 #if defined(TH_POA_PROF)
-__device__ unsigned long long th_poa_prof[20];    // 0..3 phase cycles; 4..7 traceback events (tiles loaded, run trips, run steps, single steps); 8..13 rows per category, 14..19 their cycles
+__device__ unsigned long long th_poa_prof[24];    // 0..3 phase cycles; 4..7 traceback events (tiles loaded, run trips, run steps, single steps); 8..15 rows per category, 16..23 their cycles
 #define TH_PROF_CNT(k, v) do { if (TH_LANE() == 0) atomicAdd(&th_poa_prof[k], (unsigned long long)(v)); } while (0)
 #define TH_PROF_T0() unsigned long long pt_ = __builtin_amdgcn_s_memtime()
 #define TH_PROF(k) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (TH_LANE() == 0) atomicAdd(&th_poa_prof[k], n_ - pt_); pt_ = n_; } while (0)
@@ -543,7 +543,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     for (int x = lane; x < TH_POA_RING * 3 * TH_POA_PAD; x += TH_WAVE) s_ring[x / (3 * TH_POA_PAD)][(x / TH_POA_PAD) % 3][x % TH_POA_PAD] = (RT)(WIDE ? TH_NEG : -32768);
     TH_WAVE_FENCE();
 #if defined(TH_POA_PROF)
-    unsigned long long pf_n[6] = { 0, 0, 0, 0, 0, 0 }, pf_t[6] = { 0, 0, 0, 0, 0, 0 };
+    unsigned long long pf_n[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, pf_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
     for (int i = 0; i + 1 < n; ++i) {
         if ((i & 63) == 0) {
@@ -634,7 +634,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                         if (inn_ == 1) th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, T_, 1, qs0, 0, 0, 0, qb0, 0, 0, 0, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
                         else if (inn_ == 2) th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, T_, 2, qs0, qs1, 0, 0, qb0, qb1, 0, 0, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
                         else th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, T_, inn_, qs0, qs1, qs2, qs3, qb0, qb1, qb2, qb3, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
-                        TH_POA_PK_ROW_DONE(1, 0);
+                        TH_POA_PK_ROW_DONE(inn_ == 1 ? 1 : inn_ == 2 ? 6 : 7, 0);
                         continue;
                     }
                 }
@@ -844,7 +844,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         TH_WAVE_FENCE();
     }
 #if defined(TH_POA_PROF)
-    if (lane == 0) for (int c = 0; c < 6; ++c) { atomicAdd(&th_poa_prof[8 + c], pf_n[c]); atomicAdd(&th_poa_prof[14 + c], pf_t[c]); }
+    if (lane == 0) for (int c = 0; c < 8; ++c) { atomicAdd(&th_poa_prof[8 + c], pf_n[c]); atomicAdd(&th_poa_prof[16 + c], pf_t[c]); }
 #endif
     // global end: best predecessor row of the sink (row n-1) at column qlen, first in edge order
     int bi = -1, bs = 0;

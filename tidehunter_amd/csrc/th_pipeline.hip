@@ -619,12 +619,12 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
         }
         if (cnt->n_failed) fprintf(stderr, "[tidehunter_amd] warning: %d consensus job(s) could not be aligned (POA status 3-6, or no scratch for them) and are reported without a consensus\n", cnt->n_failed);
 #if defined(TH_POA_PROF)
-        { unsigned long long pr[20]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(thpoa_n::th_poa_prof), sizeof(pr));
+        { unsigned long long pr[24]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(thpoa_n::th_poa_prof), sizeof(pr));
           fprintf(stderr, "[poa_prof] rows %llu dp %llu traceback %llu merge %llu (cycles summed over waves)\n", pr[0], pr[1], pr[2], pr[3]);
           fprintf(stderr, "[poa_prof]   traceback: %llu tiles loaded, %llu run trips emitting %llu steps, %llu single steps\n", pr[4], pr[5], pr[6], pr[7]);
-          const char *cat[6] = { "common packed", "other packed", "several predecessors", "one far predecessor", "stores full cells", "other" };
-          for (int c = 0; c < 6; ++c) fprintf(stderr, "[poa_prof]   %-22s rows %12llu cycles %16llu (%.0f per row)\n", cat[c], pr[8 + c], pr[14 + c], pr[8 + c] ? (double)pr[14 + c] / pr[8 + c] : 0.0);
-          unsigned long long z[20] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(thpoa_n::th_poa_prof), z, sizeof(z)); }
+          const char *cat[8] = { "common packed", "packed, one predecessor", "several predecessors", "one far predecessor", "stores full cells", "other", "packed, two predecessors", "packed, three or four" };
+          for (int c = 0; c < 8; ++c) fprintf(stderr, "[poa_prof]   %-26s rows %12llu cycles %16llu (%.0f per row)\n", cat[c], pr[8 + c], pr[16 + c], pr[8 + c] ? (double)pr[16 + c] / pr[8 + c] : 0.0);
+          unsigned long long z[24] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(thpoa_n::th_poa_prof), z, sizeof(z)); }
 #endif
         // ---- unit-vs-consensus alignments and flank extensions: three item lists in one array, one kernel variant each ----
         const int ns = cnt->n_item_s, nm = ns + cnt->n_item_m, ni = nm + cnt->n_item_b, max_cl = cnt->max_cl;
