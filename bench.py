@@ -134,9 +134,24 @@ def cli_e2e(set_reads, copies, cfg, batch_opt, n_runs=2):
     `wall_with_startup_s`).  Every run is listed: the first is COLD (first GPU process of this bench: HIP initialisation, device
     allocation, page cache), `steady_reads_per_s` is the rate after the first full-size batch was complete (start-up excluded)."""
     exe = os.path.join(ROOT, "tidehunter_amd", "TideHunter-amd")
-    d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    set_bytes = sum(len(s) for s in set_reads)
+    # input + warm-up input + output need ~1.25 x the FASTA: the first directory with that much room (tmpfs preferred), fewer copies if none has
+    d = None
+    while d is None and copies >= 1:
+        for cand in ("/dev/shm", "/tmp"):
+            try:
+                st = os.statvfs(cand)
+                if os.path.isdir(cand) and st.f_bavail * st.f_frsize > 1.25 * (copies + 1) * (set_bytes + 16 * len(set_reads)):
+                    d = cand
+                    break
+            except OSError:
+                pass
+        if d is None:
+            copies //= 2
+    if d is None:
+        return {"error": "no room for the end-to-end input in /dev/shm or /tmp"}
     path, outp = os.path.join(d, "th_bench_e2e_%d.fa" % os.getpid()), os.path.join(d, "th_bench_e2e_%d.out" % os.getpid())
-    n_reads, nbytes = copies * len(set_reads), copies * sum(len(s) for s in set_reads)
+    n_reads, nbytes = copies * len(set_reads), copies * set_bytes
     runs = []
     try:
         with open(path, "wb") as f:
@@ -175,7 +190,7 @@ def cli_e2e(set_reads, copies, cfg, batch_opt, n_runs=2):
                 "runs": runs, "batch_reads": batch_opt, "machine_warmup_run": machine_warmup,
                 "what": "TideHunter-amd (reader -> H2D -> kernels -> record arithmetic -> writer) on a FASTA of %d x the read set in %s" % (copies, d)}
     finally:
-        for p in (path, outp):
+        for p in (path, outp, path + ".warm"):
             if os.path.exists(p):
                 os.unlink(p)
 
@@ -286,7 +301,10 @@ def main():
     # the bench (cold), and the HBM it releases is not being scrubbed under this process's own allocations during the timed steps
     e2e = None
     if rank == 0 and world == 1 and a.e2e != 0 and not (a.e2e < 0 and a.config != "c3") and "TH_BENCH_LIB" not in os.environ:      # (by default only for the headline workload)
-        e2e = cli_e2e(set_reads, a.e2e if a.e2e > 0 else 10, cfg, 65536)
+        try:
+            e2e = cli_e2e(set_reads, a.e2e if a.e2e > 0 else 10, cfg, 65536)
+        except Exception as ex:                       # reported, never fatal for the bench line
+            e2e = {"error": repr(ex)[:400]}
     th = TH.TideHunter(device=local, lib_path=os.environ.get("TH_BENCH_LIB"), **kw)
 
     def sync_all():
@@ -481,7 +499,10 @@ def main():
             out["value_e2e"] = e2e
         if world == 1 and a.cpu_sample != 0:
             n_cpu = a.cpu_sample if a.cpu_sample > 0 else min(8192, max(256, 400 * effective_cpus()))      # ~15 s of oracle time at ~28 reads/s per core
-            out["cpu_baseline"] = cpu_baseline(read_at, n_cpu, cfg)
+            try:
+                out["cpu_baseline"] = cpu_baseline(read_at, n_cpu, cfg)
+            except Exception as ex:
+                out["cpu_baseline"] = {"error": repr(ex)[:400]}
         others = a.others if a.others is not None else ("c2,c4,c5" if (a.config == "c3" and world == 1 and "TH_BENCH_LIB" not in os.environ) else "")
         if others:
             out["other_shapes"] = other_shapes([c for c in others.split(",") if c])

@@ -141,6 +141,23 @@ def test_emul_chain_record_arena_grows(emu, monkeypatch):
     th.close()
 
 
+def test_emul_job_tables_grow(emu, monkeypatch):
+    """job / unit / par_pos tables that are too small for a batch (TH_JOB_CAP forces it) raise a flag in the scan, nothing is written,
+    and the build reruns with tables sized from the totals; all three slow paths together as well"""
+    monkeypatch.setenv("TH_JOB_CAP", "1")
+    th = TH.TideHunter(lib_path=emu)
+    seqs = _reads(th.lib, [(90, 6, 0.08), (200, 4, 0.1), (60, 9, 0.1)], seed=33)
+    para = O.default_para()
+    got = th.process(seqs)
+    U.stage_compare(th, seqs, para)
+    assert U.assert_records_equal(seqs, got, para, "job table growth") >= 3
+    th.close()
+    monkeypatch.setenv("TH_REC_CAP", "1"); monkeypatch.setenv("TH_PAR_MUL", "1")
+    th = TH.TideHunter(lib_path=emu)
+    assert U.assert_records_equal(seqs, th.process(seqs), para, "all arenas too small") >= 3
+    th.close()
+
+
 def test_emul_partition_regions_grow(emu, monkeypatch):
     """a chain whose par_pos outgrows its region makes the partition rerun with larger regions (TH_PAR_MUL forces a first
     pass with four-entry regions)"""

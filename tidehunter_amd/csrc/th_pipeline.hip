@@ -489,8 +489,9 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
     // ranges of the per-position arrays, so T + 16 per record holds every batch whose chains cover at most half of its bases;
     // a single chain that needs more than its region -- the reference allows up to the read length, src/partition.c:173 -- makes the
     // partition rerun with larger regions); the tables of the job build start at sizes that cover periods down to ~16 bases.
-    g->task_cap = std::max(g->task_cap, rec_cap); g->unit_cap = std::max<long long>(g->unit_cap, std::min<long long>(0x7fffff00LL, T / 16 + 64LL * n + 4096));
-    g->parc_cap = std::max<long long>(g->parc_cap, std::min<long long>(0x7fffff00LL, T / 8 + 64LL * n + 4096));
+    if (getenv("TH_JOB_CAP")) g->task_cap = g->unit_cap = g->parc_cap = std::max(1, atoi(getenv("TH_JOB_CAP")));      // test knob: forces the table-growth path
+    else { g->task_cap = std::max(g->task_cap, rec_cap); g->unit_cap = std::max<long long>(g->unit_cap, std::min<long long>(0x7fffff00LL, T / 16 + 64LL * n + 4096));
+    g->parc_cap = std::max<long long>(g->parc_cap, std::min<long long>(0x7fffff00LL, T / 8 + 64LL * n + 4096)); }
     int cap_mul = getenv("TH_PAR_MUL") ? 0 : 1;                          // (TH_PAR_MUL: test knob, a first pass with regions of four entries)
     long long par_cap = std::min<long long>(0x7fffff00LL, T + 16LL * rec_cap + 64);
     const long long bnd_part = (((long long)in.max_len + 128) * 6 + 3) & ~3LL;   // 16-byte aligned per-wave segments
