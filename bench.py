@@ -128,7 +128,7 @@ def cpu_baseline(read_at, n_reads, cfg):
                     "core at this shape WITHOUT abPOA, so an ideal %d-core host runs at most %.0f reads/s before any abPOA time." % (cores, cores * 50.0)}
 
 
-def cli_e2e(set_reads, copies, cfg, batch_opt, n_runs=2):
+def cli_e2e(set_reads, copies, cfg, batch_opt, n_runs=2, pause_s=6.0):
     """value_e2e: the command line on `copies` x the read set (>= 1 000 000 reads at the headline shape), wall-clock from the first byte
     parsed to the last byte written (th_run_file's own clock; process start and HIP initialisation are reported separately as
     `wall_with_startup_s`).  Every run is listed: the first is COLD (first GPU process of this bench: HIP initialisation, device
@@ -160,7 +160,7 @@ def cli_e2e(set_reads, copies, cfg, batch_opt, n_runs=2):
         # the first GPU process on a machine pays for things that are not this program's (driver and runtime start-up -- seen: 4 s until the
         # first handle is ready -- and the first large device allocation on untouched HBM -- seen: 3.5 s): a run over one small and one full
         # batch takes them, listed apart with its own rate and not part of `value`
-        wpath, n_warm = path + ".warm", min(len(set_reads), batch_opt + batch_opt // 4)
+        wpath, n_warm = path + ".warm", min(len(set_reads), 2 * batch_opt + batch_opt // 4)       # (both pipelines of the device see a full batch)
         with open(wpath, "wb") as f:
             f.write(b"".join(b">w_%d\n" % i + s + b"\n" for i, s in enumerate(set_reads[:n_warm])))
         t0 = time.time()
@@ -168,6 +168,10 @@ def cli_e2e(set_reads, copies, cfg, batch_opt, n_runs=2):
         machine_warmup = {"reads": n_warm, "wall_s": time.time() - t0, "reads_per_s_with_process_startup": n_warm / (time.time() - t0)}
         os.unlink(wpath)
         for _ in range(n_runs):
+            # the driver is still clearing the HBM the previous process released (70-140 GB) for a few seconds after its exit, and a new
+            # process's first allocation waits for that -- 1.5-4.5 s seen back to back (profiles/r03_e2e_pipelines.txt); it is the previous
+            # run's cost, not this one's, so each run starts after a pause
+            time.sleep(pause_s)
             t0 = time.time()
             err = subprocess.run([exe, *cfg.get("cli_opts", []), "-b", str(batch_opt), "-o", outp, path], check=True, capture_output=True, text=True,
                                  env=dict(os.environ, TH_TRACE="1")).stderr
@@ -187,7 +191,7 @@ def cli_e2e(set_reads, copies, cfg, batch_opt, n_runs=2):
         vals = [r["reads_per_s"] for r in runs]
         return {"value": sum(vals) / len(vals), "unit": "reads/s", "value_is": "mean of the whole-run rates of all runs (first byte parsed to last byte written), no run dropped",
                 "reads": n_reads, "runs_reads_per_s": vals, "cold_reads_per_s": vals[0], "steady_reads_per_s": [r["steady_reads_per_s"] for r in runs],
-                "runs": runs, "batch_reads": batch_opt, "machine_warmup_run": machine_warmup,
+                "runs": runs, "batch_reads": batch_opt, "machine_warmup_run": machine_warmup, "pause_before_each_run_s": pause_s,
                 "what": "TideHunter-amd (reader -> H2D -> kernels -> record arithmetic -> writer) on a FASTA of %d x the read set in %s" % (copies, d)}
     finally:
         for p in (path, outp, path + ".warm"):
@@ -302,7 +306,7 @@ def main():
     e2e = None
     if rank == 0 and world == 1 and a.e2e != 0 and not (a.e2e < 0 and a.config != "c3") and "TH_BENCH_LIB" not in os.environ:      # (by default only for the headline workload)
         try:
-            e2e = cli_e2e(set_reads, a.e2e if a.e2e > 0 else 10, cfg, 65536)
+            e2e = cli_e2e(set_reads, a.e2e if a.e2e > 0 else 10, cfg, 32768)      # (32768 = the command line's default batch)
         except Exception as ex:                       # reported, never fatal for the bench line
             e2e = {"error": repr(ex)[:400]}
     th = TH.TideHunter(device=local, lib_path=os.environ.get("TH_BENCH_LIB"), **kw)

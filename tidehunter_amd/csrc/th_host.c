@@ -1034,11 +1034,12 @@ enum { SLOT_EMPTY = 0, SLOT_FILLED = 1, SLOT_DONE = 2 };
 #define TH_MAX_SLOT (5 * TH_MAX_WORKER + 2)
 typedef struct { char **names, **seqs; int *lens; int n, state, batch; th_tandem_seq_t *ts; th_str_t arena; size_t *noff, *soff; } th_slot_t;   /* batch: index of the batch the slot holds */
 typedef struct {
-    th_slot_t slot[TH_MAX_SLOT]; int n_slot, n_dev;
+    th_slot_t slot[TH_MAX_SLOT]; int n_slot, n_dev, n_primary;     /* n_primary: listed devices; pipelines n_primary.. are the further ones per device */
     pthread_mutex_t mu; pthread_cond_t cv;
     th_reader_t *rd; FILE *out; th_para_t *p; int batch_reads, ramp0; volatile int stop;
     int eof_batch;               /* index of the empty batch that ends the input (-1 until the reader meets it) */
     int next_batch;              /* ticket counter of the device pipelines (the reference's THREAD_READ_I, src/main.c:277-281, at batch granularity) */
+    int n_reserved;              /* pipelines whose device buffers are in place (none launches a kernel before all are) */
     double t_read, t_write;      /* busy seconds of the two side threads (TH_TRACE=1 prints them) */
     double t_start; int trace;
 } th_pipe_t;
@@ -1127,6 +1128,31 @@ static void *pipe_device(void *arg)
     th_handle_t *h = th_init_sub(q->p, w->device, fsub);
     if (!h) { w->rc = -1; q->stop = 1; }
     if (q->trace) fprintf(stderr, "[th_run_file]   pipeline %d: handle ready at %.3f s\n", w->dev_index, now_s() - q->t_start);
+    /* Every pipeline sizes its device buffers for full batches from the first parsed batch (peeked, not taken) before any pipeline
+     * launches a kernel: an allocation issued next to another pipeline's running kernels waits for a kernel boundary -- seconds at
+     * these sizes -- while on an idle device the allocations take milliseconds.  The first pipeline of each device goes first; a
+     * further one joins only if its buffers fit in a third of what is then free, and retires otherwise. */
+    int retired = 0;
+    {
+        th_slot_t *s0 = &q->slot[0];
+        const int have = slot_wait(q, s0, SLOT_FILLED, 0) && s0->n > 0;
+        const int round = w->dev_index / q->n_primary;
+        pthread_mutex_lock(&q->mu);
+        while (q->n_reserved < round * q->n_primary && !q->stop) pthread_cond_wait(&q->cv, &q->mu);
+        pthread_mutex_unlock(&q->mu);
+        if (have && h && !q->stop) {
+            long long bases = 0; for (int x = 0; x < s0->n; ++x) bases += s0->lens[x];
+            const long long full = (long long)((double)bases / s0->n * q->batch_reads * 1.1) + 65536;
+            if (round > 0 && (s0->n < q->ramp0 || !th_gpu_room_for(h->gpu[0], q->batch_reads, full))) retired = 1;     /* (an input smaller than the first ramp step needs one pipeline) */
+            else if (s0->n < q->batch_reads) th_batch_reserve(h, q->batch_reads, full);
+        }
+        pthread_mutex_lock(&q->mu);
+        ++q->n_reserved; pthread_cond_broadcast(&q->cv);
+        while (q->n_reserved < q->n_dev && !q->stop) pthread_cond_wait(&q->cv, &q->mu);
+        pthread_mutex_unlock(&q->mu);
+        if (q->trace) fprintf(stderr, "[th_run_file]   pipeline %d: %s at %.3f s\n", w->dev_index, retired ? "retired (one pipeline is enough for this input / device memory)" : "buffers reserved", now_s() - q->t_start);
+    }
+    if (retired) { st3_init(&w->st, NULL); if (h) th_destroy(h); return NULL; }
     st3_init(&w->st, h); w->st.on_done = pipe_batch_done; w->st.failed = h ? 0 : 1;
     pthread_t t_run, t_col;
     pthread_create(&t_run, NULL, st3_runner, &w->st); pthread_create(&t_col, NULL, st3_collector, &w->st);
@@ -1136,10 +1162,6 @@ static void *pipe_device(void *arg)
         const int i = __atomic_fetch_add(&q->next_batch, 1, __ATOMIC_RELAXED);
         th_slot_t *s = &q->slot[i % q->n_slot];
         if (!slot_wait(q, s, SLOT_FILLED, i)) break;
-        if (s->n > 0 && h && !q->stop && k == 0 && s->n < q->batch_reads) {      /* first (small) batch of this pipeline: size the device buffers for full batches */
-            long long bases = 0; for (int x = 0; x < s->n; ++x) bases += s->lens[x];
-            th_batch_reserve(h, q->batch_reads, (long long)((double)bases / s->n * q->batch_reads * 1.1) + 65536);
-        }
         if (q->stop) w->st.failed = 1;
         st3_upload(&w->st, k, (const char *const *)s->seqs, s->lens, s->n, s->ts, s);
         ++w->batches;
@@ -1155,10 +1177,13 @@ static void *pipe_device(void *arg)
 int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *devices_in, int n_dev_in, int batch_reads)
 {
     if (n_dev_in < 1 || n_dev_in > TH_MAX_DEV) return host_fail("between 1 and 16 devices");
-    if (batch_reads <= 0) batch_reads = 65536;      /* per-position arrays + POA scratch of one pipeline: ~70 GB of HBM at 10 kb reads */
-    /* One pipeline (handle + upload / run / collect threads) per listed device.  TH_WORKERS_PER_DEV=2 puts two of them on each
-     * device (round 2's design: two handles whose kernels interleave on the device; kept for A/B measurements). */
-    int wpd = 1;
+    if (batch_reads <= 0) batch_reads = 32768;      /* per-position arrays + POA scratch of one pipeline: ~35 GB of HBM at 10 kb reads; two pipelines per device */
+    /* Two pipelines (handle + upload / run / collect threads each) per listed device: while one is inside its POA / alignment
+     * launches the other's short, latency-bound kernels (hits, sort, extraction, partition) and its three synchronisations are
+     * hidden -- 116.2 k against 112.4 k reads/s on 1 000 000 reads of config 3 (two pipelines of 32768-read batches against one of
+     * 65536: the same memory; profiles/r03_e2e_pipelines.txt).  TH_WORKERS_PER_DEV=1..4 overrides; a second pipeline
+     * that does not fit the device's memory retires (pipe_device). */
+    int wpd = 2;
     { const char *e = getenv("TH_WORKERS_PER_DEV"); if (e && atoi(e) >= 1 && atoi(e) <= 4) wpd = atoi(e); }
     int devices[TH_MAX_WORKER], n_dev = 0;
     for (int r = 0; r < wpd; ++r) for (int d = 0; d < n_dev_in; ++d) devices[n_dev++] = devices_in[d];
@@ -1167,7 +1192,7 @@ int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *d
     if (!r) { char m[300]; snprintf(m, sizeof(m), "fail to open file '%s'", read_fn); return host_fail(m); }
     th_pipe_t *q = (th_pipe_t *)calloc(1, sizeof(th_pipe_t));
     pthread_mutex_init(&q->mu, NULL); pthread_cond_init(&q->cv, NULL);
-    q->rd = r; q->out = out; q->p = p; q->batch_reads = batch_reads; q->n_dev = n_dev; q->n_slot = 5 * n_dev + 1; q->eof_batch = -1;
+    q->rd = r; q->out = out; q->p = p; q->batch_reads = batch_reads; q->n_dev = n_dev; q->n_primary = n_dev_in; q->n_slot = 5 * n_dev + 1; q->eof_batch = -1;
     q->ramp0 = batch_reads / 4 > 2048 ? batch_reads / 4 : 2048;       /* one small batch, then full ones: a mapped file parses at ~10 GB/s, so only the first launch has to wait */
     { const char *e = getenv("TH_RAMP0"); if (e && atoi(e) > 0) q->ramp0 = atoi(e); }
     for (int i = 0; i < q->n_slot; ++i) {

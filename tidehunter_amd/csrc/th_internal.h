@@ -49,6 +49,7 @@ th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device);
 void th_gpu_destroy(th_gpu_t *g);
 /* sizes the per-read / per-base buffers for batches of up to n reads and T bases (optional; avoids re-allocation when batches grow) */
 int th_gpu_reserve(th_gpu_t *g, int n, long long T);
+int th_gpu_room_for(th_gpu_t *g, int n, long long T);     /* 1 if a further pipeline of this batch size fits the device memory */
 /* A pipeline keeps TWO input sets and TWO result sets (slot 0 / 1), so that a driver can upload batch i+1 and do the record
  * arithmetic of batch i-1 while the kernels of batch i run: upload(slot) may overlap run() of the other slot (own copy stream),
  * get(slot) stays valid until the next run into that slot.  One thread at a time per function; run() is the only one that

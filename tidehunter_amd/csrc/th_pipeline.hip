@@ -194,6 +194,22 @@ static int th_select_device(const th_gpu *g)
 // The handle's arena, sized for batches of up to n reads / T bases: ~56 bytes per base of per-position arrays and both input sets,
 // the POA scratch of the full persistent grid at ~100 ints per base of the average read (3.7 MB per wave at the headline shape;
 // long-period batches need more and take their scratch from hipMalloc), and room for the per-job arrays.
+static size_t th_arena_want(const th_gpu *g, int n, long long T)
+{
+    const double avg = (double)T / n;
+    const size_t poa = (size_t)std::min<double>((double)TH_POA_SCRATCH_BYTES / 2, 100.0 * avg * 4.0 * std::min(n, g->waves_poa) * 1.3);
+    return (size_t)(68.0 * (double)T) + (size_t)n * 1280 + poa + (256u << 20);             // (buffers carry 12.5 % slack; consensus jobs, items, par_pos: ~14 bytes per base)
+}
+// does a further pipeline of this batch size fit next to what the device already holds?  (a third of the free memory at most:
+// buffers that outgrow the arena still need room)
+extern "C" int th_gpu_room_for(th_gpu_t *g, int n, long long T)
+{
+    if (th_select_device(g)) return 0;
+    if (n <= 0 || T <= 0) return 1;
+    size_t fr = 0, tot = 0;
+    if (th_rt_mem_info(&fr, &tot) != 0) return 0;
+    return th_arena_want(g, n, T) <= fr / 3;
+}
 static int th_arena_create(th_gpu *g, int n, long long T)
 {
     if (n <= 0 || T <= 0) return 0;
@@ -201,9 +217,7 @@ static int th_arena_create(th_gpu *g, int n, long long T)
         std::lock_guard<std::mutex> lk(g->arena.mu);
         if (g->arena.base) return 0;
     }
-    const double avg = (double)T / n;
-    const size_t poa = (size_t)std::min<double>((double)TH_POA_SCRATCH_BYTES / 2, 100.0 * avg * 4.0 * std::min(n, g->waves_poa) * 1.3);
-    size_t want = (size_t)(68.0 * (double)T) + (size_t)n * 1280 + poa + (256u << 20);      // (buffers carry 12.5 % slack; consensus jobs, items, par_pos: ~14 bytes per base)
+    size_t want = th_arena_want(g, n, T);
     size_t fr = 0, tot = 0;
     if (th_rt_mem_info(&fr, &tot) == 0 && want > fr / 2) want = fr / 2;     // never more than half of what is free
     if (want < TH_ARENA_MIN_BYTES) return 0;              // tiny batches (tests): plain allocations

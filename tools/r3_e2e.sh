@@ -19,6 +19,7 @@ PY
 ls -la $D/c3x.fa; free -g | head -2
 rm -f $O/e2e.txt
 for v in ${3:-2:32768 2:32768 1:32768 2:65536}; do set -- ${v//:/ }
+  sleep ${PAUSE:-6}       # the driver clears the previous process's HBM for a few seconds; a new process's first allocation waits for it
   echo "== workers/dev $1 batch $2 ${3:+env $3}" >> $O/e2e.txt
   env ${3:-TH_X=0} TH_WORKERS_PER_DEV=$1 TH_TRACE=1 $R/tidehunter_amd/TideHunter-amd -b $2 -o $D/c3x.out $D/c3x.fa 2>&1 | grep -v "^$" >> $O/e2e.txt
   echo "records: $(grep -c '^>' $D/c3x.out) md5: $(md5sum < $D/c3x.out)" >> $O/e2e.txt
