@@ -444,6 +444,26 @@ def test_emul_poa_long_variant_three_trip_rows(emu):
     th.close()
 
 
+def test_emul_flank_extension_engines(emu, monkeypatch):
+    """flank extensions (ksw2_left_ext / ksw2_right_ext, src/gen_cons.c:218-221; full matrix, no z-drop) on their three exact engines: a
+    period-1000 read at 10 % error (two registers per lane certified by th_adx_bound, the bound that also counts the matches an
+    off-diagonal path gives up), a period-1400 read at 15 % (the first band fails, its banded maximum names the one that holds) and a
+    period-2300 read at 16 % (no register band: a four-register probe sizes a band of the strip engine); TH_ALN_MODE=2 repeats the
+    first two on the full matrix on the device and flags a difference; records equal the oracle's"""
+    monkeypatch.setenv("TH_ALN_MODE", "2")
+    th = TH.TideHunter(lib_path=emu)
+    seqs = [TH.synth_read(th.lib, 21, 0, 1000, 4, 0.10), TH.synth_read(th.lib, 22, 1, 1400, 3, 0.15)]
+    got = th.process(seqs)
+    assert U.assert_records_equal(seqs, got, O.default_para(), "flank extensions, full matrix alongside") >= 1
+    th.close()
+    monkeypatch.delenv("TH_ALN_MODE")
+    th = TH.TideHunter(lib_path=emu)         # (the banded strip engine against the oracle only: the emulation takes minutes for a second full matrix)
+    seqs = [TH.synth_read(th.lib, 23, 2, 2300, 4, 0.16)]
+    got = th.process(seqs)
+    assert U.assert_records_equal(seqs, got, O.default_para(), "flank extension on a band of the strip engine") == 1
+    th.close()
+
+
 def test_emul_single_copy_reads_searched_on_the_device():
     """-F -s (src/gen_cons.c:128-171): reads that carry the adapters once -- sense, antisense, with errors, adapters twice, lower case --
     get their full-length record from th_k_adapter_reads (whole-read Myers searches over the uploaded bytes, up to three per query as

@@ -60,20 +60,20 @@ __device__ __forceinline__ int th_ad_align(int np, const uint8_t *__restrict__ q
 
 // Flank extension on the anti-diagonal engine (th_ksw_ext_ad_wave); false when the result could not be certified.
 template <int NP>
-__device__ __forceinline__ bool th_adx_run(bool has_n, const uint8_t *st, const uint8_t *sq, int qlen, int tlen, int *mq, int *mt)
+__device__ __forceinline__ bool th_adx_run(bool has_n, const uint8_t *st, const uint8_t *sq, int qlen, int tlen, int *mq, int *mt, int *bh)
 {
-    return has_n ? th_ksw_ext_ad_wave<NP, true>(st, sq, qlen, tlen, mq, mt) : th_ksw_ext_ad_wave<NP, false>(st, sq, qlen, tlen, mq, mt);
+    return has_n ? th_ksw_ext_ad_wave<NP, true>(st, sq, qlen, tlen, mq, mt, bh) : th_ksw_ext_ad_wave<NP, false>(st, sq, qlen, tlen, mq, mt, bh);
 }
 template <int NPXMAX>
-__device__ __forceinline__ bool th_adx_align(int np, const uint8_t *__restrict__ q, int qs, int qlen, const uint8_t *__restrict__ t, int ts, int tlen, uint8_t *s_seq, int *mq, int *mt)
+__device__ __forceinline__ bool th_adx_align(int np, const uint8_t *__restrict__ q, int qs, int qlen, const uint8_t *__restrict__ t, int ts, int tlen, uint8_t *s_seq, int *mq, int *mt, int *bh)
 {
     const uint8_t *st, *sq;
     const bool has_n = th_ad_stage(q, qlen, t, tlen, 128 * np, s_seq, &st, &sq, qs, ts);
     bool ok = false;
-    if (np == 1) ok = th_adx_run<1>(has_n, st, sq, qlen, tlen, mq, mt);
-    else if (np == 2) ok = th_adx_run<2>(has_n, st, sq, qlen, tlen, mq, mt);
-    else if (NPXMAX >= 3 && np == 3) ok = th_adx_run<(NPXMAX >= 3 ? 3 : 1)>(has_n, st, sq, qlen, tlen, mq, mt);
-    else if (NPXMAX >= 4 && np == 4) ok = th_adx_run<(NPXMAX >= 4 ? 4 : 1)>(has_n, st, sq, qlen, tlen, mq, mt);
+    if (np == 1) ok = th_adx_run<1>(has_n, st, sq, qlen, tlen, mq, mt, bh);
+    else if (np == 2) ok = th_adx_run<2>(has_n, st, sq, qlen, tlen, mq, mt, bh);
+    else if (NPXMAX >= 3 && np == 3) ok = th_adx_run<(NPXMAX >= 3 ? 3 : 1)>(has_n, st, sq, qlen, tlen, mq, mt, bh);
+    else if (NPXMAX >= 4 && np == 4) ok = th_adx_run<(NPXMAX >= 4 ? 4 : 1)>(has_n, st, sq, qlen, tlen, mq, mt, bh);
     TH_WAVE_FENCE();
     return ok;
 }
@@ -183,14 +183,31 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                 if (tlen > 0) {
                     if ((long long)((tlen + 63) & ~63) * 2 > bnd_stride) { if (lane == 0) atomicOr(err, 4); }
                     else {
-                        // anti-diagonal engine first: a band of 128 NP diagonals either side, wide enough to be certified when the flank
-                        // continues the repeat (banded maximum ~0.6 min(m, n) > min(m, n) - 3 - W); the strip engine otherwise
+                        // Anti-diagonal engine first, with the narrowest band of 128 NP diagonals either side whose bound (th_adx_bound) lies
+                        // below the score a flank that continues the repeat is expected to reach ((100 - xpct) % of the shorter sequence).
+                        // A band that cannot be certified still yields a banded maximum, a lower bound of the true one, and that names the
+                        // band which is certified for sure: a wider one on the same engine, or -- beyond four registers per lane -- a band
+                        // of the strip engine; pairs of a thousand bases and more whose expected score no register band reaches are probed
+                        // with four registers for that purpose (an eighth of the full matrix's cost).  The full matrix is what is left.
                         bool done = false;
+                        int bh = 0;
                         if (mode && cl + tlen < 30000) {
-                            const int need = (min(cl, tlen) * xpct) / 100 + 8;
+                            const int mn = min(cl, tlen), s_est = mn - (mn * xpct) / 100;
                             int np = 0;
-                            for (int c = 1; c <= 4; ++c) if (128 * c - 1 >= need) { np = c; break; }
-                            if (np && cl + tlen + 512 * np + 16 <= LDSB) done = th_adx_align<4>(np, qp, st, cl, tp, st, tlen, s_seq, &mq, &mt);
+                            for (int c = 1; c <= 4; ++c) if (th_adx_bound(c, cl, tlen) < s_est) { np = c; break; }
+                            if (!np && mn >= 1024) np = 4;
+                            while (np && cl + tlen + 512 * np + 16 <= LDSB) {
+                                done = th_adx_align<4>(np, qp, st, cl, tp, st, tlen, s_seq, &mq, &mt, &bh);
+                                if (done || bh <= 0) break;
+                                int np2 = 0;
+                                for (int c = np + 1; c <= 4; ++c) if (th_adx_bound(c, cl, tlen) < bh) { np2 = c; break; }
+                                np = np2;
+                            }
+                            if (!done && bh > 0) {
+                                int W = 512;
+                                while (W < cl + tlen && th_ext_bound_w(W, cl, tlen) >= bh) W += 64;
+                                if (2 * W + 64 < (tlen * 4) / 5) done = th_ksw_ext_band_wave(qp, st, cl, tp, st, tlen, W, mybnd, &mq, &mt);
+                            }
                         }
                         if (!done) th_ksw_ext_wave(qp, st, cl, tp, st, tlen, mybnd, &mq, &mt);
                         else if (mode == 2) {

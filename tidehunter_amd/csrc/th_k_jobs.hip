@@ -182,19 +182,18 @@ th_k_scan_rows(const int *__restrict__ n_ptr, int n_fixed, int *__restrict__ row
 
 // ---- after the POA: alignment item lists (three staging-area classes) and compacted consensus offsets, per job ----
 struct ThAlnItem { int task, which; };   // which >= 0: unit index in the run; -1 left extension; -2 right extension
-#define TH_ALN_SMALL 4096
-#define TH_ALN_MID 7168
+#define TH_ALN_SMALL 12288
 #define TH_ALN_BIG16 16384
 #define TH_ALN_BIG 24576
-// Items whose two sequences fit the small staging area of the anti-diagonal engine (4 KB: 5 waves per SIMD) form the first list; jobs
-// whose unit + consensus fit 7 KB with at most two registers per lane (periods up to ~2500) a second one for the same register budget
-// with a larger area; the rest a third one for the variant with a 24 KB area and up to 6 registers per lane (two waves per SIMD).  The
-// two flank extensions of every job go to the first list.
+// Jobs whose unit + consensus fit the 12 KB staging area of the two-register variant of the anti-diagonal engine (periods up to ~2500;
+// that variant runs at three waves per SIMD by its registers, which leaves 13 KB of LDS per wave) form the first list, the rest a
+// third one for the variant with a 16 / 24 KB area and up to 6 registers per lane (two waves per SIMD).  (Round 2 had a 4 KB and a 7 KB
+// list: the 4 KB one dated from a variant with five waves per SIMD.)  The two flank extensions of every job go to the first list.
 __device__ __forceinline__ int th_aln_class(const ThTask &T, int cl, int wdiv, int wadd, int wtol)
 {
     const long long need2 = (long long)T.max_len + cl + 512 * 2 + 16;
     const bool two_regs = 2 * (cl / wdiv + wadd - wtol) + 2 + 64 <= 512;     // th_ad_pick would settle for NP <= 2
-    return need2 <= TH_ALN_SMALL ? 0 : (need2 <= TH_ALN_MID && two_regs) ? 1 : 2;
+    return (need2 <= TH_ALN_SMALL && two_regs) ? 0 : 2;
 }
 __global__ void __launch_bounds__(256)
 th_k_items_count(const int *__restrict__ n_tasks, const ThTask *__restrict__ tasks, int *__restrict__ cons_len, const int *__restrict__ status,

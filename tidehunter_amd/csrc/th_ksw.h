@@ -388,10 +388,18 @@ __device__ __forceinline__ int th_ksw_band_ad_wave(const uint8_t *s_t, const uin
 // Same geometry as th_ksw_band_ad_wave with the band [lo, hi] = [-128 NP, 128 NP - 1] around the main diagonal, the recurrence of
 // th_ksw_ext_wave below (no path functionals), and per position a running best (H, anti-diagonal): within one position the
 // anti-diagonal only grows, so a strict '>' keeps the earliest one; the final arg-max ranks candidates by (H desc, anti-diagonal
-// asc, ksw2's SSE visiting order asc) exactly as th_ksw_ext_wave does.  Exactness certificate: a path that reaches a diagonal
-// outside the band holds at least W + 1 gap bases (W = 128 NP - 1) and at most min(qlen, tlen) matches, so every cell whose
-// true H differs from the banded one, and every cell outside the band, has H <= min(qlen, tlen) - 3 - W; if the banded maximum
-// S is above that bound (or the band is the whole matrix, or neither S nor the bound is positive) the result is ksw2's.
+// asc, ksw2's SSE visiting order asc) exactly as th_ksw_ext_wave does.  Exactness certificate: a path that touches a diagonal d
+// outside the band (d = i' - j', t along i) holds at least |d| gap bases (q + |d| e) AND has given up the diagonal steps the
+// shorter remaining sequence no longer offers -- at most min(tlen - d, qlen) of them in all for d > 0, min(qlen + d, tlen) for
+// d < 0 -- so every cell whose true H differs from the banded one, and every cell outside the band, has H <= th_adx_bound(); if the
+// banded maximum S is above that bound (or the band is the whole matrix, or neither S nor the bound is positive) the result is
+// ksw2's.  (Round 2 counted the gap bases only: min(qlen, tlen) - 3 - W, twice the band for sequences of similar length.)
+__device__ __forceinline__ int th_adx_bound(int np, int qlen, int tlen)
+{
+    const int dt = 128 * np, dq = 128 * np + 1;            // the first diagonals outside [-128 NP, 128 NP - 1] on the t and on the q side
+    const int bt = min(tlen - dt, qlen) - TH_KQ - dt * TH_KE, bq = min(qlen - dq, tlen) - TH_KQ - dq * TH_KE;
+    return max(bt, bq);
+}
 template <int NP> struct ThAdxState { uint32_t E1[NP], F1[NP], Tp[NP], Qp[NP], NT[NP], NQ[NP], POS[NP], BH[NP], BR[NP]; };
 
 template <int NP, bool HASN, int C, int PH>
@@ -461,9 +469,10 @@ __device__ __forceinline__ void th_adx_pair_steps(ThAdxState<NP> &S, uint32_t (&
 
 __device__ __forceinline__ int th_ext_rank(int r, int t, int qlen, int tlen);
 
-// returns true when the result is certified; (max_q, max_t) as th_ksw_ext_wave
+// returns true when the result is certified; (max_q, max_t) as th_ksw_ext_wave; *best_h: the banded maximum (a lower bound of the
+// true one: the smallest band whose th_adx_bound() lies below it is certified for sure)
 template <int NP, bool HASN>
-__device__ __forceinline__ bool th_ksw_ext_ad_wave(const uint8_t *s_t, const uint8_t *s_q, int qlen, int tlen, int *max_q, int *max_t)
+__device__ __forceinline__ bool th_ksw_ext_ad_wave(const uint8_t *s_t, const uint8_t *s_q, int qlen, int tlen, int *max_q, int *max_t, int *best_h)
 {
     const int lane = TH_LANE();
     const int lo = -128 * NP, hi = 128 * NP - 1, lo2 = lo / 2, R = tlen + qlen;
@@ -509,7 +518,8 @@ __device__ __forceinline__ bool th_ksw_ext_ad_wave(const uint8_t *s_t, const uin
         if (take) { bestH = oH2; bestR = oR; bestRank = oK; bestT = oT; }
     }
     if (bestH > 0) { *max_t = bestT; *max_q = bestR - bestT; } else { *max_t = -1; *max_q = -1; }
-    const int bound = min(qlen, tlen) - 3 - min(hi, -lo);
+    const int bound = th_adx_bound(NP, qlen, tlen);
+    *best_h = bestH;
     return (lo <= -qlen && hi >= tlen) || bestH > bound || (bestH <= 0 && bound <= 0);
 }
 
@@ -579,4 +589,73 @@ __device__ void th_ksw_ext_wave(const uint8_t *__restrict__ q, int qs, int qlen,
         if (take) { bestH = oH2; bestR = oR; bestRank = oK; bestT = oT; }
     }
     if (bestH > 0) { *max_t = bestT; *max_q = bestR - bestT; } else { *max_t = -1; *max_q = -1; }
+}
+
+// The bound of th_adx_bound() for the symmetric band |i - j| <= W of the strip engine below.
+__device__ __forceinline__ int th_ext_bound_w(int W, int qlen, int tlen)
+{
+    const int d = W + 1;
+    return max(min(tlen - d, qlen), min(qlen - d, tlen)) - TH_KQ - d * TH_KE;
+}
+
+// th_ksw_ext_wave restricted to the diagonals |i - j| <= W (cells outside are minus infinity; the matrix borders keep their exact
+// values, which only adds real paths): strip j0 sweeps rows max(0, j0 - W) .. min(tlen - 1, j0 + 63 + W) instead of all of them.
+// Returns true when the result is certified to be the full matrix's (th_ext_bound_w; the caller sizes W from a banded maximum of
+// the anti-diagonal engine, for which the certificate cannot fail); (max_q, max_t) are valid only then.
+__device__ bool th_ksw_ext_band_wave(const uint8_t *__restrict__ q, int qs, int qlen, const uint8_t *__restrict__ t, int ts, int tlen, int W,
+                                     int *__restrict__ bnd, int *max_q, int *max_t)
+{
+    const int lane = TH_LANE();
+    int2 *bnd2 = (int2 *)bnd;                 // {H, F'} of the parked column
+    int bestH = 0, bestR = 0x7fffffff, bestT = -1;
+    for (int j0 = 0; j0 < qlen; j0 += TH_WAVE) {
+        const int j = j0 + lane;
+        const bool colok = j < qlen;
+        const int qj = colok ? q[(long long)j * qs] : 4;
+        const bool first = j0 == 0, last = j0 + TH_WAVE >= qlen;
+        const int rs = max(0, j0 - W), re = min(tlen - 1, j0 + 63 + W);       // rows this strip touches
+        if (rs > re) break;                                                    // the band has left the matrix: so have all further strips
+        const int pre = min(tlen - 1, j0 - 1 + W);                            // last in-band row of column j0 - 1
+        const int nsteps = re - rs + TH_WAVE;
+        int Ein = TH_NEG, Hdiag = TH_NEG, oH = TH_NEG, oF = TH_NEG, tcur = 4;
+        int2 nb = { TH_NEG, TH_NEG }; int nt = 4;
+        { const int row = rs + lane; if (row < tlen) { nt = t[(long long)row * ts]; if (!first && row <= pre) nb = bnd2[row]; } }
+        for (int s0 = 0; s0 < nsteps; s0 += TH_WAVE) {
+            int ibH, ibF, ibT = nt;
+            if (first) { ibH = -(TH_KQ + (rs + s0 + lane + 1) * TH_KE); ibF = ibH - TH_KQ - TH_KE; }
+            else { ibH = nb.x; ibF = nb.y; }
+            {
+                const int row = rs + s0 + TH_WAVE + lane;
+                nt = 4; nb.x = TH_NEG; nb.y = TH_NEG;
+                if (row < tlen) { nt = t[(long long)row * ts]; if (!first && row <= pre) nb = bnd2[row]; }
+            }
+            const int kend = min(TH_WAVE, nsteps - s0);
+            for (int k = 0; k < kend; ++k) {
+                const int i = rs + s0 + k - lane;
+                const int lH = th_shr1_inject(oH, ibH), lF = th_shr1_inject(oF, ibF), ti = th_shr1_inject(tcur, ibT);
+                ibH = th_rol1(ibH); ibF = th_rol1(ibF); ibT = th_rol1(ibT);
+                tcur = ti;
+                if (i == 0) { const int hu = -(TH_KQ + (j + 1) * TH_KE); Ein = hu - TH_KQ - TH_KE; Hdiag = j == 0 ? 0 : -(TH_KQ + j * TH_KE); }
+                const bool inb = (unsigned)(i - j + W) <= (unsigned)(2 * W) && i >= 0 && i < tlen;
+                int h = Hdiag + th_ksw_sc(ti, qj);
+                h = max(h, Ein); h = max(h, lF);
+                Hdiag = lH;
+                Ein = inb ? max(Ein, h - TH_KQ) - TH_KE : TH_NEG;
+                oH = inb ? h : TH_NEG; oF = inb ? max(lF, h - TH_KQ) - TH_KE : TH_NEG;
+                if (colok && inb && h > bestH) { bestH = h; bestR = i + j; bestT = i; }
+                if (!last && lane == 63 && i >= 0 && i < tlen) { int2 o; o.x = oH; o.y = oF; bnd2[i] = o; }
+            }
+        }
+        TH_WAVE_FENCE();
+    }
+    int bestRank = bestT >= 0 ? th_ext_rank(bestR, bestT, qlen, tlen) : 0x7fffffff;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int oH2 = __shfl_xor(bestH, d), oR = __shfl_xor(bestR, d), oK = __shfl_xor(bestRank, d), oT = __shfl_xor(bestT, d);
+        const bool take = oH2 > bestH || (oH2 == bestH && (oR < bestR || (oR == bestR && oK < bestRank)));
+        if (take) { bestH = oH2; bestR = oR; bestRank = oK; bestT = oT; }
+    }
+    if (bestH > 0) { *max_t = bestT; *max_q = bestR - bestT; } else { *max_t = -1; *max_q = -1; }
+    const int bound = th_ext_bound_w(W, qlen, tlen);
+    return bestH > bound || (bestH <= 0 && bound <= 0);
 }

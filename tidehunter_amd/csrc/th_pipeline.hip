@@ -652,11 +652,9 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
 #define TH_ALN_ARGS(first, n, q) (const ThAlnItem *)g->d_items.p + (first), (n), (const ThTask *)g->d_tasks.p, (const int *)g->d_parc.p, \
                   (const uint32_t *)in.d_roff.p, (const uint8_t *)g->d_bseq.p, (const uint8_t *)g->d_cons.p, (const int *)g->d_cons_len.p, \
                   g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, &dc->err, (q), g->aln_wdiv, g->aln_wadd, g->aln_wtol
-            // (a second list of fewer than 512 items -- the odd long unit of a short-period batch -- rides with the third: one launch fewer)
-            const int mid_first = ns, mid_n = (nm - ns >= 512 || ni == nm) ? nm - ns : 0, big_first = mid_n ? nm : ns, big_n = ni - big_first;
+            const int big_first = nm, big_n = ni - big_first;           // (the second list is empty since round 3: th_aln_class)
             const int *no_n = nullptr, *no_s1 = nullptr; ThAlnItem *no_defer = nullptr; int *no_dn = nullptr, *no_ws = nullptr, *no_ds1 = nullptr;
-            if (ns) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(0, ns, &dc->q_aln_s), g->aln_mode, g->aln_xpct, no_n, no_defer, no_dn, no_ws, no_s1, no_ds1);
-            if (mid_n) TH_LAUNCH((th_k_align<TH_ALN_MID, 2>), std::min(mid_n, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(mid_first, mid_n, &dc->q_aln_m), g->aln_mode, g->aln_xpct, no_n, no_defer, no_dn, no_ws, no_s1, no_ds1);
+            if (nm) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(nm, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(0, nm, &dc->q_aln_s), g->aln_mode, g->aln_xpct, no_n, no_defer, no_dn, no_ws, no_s1, no_ds1);
             if (big_n && big_first < ni) {
                 // the big-area variant hands the alignments its anti-diagonal engine could not certify on to a second launch of the small-area one
                 // (mode 3): same results, but their strip-engine work then runs at three waves per SIMD instead of one or two
