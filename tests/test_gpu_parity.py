@@ -234,12 +234,14 @@ def test_gpu_large_batch_is_deterministic(th):
 def test_gpu_alignment_engines(monkeypatch, env):
     """unit-vs-consensus alignments: the anti-diagonal band engine with 1..6 registers per lane (TH_ALN_WADD widens the
     requested band), verified on the device against the full matrix (TH_ALN_MODE=2 fails the run on any difference), and the
-    strip engine alone (TH_ALN_MODE=0); records compared with the oracle as everywhere else"""
+    strip engine alone (TH_ALN_MODE=0); the flank extensions likewise (register bands certified by th_adx_bound, the retry with the band
+    the banded maximum names, the banded strip engine behind a four-register probe for the 2500- and 5000-base units at 15 % error);
+    records compared with the oracle as everywhere else"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     t = TH.TideHunter(device=0)
     para = O.default_para()
-    seqs = _synth(t.lib, 12, 1000, 10, 0.10, 1) + _synth(t.lib, 6, 200, 20, 0.10, 2) + _synth(t.lib, 3, 2500, 4, 0.15, 3) + _synth(t.lib, 4, 700, 6, 0.2, 6)
+    seqs = _synth(t.lib, 12, 1000, 10, 0.10, 1) + _synth(t.lib, 6, 200, 20, 0.10, 2) + _synth(t.lib, 3, 2500, 4, 0.15, 3) + _synth(t.lib, 4, 700, 6, 0.2, 6) + _synth(t.lib, 2, 5000, 4, 0.15, 4)
     s = bytearray(seqs[0])
     for x in range(1500, 1510):
         s[x] = ord("N")

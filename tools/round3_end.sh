@@ -40,5 +40,6 @@ bash tools/pmc_instr.sh > $O/pmc_instr_summary.txt 2>&1; cp $R/gpurun_out/pmc_in
 TH_BENCH_BATCH=100000 bash tools/pmc_lds.sh > $O/pmc_lds_summary.txt 2>&1; cp $R/gpurun_out/pmc_lds/pmc_lds.json $O/r03_pmc_lds.json
 # the command line end to end with its per-batch timeline (10 x the headline set), one and two pipelines per device
 bash tools/r3_e2e.sh round3 10 "2:32768 2:32768 1:65536 1:65536 3:32768" > /dev/null 2>&1; grep -v "^\[th\] " $O/e2e.txt | grep -v "complete at" > $O/r03_cli_e2e.txt
+bash tools/r3_shape_stats.sh "c3 c4 c5" > $O/r03_shape_launches.txt 2>&1
 cp $O/r03_hbm_traffic.json $R/profiles/r03_hbm_traffic.json; timeout 600 python3 bench.py --quick > $O/r03_bench_quoting_traffic.json 2>/dev/null
 cat $O/r03_pytest_gpu.txt; tail -c 1500 $O/r03_bench.json; tail -12 $O/pmc_instr_summary.txt; head -14 $O/r03_kernel_stats.csv | cut -c1-60,200-300
