@@ -186,9 +186,10 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                         // Anti-diagonal engine first, with the narrowest band of 128 NP diagonals either side whose bound (th_adx_bound) lies
                         // below the score a flank that continues the repeat is expected to reach ((100 - xpct) % of the shorter sequence).
                         // A band that cannot be certified still yields a banded maximum, a lower bound of the true one, and that names the
-                        // band which is certified for sure: a wider one on the same engine, or -- beyond four registers per lane -- a band
-                        // of the strip engine; pairs of a thousand bases and more whose expected score no register band reaches are probed
-                        // with four registers for that purpose (an eighth of the full matrix's cost).  The full matrix is what is left.
+                        // band which is certified for sure: a wider one on the same engine, or -- beyond four registers per lane -- the
+                        // strip engine with everything pruned that cannot reach that maximum (th_ksw_ext_band_wave: exact for any lower
+                        // bound); pairs of a thousand bases and more whose expected score no register band reaches are probed with four
+                        // registers for that purpose (an eighth of the full matrix's cost).  The full matrix is what is left.
                         bool done = false;
                         int bh = 0;
                         if (mode && cl + tlen < 30000) {
@@ -206,7 +207,7 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                             if (!done && bh > 0) {
                                 int W = 512;
                                 while (W < cl + tlen && th_ext_bound_w(W, cl, tlen) >= bh) W += 64;
-                                if (2 * W + 64 < (tlen * 4) / 5) done = th_ksw_ext_band_wave(qp, st, cl, tp, st, tlen, W, mybnd, &mq, &mt);
+                                th_ksw_ext_band_wave(qp, st, cl, tp, st, tlen, W, bh, mybnd, &mq, &mt); done = true;        // exact for any lower bound bh (th_ksw.h)
                             }
                         }
                         if (!done) th_ksw_ext_wave(qp, st, cl, tp, st, tlen, mybnd, &mq, &mt);

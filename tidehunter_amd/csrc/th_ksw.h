@@ -598,28 +598,50 @@ __device__ __forceinline__ int th_ext_bound_w(int W, int qlen, int tlen)
     return max(min(tlen - d, qlen), min(qlen - d, tlen)) - TH_KQ - d * TH_KE;
 }
 
-// th_ksw_ext_wave restricted to the diagonals |i - j| <= W (cells outside are minus infinity; the matrix borders keep their exact
-// values, which only adds real paths): strip j0 sweeps rows max(0, j0 - W) .. min(tlen - 1, j0 + 63 + W) instead of all of them.
-// Returns true when the result is certified to be the full matrix's (th_ext_bound_w; the caller sizes W from a banded maximum of
-// the anti-diagonal engine, for which the certificate cannot fail); (max_q, max_t) are valid only then.
-__device__ bool th_ksw_ext_band_wave(const uint8_t *__restrict__ q, int qs, int qlen, const uint8_t *__restrict__ t, int ts, int tlen, int W,
+// th_ksw_ext_wave with everything pruned that cannot matter, given a LOWER BOUND slb of the maximum (a banded maximum of the
+// anti-diagonal engine: any banded result is one).  A cell can only matter -- be the maximum, tie with it, or lie on a path to such a
+// cell -- if its H plus the diagonal steps still possible after it reaches slb; cells that cannot are minus infinity.  Two prunings
+// follow, both exact for any slb <= the true maximum (no certificate, no retry):
+//   * the diagonals |i - j| <= W, W chosen by the caller with th_ext_bound_w(W) < slb (the matrix borders keep their exact values,
+//     which only adds real paths): strip j0 sweeps rows max(0, j0 - W) .. min(tlen - 1, j0 + 63 + W) at most;
+//   * once the top border has left that band, paths enter a strip through the parked column only: a parked cell (i, j0 - 1) with
+//     H + min(A, B) < slb (A = tlen - 1 - i, B = qlen - j0 diagonal steps left) is dead, and a live one reaches no cell that matters
+//     below row i + 64 + min(H + B - slb, (H + A - slb) / 2) (a - c surplus rows cost a gap base each and, where t binds, a diagonal
+//     step each).  The live rows of a repeat's flank shrink towards the end of the matrix, to about a quarter of its cells at 15 %
+//     divergence where the band alone keeps half.
+__device__ void th_ksw_ext_band_wave(const uint8_t *__restrict__ q, int qs, int qlen, const uint8_t *__restrict__ t, int ts, int tlen, int W, int slb,
                                      int *__restrict__ bnd, int *max_q, int *max_t)
 {
     const int lane = TH_LANE();
     int2 *bnd2 = (int2 *)bnd;                 // {H, F'} of the parked column
     int bestH = 0, bestR = 0x7fffffff, bestT = -1;
+    int prs = 0, ppre = -1;                   // rows the previous strip swept (its parked column is valid there and nowhere else)
     for (int j0 = 0; j0 < qlen; j0 += TH_WAVE) {
         const int j = j0 + lane;
         const bool colok = j < qlen;
         const int qj = colok ? q[(long long)j * qs] : 4;
         const bool first = j0 == 0, last = j0 + TH_WAVE >= qlen;
-        const int rs = max(0, j0 - W), re = min(tlen - 1, j0 + 63 + W);       // rows this strip touches
-        if (rs > re) break;                                                    // the band has left the matrix: so have all further strips
-        const int pre = min(tlen - 1, j0 - 1 + W);                            // last in-band row of column j0 - 1
+        int rs = max(0, j0 - W), re = min(tlen - 1, j0 + 63 + W);             // rows of the band in this strip
+        if (j0 > W) {                                                          // the top border is outside the band: entries through the parked column only
+            int vmin = 0x7fffffff, vmax = -1;
+            const int B = qlen - j0;
+            for (int r0 = prs; r0 <= ppre; r0 += TH_WAVE) {
+                const int row = r0 + lane;
+                if (row <= ppre) {
+                    const int H = bnd2[row].x, A = tlen - 1 - row;
+                    if (H + min(A, B) >= slb) { vmin = min(vmin, row); vmax = max(vmax, row + 64 + min(H + B - slb, (H + A - slb) >> 1)); }
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { vmin = min(vmin, __shfl_xor(vmin, d)); vmax = max(vmax, __shfl_xor(vmax, d)); }
+            rs = max(rs, vmin); re = min(re, vmax);
+        }
+        rs = TH_UNI(rs); re = TH_UNI(re);
+        if (rs > re) break;                                                    // nothing alive crosses into this strip: nor into any later one
         const int nsteps = re - rs + TH_WAVE;
         int Ein = TH_NEG, Hdiag = TH_NEG, oH = TH_NEG, oF = TH_NEG, tcur = 4;
         int2 nb = { TH_NEG, TH_NEG }; int nt = 4;
-        { const int row = rs + lane; if (row < tlen) { nt = t[(long long)row * ts]; if (!first && row <= pre) nb = bnd2[row]; } }
+        { const int row = rs + lane; if (row < tlen) { nt = t[(long long)row * ts]; if (!first && row >= prs && row <= ppre) nb = bnd2[row]; } }
         for (int s0 = 0; s0 < nsteps; s0 += TH_WAVE) {
             int ibH, ibF, ibT = nt;
             if (first) { ibH = -(TH_KQ + (rs + s0 + lane + 1) * TH_KE); ibF = ibH - TH_KQ - TH_KE; }
@@ -627,7 +649,7 @@ __device__ bool th_ksw_ext_band_wave(const uint8_t *__restrict__ q, int qs, int 
             {
                 const int row = rs + s0 + TH_WAVE + lane;
                 nt = 4; nb.x = TH_NEG; nb.y = TH_NEG;
-                if (row < tlen) { nt = t[(long long)row * ts]; if (!first && row <= pre) nb = bnd2[row]; }
+                if (row < tlen) { nt = t[(long long)row * ts]; if (!first && row >= prs && row <= ppre) nb = bnd2[row]; }
             }
             const int kend = min(TH_WAVE, nsteps - s0);
             for (int k = 0; k < kend; ++k) {
@@ -636,16 +658,17 @@ __device__ bool th_ksw_ext_band_wave(const uint8_t *__restrict__ q, int qs, int 
                 ibH = th_rol1(ibH); ibF = th_rol1(ibF); ibT = th_rol1(ibT);
                 tcur = ti;
                 if (i == 0) { const int hu = -(TH_KQ + (j + 1) * TH_KE); Ein = hu - TH_KQ - TH_KE; Hdiag = j == 0 ? 0 : -(TH_KQ + j * TH_KE); }
-                const bool inb = (unsigned)(i - j + W) <= (unsigned)(2 * W) && i >= 0 && i < tlen;
+                const bool inb = (unsigned)(i - j + W) <= (unsigned)(2 * W) && i >= rs && i <= re;
                 int h = Hdiag + th_ksw_sc(ti, qj);
                 h = max(h, Ein); h = max(h, lF);
                 Hdiag = lH;
                 Ein = inb ? max(Ein, h - TH_KQ) - TH_KE : TH_NEG;
                 oH = inb ? h : TH_NEG; oF = inb ? max(lF, h - TH_KQ) - TH_KE : TH_NEG;
                 if (colok && inb && h > bestH) { bestH = h; bestR = i + j; bestT = i; }
-                if (!last && lane == 63 && i >= 0 && i < tlen) { int2 o; o.x = oH; o.y = oF; bnd2[i] = o; }
+                if (!last && lane == 63 && i >= rs && i <= re) { int2 o; o.x = oH; o.y = oF; bnd2[i] = o; }
             }
         }
+        prs = rs; ppre = re;
         TH_WAVE_FENCE();
     }
     int bestRank = bestT >= 0 ? th_ext_rank(bestR, bestT, qlen, tlen) : 0x7fffffff;
@@ -656,6 +679,4 @@ __device__ bool th_ksw_ext_band_wave(const uint8_t *__restrict__ q, int qs, int 
         if (take) { bestH = oH2; bestR = oR; bestRank = oK; bestT = oT; }
     }
     if (bestH > 0) { *max_t = bestT; *max_q = bestR - bestT; } else { *max_t = -1; *max_q = -1; }
-    const int bound = th_ext_bound_w(W, qlen, tlen);
-    return bestH > bound || (bestH <= 0 && bound <= 0);
 }

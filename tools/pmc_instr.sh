@@ -2,7 +2,7 @@
 # Instruction counters of one bench step (own rocprofv3 pass, kernel trace only): VALU / SALU wave-instructions per launch
 # and the share of VALU issue slots they fill (1024 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz).
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/pmc_instr; mkdir -p $O; cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $O -o run -- python3 $R/bench.py --steps 1 --warmup 0 --quick > $O/log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $O -o run -- python3 $R/bench.py --steps 1 --warmup 0 --quick $BENCH_ARGS > $O/log 2>&1
 python3 - <<'PY'
 import csv, glob, json, os, collections
 O = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out/pmc_instr")
