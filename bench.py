@@ -44,9 +44,9 @@ CONFIGS = {
                label="C2: period 200 x 20 copies, 10 percent error, ~4 kb reads (chain-dominated)"),
     "c3": dict(period=1000, copies=10, err=0.10, seed=1, set_size=100000, batch=100000,
                label="C3 headline: synthetic tandem-repeat reads, period 1000 x 10 copies, 10 percent error (sub/ins/del), ~10 kb"),
-    "c4": dict(period=5000, copies=4, err=0.15, seed=3, set_size=20000, batch=8192,
+    "c4": dict(period=5000, copies=4, err=0.15, seed=3, set_size=20000, batch=20000,
                label="C4: period 5000 x 4 copies, 15 percent error, ~20 kb reads (long period)"),
-    "c5": dict(period=None, copies=None, err=0.10, seed=5, set_size=100000, batch=50000,
+    "c5": dict(period=None, copies=None, err=0.10, seed=5, set_size=100000, batch=100000,
                label="C5: periods {200,500,1000,2000,5000} by read index, copies max(3, 10000 // period), 10 percent error, both strands, "
                      "5'/3' adapters (-5/-3: full-length path + adapter search)"),
     # rehearsal shape for the CPU-emulation tests of the multi-rank path (never a bench line)

@@ -161,10 +161,12 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                         continue;
                     }
                     if (v < 0 && have_s1) {
-                        // strip engine for the second, wider certified band (more divergent than ~12 %) if it is still clearly narrower than the matrix
+                        // strip engine for the second, wider certified band (more divergent than ~12 %)
                         const long long g2 = ((long long)len + cl - 2LL * s1 - 4 * TH_KQ) / (1 + 2 * TH_KE) + 2;
                         const long long W2 = (g2 - 2 - aD + 1) / 2 + 8;
-                        if (W2 > W && 64 + 2 * W2 + aD < (cl * 3) / 4) v = th_ksw_global_band_wave(qp, len, cs, cl, (int)W2, mybnd, s_in, &s1);
+                        // (with the banded score as a lower bound the engine also drops every cell no path of that score can pass through:
+                        // never more work than the matrix, so no area test)
+                        if (W2 > W && W2 < 30000) { const int lb = s1; v = th_ksw_global_band_wave(qp, len, cs, cl, (int)W2, mybnd, s_in, &s1, lb); }
                     }
                     if (v < 0) v = th_ksw_global_wave<false>(qp, len, cs, cl, 0, mybnd, nullptr);
                     if (mode == 2) {

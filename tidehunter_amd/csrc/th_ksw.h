@@ -130,28 +130,51 @@ __device__ int th_ksw_global_wave(const uint8_t *__restrict__ q, int qlen, const
 // the traceback -- lies inside the band, hence H, the tie-breaks and the '=' count along ksw_backtrack's
 // path are those of the full computation.  Returns -1 when the certificate fails (the caller then
 // runs the full matrix).  Strip geometry: columns j0..j0+63 need rows [j0+lo, j0+63+hi] only.
-__device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, int W, int *__restrict__ bnd, int (*s_in)[TH_WAVE][8], int *band_score)
+//
+// slb > TH_NEG: a LOWER BOUND of the optimum (the banded score of an earlier pass).  Inside the band, every cell that no path of
+// score >= slb can pass through is minus infinity as well: once the top border has left the band, paths enter a strip through the
+// parked column only; a parked cell (i, j0 - 1) with H + min(a, b) - gap(|a - b|) < slb (a = tlen - 1 - i, b = qlen - j0: what is left
+// to the end corner) is dead, and a live one reaches nothing that matters below row i + 64 + min(H + b - slb, (H + a - slb) / 2).
+// Every optimal path, and every candidate that ties with one at a cell of the traceback, consists of live cells, so the result is
+// the band's (th_ksw_ext_band_wave has the argument in full); the live region is a lens around the path, not a band.
+__device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, int W, int *__restrict__ bnd, int (*s_in)[TH_WAVE][8], int *band_score, int slb = TH_NEG)
 {
     const int lane = TH_LANE();
     const int D = tlen - qlen;
     const int lo = min(0, D) - W, hi = max(0, D) + W;
     int4 *bnd4 = (int4 *)bnd;
     int res_iden = 0, res_h = TH_NEG;
+    int prs = 0, ppre = -1;                   // rows the previous strip swept (its parked column is valid there and nowhere else)
     for (int j0 = 0; j0 < qlen; j0 += TH_WAVE) {
         const int j = j0 + lane;
         const bool colok = j < qlen;
         const int qj = colok ? q[j] : 4;
         const bool first = j0 == 0, last = j0 + TH_WAVE >= qlen;
         const bool owner = j == qlen - 1;
-        const int rs = max(0, j0 + lo), re = min(tlen - 1, j0 + 63 + hi);     // rows this strip touches
-        const int pre = min(tlen - 1, j0 - 1 + hi);                            // last in-band row of column j0-1
+        int rs = max(0, j0 + lo), re = min(tlen - 1, j0 + 63 + hi);           // rows of the band in this strip
+        if (slb > TH_NEG && j0 + lo > 0) {                                     // (the top border is outside the band: entries through the parked column only)
+            int vmin = 0x7fffffff, vmax = -1;
+            const int b = qlen - j0;
+            for (int r0 = prs; r0 <= ppre; r0 += TH_WAVE) {
+                const int row = r0 + lane;
+                if (row <= ppre) {
+                    const int H = bnd4[row].x, a = tlen - 1 - row, dab = a > b ? a - b : b - a;
+                    if (H + min(a, b) - (dab ? TH_KQ + dab * TH_KE : 0) >= slb) { vmin = min(vmin, row); vmax = max(vmax, row + 64 + min(H + b - slb, (H + a - slb) >> 1)); }
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { vmin = min(vmin, __shfl_xor(vmin, d)); vmax = max(vmax, __shfl_xor(vmax, d)); }
+            rs = max(rs, vmin); re = min(re, vmax);
+        }
+        rs = TH_UNI(rs); re = TH_UNI(re);
+        if (rs > re) { *band_score = TH_NEG; return -1; }                      // (cannot happen with a valid lower bound: the optimal path is alive)
         const int nsteps = re - rs + TH_WAVE;
         int Hup = TH_NEG, Ein = TH_NEG, T1up = 0, Hdiag = TH_NEG, CHdiag = 0;
         int oH = TH_NEG, oF = TH_NEG, oCH = 0, oT2 = 0, tcur = 4;
         int4 nb = { TH_NEG, TH_NEG, 0, 0 }; int nt = 4;
         {
             const int row = rs + lane;
-            if (row < tlen) { nt = t[row]; if (!first && row <= pre) nb = bnd4[row]; }
+            if (row < tlen) { nt = t[row]; if (!first && row >= prs && row <= ppre) nb = bnd4[row]; }
         }
         for (int s0 = 0; s0 < nsteps; s0 += TH_WAVE) {
             // the 64 rows' left-border cells (previous strip's last column, or the matrix border) are parked in LDS, one
@@ -171,7 +194,7 @@ __device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, 
             {
                 const int row = rs + s0 + TH_WAVE + lane;
                 nt = 4; nb.x = TH_NEG; nb.y = TH_NEG; nb.z = 0; nb.w = 0;
-                if (row < tlen) { nt = t[row]; if (!first && row <= pre) nb = bnd4[row]; }
+                if (row < tlen) { nt = t[row]; if (!first && row >= prs && row <= ppre) nb = bnd4[row]; }
             }
             const int kend = min(TH_WAVE, nsteps - s0);
             int4 in = *(const int4 *)&inbox[0][0]; int inT = inbox[0][4];
@@ -188,7 +211,7 @@ __device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, 
                     Hup = (-1 - j >= lo) ? -(TH_KQ + (j + 1) * TH_KE) : TH_NEG; Ein = Hup > TH_NEG ? Hup - TH_KQ - TH_KE : TH_NEG; T1up = 0;
                     Hdiag = j == 0 ? 0 : ((-j >= lo) ? -(TH_KQ + j * TH_KE) : TH_NEG); CHdiag = 0;
                 }
-                const bool inb = colok && (unsigned)i < (unsigned)tlen && (unsigned)(i - j - lo) <= (unsigned)(hi - lo);
+                const bool inb = colok && (unsigned)(i - rs) <= (unsigned)(re - rs) && (unsigned)(i - j - lo) <= (unsigned)(hi - lo);
                 // ties prefer the diagonal over E over F (ksw2_extz2_sse.c:177-195); written as selects so that no lane diverges
                 const int diag = Hdiag + th_ksw_sc(ti, qj);
                 const bool e_gt = Ein > diag;
@@ -204,13 +227,14 @@ __device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, 
                 Ein = inb ? max(Ein, h - TH_KQ) - TH_KE : TH_NEG;
                 oH = inb ? h : TH_NEG; oF = inb ? max(lF, h - TH_KQ) - TH_KE : TH_NEG; oCH = ch; oT2 = t2;
                 if (last && owner && i == tlen - 1) { res_iden = ch; res_h = h; }
-                if (!last && lane == 63 && i >= 0 && i < tlen) { int4 o; o.x = oH; o.y = oF; o.z = oCH; o.w = oT2; bnd4[i] = o; }
+                if (!last && lane == 63 && i >= rs && i <= re) { int4 o; o.x = oH; o.y = oF; o.z = oCH; o.w = oT2; bnd4[i] = o; }
             };
             int4 in2; int in2T;
             int k = 0;
             for (; k + 1 < kend; k += 2) { step(k, in, inT, in2, in2T); step(k + 1, in2, in2T, in, inT); }
             if (k < kend) step(k, in, inT, in2, in2T);
         }
+        prs = rs; ppre = re;
         TH_WAVE_FENCE();
     }
     const int ol = (qlen - 1) & 63;
