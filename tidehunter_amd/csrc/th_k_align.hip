@@ -209,7 +209,7 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                             if (!done && bh > 0) {
                                 int W = 512;
                                 while (W < cl + tlen && th_ext_bound_w(W, cl, tlen) >= bh) W += 64;
-                                th_ksw_ext_band_wave(qp, st, cl, tp, st, tlen, W, bh, mybnd, &mq, &mt); done = true;        // exact for any lower bound bh (th_ksw.h)
+                                th_ksw_ext_band_wave(qp, st, cl, tp, st, tlen, W, bh, mybnd, s_in, &mq, &mt); done = true;        // exact for any lower bound bh (th_ksw.h)
                             }
                         }
                         if (!done) th_ksw_ext_wave(qp, st, cl, tp, st, tlen, mybnd, &mq, &mt);

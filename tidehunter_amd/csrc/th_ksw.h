@@ -574,6 +574,7 @@ __device__ void th_ksw_ext_wave(const uint8_t *__restrict__ q, int qs, int qlen,
         const int qj = colok ? q[(long long)j * qs] : 4;
         const bool first = j0 == 0, last = j0 + TH_WAVE >= qlen;
         int Ein = 0, Hdiag = 0, oH = 0, oF = 0, tcur = 4;
+        int lbH = bestH - 1, lbT = -1;            // this strip's best at or above the running one (see the merge below)
         int2 nb = { 0, 0 }; int nt = 4;
         if (lane < tlen) { nt = t[(long long)lane * ts]; if (!first) nb = bnd2[lane]; }
         for (int s0 = 0; s0 < nsteps; s0 += TH_WAVE) {
@@ -597,11 +598,14 @@ __device__ void th_ksw_ext_wave(const uint8_t *__restrict__ q, int qs, int qlen,
                 Hdiag = lH;
                 Ein = max(Ein, h - TH_KQ) - TH_KE;
                 oH = h; oF = max(lF, h - TH_KQ) - TH_KE;
-                // within this lane r = i + j only grows, so a strict '>' keeps the earliest anti-diagonal
-                if (colok && i >= 0 && i < tlen && h > bestH) { bestH = h; bestR = i + j; bestT = i; }
+                // within one strip this lane's r = i + j only grows, so a strict '>' keeps the earliest anti-diagonal of the strip
+                if (colok && i >= 0 && i < tlen && h > lbH) { lbH = h; lbT = i; }
                 if (!last && lane == 63 && i >= 0 && i < tlen) { int2 o; o.x = oH; o.y = oF; bnd2[i] = o; }
             }
         }
+        // across strips the lane's columns grow by 64 while the rows start over: an equal score on an EARLIER anti-diagonal may turn up in
+        // a later strip, and ksw2 reports the earliest
+        if (lbT >= 0 && (lbH > bestH || lbT + j < bestR)) { bestH = lbH; bestR = lbT + j; bestT = lbT; }
         TH_WAVE_FENCE();
     }
     // wave arg-max by (H desc, anti-diagonal asc, SSE visiting rank asc)
@@ -634,7 +638,7 @@ __device__ __forceinline__ int th_ext_bound_w(int W, int qlen, int tlen)
 //     step each).  The live rows of a repeat's flank shrink towards the end of the matrix, to about a quarter of its cells at 15 %
 //     divergence where the band alone keeps half.
 __device__ void th_ksw_ext_band_wave(const uint8_t *__restrict__ q, int qs, int qlen, const uint8_t *__restrict__ t, int ts, int tlen, int W, int slb,
-                                     int *__restrict__ bnd, int *max_q, int *max_t)
+                                     int *__restrict__ bnd, int (*s_in)[TH_WAVE][8], int *max_q, int *max_t)
 {
     const int lane = TH_LANE();
     int2 *bnd2 = (int2 *)bnd;                 // {H, F'} of the parked column
@@ -663,35 +667,54 @@ __device__ void th_ksw_ext_band_wave(const uint8_t *__restrict__ q, int qs, int 
         rs = TH_UNI(rs); re = TH_UNI(re);
         if (rs > re) break;                                                    // nothing alive crosses into this strip: nor into any later one
         const int nsteps = re - rs + TH_WAVE;
+        const int jmW = colok ? j - W : -0x40000000;                           // in-band test: 0 <= i - jmW <= 2 W (never true beyond the last column)
+        const unsigned rr = (unsigned)(re - rs), w2 = (unsigned)(2 * W);
         int Ein = TH_NEG, Hdiag = TH_NEG, oH = TH_NEG, oF = TH_NEG, tcur = 4;
+        int lbH = bestH - 1, lbT = -1;                                         // this strip's best at or above the running one
         int2 nb = { TH_NEG, TH_NEG }; int nt = 4;
         { const int row = rs + lane; if (row < tlen) { nt = t[(long long)row * ts]; if (!first && row >= prs && row <= ppre) nb = bnd2[row]; } }
         for (int s0 = 0; s0 < nsteps; s0 += TH_WAVE) {
-            int ibH, ibF, ibT = nt;
-            if (first) { ibH = -(TH_KQ + (rs + s0 + lane + 1) * TH_KE); ibF = ibH - TH_KQ - TH_KE; }
-            else { ibH = nb.x; ibF = nb.y; }
+            // the 64 rows' left-border cells and their t bases sit in LDS, one entry per row; every step all lanes read the entry of their
+            // step (one broadcast ds_read, issued a step ahead) and wave_shr:1 injects it at lane 0 (as th_ksw_global_band_wave)
+            int (*inbox)[8] = s_in[(s0 >> 6) & 1];
+            {
+                int4 ib;
+                if (first) { ib.x = -(TH_KQ + (rs + s0 + lane + 1) * TH_KE); ib.y = ib.x - TH_KQ - TH_KE; }
+                else { ib.x = nb.x; ib.y = nb.y; }
+                ib.z = nt; ib.w = 0;
+                *(int4 *)&inbox[lane][0] = ib;
+            }
+            TH_WAVE_FENCE();
             {
                 const int row = rs + s0 + TH_WAVE + lane;
                 nt = 4; nb.x = TH_NEG; nb.y = TH_NEG;
                 if (row < tlen) { nt = t[(long long)row * ts]; if (!first && row >= prs && row <= ppre) nb = bnd2[row]; }
             }
             const int kend = min(TH_WAVE, nsteps - s0);
-            for (int k = 0; k < kend; ++k) {
+            const bool top_ok = rs + s0 < TH_WAVE;               // row 0 can only be met in a block that starts above row 64
+            int4 in = *(const int4 *)&inbox[0][0];
+            auto step = [&](int k, int4 &cin, int4 &nin) {
                 const int i = rs + s0 + k - lane;
-                const int lH = th_shr1_inject(oH, ibH), lF = th_shr1_inject(oF, ibF), ti = th_shr1_inject(tcur, ibT);
-                ibH = th_rol1(ibH); ibF = th_rol1(ibF); ibT = th_rol1(ibT);
+                const int lH = th_shr1_inject(oH, cin.x), lF = th_shr1_inject(oF, cin.y), ti = th_shr1_inject(tcur, cin.z);
+                { const int kn = min(k + 1, TH_WAVE - 1); nin = *(const int4 *)&inbox[kn][0]; }
                 tcur = ti;
-                if (i == 0) { const int hu = -(TH_KQ + (j + 1) * TH_KE); Ein = hu - TH_KQ - TH_KE; Hdiag = j == 0 ? 0 : -(TH_KQ + j * TH_KE); }
-                const bool inb = (unsigned)(i - j + W) <= (unsigned)(2 * W) && i >= rs && i <= re;
+                if (top_ok && i == 0) { const int hu = -(TH_KQ + (j + 1) * TH_KE); Ein = hu - TH_KQ - TH_KE; Hdiag = j == 0 ? 0 : -(TH_KQ + j * TH_KE); }
+                const bool inr = (unsigned)(i - rs) <= rr;
+                const bool inb = inr && (unsigned)(i - jmW) <= w2;
                 int h = Hdiag + th_ksw_sc(ti, qj);
                 h = max(h, Ein); h = max(h, lF);
                 Hdiag = lH;
                 Ein = inb ? max(Ein, h - TH_KQ) - TH_KE : TH_NEG;
                 oH = inb ? h : TH_NEG; oF = inb ? max(lF, h - TH_KQ) - TH_KE : TH_NEG;
-                if (colok && inb && h > bestH) { bestH = h; bestR = i + j; bestT = i; }
-                if (!last && lane == 63 && i >= rs && i <= re) { int2 o; o.x = oH; o.y = oF; bnd2[i] = o; }
-            }
+                if (inb && h > lbH) { lbH = h; lbT = i; }       // within a strip this lane's anti-diagonal only grows: '>' keeps the earliest
+                if (!last && lane == 63 && inr) { int2 o; o.x = oH; o.y = oF; bnd2[i] = o; }
+            };
+            int4 in2;
+            int k = 0;
+            for (; k + 1 < kend; k += 2) { step(k, in, in2); step(k + 1, in2, in); }
+            if (k < kend) step(k, in, in2);
         }
+        if (lbT >= 0 && (lbH > bestH || lbT + j < bestR)) { bestH = lbH; bestR = lbT + j; bestT = lbT; }      // (as th_ksw_ext_wave)
         prs = rs; ppre = re;
         TH_WAVE_FENCE();
     }
