@@ -1,0 +1,164 @@
+"""The two exactness arguments the round-3 flank-extension engines rest on (tidehunter_amd/csrc/th_ksw.h: th_adx_bound /
+th_ext_bound_w and th_ksw_ext_band_wave), checked on thousands of small random pairs against the plain full-matrix extension
+(ksw_extz2_sse with KSW_EZ_EXTZ_ONLY, no band, no z-drop: src/ksw2_align.c:153-173 -- match 1, mismatch -2, gap 2 + 1 per base).
+The model below restates the engine's pruning rules with the strip width as a parameter (the device uses 64), so that small matrices
+exercise them: it is a check of the ARGUMENT (bounds, off-by-ones), the device code itself is checked by TH_ALN_MODE=2 on the GPU
+and by tests/test_emul_parity.py."""
+import random
+
+Q, E, NEG = 2, 1, -(1 << 29)
+
+
+def sc(a, b):
+    return 1 if a == b else -2
+
+
+def full_ext(q, t):
+    """H of every cell (rows = t, columns = q), extension from the corner"""
+    n, m = len(t), len(q)
+    H = [[NEG] * m for _ in range(n)]
+    Ecol = [-(Q + (j + 1) * E) - Q - E for j in range(m)]            # E entering row 0 of column j
+    Hup = [-(Q + (j + 1) * E) for j in range(m)]                      # H(-1, j)
+    for i in range(n):
+        hleft, F = -(Q + (i + 1) * E), -(Q + (i + 1) * E) - Q - E     # H(i, -1) and F entering column 0
+        hdiag = 0 if i == 0 else -(Q + i * E)                         # H(i-1, -1)
+        for j in range(m):
+            h = max(hdiag + sc(t[i], q[j]), Ecol[j], F)
+            hdiag = Hup[j]
+            Hup[j] = h
+            Ecol[j] = max(Ecol[j], h - Q) - E
+            F = max(F, h - Q) - E
+            H[i][j] = h
+    return H
+
+
+def best_cells(H):
+    mx = max(max(r) for r in H)
+    if mx <= 0:
+        return 0, None
+    cells = [(i + j, i, j) for i, r in enumerate(H) for j, h in enumerate(r) if h == mx]
+    r0 = min(c[0] for c in cells)
+    return mx, sorted(c for c in cells if c[0] == r0)
+
+
+def bound_w(W, qlen, tlen):
+    d = W + 1                                                         # th_ext_bound_w
+    return max(min(tlen - d, qlen), min(qlen - d, tlen)) - Q - d * E
+
+
+def banded_ext(q, t, W):
+    """cells with |i - j| > W are minus infinity (the borders keep their values)"""
+    return pruned_ext(q, t, W, NEG, len(q) + len(t) + 8)
+
+
+def pruned_ext(q, t, W, slb, S):
+    """th_ksw_ext_band_wave with strips of S columns: strip j0 sweeps rows rs..re only -- the band |i - j| <= W and, once the top border
+    has left the band (j0 > W), the rows that live cells of the parked column j0 - 1 can reach; everything else is minus infinity"""
+    n, m = len(t), len(q)
+    H = [[NEG] * m for _ in range(n)]
+    parkH, parkF, prs, ppre = {}, {}, 0, -1            # column j0 - 1 of the previous strip: valid on its rows prs..ppre only
+    for j0 in range(0, m, S):
+        rs, re = max(0, j0 - W), min(n - 1, j0 + S - 1 + W)
+        if j0 > W and slb > NEG:
+            vmin, vmax, B = 1 << 30, -1, m - j0
+            for row in range(prs, ppre + 1):
+                h, A = parkH[row], n - 1 - row
+                if h + min(A, B) >= slb:
+                    vmin = min(vmin, row)
+                    vmax = max(vmax, row + S + min(h + B - slb, (h + A - slb) >> 1))
+            rs, re = max(rs, vmin), min(re, vmax)
+        if rs > re:
+            break
+        cols = range(j0, min(j0 + S, m))
+        rowH = {j: NEG for j in cols}                  # H of the row above (minus infinity above rs; the border above row 0)
+        rowE = {j: NEG for j in cols}                  # E entering this row
+        newH, newF = {}, {}
+        for i in range(rs, re + 1):
+            if i == 0:
+                for j in cols:
+                    rowH[j] = -(Q + (j + 1) * E)
+                    rowE[j] = rowH[j] - Q - E
+            if j0 == 0:
+                left_h, F = -(Q + (i + 1) * E), -(Q + (i + 1) * E) - Q - E
+                diag = 0 if i == 0 else -(Q + i * E)
+            else:
+                left_h, F = (parkH[i], parkF[i]) if prs <= i <= ppre else (NEG, NEG)
+                diag = -(Q + j0 * E) if i == 0 else (parkH[i - 1] if prs <= i - 1 <= ppre else NEG)
+            for j in cols:
+                h = max(diag + sc(t[i], q[j]), rowE[j], F)
+                diag = rowH[j]
+                if abs(i - j) <= W:
+                    rowH[j], rowE[j], F = h, max(rowE[j], h - Q) - E, max(F, h - Q) - E
+                else:
+                    rowH[j], rowE[j], F = NEG, NEG, NEG
+                H[i][j] = rowH[j]
+            newH[i], newF[i] = rowH[cols[-1]], F
+        parkH, parkF, prs, ppre = newH, newF, rs, re
+    return H
+
+
+def mutate(rng, s, p):
+    out = []
+    for c in s:
+        x = rng.random()
+        if x < p / 3:
+            out.append(rng.choice("ACGT"))
+        elif x < 2 * p / 3:
+            out.append(c); out.append(rng.choice("ACGT"))
+        elif x < p:
+            continue
+        else:
+            out.append(c)
+    return "".join(out)
+
+
+def test_band_bound_covers_every_cell_a_band_can_get_wrong():
+    """th_ext_bound_w / th_adx_bound: every cell outside the band, and every cell whose banded H differs from the true one, has true
+    H <= the bound -- so a banded maximum above the bound is the true one, with the true tie candidates"""
+    rng = random.Random(7)
+    for _ in range(150):
+        base = "".join(rng.choice("ACGT") for _ in range(rng.randint(20, 70)))
+        q, t = mutate(rng, base, 0.25) or "A", mutate(rng, base, 0.25) or "C"
+        H = full_ext(q, t)
+        for W in (2, 5, 9, 14, 22):
+            Hb = banded_ext(q, t, W)
+            bnd = bound_w(W, len(q), len(t))
+            for i in range(len(t)):
+                for j in range(len(q)):
+                    assert Hb[i][j] <= H[i][j]
+                    if abs(i - j) > W or Hb[i][j] != H[i][j]:
+                        assert H[i][j] <= bnd, (q, t, W, i, j, H[i][j], bnd)
+
+
+def test_pruned_strip_engine_is_exact_for_any_lower_bound():
+    """th_ksw_ext_band_wave: with slb <= the true maximum (the true one, a looser one, the banded maximum of a narrow probe) and W from
+    th_ext_bound_w(W) < slb, the pruned sweep reports the full matrix's maximum on the same earliest anti-diagonal cells"""
+    rng = random.Random(11)
+    n_pruned = 0
+    for it in range(400):
+        base = "".join(rng.choice("ACGT") for _ in range(rng.randint(30, 110)))
+        p = rng.choice((0.08, 0.2, 0.35))
+        q, t = mutate(rng, base, p) or "A", mutate(rng, base, p) or "C"
+        if it % 5 == 0:
+            t = t[: max(1, len(t) // 2)]
+        if it % 7 == 0:
+            q = q + "".join(rng.choice("ACGT") for _ in range(20))
+        H = full_ext(q, t)
+        mx, cells = best_cells(H)
+        if mx <= 0:
+            continue
+        probe = best_cells(banded_ext(q, t, 4))[0]
+        for S in (4, 8):
+            for slb in {mx, max(1, mx - rng.randint(1, 6)), max(1, probe)}:
+                W = S
+                while W < len(q) + len(t) and bound_w(W, len(q), len(t)) >= slb:
+                    W += S
+                Hp = pruned_ext(q, t, W, slb, S)
+                n_pruned += sum(1 for i in range(len(t)) for j in range(len(q)) if Hp[i][j] == NEG and abs(i - j) <= W)
+                for i in range(len(t)):
+                    for j in range(len(q)):
+                        assert Hp[i][j] <= H[i][j]
+                        if H[i][j] >= slb:
+                            assert Hp[i][j] == H[i][j], (q, t, S, slb, W, i, j)
+                assert best_cells(Hp) == (mx, cells), (q, t, S, slb, W)
+    assert n_pruned > 10000          # the viability rule did prune inside the band
