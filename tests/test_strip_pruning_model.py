@@ -162,3 +162,94 @@ def test_pruned_strip_engine_is_exact_for_any_lower_bound():
                             assert Hp[i][j] == H[i][j], (q, t, S, slb, W, i, j)
                 assert best_cells(Hp) == (mx, cells), (q, t, S, slb, W)
     assert n_pruned > 10000          # the viability rule did prune inside the band
+
+
+# ---------------------------------------------------------------- the second band of the unit alignments (th_ksw_global_band_wave, slb)
+def global_dp(q, t, W, slb, S):
+    """H of the global alignment's matrix (ksw2 with flag 0: src/ksw2_align.c:117-151) restricted as th_ksw_global_band_wave restricts it:
+    diagonals lo..hi = min(0, D) - W .. max(0, D) + W and, with a lower bound slb of the optimum, strips of S columns that sweep only the
+    rows live cells of the parked column can reach"""
+    n, m = len(t), len(q)
+    D = n - m
+    lo, hi = min(0, D) - W, max(0, D) + W
+    H = [[NEG] * m for _ in range(n)]
+    parkH, parkF, prs, ppre = {}, {}, 0, -1
+    for j0 in range(0, m, S):
+        rs, re = max(0, j0 + lo), min(n - 1, j0 + S - 1 + hi)
+        if slb > NEG and j0 + lo > 0:
+            vmin, vmax, b = 1 << 30, -1, m - j0
+            for row in range(prs, ppre + 1):
+                h, a = parkH[row], n - 1 - row
+                d = abs(a - b)
+                if h + min(a, b) - ((d + 1) * E if d else 0) >= slb:
+                    vmin = min(vmin, row)
+                    vmax = max(vmax, row + S + min(h + b - slb, (h + a - slb) >> 1))
+            rs, re = max(rs, vmin), min(re, vmax)
+        if rs > re:
+            return None
+        cols = range(j0, min(j0 + S, m))
+        rowH = {j: NEG for j in cols}
+        rowE = {j: NEG for j in cols}
+        newH, newF = {}, {}
+        for i in range(rs, re + 1):
+            if i == 0:
+                for j in cols:
+                    inb = -1 - j >= lo
+                    rowH[j] = -(Q + (j + 1) * E) if inb else NEG
+                    rowE[j] = rowH[j] - Q - E if inb else NEG
+            if j0 == 0:
+                inb = i + 1 <= hi
+                left_f = -(Q + (i + 1) * E) - Q - E if inb else NEG
+                diag = 0 if i == 0 else (-(Q + i * E) if i <= hi else NEG)
+                F = left_f
+            else:
+                F = parkF[i] if prs <= i <= ppre else NEG
+                diag = (-(Q + j0 * E) if -j0 >= lo else NEG) if i == 0 else (parkH[i - 1] if prs <= i - 1 <= ppre else NEG)
+            for j in cols:
+                h = max(diag + sc(t[i], q[j]), rowE[j], F)
+                diag = rowH[j]
+                if lo <= i - j <= hi:
+                    rowH[j], rowE[j], F = h, max(rowE[j], h - Q) - E, max(F, h - Q) - E
+                else:
+                    rowH[j], rowE[j], F = NEG, NEG, NEG
+                H[i][j] = rowH[j]
+            newH[i], newF[i] = rowH[cols[-1]], F
+        parkH, parkF, prs, ppre = newH, newF, rs, re
+    return H
+
+
+def test_pruned_global_band_keeps_every_cell_an_optimal_path_can_use():
+    """th_ksw_global_band_wave with slb: the corner's score is the full matrix's, no cell exceeds its true value, and every cell through
+    which a path of score >= slb can still pass -- H + what is left to the corner, counted as the engine counts it -- keeps its true H"""
+    rng = random.Random(23)
+    n_pruned = 0
+    for it in range(300):
+        base = "".join(rng.choice("ACGT") for _ in range(rng.randint(30, 100)))
+        p = rng.choice((0.08, 0.2, 0.3))
+        q, t = mutate(rng, base, p), mutate(rng, base, p)
+        if len(q) < 4 or len(t) < 4:
+            continue
+        n, m = len(t), len(q)
+        full = global_dp(q, t, n + m, NEG, n + m)
+        opt = full[n - 1][m - 1]
+        narrow = global_dp(q, t, 3, NEG, n + m)[n - 1][m - 1]          # a banded score: a lower bound of the optimum
+        for S in (4, 8):
+            for slb in {opt, opt - rng.randint(1, 5), narrow}:
+                if slb <= NEG // 2:
+                    continue
+                for W in (n + m, max(4, abs(n - m) + rng.randint(4, 20))):
+                    ref = global_dp(q, t, W, NEG, n + m)              # the band alone
+                    got = global_dp(q, t, W, slb, S)
+                    if ref[n - 1][m - 1] < slb:
+                        continue                                    # (this band does not hold a path of that score: the caller never asks for it)
+                    assert got is not None and got[n - 1][m - 1] == ref[n - 1][m - 1], (q, t, S, slb, W)
+                    for i in range(n):
+                        for j in range(m):
+                            assert got[i][j] <= ref[i][j]
+                            a, b = n - 1 - i, m - 1 - j
+                            d = abs(a - b)
+                            if ref[i][j] + min(a, b) - ((d + 1) * E if d else 0) >= slb:
+                                assert got[i][j] == ref[i][j], (q, t, S, slb, W, i, j)
+                            elif got[i][j] == NEG and ref[i][j] > NEG:
+                                n_pruned += 1
+    assert n_pruned > 10000

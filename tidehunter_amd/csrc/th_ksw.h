@@ -133,8 +133,9 @@ __device__ int th_ksw_global_wave(const uint8_t *__restrict__ q, int qlen, const
 //
 // slb > TH_NEG: a LOWER BOUND of the optimum (the banded score of an earlier pass).  Inside the band, every cell that no path of
 // score >= slb can pass through is minus infinity as well: once the top border has left the band, paths enter a strip through the
-// parked column only; a parked cell (i, j0 - 1) with H + min(a, b) - gap(|a - b|) < slb (a = tlen - 1 - i, b = qlen - j0: what is left
-// to the end corner) is dead, and a live one reaches nothing that matters below row i + 64 + min(H + b - slb, (H + a - slb) / 2).
+// parked column only; a parked cell (i, j0 - 1) with H + min(a, b) - (|a - b| + 1) e < slb where a != b (a = tlen - 1 - i, b = qlen - j0:
+// what is left to the end corner; the path may cross in an open horizontal gap, at most H - e, and then closes the difference without a
+// new opening) is dead, and a live one reaches nothing that matters below row i + 64 + min(H + b - slb, (H + a - slb) / 2).
 // Every optimal path, and every candidate that ties with one at a cell of the traceback, consists of live cells, so the result is
 // the band's (th_ksw_ext_band_wave has the argument in full); the live region is a lens around the path, not a band.
 __device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, int W, int *__restrict__ bnd, int (*s_in)[TH_WAVE][8], int *band_score, int slb = TH_NEG)
@@ -159,7 +160,7 @@ __device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, 
                 const int row = r0 + lane;
                 if (row <= ppre) {
                     const int H = bnd4[row].x, a = tlen - 1 - row, dab = a > b ? a - b : b - a;
-                    if (H + min(a, b) - (dab ? TH_KQ + dab * TH_KE : 0) >= slb) { vmin = min(vmin, row); vmax = max(vmax, row + 64 + min(H + b - slb, (H + a - slb) >> 1)); }
+                    if (H + min(a, b) - (dab ? (dab + 1) * TH_KE : 0) >= slb) { vmin = min(vmin, row); vmax = max(vmax, row + 64 + min(H + b - slb, (H + a - slb) >> 1)); }
                 }
             }
 #pragma unroll
