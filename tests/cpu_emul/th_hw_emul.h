@@ -67,10 +67,16 @@ static inline uint32_t th_pk_sign(uint32_t a) { return (TH_PK_LO(a) < 0 ? 1u : 0
 static inline uint32_t th_ubfe(uint32_t v, uint32_t off, uint32_t w) { return (v >> (off & 31)) & ((1u << w) - 1); }
 static inline uint32_t th_cvt_pk_i16(int lo, int hi) { return TH_PK(th_sat16_(lo), th_sat16_(hi)); }     // two ints to a saturated int16 pair
 // v_perm_b32: result byte k is picked by selector byte k: 0..3 byte of s1, 4..7 byte of s0, 12 the constant 0 (the other codes are not used here)
+#define TH_PERM_SIGNS 0x0b090a08u
+static inline uint32_t th_and_or(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | c; }
 static inline uint32_t th_perm(uint32_t s0, uint32_t s1, uint32_t sel)
 {
     const unsigned long long src = ((unsigned long long)s0 << 32) | s1; uint32_t r = 0;
-    for (int k = 0; k < 4; ++k) { const uint32_t c = (sel >> (8 * k)) & 0xff; r |= (c < 8 ? (uint32_t)((src >> (8 * c)) & 0xff) : c >= 13 ? 0xffu : 0u) << (8 * k); }
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t c = (sel >> (8 * k)) & 0xff;
+        // 0..7: a byte of {s0, s1}; 8..11: 0xff / 0x00 from the sign of byte 1, 3, 5, 7; 12: 0x00; 13 and above: 0xff
+        r |= (c < 8 ? (uint32_t)((src >> (8 * c)) & 0xff) : c < 12 ? (((src >> (16 * (c - 8) + 15)) & 1) ? 0xffu : 0u) : c >= 13 ? 0xffu : 0u) << (8 * k);
+    }
     return r;
 }
 __device__ __forceinline__ uint32_t th_wave_incl_pkmax(uint32_t v)

@@ -32,19 +32,30 @@
 #define TH_POA_QCAP_WIDE 8192   // ... by the 32-bit-ring variant (longer units read the query from HBM: QCAP = 0)
 
 // Direction words.  In registers (traceback) a word has the layout of the TH_D_* macros below.  In HBM a cell of a row with at
-// most four predecessors -- every packed row, nearly every other row -- is a 16-bit word made of raw comparison results:
-//   bits 7..4  "strictly better than everything before it" for E1, E2, F1, F2 in that order (the source is the last one set)
-//   bits 3..0  XE1, XE2, XF1, XF2: the gap was extended rather than opened
-//   bits 9..8 / 11..10 / 13..12  edge index of the predecessor that gave the diagonal / the E1 / the E2 value
-// so the packed row stores the sign bits of eight saturating differences as they come (two instructions per bit) instead of
+// most four predecessors -- every packed row, nearly every other row -- is a 16-bit word made of raw comparison results, laid out
+// as the packed row's byte permutes deliver them (v_perm_b32 with the sign selectors turns the sign bits of TWO packed differences
+// into four bytes of 0xff / 0x00: the upper byte of a cell's word takes the first difference of a pair, the lower byte the second):
+//   bits 8, 0, 9, 1    "strictly better than everything before it" for E1, E2, F1, F2 in that order (the source is the last one set)
+//   bits 10, 2, 11, 3  XE1, XE2, XF1, XF2: the gap was extended rather than opened
+//   bits 13..12 / 15..14 / 5..4  edge index of the predecessor that gave the diagonal / the E1 / the E2 value
+// so the packed row spends one instruction per comparison (a permute and an and-or per pair; round 2: two per comparison) instead of
 // assembling a 32-bit word per cell, and the traffic of the direction matrix halves.  Rows with more than four predecessors
 // store whole cells (int4, the 32-bit word in .w); th_poa_dir() returns the register layout for either kind.
 #define TH_D16_WIDE_DEG 4
+#define TH_D16_PM_SHIFT 12
+#define TH_D16_PE1_SHIFT 14
+#define TH_D16_PE2_SHIFT 4
 __device__ __forceinline__ uint32_t th_d16_expand(uint32_t w)
 {
-    const uint32_t src = (w & 0x10u) ? 4u : (w & 0x20u) ? 3u : (w & 0x40u) ? 2u : (w & 0x80u) ? 1u : 0u;
-    return src | ((w >> 8) & 3u) << 3 | ((w >> 10) & 3u) << 11 | ((w >> 12) & 3u) << 19
-         | ((w >> 3) & 1u) << 27 | ((w >> 2) & 1u) << 28 | ((w >> 1) & 1u) << 29 | (w & 1u) << 30;
+    const uint32_t src = (w & 0x002u) ? 4u : (w & 0x200u) ? 3u : (w & 0x001u) ? 2u : (w & 0x100u) ? 1u : 0u;
+    return src | ((w >> TH_D16_PM_SHIFT) & 3u) << 3 | ((w >> TH_D16_PE1_SHIFT) & 3u) << 11 | ((w >> TH_D16_PE2_SHIFT) & 3u) << 19
+         | ((w >> 10) & 1u) << 27 | ((w >> 2) & 1u) << 28 | ((w >> 11) & 1u) << 29 | ((w >> 3) & 1u) << 30;
+}
+// the 16-bit word from a source (0..4), the four extension flags and the three edge indices (the one-column-per-lane rows)
+__device__ __forceinline__ uint32_t th_d16_pack(int src, uint32_t xe1, uint32_t xe2, uint32_t xf1, uint32_t xf2, uint32_t pm, uint32_t pe1, uint32_t pe2)
+{
+    const uint32_t s = src == 1 ? 0x100u : src == 2 ? 0x001u : src == 3 ? 0x200u : src == 4 ? 0x002u : 0u;
+    return s | xe1 << 10 | xe2 << 2 | xf1 << 11 | xf2 << 3 | pm << TH_D16_PM_SHIFT | pe1 << TH_D16_PE1_SHIFT | pe2 << TH_D16_PE2_SHIFT;
 }
 #define TH_D_SRC(d)  ((d) & 7)
 #define TH_D_PM(d)   (((d) >> 3) & 0xff)

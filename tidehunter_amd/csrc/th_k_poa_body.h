@@ -394,7 +394,7 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
                 else {
                     const uint32_t gm = th_pk_negmask_op(th_pk_sub(m, mo)), ge1 = th_pk_negmask_op(th_pk_sub(e1v, c1)), ge2 = th_pk_negmask_op(th_pk_sub(e2v, c2));
                     m = th_pk_max(m, mo); e1v = th_pk_max(e1v, c1); e2v = th_pk_max(e2v, c2);
-                    PMV = th_sel(gm, TH_PK_DUP(o << 8), PMV); PE1V = th_sel(ge1, TH_PK_DUP(o << 10), PE1V); PE2V = th_sel(ge2, TH_PK_DUP(o << 12), PE2V);
+                    PMV = th_sel(gm, TH_PK_DUP(o << TH_D16_PM_SHIFT), PMV); PE1V = th_sel(ge1, TH_PK_DUP(o << TH_D16_PE1_SHIFT), PE1V); PE2V = th_sel(ge2, TH_PK_DUP(o << TH_D16_PE2_SHIFT), PE2V);
                 }
             }
         }
@@ -419,16 +419,14 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
         const uint32_t f1 = th_pk_sub(x1, JE1), f2 = th_pk_sub(x2, JE2);
         const uint32_t h3 = th_pk_max(hnf, f1), dg3 = th_pk_sub(hnf, f1);
         const uint32_t h = th_pk_max(h3, f2), dg4 = th_pk_sub(h3, f2);
-        // direction word of the two columns: the sign bits of eight saturating differences, the first one ending in bit 7
+        // direction word of the two columns: the sign bits of eight saturating differences, two differences per byte permute (its sign
+        // selectors deliver 0xff / 0x00 per half), one bit position per pair (layout: th_k_poa.hip)
         const uint32_t hO1 = th_pk_sub(h, O1P), hO2 = th_pk_sub(h, O2P);
-        uint32_t code = th_pk_sign(dg1);
-        code = (code << 1) | th_pk_sign(dg2);
-        code = (code << 1) | th_pk_sign(dg3);
-        code = (code << 1) | th_pk_sign(dg4);
-        code = (code << 1) | th_pk_sign(th_pk_sub(hO1, e1v));
-        code = (code << 1) | th_pk_sign(th_pk_sub(hO2, e2v));
-        code = (code << 1) | th_pk_sign(th_pk_sub(hO1, f1));
-        code = (code << 1) | th_pk_sign(th_pk_sub(hO2, f2));
+        const uint32_t xf1 = th_pk_sub(hO1, f1), xf2 = th_pk_sub(hO2, f2);
+        uint32_t code = th_perm(dg1, dg2, TH_PERM_SIGNS) & 0x01010101u;
+        code = th_and_or(th_perm(dg3, dg4, TH_PERM_SIGNS), 0x02020202u, code);
+        code = th_and_or(th_perm(th_pk_sub(hO1, e1v), th_pk_sub(hO2, e2v), TH_PERM_SIGNS), 0x04040404u, code);
+        code = th_and_or(th_perm(xf1, xf2, TH_PERM_SIGNS), 0x08080808u, code);
         if (npk > 1) code |= PMV | PE1V | PE2V;
         const uint32_t n1 = th_pk_sub(th_pk_max(hO1, e1v), E1P), n2 = th_pk_sub(th_pk_max(hO2, e2v), E2P);
         // column b-1 / e+1 of an odd edge land in the row's own padding.  Wave-uniform base + the lane's constant byte offset:
@@ -817,8 +815,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 }
                 const int n1 = max(h - O1, e1v) - E1, n2 = max(h - O2, e2v) - E2;
                 if (inn <= TH_D16_WIDE_DEG)
-                    drow[j - b] = (uint16_t)((src ? 0x100u >> src : 0u) | (d >> 27 & 1u) << 3 | (d >> 28 & 1u) << 2 | (d >> 29 & 1u) << 1 | (d >> 30 & 1u)
-                                             | (uint32_t)pm << 8 | (uint32_t)pe1 << 10 | (uint32_t)pe2 << 12);
+                    drow[j - b] = (uint16_t)th_d16_pack(src, d >> 27 & 1u, d >> 28 & 1u, d >> 29 & 1u, d >> 30 & 1u, (uint32_t)pm, (uint32_t)pe1, (uint32_t)pe2);
                 if (store_full) { int4 cv; cv.x = h; cv.y = n1; cv.z = n2; cv.w = (int)d; row[j - b] = cv; }
                 if (cache_me) { s_ring[myslot][0][TH_RIDX(j, b)] = TH_RING_ST(h); s_ring[myslot][1][TH_RIDX(j, b)] = TH_RING_ST(n1); s_ring[myslot][2][TH_RIDX(j, b)] = TH_RING_ST(n2); }
             }
