@@ -67,6 +67,7 @@ static inline uint32_t th_pk_sign(uint32_t a) { return (TH_PK_LO(a) < 0 ? 1u : 0
 static inline uint32_t th_ubfe(uint32_t v, uint32_t off, uint32_t w) { return (v >> (off & 31)) & ((1u << w) - 1); }
 static inline uint32_t th_cvt_pk_i16(int lo, int hi) { return TH_PK(th_sat16_(lo), th_sat16_(hi)); }     // two ints to a saturated int16 pair
 // v_perm_b32: result byte k is picked by selector byte k: 0..3 byte of s1, 4..7 byte of s0, 12 the constant 0 (the other codes are not used here)
+static inline int th_mbcnt(unsigned long long m) { return __builtin_popcountll(m & ((1ull << TH_LANE()) - 1)); }
 #define TH_PERM_SIGNS 0x0b090a08u
 static inline uint32_t th_and_or(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | c; }
 static inline uint32_t th_perm(uint32_t s0, uint32_t s1, uint32_t sel)

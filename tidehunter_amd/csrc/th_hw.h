@@ -128,6 +128,8 @@ __device__ __forceinline__ uint32_t th_cvt_pk_i16(int lo, int hi) { return __bui
 __device__ __forceinline__ uint32_t th_perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
 // v_perm_b32 selectors 8..11: a byte of 0xff / 0x00 from the sign of S1[15], S1[31], S0[15], S0[31].  TH_PERM_SIGNS: the signs of the two
 // 16-bit halves of s0 and s1 as bytes (s0.hi, s1.hi, s0.lo, s1.lo)
+// set bits of a ballot below this lane (v_mbcnt_lo / _hi: no per-lane 64-bit mask to keep alive)
+__device__ __forceinline__ int th_mbcnt(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 #define TH_PERM_SIGNS 0x0b090a08u
 __device__ __forceinline__ uint32_t th_and_or(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | c; }
 __device__ __forceinline__ uint32_t th_wave_incl_pkmax(uint32_t v)

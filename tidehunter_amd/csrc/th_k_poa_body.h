@@ -991,7 +991,7 @@ __device__ void th_poa_merge(ThPoaG &g, const uint8_t *__restrict__ q, int n_ops
         const bool isnew = kind != 0;
         const unsigned long long nm = __ballot(isnew);
         if (isnew) {
-            v = n_old + new_cnt + __popcll(nm & ((1ull << lane) - 1));
+            v = n_old + new_cnt + th_mbcnt(nm);
             th_poa_init_node(g, v, b, 0);
             if (kind == 1) { g.ring[v] = g.ring[u]; g.ring[u] = v; g.aft[hi] = v; }
         }
@@ -999,7 +999,7 @@ __device__ void th_poa_merge(ThPoaG &g, const uint8_t *__restrict__ q, int n_ops
         const bool isnode = ok && op != 2;
         if (isnode) g.nread[v] += 1;
         const unsigned long long pmk = __ballot(isnode);
-        if (isnode) g.pth[1 + path_cnt + __popcll(pmk & ((1ull << lane) - 1))] = v;
+        if (isnode) g.pth[1 + path_cnt + th_mbcnt(pmk)] = v;
         path_cnt += __popcll(pmk);
         if (ok) { g.pv[f] = kind == 2 ? v : -1; g.glo[f] = op == 0 ? lo : -1; }
     }
@@ -1017,8 +1017,10 @@ __device__ void th_poa_merge(ThPoaG &g, const uint8_t *__restrict__ q, int n_ops
         const int f = f0 + lane; const bool ok = f < n_ops;
         const int lo = ok ? g.glo[f] : -1, vi = ok ? g.pv[f] : -1;
         const unsigned long long mM = __ballot(lo >= 0);
-        const unsigned long long higher = lane == 63 ? 0ull : (mM & ~((2ull << lane) - 1));
-        const int srcl = higher ? th_ctz64(higher) : 0;
+        // (the lanes above this one as a shift of the ballot, not as a per-lane 64-bit mask: the compiler hoists such a mask to the kernel's
+        // entry, and it then lives -- spilled and reloaded inside the two-predecessor rows -- across the whole DP loop; th_mbcnt likewise)
+        const unsigned long long higher = lane == 63 ? 0ull : (mM >> (lane + 1));
+        const int srcl = higher ? lane + 1 + th_ctz64(higher) : 0;
         const int alo = __shfl(lo, srcl);
         const int anchor = higher ? alo : carry_lo;
         if (vi >= 0) { atomicAdd(&g.cntB[anchor], 1); atomicMin(&g.headB[anchor], vi); }
@@ -1077,7 +1079,7 @@ __device__ int th_poa_consensus(ThPoaG &g, int n_seqs, uint8_t *__restrict__ con
         }
         const unsigned long long em = __ballot(bb >= 0);
         if (bb >= 0) {
-            const int o = cl + __popcll(em & ((1ull << lane) - 1));
+            const int o = cl + th_mbcnt(em);
             if (o < cons_cap) { cons[o] = (uint8_t)bb; cov[o] = best; } else over = 1;
         }
         cl += __popcll(em);
