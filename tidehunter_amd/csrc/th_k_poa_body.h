@@ -413,8 +413,10 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
         // step), a packed max would need a move and an identity fill per step
         const int a1l = TH_PK_LO(a1), a2l = TH_PK_LO(a2);
         const int i1 = th_wave_incl_max(max(a1l, TH_PK_HI(a1))), i2 = th_wave_incl_max(max(a2l, TH_PK_HI(a2)));
-        const int b1 = max(th_shr1(i1, carry1), carry1), b2 = max(th_shr1(i2, carry2), carry2);    // best before this lane's pair
-        carry1 = max(carry1, TH_READLANE(i1, 63)); carry2 = max(carry2, TH_READLANE(i2, 63));
+        // best before this lane's pair.  (In the first trip the carries are minus infinity, the smallest value of the domain: nothing to take the
+        // maximum with; the compiler peels that trip, so the test costs nothing.)
+        const int b1 = t0 ? max(th_shr1(i1, carry1), carry1) : th_shr1(i1, -32768), b2 = t0 ? max(th_shr1(i2, carry2), carry2) : th_shr1(i2, -32768);
+        carry1 = t0 ? max(carry1, TH_READLANE(i1, 63)) : TH_READLANE(i1, 63); carry2 = t0 ? max(carry2, TH_READLANE(i2, 63)) : TH_READLANE(i2, 63);
         const uint32_t x1 = TH_PK(b1, max(b1, a1l)), x2 = TH_PK(b2, max(b2, a2l));                 // (before lo, before hi)
         const uint32_t f1 = th_pk_sub(x1, JE1), f2 = th_pk_sub(x2, JE2);
         const uint32_t h3 = th_pk_max(hnf, f1), dg3 = th_pk_sub(hnf, f1);
