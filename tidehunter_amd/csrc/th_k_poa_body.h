@@ -452,8 +452,8 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
         // the row maximum's first / last column: the first / last lane with either half at the maximum, then which half.  (Some
         // in-band lane holds the maximum, so the masks are never both empty; the first trip always sets all three.)
         const int hm = TH_READLANE(hmv, 63);
-        const uint32_t eqx = hm2 ^ TH_PK_DUP(hm);
-        const unsigned long long mlo = __ballot((eqx & 0xffffu) == 0), mhi = __ballot((eqx >> 16) == 0);
+        // (each half compared with the scalar maximum as a sign-extended operand: no packed copy of the maximum to build on the scalar unit)
+        const unsigned long long mlo = __ballot(TH_PK_LO(hm2) == hm), mhi = __ballot(TH_PK_HI(hm2) == hm);
         const unsigned long long many = mlo | mhi;
         if (t0 == 0 || (hm >= rmax && many)) {
             const int fa = th_ctz64nz(many), la = th_msb64nz(many);
