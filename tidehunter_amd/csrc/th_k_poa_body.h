@@ -316,7 +316,7 @@ __device__ unsigned long long th_poa_prof[24];    // 0..3 phase cycles; 4..7 tra
 #define TH_RIDX(j, beg) ((j) - ((beg) & ~1) + TH_POA_PAD)
 
 // One packed row: lane l owns columns B0 + 128 t + 2 l and the next one; every predecessor (npk of them, ring slot q_slot*, even
-// band base q_pb*) sits clean in the LDS ring.  Writes the row's ring slot and its 16-bit direction words (drow: column b), returns
+// band base q_pb*) sits clean in the LDS ring.  Writes the row's ring slot and its 16-bit direction words (drow: column B0), returns
 // the row maximum and its first / last column through rmax / left / right.  Forced inline: the row loop calls it twice, once
 // with npk = 1 and the previous row's slot as constants (the common row: COMMON, its band never starts left of its predecessor's), once in general.
 // FAR: one predecessor (edge index far_o; none if negative) is NOT in the ring -- more than three rows back, or too wide to be cached --
@@ -431,9 +431,9 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
         code = th_and_or(th_perm(xf1, xf2, TH_PERM_SIGNS), 0x08080808u, code);
         if (npk > 1) code |= PMV | PE1V | PE2V;
         const uint32_t n1 = th_pk_sub(th_pk_max(hO1, e1v), E1P), n2 = th_pk_sub(th_pk_max(hO2, e2v), E2P);
-        // column b-1 / e+1 of an odd edge land in the row's own padding.  Wave-uniform base + the lane's constant byte offset:
-        // the store takes its address as scalar pair + 32-bit vector offset, no per-row 64-bit address arithmetic
-        if (j0 <= e) TH_STORE_U32_SADDR(drow + (B0 + t0 - b), 4 * lane, code);
+        // column b-1 / e+1 of an odd edge land in the row's own padding.  drow is the word of column B0 (the row's even base): a
+        // wave-uniform pointer + the lane's constant byte offset (+ the trip's): no 64-bit address arithmetic per trip on the scalar unit
+        if (j0 <= e) TH_STORE_U32_SADDR(drow, (uint32_t)(4 * lane + 2 * t0), code);
         if (t0 == 0 || wi < TH_POA_RS / 2) {     // (every lane of the first trip is inside the slot)
 #if TH_POA_REL
             const uint32_t THRP = TH_PK_DUP(TH_POA_REL_THR);          // below the threshold: minus infinity, stored as exactly that
@@ -588,7 +588,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                     const int my_off = (int)ncell + (b - B0);
                     ncell += span;
                     int rmax = TH_NEG - 0x10000000, left = b, right = b;
-                    th_poa_pk_row<QCAP, RT, true, false>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), 1, (i - 1) & 3, 0, 0, 0, L_b & ~1, 0, 0, 0,
+                    th_poa_pk_row<QCAP, RT, true, false>(s_qs, s_ring, g.dcell + (my_off - (b - B0)), lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), 1, (i - 1) & 3, 0, 0, 0, L_b & ~1, 0, 0, 0,
                                             E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
                     TH_POA_PK_ROW_DONE(0, 0);
                     continue;
@@ -631,9 +631,9 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                         int rmax = TH_NEG - 0x10000000, left = b, right = b;
                         const uint32_t T_ = (uint32_t)TH_READLANE((int)v_T, meta & 0xff);
                         // (one or two predecessors as compile-time constants: the body's per-predecessor tests disappear)
-                        if (inn_ == 1) th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, T_, 1, qs0, 0, 0, 0, qb0, 0, 0, 0, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
-                        else if (inn_ == 2) th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, T_, 2, qs0, qs1, 0, 0, qb0, qb1, 0, 0, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
-                        else th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, T_, inn_, qs0, qs1, qs2, qs3, qb0, qb1, qb2, qb3, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
+                        if (inn_ == 1) th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, g.dcell + (my_off - (b - B0)), lane, b, e, B0, i & 3, T_, 1, qs0, 0, 0, 0, qb0, 0, 0, 0, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
+                        else if (inn_ == 2) th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, g.dcell + (my_off - (b - B0)), lane, b, e, B0, i & 3, T_, 2, qs0, qs1, 0, 0, qb0, qb1, 0, 0, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
+                        else th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, g.dcell + (my_off - (b - B0)), lane, b, e, B0, i & 3, T_, inn_, qs0, qs1, qs2, qs3, qb0, qb1, qb2, qb3, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
                         TH_POA_PK_ROW_DONE(inn_ == 1 ? 1 : inn_ == 2 ? 6 : 7, 0);
                         continue;
                     }
@@ -679,7 +679,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                         const int my_off = (int)ncell + (b - B0), my_foff = full ? -(int)nfull + (b - B0) : 0;
                         ncell += span;
                         int rmax = TH_NEG - 0x10000000, left = b, right = b;
-                        th_poa_pk_row<QCAP, RT, false, true>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), inn_, qs0, qs1, qs2, qs3, qb0, qb1, qb2, qb3,
+                        th_poa_pk_row<QCAP, RT, false, true>(s_qs, s_ring, g.dcell + (my_off - (b - B0)), lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), inn_, qs0, qs1, qs2, qs3, qb0, qb1, qb2, qb3,
                                                 E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right, far_o, far_pb, far_pe, g.cell + far_po, full ? g.cell + my_foff : nullptr, neg_thr, base);
                         TH_POA_PK_ROW_DONE(2, my_foff);
                         continue;
@@ -738,7 +738,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         const bool pk = !WIDE && LQ && ring_all && cache_me && !needfull;    // rows some far row will read take the 32-bit path (they store whole cells)
         const int npk = fast ? 1 : inn;
         if (pk) {
-            th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, drow, lane, b, e, B0, myslot, (uint32_t)TH_READLANE((int)v_T, nb), npk, q_slot0, q_slot1, q_slot2, q_slot3, q_pb0, q_pb1, q_pb2, q_pb3,
+            th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, drow - (b - B0), lane, b, e, B0, myslot, (uint32_t)TH_READLANE((int)v_T, nb), npk, q_slot0, q_slot1, q_slot2, q_slot3, q_pb0, q_pb1, q_pb2, q_pb3,
                                     E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
         } else {
         if (!WIDE && cache_me) {      // leave the slot clean for a packed successor: minus infinity wherever this row stores nothing
