@@ -23,6 +23,8 @@ static inline int th_rt_event_create(th_event_t *e) { *e = 0; return 0; }
 static inline int th_rt_event_record(th_event_t, th_stream_t) { return 0; }
 static inline int th_rt_event_wait(th_event_t) { return 0; }
 static inline int th_rt_event_destroy(th_event_t) { return 0; }
+static inline int th_rt_sync_event(th_stream_t, th_event_t) { return 0; }
+static inline void th_rt_prefer_blocking() {}
 #define TH_LAUNCH(kernel, grid, block, stream, ...) hipemul::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
 #define TH_LANE() ((int)(threadIdx.x & 63))
 static inline int th_rt_device_count(int *n) { *n = 1; return 0; }

@@ -94,3 +94,41 @@ def test_mmap_reader_rate(tmp_path):
     finally:
         if os.path.exists(fn):
             os.unlink(fn)
+
+
+def test_line_index_agrees_with_the_plain_scan(tmp_path):
+    """mapped inputs of 16 MiB and more are parsed through the line index (helper threads leave the newline offsets of 4 MiB chunks,
+    the grammar walks them on one thread): same records as the parser's own memchr (TH_READER_NOINDEX=1) and as the zlib stream path on
+    a file that mixes one-line 10 kb reads, multi-line records, FASTQ whose quality lines start with '@', CRLF, a line longer than a
+    chunk and a stretch of one-byte lines (a dense chunk, which is not indexed)"""
+    lib = U.synth_lib()
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path)
+    fn = os.path.join(d, "th_reader_lidx_%d.fx" % os.getpid())
+    long_read = U.synth_read(lib, 2, 0, 1000, 10, 0.10)
+    try:
+        n_rec, n_bases = 0, 0
+        with open(fn, "wb") as f:
+            for i in range(2600):
+                s = U.synth_read(lib, 9, i, 400 + (i % 7) * 100, 8, 0.1) if i % 50 else long_read
+                if i % 5 == 0:
+                    f.write(b">m%d c\r\n" % i + b"\r\n".join(s[k:k + 61] for k in range(0, len(s), 61)) + b"\r\n")
+                elif i % 5 == 1:
+                    f.write(b"@q%d\n" % i + s + b"\n+\n@" + b"+>" * ((len(s) - 1) // 2) + b"@" * ((len(s) - 1) % 2) + b"\n")
+                else:
+                    f.write(b">s%d\n" % i + s + b"\n")
+                n_rec += 1; n_bases += len(s)
+                if i == 700:      # a sequence line longer than a chunk
+                    big = long_read * 500
+                    f.write(b">big\n" + big + b"\n"); n_rec += 1; n_bases += len(big)
+                if i == 1500:     # a dense stretch: a multi-line record of one base per line, then empty lines
+                    f.write(b">dense\n" + b"\n".join(bytes([c]) for c in (long_read * 30)) + b"\n" + b"\n" * 300000); n_rec += 1; n_bases += len(long_read) * 30
+        assert os.path.getsize(fn) > (20 << 20)
+        a = _parse(lib, fn)
+        b = _parse(lib, fn, env={"TH_READER_NOINDEX": "1"})
+        c = _parse(lib, fn, env={"TH_READER_STREAM": "1"})
+        e = _parse(lib, fn, env={"TH_READER_THREADS": "1"})
+        assert a[:2] == (n_rec, n_bases), (a[:2], n_rec, n_bases)
+        assert a[:3] == b[:3] == c[:3] == e[:3]
+    finally:
+        if os.path.exists(fn):
+            os.unlink(fn)

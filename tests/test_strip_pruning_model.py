@@ -165,7 +165,19 @@ def test_pruned_strip_engine_is_exact_for_any_lower_bound():
 
 
 # ---------------------------------------------------------------- the second band of the unit alignments (th_ksw_global_band_wave, slb)
-def global_dp(q, t, W, slb, S):
+def live_new(h, a, b, slb):
+    """the engine's liveness test of a parked cell (th_ksw.h, th_ksw_global_band_wave): a path may cross the parked column INSIDE an open
+    horizontal gap, so only |a - b| further extension bases may be charged"""
+    return h + min(a, b) - abs(a - b) * E >= slb
+
+
+def live_round3(h, a, b, slb):
+    """round 3's rule, one extension base too strict (kept to show that the structured cases below have teeth)"""
+    d = abs(a - b)
+    return h + min(a, b) - ((d + 1) * E if d else 0) >= slb
+
+
+def global_dp(q, t, W, slb, S, live=live_new):
     """H of the global alignment's matrix (ksw2 with flag 0: src/ksw2_align.c:117-151) restricted as th_ksw_global_band_wave restricts it:
     diagonals lo..hi = min(0, D) - W .. max(0, D) + W and, with a lower bound slb of the optimum, strips of S columns that sweep only the
     rows live cells of the parked column can reach"""
@@ -180,8 +192,7 @@ def global_dp(q, t, W, slb, S):
             vmin, vmax, b = 1 << 30, -1, m - j0
             for row in range(prs, ppre + 1):
                 h, a = parkH[row], n - 1 - row
-                d = abs(a - b)
-                if h + min(a, b) - ((d + 1) * E if d else 0) >= slb:
+                if live(h, a, b, slb):
                     vmin = min(vmin, row)
                     vmax = max(vmax, row + S + min(h + b - slb, (h + a - slb) >> 1))
             rs, re = max(rs, vmin), min(re, vmax)
@@ -247,9 +258,117 @@ def test_pruned_global_band_keeps_every_cell_an_optimal_path_can_use():
                         for j in range(m):
                             assert got[i][j] <= ref[i][j]
                             a, b = n - 1 - i, m - 1 - j
-                            d = abs(a - b)
-                            if ref[i][j] + min(a, b) - ((d + 1) * E if d else 0) >= slb:
+                            if ref[i][j] + min(a, b) - abs(a - b) * E >= slb:
                                 assert got[i][j] == ref[i][j], (q, t, S, slb, W, i, j)
                             elif got[i][j] == NEG and ref[i][j] > NEG:
                                 n_pruned += 1
     assert n_pruned > 10000
+
+
+# ---------------------------------------------------------------- structured cases, judged by the unpruned full matrix only
+def plain_global(q, t):
+    """corner score of the plain global affine alignment (match 1, mismatch -2, gap 2 + 1 per base), written independently of the strip
+    model above: three full matrices, no band, no pruning"""
+    n, m = len(t), len(q)
+    Hm = [[NEG] * (m + 1) for _ in range(n + 1)]
+    Em = [[NEG] * (m + 1) for _ in range(n + 1)]
+    Fm = [[NEG] * (m + 1) for _ in range(n + 1)]
+    Hm[0][0] = 0
+    for j in range(1, m + 1):
+        Hm[0][j] = Fm[0][j] = -(Q + j * E)
+    for i in range(1, n + 1):
+        Hm[i][0] = Em[i][0] = -(Q + i * E)
+        for j in range(1, m + 1):
+            Em[i][j] = max(Em[i - 1][j], Hm[i - 1][j] - Q) - E
+            Fm[i][j] = max(Fm[i][j - 1], Hm[i][j - 1] - Q) - E
+            Hm[i][j] = max(Hm[i - 1][j - 1] + sc(t[i - 1], q[j - 1]), Em[i][j], Fm[i][j])
+    return Hm[n][m]
+
+
+def device_flow(q, t, S, W1, live):
+    """the device's sequence for one unit alignment (th_k_align.hip): first band W1 -> banded score s1 -> not certified -> W2 from s1 ->
+    the pruned second band with slb = s1 -> certificate.  Returns (status, corner): 'certified' / 'uncertified' / 'empty'"""
+    n, m = len(t), len(q)
+    D = n - m
+    aD = abs(D)
+
+    def certified(h, W):
+        gmin = 2 * W + 2 + aD
+        return 2 * h > (m + n - gmin) - 4 * Q - 2 * gmin * E
+
+    first = global_dp(q, t, W1, NEG, n + m)
+    s1 = first[n - 1][m - 1]
+    if s1 <= NEG // 2:
+        return "noband", None
+    if certified(s1, W1):
+        return "first", s1
+    g2 = (m + n - 2 * s1 - 4 * Q) // (1 + 2 * E) + 2
+    W2 = (g2 - 2 - aD + 1) // 2 + 8
+    got = global_dp(q, t, max(W2, W1 + 1), s1, S, live)
+    if got is None:
+        return "empty", None
+    h = got[n - 1][m - 1]
+    return ("certified" if certified(h, max(W2, W1 + 1)) else "uncertified"), h
+
+
+def structured_pairs(rng, S):
+    """one insertion or deletion run placed across a strip boundary, an exact suffix after it, a few substitutions before it: the
+    optimal path crosses the parked column inside its open gap and the rest is all matches"""
+    for _ in range(4000):
+        k = rng.randint(1, 4)                                  # strip boundary the gap straddles
+        pre = k * S + rng.randint(-3, 3)
+        glen = rng.randint(1, 6)
+        suf = rng.randint(3, 4 * S)
+        base = [rng.choice("ACGT") for _ in range(max(2, pre) + suf)]
+        t = list(base)
+        q = list(base)
+        for _s in range(rng.randint(0, 3)):
+            x = rng.randrange(0, max(1, pre - 1))
+            q[x] = rng.choice([c for c in "ACGT" if c != q[x]])
+        ins = [rng.choice("ACGT") for _ in range(glen)]
+        if rng.random() < 0.5:
+            q[pre:pre] = ins                                   # insertion in the query: a horizontal gap across column pre
+        else:
+            t[pre:pre] = ins
+        yield "".join(q), "".join(t)
+
+
+def test_structured_gap_across_a_strip_boundary_judged_by_the_full_matrix():
+    """the liveness test of the parked column must not charge an extension base a path that crosses inside an open
+    horizontal gap never pays.  Oracle = the plain full matrix (plain_global), not the liveness formula."""
+    rng = random.Random(5)
+    bad_new = bad_r3 = n = n_second = 0
+    for S in (4, 8):
+        for q, t in structured_pairs(rng, S):
+            opt = plain_global(q, t)
+            n += 1
+            # (a) slb equal to the optimum, a band that holds the optimal path (diagonals 0 .. D and three either side)
+            if global_dp(q, t, 3, NEG, len(q) + len(t))[len(t) - 1][len(q) - 1] == opt:
+                got = global_dp(q, t, 3, opt, S)
+                assert got is not None and got[len(t) - 1][len(q) - 1] == opt, (q, t, S)
+                old = global_dp(q, t, 3, opt, S, live_round3)
+                bad_r3 += old is None or old[len(t) - 1][len(q) - 1] != opt
+            # (b) the device's flow with a narrow first band
+            for W1 in (1, 2):
+                st, h = device_flow(q, t, S, W1, live_new)
+                if st in ("certified", "uncertified", "empty"):
+                    n_second += 1
+                    assert st != "empty", (q, t, S, W1)
+                    if st == "certified":
+                        bad_new += h != opt
+                        assert h == opt, (q, t, S, W1, h, opt)
+    assert bad_new == 0
+    assert n_second > 500            # the second, pruned band was exercised
+    assert bad_r3 > 0                # ... and these cases do catch round 3's rule
+
+
+def test_advice_example_pair():
+    """the pair the round-3 advisor reported: S = 4, first band such that s1 = opt = 12, W2 = 10 -- round 3's rule returned 9 and passed
+    the certificate"""
+    q, t = "GCTATCGTCCAGGAAGGGACGATGGACAAGCATCG", "GCTATCTTCCAGCAAGGGATGATGGACCG"
+    opt = plain_global(q, t)
+    assert opt == 12
+    got = global_dp(q, t, 10, opt, 4)
+    assert got is not None and got[len(t) - 1][len(q) - 1] == opt
+    old = global_dp(q, t, 10, opt, 4, live_round3)
+    assert old is None or old[len(t) - 1][len(q) - 1] != opt

@@ -11,10 +11,13 @@
  *   edlib_align_HW                                            src/edlib_align.c:73-85
  *   mini_tandem_output                                        src/main.c:214-271
  */
+#define _GNU_SOURCE
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <sched.h>
+#include <sys/resource.h>
 #include <limits.h>
 #include <ctype.h>
 #include <zlib.h>
@@ -69,6 +72,89 @@ void th_free_para(th_para_t *p)
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
+/* ---------------------------------------------------------------- host CPU budget */
+/* CPU seconds by role, summed over every thread the host layer starts (CLOCK_THREAD_CPUTIME_ID, added when a thread ends or hands a
+ * batch on); what the process spent beyond them -- getrusage minus the sum -- is the HIP runtime's own threads.  th_run_file prints the
+ * table under TH_TRACE and bench.py reports it as host_cpu_s_per_1M_reads: the seam this layer replaces runs n_thread workers and one
+ * writer (src/main.c:273-291, :214-271), and a node has perhaps two cores per GPU to give. */
+enum { CPU_READER = 0, CPU_INFLATE, CPU_UPLOAD, CPU_RUN, CPU_COLLECT, CPU_WRITER, CPU_N };
+static double g_cpu_s[CPU_N];
+static pthread_mutex_t g_cpu_mu = PTHREAD_MUTEX_INITIALIZER;
+static double thread_cpu_s(void) { struct timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static void cpu_account(int cat, double s) { pthread_mutex_lock(&g_cpu_mu); g_cpu_s[cat] += s; pthread_mutex_unlock(&g_cpu_mu); }
+int th_host_cpu_seconds(double *out, int n)       /* [0] reader [1] inflate [2] upload [3] run [4] collect + format [5] writer; returns 6 */
+{
+    pthread_mutex_lock(&g_cpu_mu);
+    for (int i = 0; i < n && i < CPU_N; ++i) out[i] = g_cpu_s[i];
+    pthread_mutex_unlock(&g_cpu_mu);
+    return CPU_N;
+}
+
+/* CPUs this process may actually use: the affinity mask cut down to the cgroup's CPU quota (v2 cpu.max, v1 cpu.cfs_quota_us /
+ * cpu.cfs_period_us; the tightest limit on the way up from the process's own group).  sysconf(_SC_NPROCESSORS_ONLN) says 256 on a box
+ * whose container may use 16. */
+static double quota_of(const char *dir)
+{
+    char fn[600], buf[128]; FILE *f; double q = 0;
+    snprintf(fn, sizeof(fn), "%s/cpu.max", dir);
+    if ((f = fopen(fn, "r")) != NULL) {
+        if (fgets(buf, sizeof(buf), f)) { double a, b; if (sscanf(buf, "%lf %lf", &a, &b) == 2 && b > 0) q = a / b; }
+        fclose(f);
+        return q;
+    }
+    snprintf(fn, sizeof(fn), "%s/cpu.cfs_quota_us", dir);
+    if ((f = fopen(fn, "r")) != NULL) {
+        double a = -1, b = 0; if (fscanf(f, "%lf", &a) != 1) a = -1;
+        fclose(f);
+        snprintf(fn, sizeof(fn), "%s/cpu.cfs_period_us", dir);
+        if (a > 0 && (f = fopen(fn, "r")) != NULL) { if (fscanf(f, "%lf", &b) == 1 && b > 0) q = a / b; fclose(f); }
+    }
+    return q;
+}
+int th_effective_cpus(void)
+{
+    static int cached = 0;
+    if (cached) return cached;
+    int n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) { long c = sysconf(_SC_NPROCESSORS_ONLN); n = c > 0 ? (int)c : 1; }
+    double best = 0;
+    /* /proc/self/cgroup: "0::<path>" (v2) and / or "<id>:<controllers>:<path>" (v1; the line whose controller list holds "cpu") */
+    char rel2[400] = "", rel1[400] = "";
+    FILE *f = fopen("/proc/self/cgroup", "r");
+    if (f) {
+        char line[512];
+        while (fgets(line, sizeof(line), f)) {
+            line[strcspn(line, "\n")] = 0;
+            char *c1 = strchr(line, ':'), *c2 = c1 ? strchr(c1 + 1, ':') : NULL;
+            if (!c2) continue;
+            *c2 = 0;
+            if (c1[1] == 0) { snprintf(rel2, sizeof(rel2), "%s", c2 + 1); continue; }
+            for (char *tok = strtok(c1 + 1, ","); tok; tok = strtok(NULL, ",")) if (!strcmp(tok, "cpu")) snprintf(rel1, sizeof(rel1), "%s", c2 + 1);
+        }
+        fclose(f);
+    }
+    const char *roots[2] = { "/sys/fs/cgroup", "/sys/fs/cgroup/cpu" }; const char *rels[2] = { rel2, rel1 };
+    for (int r = 0; r < 2; ++r) {      /* the tightest limit on the way up from the process's own group to the root of the hierarchy */
+        char dir[1100]; snprintf(dir, sizeof(dir), "%s%s", roots[r], rels[r]);
+        size_t l = strlen(dir); while (l > 1 && dir[l - 1] == '/') dir[--l] = 0;
+        for (;;) {
+            const double q = quota_of(dir);
+            if (q > 0 && (best == 0 || q < best)) best = q;
+            if (strlen(dir) <= strlen(roots[r])) break;
+            char *sl = strrchr(dir, '/');
+            if (!sl) break;
+            *sl = 0;
+        }
+    }
+    if (best > 0) { const int q = (int)(best + 0.999); if (q < n) n = q; }
+    { const char *e = getenv("TH_EFFECTIVE_CPUS"); if (e && atoi(e) > 0) n = atoi(e); }      /* (tests) */
+    cached = n < 1 ? 1 : n;
+    return cached;
+}
+static int g_live_handles = 0;      /* handles of this process: they share the CPUs */
+
 /* ---------------------------------------------------------------- FASTA/FASTQ(.gz) reader (kseq grammar, src/kseq.h:176-215) */
 /* Three sources behind one record grammar (the reference reads everything through one gzread loop, src/kseq.h:52-72):
  *   MEM     an uncompressed regular file is mmap'ed and parsed in place: a sequence that sits on one line is handed on as a
@@ -104,6 +190,8 @@ typedef struct th_reader {
     gzFile fp; unsigned char *sbuf[2]; long slen[2]; int sfull[2], scur, sdone, squit; pthread_t sthr; pthread_mutex_t smu; pthread_cond_t scv; int sthr_on;
     /* MEM / BGZF: the mapping */
     const unsigned char *map; size_t map_len;
+    /* MEM: the line index (below) */
+    struct th_lidx *lx;
     /* BGZF: groups of members, inflated by a pool */
     size_t zpos; unsigned char *gbuf[2]; size_t gcap[2], glen[2]; int gcur, gpending, zbusy, zfinished; bgzf_blk_t *blk; int nblk; volatile int next_blk; int zerr;
     pthread_t zthr[16]; int nz; pthread_mutex_t zmu; pthread_cond_t zcv; int zgo, zdone, zquit;
@@ -117,13 +205,13 @@ static void *stream_producer(void *arg)
         while (r->sfull[b] && !r->squit) pthread_cond_wait(&r->scv, &r->smu);
         const int quit = r->squit;
         pthread_mutex_unlock(&r->smu);
-        if (quit) return NULL;
+        if (quit) { cpu_account(CPU_INFLATE, thread_cpu_s()); return NULL; }
         const long n = gzread(r->fp, r->sbuf[b], RD_CHUNK);
         pthread_mutex_lock(&r->smu);
         if (n < 0) { int en = 0; fprintf(stderr, "[tidehunter_amd] read error: %s\n", gzerror(r->fp, &en)); r->failed = 1; }
         r->slen[b] = n > 0 ? n : 0; r->sfull[b] = 1; if (n <= 0) r->sdone = 1;
         pthread_cond_broadcast(&r->scv); pthread_mutex_unlock(&r->smu);
-        if (n <= 0) return NULL;
+        if (n <= 0) { cpu_account(CPU_INFLATE, thread_cpu_s()); return NULL; }
     }
 }
 /* BGZF member at p: returns its total size and the sizes of its deflate data / text, 0 if p is not a BGZF member */
@@ -153,7 +241,7 @@ static void *bgzf_worker(void *arg)
         gen = r->zgo;
         const int quit = r->zquit;
         pthread_mutex_unlock(&r->zmu);
-        if (quit) return NULL;
+        if (quit) { cpu_account(CPU_INFLATE, thread_cpu_s()); return NULL; }
         unsigned char *out = r->gbuf[r->gpending];
         for (;;) {
             const int i = __atomic_fetch_add(&r->next_blk, 1, __ATOMIC_RELAXED);
@@ -197,6 +285,120 @@ static void bgzf_wait_group(th_reader_t *r)
     pthread_mutex_unlock(&r->zmu);
     r->zbusy = 0;
 }
+/* ---- MEM mode: the line index.  Finding the ends of lines is all the grammar needs from the bytes of a sequence, and it is the one
+ * part of parsing that costs per BYTE (memchr over 10 GB per million headline reads: ~1 s on the one thread that hands batches to every
+ * device -- exactly the million reads per second eight GPUs take).  So helper threads scan the mapping ahead of the parser, a chunk at a
+ * time, and leave the newline offsets of each chunk in an array; the parser walks those arrays and touches only the header lines.  The
+ * split is by BYTES, not by records, so it needs no guess about where a record starts (a FASTQ quality line may begin with '@'): the
+ * grammar still runs on one thread, in order, at a cost per LINE.  A chunk with more than one newline per 16 bytes is not indexed
+ * (the parser falls back to memchr there), which bounds the index at a quarter of the text. */
+#define LX_CHUNK ((size_t)4 << 20)
+#define LX_AHEAD 48                      /* chunks the helpers may run ahead of the parser (192 MiB of page cache touched early) */
+typedef struct { uint32_t *off; int n; int state; } lx_chunk_t;      /* state: 0 untouched, 1 being scanned, 2 ready (n < 0: dense, not indexed) */
+typedef struct th_lidx {
+    const unsigned char *map; size_t len; size_t n_chunk;
+    lx_chunk_t *ch;
+    pthread_mutex_t mu; pthread_cond_t cv;
+    size_t next, parser_chunk; int quit;
+    pthread_t thr[8]; int n_thr;
+    size_t cur_chunk; int cur_i;          /* the parser's cursor: first newline not yet passed */
+} th_lidx_t;
+static void lx_scan(th_lidx_t *x, size_t c)
+{
+    const size_t a = c * LX_CHUNK, b = a + LX_CHUNK < x->len ? a + LX_CHUNK : x->len;
+    const size_t cap_max = (b - a) / 16 + 16;
+    size_t cap = 1024, n = 0;
+    uint32_t *off = (uint32_t *)malloc(cap * sizeof(uint32_t));
+    const unsigned char *p = x->map + a, *e = x->map + b;
+    while (p < e) {
+        const unsigned char *q = (const unsigned char *)memchr(p, '\n', (size_t)(e - p));
+        if (!q) break;
+        if (n == cap) {
+            if (cap >= cap_max) { free(off); off = NULL; break; }
+            cap = cap * 2 < cap_max ? cap * 2 : cap_max; off = (uint32_t *)realloc(off, cap * sizeof(uint32_t));
+        }
+        off[n++] = (uint32_t)(q - (x->map + a));
+        p = q + 1;
+    }
+    pthread_mutex_lock(&x->mu);
+    x->ch[c].off = off; x->ch[c].n = off ? (int)n : -1; x->ch[c].state = 2;
+    pthread_cond_broadcast(&x->cv);
+    pthread_mutex_unlock(&x->mu);
+}
+static void *lx_helper(void *arg)
+{
+    th_lidx_t *x = (th_lidx_t *)arg;
+    for (;;) {
+        pthread_mutex_lock(&x->mu);
+        size_t c;
+        for (;;) {
+            if (x->quit) { pthread_mutex_unlock(&x->mu); cpu_account(CPU_READER, thread_cpu_s()); return NULL; }
+            while (x->next < x->n_chunk && x->ch[x->next].state != 0) ++x->next;      /* (the parser may have taken one itself) */
+            if (x->next >= x->n_chunk) { pthread_mutex_unlock(&x->mu); cpu_account(CPU_READER, thread_cpu_s()); return NULL; }
+            if (x->next <= x->parser_chunk + LX_AHEAD) { c = x->next++; x->ch[c].state = 1; break; }
+            pthread_cond_wait(&x->cv, &x->mu);
+        }
+        pthread_mutex_unlock(&x->mu);
+        lx_scan(x, c);
+    }
+}
+static th_lidx_t *lx_open(const unsigned char *map, size_t len)
+{
+    if (len < 4 * LX_CHUNK || getenv("TH_READER_NOINDEX")) return NULL;          /* small inputs: the parser's own memchr is cheaper than threads */
+    th_lidx_t *x = (th_lidx_t *)calloc(1, sizeof(*x));
+    x->map = map; x->len = len; x->n_chunk = (len + LX_CHUNK - 1) / LX_CHUNK;
+    x->ch = (lx_chunk_t *)calloc(x->n_chunk, sizeof(lx_chunk_t));
+    pthread_mutex_init(&x->mu, NULL); pthread_cond_init(&x->cv, NULL);
+    int want = th_effective_cpus() >= 8 ? 3 : th_effective_cpus() >= 4 ? 2 : 1;
+    { const char *e = getenv("TH_READER_THREADS"); if (e && atoi(e) >= 1 && atoi(e) <= 8) want = atoi(e); }
+    for (int t = 0; t < want; ++t) if (pthread_create(&x->thr[x->n_thr], NULL, lx_helper, x) == 0) ++x->n_thr;
+    return x;                              /* (no helper at all: the parser scans every chunk itself, below) */
+}
+static void lx_close(th_lidx_t *x)
+{
+    if (!x) return;
+    pthread_mutex_lock(&x->mu); x->quit = 1; pthread_cond_broadcast(&x->cv); pthread_mutex_unlock(&x->mu);
+    for (int t = 0; t < x->n_thr; ++t) pthread_join(x->thr[t], NULL);
+    for (size_t c = 0; c < x->n_chunk; ++c) free(x->ch[c].off);
+    free(x->ch); pthread_mutex_destroy(&x->mu); pthread_cond_destroy(&x->cv); free(x);
+}
+/* chunk c, ready: scanned here if no helper has taken it yet */
+static lx_chunk_t *lx_get(th_lidx_t *x, size_t c)
+{
+    pthread_mutex_lock(&x->mu);
+    if (c > x->parser_chunk) { x->parser_chunk = c; pthread_cond_broadcast(&x->cv); }
+    if (x->ch[c].state == 0) { x->ch[c].state = 1; pthread_mutex_unlock(&x->mu); lx_scan(x, c); return &x->ch[c]; }
+    while (x->ch[c].state != 2) pthread_cond_wait(&x->cv, &x->mu);
+    pthread_mutex_unlock(&x->mu);
+    return &x->ch[c];
+}
+/* first newline at or after byte `pos`, or the end of the mapping */
+static size_t lx_next_nl(th_lidx_t *x, size_t pos)
+{
+    size_t c = pos / LX_CHUNK;
+    if (c != x->cur_chunk) {
+        for (size_t d = x->cur_chunk; d < c && d < x->n_chunk; ++d) { free(x->ch[d].off); x->ch[d].off = NULL; }      /* (passed for good: positions only grow) */
+        x->cur_chunk = c; x->cur_i = 0;
+    }
+    for (; c < x->n_chunk; ++c) {
+        lx_chunk_t *k = lx_get(x, c);
+        const size_t base = c * LX_CHUNK;
+        if (c != x->cur_chunk) { free(x->ch[x->cur_chunk].off); x->ch[x->cur_chunk].off = NULL; x->cur_chunk = c; x->cur_i = 0; }
+        if (k->n < 0) {                    /* dense chunk: not indexed */
+            const size_t from = pos > base ? pos : base, to = base + LX_CHUNK < x->len ? base + LX_CHUNK : x->len;
+            const unsigned char *q = (const unsigned char *)memchr(x->map + from, '\n', to - from);
+            if (q) return (size_t)(q - x->map);
+            continue;
+        }
+        const uint32_t rel = pos > base ? (uint32_t)(pos - base) : 0;
+        int i = x->cur_i;
+        while (i < k->n && k->off[i] < rel) ++i;
+        x->cur_i = i;
+        if (i < k->n) return base + k->off[i];
+    }
+    return x->len;
+}
+
 /* next window of text; 0 at the end of the input */
 static int rd_fill(th_reader_t *r)
 {
@@ -243,7 +445,9 @@ static long rd_line(th_reader_t *r, th_str_t *s, const char **zc, size_t *zn)
         if (r->beg >= r->end && !rd_fill(r)) return got ? got : -1;
         const unsigned char *p = r->buf + r->beg;
         const size_t avail = r->end - r->beg;
-        const unsigned char *nl = (const unsigned char *)memchr(p, '\n', avail);
+        const unsigned char *nl;
+        if (r->lx) { const size_t at = lx_next_nl(r->lx, r->beg); nl = at < r->end ? r->buf + at : NULL; }      /* (MEM: buf is the mapping) */
+        else nl = (const unsigned char *)memchr(p, '\n', avail);
         const size_t n = nl ? (size_t)(nl - p) : avail;
         if (zc && got == 0 && r->mode == RD_MEM) { *zc = (const char *)p; *zn = n; }        /* one window: a line never spans two */
         else if (s && n) str_append(s, (const char *)p, n);
@@ -268,9 +472,10 @@ static th_reader_t *rd_open(const char *fn)
                     r->mode = RD_BGZF; r->map = p; r->map_len = (size_t)st.st_size;
                     r->blk = (bgzf_blk_t *)malloc(sizeof(bgzf_blk_t) * BGZF_GROUP);
                     pthread_mutex_init(&r->zmu, NULL); pthread_cond_init(&r->zcv, NULL);
-                    long nc = sysconf(_SC_NPROCESSORS_ONLN); r->nz = nc >= 32 ? 12 : nc >= 8 ? 6 : 2;
+                    const int nc = th_effective_cpus(); r->nz = nc >= 32 ? 12 : nc >= 8 ? 6 : 2;       /* (the CPUs the process may use, not the host's) */
                     { const char *e = getenv("TH_READER_THREADS"); if (e && atoi(e) >= 1 && atoi(e) <= 16) r->nz = atoi(e); }
-                    for (int t = 0; t < r->nz; ++t) pthread_create(&r->zthr[t], NULL, bgzf_worker, r);
+                    { int made = 0; for (int t = 0; t < r->nz; ++t) if (pthread_create(&r->zthr[made], NULL, bgzf_worker, r) == 0) ++made; r->nz = made; }
+                    if (r->nz == 0) { pthread_mutex_destroy(&r->zmu); pthread_cond_destroy(&r->zcv); free(r->blk); munmap(m, (size_t)st.st_size); close(fd); free(r); return NULL; }
                     madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
                     close(fd);
                     return r;
@@ -279,6 +484,7 @@ static th_reader_t *rd_open(const char *fn)
             } else {
                 r->mode = RD_MEM; r->map = p; r->map_len = (size_t)st.st_size; r->buf = p; r->beg = 0; r->end = (size_t)st.st_size;
                 madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                r->lx = lx_open(p, (size_t)st.st_size);
                 close(fd);
                 return r;
             }
@@ -290,7 +496,8 @@ static th_reader_t *rd_open(const char *fn)
     gzbuffer(r->fp, 1 << 20);
     r->sbuf[0] = (unsigned char *)malloc(RD_CHUNK); r->sbuf[1] = (unsigned char *)malloc(RD_CHUNK);
     pthread_mutex_init(&r->smu, NULL); pthread_cond_init(&r->scv, NULL);
-    pthread_create(&r->sthr, NULL, stream_producer, r); r->sthr_on = 1;
+    if (pthread_create(&r->sthr, NULL, stream_producer, r) != 0) { gzclose(r->fp); free(r->sbuf[0]); free(r->sbuf[1]); free(r); return NULL; }
+    r->sthr_on = 1;
     return r;
 }
 static void rd_close(th_reader_t *r)
@@ -309,6 +516,7 @@ static void rd_close(th_reader_t *r)
             for (int t = 0; t < r->nz; ++t) pthread_join(r->zthr[t], NULL);
             free(r->gbuf[0]); free(r->gbuf[1]); free(r->blk);
         }
+        lx_close(r->lx);
         munmap((void *)r->map, r->map_len);
     }
     free(r);
@@ -572,6 +780,7 @@ static th_handle_t *th_init_sub(const th_para_t *p, int device, int n_sub_max)
         h->gpu[s] = th_gpu_create(&gp, device);
         if (!h->gpu[s]) { for (int x = 0; x < s; ++x) th_gpu_destroy(h->gpu[x]); free(h); return NULL; }
     }
+    __atomic_fetch_add(&g_live_handles, 1, __ATOMIC_RELAXED);
     return h;
 }
 th_handle_t *th_init(const th_para_t *p, int device)
@@ -581,7 +790,7 @@ th_handle_t *th_init(const th_para_t *p, int device)
     if (e && atoi(e) >= 1) ns = atoi(e);
     return th_init_sub(p, device, ns);
 }
-void th_destroy(th_handle_t *h) { if (!h) return; for (int s = 0; s < h->n_sub_max; ++s) th_gpu_destroy(h->gpu[s]); free(h); }
+void th_destroy(th_handle_t *h) { if (!h) return; for (int s = 0; s < h->n_sub_max; ++s) th_gpu_destroy(h->gpu[s]); __atomic_fetch_sub(&g_live_handles, 1, __ATOMIC_RELAXED); free(h); }
 
 static int batch_upload_s(th_handle_t *h, int slot, const char *const *seqs, const int *lens, int n, int wait)
 {
@@ -703,8 +912,18 @@ static int code_of(unsigned char c)
                  case 3: case 'T': case 't': return 3; case '-': return 5; default: return 4; }
 }
 
+/* per-thread scratch of the record arithmetic: four byte buffers that only ever grow (a malloc / free pair per job and buffer was a
+ * measurable share of the collecting threads' time at a million jobs per 8 s) */
+typedef struct { char *b[4]; size_t m[4]; } th_scratch_t;
+static void *scr(th_scratch_t *sc, int which, size_t n)
+{
+    if (n > sc->m[which]) { sc->m[which] = n + (n >> 2) + 256; free(sc->b[which]); sc->b[which] = (char *)malloc(sc->m[which]); }
+    return sc->b[which];
+}
+static void scr_free(th_scratch_t *sc) { for (int i = 0; i < 4; ++i) { free(sc->b[i]); sc->b[i] = NULL; sc->m[i] = 0; } }
+
 /* host half of seqs_msa()/abpoa_gen_cons() for one run, from the integer evidence the device produced */
-static void finish_job(const th_handle_t *h, const th_batch_t *B, const th_gpu_out_t *o, const th_job_t *j, th_tandem_seq_t *t, int rb)
+static void finish_job(const th_handle_t *h, const th_batch_t *B, const th_gpu_out_t *o, const th_job_t *j, th_tandem_seq_t *t, int rb, th_scratch_t *sc)
 {
     const th_para_t *p = &h->para;
     const int *ext = o->ext + 4 * (j - o->jobs);            /* max_q_l, max_t_l, max_q_r, max_t_r */
@@ -717,7 +936,7 @@ static void finish_job(const th_handle_t *h, const th_batch_t *B, const th_gpu_o
     const int want_q = p->out_fmt == TH_FASTQ_FMT || p->out_fmt == TH_TAB_QUAL_FMT;
     int min_cov = 0;
     if (p->min_frac > 0.0) min_cov = (int)(n_seqs * p->min_frac); else if (p->min_cov > 0) min_cov = p->min_cov;
-    uint8_t *qual = want_q ? (uint8_t *)malloc((size_t)cons_len * 2 + 2) : NULL;
+    uint8_t *qual = want_q ? (uint8_t *)scr(sc, 0, (size_t)cons_len * 2 + 2) : NULL;
     if (n_seqs <= 2) {                                             /* src/abpoa_cons.c:60-83 */
         if (min_cov > 0) {
             /* the first two units that pass the filter at :43 */
@@ -730,11 +949,11 @@ static void finish_job(const th_handle_t *h, const th_batch_t *B, const th_gpu_o
             int mc = 2, l0 = pos[u[0] + 1] - pos[u[0]], l1 = pos[u[1] + 1] - pos[u[1]];
             if (l0 != l1) mc = 1;
             else for (int i = 0; i < l0; ++i) if (code_of((unsigned char)seq[pos[u[0]] + 1 + i]) != code_of((unsigned char)seq[pos[u[1]] + 1 + i])) { mc = 1; break; }
-            if (mc < min_cov) { free(qual); return; }
+            if (mc < min_cov) return;
         }
         if (qual) memset(qual, 33, cons_len);
     } else {                                                       /* :88-108 */
-        if (min_cov > 0) for (int i = 0; i < cons_len; ++i) if (cov[i] < min_cov) { free(qual); return; }
+        if (min_cov > 0) for (int i = 0; i < cons_len; ++i) if (cov[i] < min_cov) return;
         if (qual) for (int i = 0; i < cons_len; ++i) {
             double x = 13.8 * (1.25 * cov[i] / n_seqs - 0.25);
             double pe = 1 - 1.0 / (1.0 + pow(2.718281828459045, -1 * x));
@@ -743,7 +962,7 @@ static void finish_job(const th_handle_t *h, const th_batch_t *B, const th_gpu_o
     }
     double ave = 0;                                                /* src/gen_cons.c:208-214 */
     for (int k = 0; k < pos_n - 1; ++k) { int len = pos[k + 1] - pos[k]; ave += (o->iden[j->aln_off + k] * 100 / (len + 0.0)); }
-    char *cons_seq = (char *)malloc((size_t)cons_len * 2 + 2);
+    char *cons_seq = (char *)scr(sc, 1, (size_t)cons_len * 2 + 2);
     for (int s = 0; s < cons_len; ++s) cons_seq[s] = cb[s] <= 4 ? "ACGTN"[cb[s]] : 'N';
     cons_seq[cons_len] = 0;
     double copy_num = n_seqs;                                      /* :217-223 */
@@ -753,9 +972,9 @@ static void finish_job(const th_handle_t *h, const th_batch_t *B, const th_gpu_o
     copy_num += (ext[2] + 1.0) / cons_len;
     int full_length = 0, out_len = cons_len;
     if (p->five_seq != NULL && p->three_seq != NULL && cons_len > p->five_len + p->three_len) {   /* :226-291 */
-        char *cons2 = (char *)malloc(((size_t)cons_len << 1) + 1); uint8_t *qual2 = NULL;
+        char *cons2 = (char *)scr(sc, 2, ((size_t)cons_len << 1) + 1); uint8_t *qual2 = NULL;
         memcpy(cons2, cons_seq, cons_len); memcpy(cons2 + cons_len, cons_seq, cons_len); cons2[cons_len << 1] = 0;
-        if (qual) { qual2 = (uint8_t *)malloc((size_t)cons_len << 1); memcpy(qual2, qual, cons_len); memcpy(qual2 + cons_len, qual, cons_len); }
+        if (qual) { qual2 = (uint8_t *)scr(sc, 3, (size_t)cons_len << 1); memcpy(qual2, qual, cons_len); memcpy(qual2 + cons_len, qual, cons_len); }
         int tar_start = -1, tar_end = -1, tot_ed = INT_MAX, e5, e3, s5 = -1, n5 = -1, s3 = -1, n3 = -1;
         int k5 = (int)(p->five_len * (1 - p->ada_match_rat)), k3 = (int)(p->three_len * (1 - p->ada_match_rat));
         /* the four searches ran on the device (th_k_adapter) when o->adapt is set: (ed, start, end) of 5', rc(3'), rc(5'), 3' */
@@ -786,50 +1005,143 @@ WRITE:
             memcpy(cons_seq, cons2 + tar_start, out_len); cons_seq[out_len] = 0;
             if (qual) for (int k = tar_start; k <= tar_end; ++k) qual[k - tar_start] = qual2[k];
         }
-        free(cons2); free(qual2);
     }
     if (!p->only_full_length || full_length > 0)
         write_cons(t, cons_seq, qual, out_len, cons_start, cons_end, copy_num, ave / (pos_n - 1), p, full_length, pos, pos_n);
-    free(cons_seq); free(qual);
+}
+
+/* ---------------------------------------------------------------- output, src/main.c:214-271 */
+/* The records of one read as text, appended to a growing buffer.  The file driver formats inside the threads that do the record
+ * arithmetic (a range of reads each, in read order) and its writer only hands the finished buffers to fwrite; th_output() formats
+ * and writes in one go.  The reference prints with fprintf, a "%c" per base (src/main.c:225,232,255,260): one writer thread at
+ * ~1 microsecond per record is exactly the 10^6 records/s eight GPUs deliver, so nothing per record may sit on the writer. */
+static inline void sb_reserve(th_str_t *b, size_t n)
+{
+    if (b->l + n + 1 <= b->m) return;
+    size_t m = b->m ? b->m : 65536;
+    while (b->l + n + 1 > m) m += m >> 1;
+    b->s = (char *)realloc(b->s, m); b->m = m;
+}
+static inline void sb_put(th_str_t *b, const char *p, size_t n) { sb_reserve(b, n); memcpy(b->s + b->l, p, n); b->l += n; }
+static inline void sb_c(th_str_t *b, char c) { sb_reserve(b, 1); b->s[b->l++] = c; }
+static inline void sb_int(th_str_t *b, int v)             /* "%d" */
+{
+    char tmp[12]; int n = 0; unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    sb_reserve(b, 12);
+    if (v < 0) b->s[b->l++] = '-';
+    while (n) b->s[b->l++] = tmp[--n];
+}
+static inline void sb_f1(th_str_t *b, double x) { sb_reserve(b, 340); b->l += (size_t)snprintf(b->s + b->l, 340, "%.1f", x); }     /* "%.1f": the C library's rounding */
+static void sb_subpos(th_str_t *b, const int *sp, int pos_n, char term)      /* src/main.c:239-241: +2, the last one +1 */
+{
+    int i;
+    sb_int(b, sp[0] + 2);
+    for (i = 1; i < pos_n - 1; ++i) { sb_c(b, ','); sb_int(b, sp[i] + 2); }
+    sb_c(b, ','); sb_int(b, sp[i] + 1); sb_c(b, term);
+}
+static void fmt_read(th_str_t *b, const char *name, const char *seq, int len, th_tandem_seq_t *t, const th_para_t *p)
+{
+    const size_t nl = strlen(name);
+    size_t cs = 0;
+    for (int ci = 0; ci < t->cons_n; ++ci) {
+        if (p->only_unit) {
+            for (int i = 0; i < t->pos_n[ci] - 1; ++i) {
+                if (p->out_fmt == TH_FASTA_FMT) {
+                    sb_c(b, '>'); sb_put(b, name, nl); sb_put(b, "_rep", 4); sb_int(b, ci); sb_put(b, "_sub", 4); sb_int(b, i); sb_c(b, '\n');
+                    sb_put(b, seq + t->sub_pos[ci][i] + 1, (size_t)(t->sub_pos[ci][i + 1] - t->sub_pos[ci][i]));
+                    sb_c(b, '\n');
+                } else if (p->out_fmt == TH_TAB_FMT) {
+                    sb_put(b, name, nl); sb_put(b, "\trep", 4); sb_int(b, ci); sb_put(b, "\tsub", 4); sb_int(b, i); sb_c(b, '\t');
+                    const int ul = t->sub_pos[ci][i + 1] - t->sub_pos[ci][i] - 1;           /* '<' at src/main.c:224: one base fewer */
+                    if (ul > 0) sb_put(b, seq + t->sub_pos[ci][i] + 1, (size_t)ul);
+                    sb_c(b, '\n');
+                }
+            }
+            continue;
+        }
+        if (p->out_fmt == TH_FASTA_FMT || p->out_fmt == TH_FASTQ_FMT) {      /* ">%s_rep%d_%.1f %d_%d_%d_%d_%.1f_%d_" */
+            sb_c(b, p->out_fmt == TH_FASTA_FMT ? '>' : '@'); sb_put(b, name, nl); sb_put(b, "_rep", 4); sb_int(b, ci); sb_c(b, '_'); sb_f1(b, t->copy_num[ci]);
+            sb_c(b, ' '); sb_int(b, len); sb_c(b, '_'); sb_int(b, t->cons_start[ci] + 1); sb_c(b, '_'); sb_int(b, t->cons_end[ci] + 1); sb_c(b, '_'); sb_int(b, t->cons_len[ci]);
+            sb_c(b, '_'); sb_f1(b, t->ave_match[ci]); sb_c(b, '_'); sb_int(b, t->full_length[ci]); sb_c(b, '_');
+            sb_subpos(b, t->sub_pos[ci], t->pos_n[ci], '\n');
+        } else {                                                             /* "%s\trep%d\t%.1f\t%d\t%d\t%d\t%d\t%.1f\t%d\t" */
+            sb_put(b, name, nl); sb_put(b, "\trep", 4); sb_int(b, ci); sb_c(b, '\t'); sb_f1(b, t->copy_num[ci]);
+            sb_c(b, '\t'); sb_int(b, len); sb_c(b, '\t'); sb_int(b, t->cons_start[ci] + 1); sb_c(b, '\t'); sb_int(b, t->cons_end[ci] + 1); sb_c(b, '\t'); sb_int(b, t->cons_len[ci]);
+            sb_c(b, '\t'); sb_f1(b, t->ave_match[ci]); sb_c(b, '\t'); sb_int(b, t->full_length[ci]); sb_c(b, '\t');
+            sb_subpos(b, t->sub_pos[ci], t->pos_n[ci], '\t');
+        }
+        sb_put(b, t->cons_seq->seq.s + cs, (size_t)t->cons_len[ci]);
+        if (p->out_fmt == TH_FASTQ_FMT) sb_put(b, "\n+\n", 3); else if (p->out_fmt == TH_TAB_QUAL_FMT) sb_c(b, '\t');
+        if (p->out_fmt == TH_FASTQ_FMT || p->out_fmt == TH_TAB_QUAL_FMT) sb_put(b, t->cons_seq->qual.s + cs, (size_t)t->cons_len[ci]);
+        sb_c(b, '\n');
+        cs += (size_t)t->cons_len[ci];
+    }
+    t->cons_n = 0; t->cons_seq->seq.l = 0; t->cons_seq->qual.l = 0;          /* src/main.c:266-268 (and the quality buffer: DESIGN.md) */
+}
+void th_output(FILE *fp, int n, const char *const *names, const char *const *seqs, const int *lens, th_tandem_seq_t *tseq, const th_para_t *p)
+{
+    th_str_t b = { 0, 0, 0 };
+    for (int si = 0; si < n; ++si) {
+        fmt_read(&b, names[si], seqs[si], lens[si], tseq + si, p);
+        if (b.l >= ((size_t)1 << 20)) { fwrite(b.s, 1, b.l, fp); b.l = 0; }
+    }
+    if (b.l) fwrite(b.s, 1, b.l, fp);
+    free(b.s);
 }
 
 /* Record arithmetic of a batch (src/gen_cons.c:208-301 per consensus job): reads are independent and each writes only its
  * own tandem_seq_t slot, so the batch is cut into contiguous read ranges for a few worker threads. */
-typedef struct { th_handle_t *h; const th_batch_t *B; const th_gpu_out_t *o; th_tandem_seq_t *out; int r0, r1, rb; } collect_arg_t;   /* reads rb + r0 .. rb + r1 of the batch = r0 .. r1 of the part */
+#define TH_MAX_COLLECT 64
+/* text of one batch: buffer t holds the records of the reads collecting thread t took, and the threads' ranges follow each other in read order */
+typedef struct { th_str_t buf[TH_MAX_COLLECT]; int n; } th_fmt_t;
+typedef struct { th_handle_t *h; const th_batch_t *B; const th_gpu_out_t *o; th_tandem_seq_t *out; int r0, r1, rb; const char *const *names; th_str_t *fmt; double cpu; } collect_arg_t;   /* reads rb + r0 .. rb + r1 of the batch = r0 .. r1 of the part */
 static void *collect_range(void *arg)
 {
     collect_arg_t *a = (collect_arg_t *)arg;
+    const double c0 = thread_cpu_s();
     th_handle_t *h = a->h; const th_gpu_out_t *o = a->o; const th_para_t *p = &h->para; const th_batch_t *B = a->B;
+    th_scratch_t sc; memset(&sc, 0, sizeof(sc));
     int lo = 0, hi = o->n_jobs;                  /* first job of read >= r0 (jobs are ordered by read) */
     while (lo < hi) { int mid = (lo + hi) >> 1; if (o->jobs[mid].read < a->r0) lo = mid + 1; else hi = mid; }
     int ji = lo;
+    if (a->fmt) a->fmt->l = 0;
     for (int r = a->r0; r < a->r1; ++r) {
         th_tandem_seq_t *t = &a->out[a->rb + r];
         t->cons_n = 0; t->cons_seq->seq.l = 0; t->cons_seq->qual.l = 0;
-        while (ji < o->n_jobs && o->jobs[ji].read == r) { finish_job(h, B, o, &o->jobs[ji], t, a->rb); ++ji; }
+        while (ji < o->n_jobs && o->jobs[ji].read == r) { finish_job(h, B, o, &o->jobs[ji], t, a->rb, &sc); ++ji; }
         if (B->lens[a->rb + r] >= p->k && p->single_copy == 1 && p->only_full_length && p->five_seq != NULL && p->three_seq != NULL)
             single_copy(B->lens[a->rb + r], B->seqs[a->rb + r], t, p, o->single ? o->single + 40 * r : NULL);   /* src/tidehunter.c:24,49-51 */
+        if (a->fmt) fmt_read(a->fmt, a->names[a->rb + r], B->seqs[a->rb + r], B->lens[a->rb + r], t, p);
     }
+    scr_free(&sc);
+    a->cpu = thread_cpu_s() - c0;
     return NULL;
 }
-/* threads one handle may use for the record arithmetic: -t if given above the reference's default of 4, else what the host offers
- * (8, or 16 with 32 cores and more); TH_HOST_THREADS overrides (bench.py sets it to its share of the CPUs when several ranks share a host) */
+/* Threads one handle may use for the record arithmetic: the CPUs the process may really use (affinity and cgroup quota, not the
+ * host's core count) shared out over its live handles, eight at most -- the work is a few hundred milliseconds per million reads and
+ * overlaps the kernels of the next batch; -t above the reference's default of 4 raises the cap; TH_HOST_THREADS overrides
+ * (bench.py sets it to the rank's share when several processes share a host). */
 static int host_threads(const th_handle_t *h)
 {
-    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-    int nth = h->para.n_thread > 4 ? h->para.n_thread : (ncpu >= 32 ? 16 : 8);
+    const int eff = th_effective_cpus();
+    int live = __atomic_load_n(&g_live_handles, __ATOMIC_RELAXED); if (live < 1) live = 1;
+    int nth = eff / live; if (nth > 8) nth = 8;
+    if (h->para.n_thread > 4) nth = h->para.n_thread < eff ? h->para.n_thread : eff;
     const char *e = getenv("TH_HOST_THREADS");
     if (e && atoi(e) > 0) nth = atoi(e);
-    return nth > 64 ? 64 : nth;
+    return nth > TH_MAX_COLLECT ? TH_MAX_COLLECT : nth < 1 ? 1 : nth;
 }
-static int batch_collect_s(th_handle_t *h, int out_slot, th_tandem_seq_t *out)
+/* names / fmt: NULL, or the reads' names and the batch's text buffers -- then every thread also formats the records of its reads
+ * (and resets the slots as th_output would) */
+static int batch_collect_s(th_handle_t *h, int out_slot, th_tandem_seq_t *out, const char *const *names, th_fmt_t *fmt)
 {
     const th_batch_t *B = &h->res[out_slot & 1];
     th_gpu_out_t o[TH_MAX_SUB];
     for (int s = 0; s < B->n_sub; ++s) th_gpu_get(h->gpu[s], out_slot, &o[s]);
     int nth = host_threads(h);
     if (B->n < 256 * nth) nth = 1;
-    collect_arg_t arg[64]; pthread_t tid[64];
+    collect_arg_t arg[TH_MAX_COLLECT]; pthread_t tid[TH_MAX_COLLECT]; int started[TH_MAX_COLLECT];
     if (nth < B->n_sub) nth = B->n_sub;
     {   /* the threads are shared out over the parts in proportion to their reads, at least one each */
         int first[TH_MAX_SUB + 1]; first[0] = 0;
@@ -844,14 +1156,20 @@ static int batch_collect_s(th_handle_t *h, int out_slot, th_tandem_seq_t *out)
                 const int k = t - first[sp], m = first[sp + 1] - first[sp], cnt = B->sub_off[sp + 1] - B->sub_off[sp];
                 arg[t].h = h; arg[t].B = B; arg[t].o = &o[sp]; arg[t].out = out; arg[t].rb = B->sub_off[sp];
                 arg[t].r0 = (int)((long long)cnt * k / m); arg[t].r1 = (int)((long long)cnt * (k + 1) / m);
+                arg[t].names = names; arg[t].fmt = fmt ? &fmt->buf[t] : NULL; arg[t].cpu = 0;
             }
     }
-    for (int t = 1; t < nth; ++t) pthread_create(&tid[t], NULL, collect_range, &arg[t]);
+    if (fmt) fmt->n = nth;
+    /* a thread that cannot be started does not lose its reads: the range is taken inline */
+    for (int t = 1; t < nth; ++t) started[t] = pthread_create(&tid[t], NULL, collect_range, &arg[t]) == 0;
     collect_range(&arg[0]);
-    for (int t = 1; t < nth; ++t) pthread_join(tid[t], NULL);
+    for (int t = 1; t < nth; ++t) { if (started[t]) pthread_join(tid[t], NULL); else collect_range(&arg[t]); }
+    double cpu = 0;
+    for (int t = 1; t < nth; ++t) if (started[t]) cpu += arg[t].cpu;      /* (thread 0 and inline ranges are on the caller's own clock) */
+    cpu_account(CPU_COLLECT, cpu);
     return 0;
 }
-int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out) { return batch_collect_s(h, 0, out); }
+int th_batch_collect(th_handle_t *h, th_tandem_seq_t *out) { return batch_collect_s(h, 0, out, NULL, NULL); }
 
 int th_process_batch(th_handle_t *h, const char *const *seqs, const int *lens, int n, th_tandem_seq_t *out)
 {
@@ -869,54 +1187,6 @@ int th_process_batch(th_handle_t *h, const char *const *seqs, const int *lens, i
     return rc;
 }
 
-/* ---------------------------------------------------------------- output, src/main.c:214-271 */
-static void put_subpos(FILE *fp, const int *sp, int pos_n, char term)
-{
-    int i;
-    fprintf(fp, "%d", sp[0] + 2);
-    for (i = 1; i < pos_n - 1; ++i) fprintf(fp, ",%d", sp[i] + 2);
-    fprintf(fp, ",%d%c", sp[i] + 1, term);
-}
-void th_output(FILE *fp, int n, const char *const *names, const char *const *seqs, const int *lens, th_tandem_seq_t *tseq, const th_para_t *p)
-{
-    for (int si = 0; si < n; ++si) {
-        th_tandem_seq_t *t = tseq + si;
-        size_t cs = 0;
-        for (int ci = 0; ci < t->cons_n; ++ci) {
-            if (p->only_unit) {
-                for (int i = 0; i < t->pos_n[ci] - 1; ++i) {
-                    if (p->out_fmt == TH_FASTA_FMT) {
-                        fprintf(fp, ">%s_rep%d_sub%d\n", names[si], ci, i);
-                        fwrite(seqs[si] + t->sub_pos[ci][i] + 1, 1, (size_t)(t->sub_pos[ci][i + 1] - t->sub_pos[ci][i]), fp);
-                        fputc('\n', fp);
-                    } else if (p->out_fmt == TH_TAB_FMT) {
-                        fprintf(fp, "%s\trep%d\tsub%d\t", names[si], ci, i);
-                        int len = t->sub_pos[ci][i + 1] - t->sub_pos[ci][i] - 1;           /* '<' at src/main.c:224: one base fewer */
-                        if (len > 0) fwrite(seqs[si] + t->sub_pos[ci][i] + 1, 1, (size_t)len, fp);
-                        fputc('\n', fp);
-                    }
-                }
-                continue;
-            }
-            if (p->out_fmt == TH_FASTA_FMT || p->out_fmt == TH_FASTQ_FMT) {
-                fprintf(fp, "%c%s_rep%d_%.1f %d_%d_%d_%d_%.1f_%d_", p->out_fmt == TH_FASTA_FMT ? '>' : '@', names[si], ci, t->copy_num[ci], lens[si],
-                        t->cons_start[ci] + 1, t->cons_end[ci] + 1, t->cons_len[ci], t->ave_match[ci], t->full_length[ci]);
-                put_subpos(fp, t->sub_pos[ci], t->pos_n[ci], '\n');
-            } else {
-                fprintf(fp, "%s\trep%d\t%.1f\t%d\t%d\t%d\t%d\t%.1f\t%d\t", names[si], ci, t->copy_num[ci], lens[si],
-                        t->cons_start[ci] + 1, t->cons_end[ci] + 1, t->cons_len[ci], t->ave_match[ci], t->full_length[ci]);
-                put_subpos(fp, t->sub_pos[ci], t->pos_n[ci], '\t');
-            }
-            fwrite(t->cons_seq->seq.s + cs, 1, (size_t)t->cons_len[ci], fp);
-            if (p->out_fmt == TH_FASTQ_FMT) fputs("\n+\n", fp); else if (p->out_fmt == TH_TAB_QUAL_FMT) fputc('\t', fp);
-            if (p->out_fmt == TH_FASTQ_FMT || p->out_fmt == TH_TAB_QUAL_FMT) fwrite(t->cons_seq->qual.s + cs, 1, (size_t)t->cons_len[ci], fp);
-            fputc('\n', fp);
-            cs += (size_t)t->cons_len[ci];
-        }
-        t->cons_n = 0; t->cons_seq->seq.l = 0; t->cons_seq->qual.l = 0;
-    }
-}
-
 /* ---------------------------------------------------------------- the batch seam, pipelined */
 /* A sequence of batches through one handle as a three-stage software pipeline: while the kernels of batch i run, batch i+1 is
  * uploaded (own copy stream, second input set) and the record arithmetic of batch i-1 fills its tandem_seq_t slots (second
@@ -930,7 +1200,7 @@ typedef struct th_stage3 {
     int resident;                /* th_batch_run_steps(): every step runs the batch that sits in input set 0 (nothing is uploaded) */
     double ms_kernel[8];         /* device milliseconds per kernel, summed over the runs */
     /* batch k of this pipeline: reads and result slots (ring of 8: at most 4 batches are in flight) */
-    struct { const char *const *seqs; const int *lens; int n; th_tandem_seq_t *out; void *tag; } b[8];
+    struct { const char *const *seqs; const int *lens; int n; th_tandem_seq_t *out; void *tag; const char *const *names; th_fmt_t *fmt; } b[8];
     void (*on_done)(struct th_stage3 *, int k, void *tag);      /* called by the collecting thread when batch k is complete */
     double busy_up, busy_run, busy_col;
 } th_stage3_t;
@@ -948,11 +1218,11 @@ static int st3_wait(th_stage3_t *p, const int *ctr, int k)
     return ok;
 }
 /* stage 1, called by whoever produces batches: input set k & 1 is free once batch k-2 has run */
-static int st3_upload(th_stage3_t *p, int k, const char *const *seqs, const int *lens, int n, th_tandem_seq_t *out, void *tag)
+static int st3_upload(th_stage3_t *p, int k, const char *const *seqs, const int *lens, int n, th_tandem_seq_t *out, void *tag, const char *const *names, th_fmt_t *fmt)
 {
     if (k >= 2) st3_wait(p, &p->run_done, k - 2);
     const double t0 = now_s();
-    p->b[k & 7].seqs = seqs; p->b[k & 7].lens = lens; p->b[k & 7].n = n; p->b[k & 7].out = out; p->b[k & 7].tag = tag;
+    p->b[k & 7].seqs = seqs; p->b[k & 7].lens = lens; p->b[k & 7].n = n; p->b[k & 7].out = out; p->b[k & 7].tag = tag; p->b[k & 7].names = names; p->b[k & 7].fmt = fmt;
     if (!p->failed && n > 0 && batch_upload_s(p->h, k, seqs, lens, n, 0)) p->failed = 1;
     p->busy_up += now_s() - t0;
     st3_bump(p, &p->up_done);
@@ -962,7 +1232,7 @@ static void *st3_runner(void *arg)
 {
     th_stage3_t *p = (th_stage3_t *)arg;
     for (int k = 0;; ++k) {
-        if (!st3_wait(p, &p->up_done, k)) return NULL;
+        if (!st3_wait(p, &p->up_done, k)) { cpu_account(CPU_RUN, thread_cpu_s()); return NULL; }
         if (k >= 2) st3_wait(p, &p->col_done, k - 2);            /* result set k & 1 is free once batch k-2 has been collected */
         const double t0 = now_s();
         if (!p->failed && p->b[k & 7].n > 0 && batch_run_s(p->h, p->resident ? 0 : k, k)) p->failed = 1;
@@ -976,9 +1246,10 @@ static void *st3_collector(void *arg)
 {
     th_stage3_t *p = (th_stage3_t *)arg;
     for (int k = 0;; ++k) {
-        if (!st3_wait(p, &p->run_done, k)) return NULL;
+        if (!st3_wait(p, &p->run_done, k)) { cpu_account(CPU_COLLECT, thread_cpu_s()); return NULL; }
         const double t0 = now_s();
-        if (!p->failed && p->b[k & 7].n > 0 && batch_collect_s(p->h, k, p->b[k & 7].out)) p->failed = 1;
+        if (p->b[k & 7].fmt) p->b[k & 7].fmt->n = 0;
+        if (!p->failed && p->b[k & 7].n > 0 && batch_collect_s(p->h, k, p->b[k & 7].out, p->b[k & 7].names, p->b[k & 7].fmt)) p->failed = 1;
         p->busy_col += now_s() - t0;
         if (p->on_done) p->on_done(p, k, p->b[k & 7].tag);
         st3_bump(p, &p->col_done);
@@ -990,7 +1261,7 @@ int th_process_batches(th_handle_t *h, int n_batches, const char *const *const *
     pthread_t t_run, t_col;
     if (pthread_create(&t_run, NULL, st3_runner, &p) != 0) { st3_destroy(&p); return host_fail("pthread_create failed"); }
     if (pthread_create(&t_col, NULL, st3_collector, &p) != 0) { st3_finish(&p, 0); pthread_join(t_run, NULL); st3_destroy(&p); return host_fail("pthread_create failed"); }
-    for (int k = 0; k < n_batches; ++k) st3_upload(&p, k, seqs[k], lens[k], n[k], out[k], NULL);
+    for (int k = 0; k < n_batches; ++k) st3_upload(&p, k, seqs[k], lens[k], n[k], out[k], NULL, NULL, NULL);
     st3_finish(&p, n_batches);
     pthread_join(t_run, NULL); pthread_join(t_col, NULL);
     const int bad = p.failed;
@@ -1011,7 +1282,7 @@ int th_batch_run_steps(th_handle_t *h, int steps, th_tandem_seq_t *out, double *
     if (pthread_create(&t_col, NULL, st3_collector, &p) != 0) { st3_finish(&p, 0); pthread_join(t_run, NULL); st3_destroy(&p); return host_fail("pthread_create failed"); }
     for (int k = 0; k < steps; ++k) {
         if (k >= 2) st3_wait(&p, &p.run_done, k - 2);
-        p.b[k & 7].seqs = h->up[0].seqs; p.b[k & 7].lens = h->up[0].lens; p.b[k & 7].n = h->up[0].n; p.b[k & 7].out = out; p.b[k & 7].tag = NULL;
+        p.b[k & 7].seqs = h->up[0].seqs; p.b[k & 7].lens = h->up[0].lens; p.b[k & 7].n = h->up[0].n; p.b[k & 7].out = out; p.b[k & 7].tag = NULL; p.b[k & 7].names = NULL; p.b[k & 7].fmt = NULL;
         st3_bump(&p, &p.up_done);
     }
     st3_finish(&p, steps);
@@ -1032,7 +1303,7 @@ enum { SLOT_EMPTY = 0, SLOT_FILLED = 1, SLOT_DONE = 2 };
 #define TH_MAX_DEV 16
 #define TH_MAX_WORKER (4 * TH_MAX_DEV)          /* up to four pipelines (handles) per device */
 #define TH_MAX_SLOT (5 * TH_MAX_WORKER + 2)
-typedef struct { char **names, **seqs; int *lens; int n, state, batch; th_tandem_seq_t *ts; th_str_t arena; size_t *noff, *soff; } th_slot_t;   /* batch: index of the batch the slot holds */
+typedef struct { char **names, **seqs; int *lens; int n, state, batch; th_tandem_seq_t *ts; th_str_t arena; size_t *noff, *soff; th_fmt_t fmt; } th_slot_t;   /* batch: index of the batch the slot holds */
 typedef struct {
     th_slot_t slot[TH_MAX_SLOT]; int n_slot, n_dev, n_primary;     /* n_primary: listed devices; pipelines n_primary.. are the further ones per device */
     pthread_mutex_t mu; pthread_cond_t cv;
@@ -1085,7 +1356,7 @@ static void *pipe_reader(void *arg)
         s->n = n; s->batch = i;
         if (n == 0) { pthread_mutex_lock(&q->mu); q->eof_batch = i; pthread_mutex_unlock(&q->mu); }
         slot_set(q, s, SLOT_FILLED);
-        if (n == 0) return NULL;
+        if (n == 0) { cpu_account(CPU_READER, thread_cpu_s()); return NULL; }
     }
 }
 static void *pipe_writer(void *arg)
@@ -1096,10 +1367,12 @@ static void *pipe_writer(void *arg)
         slot_wait(q, s, SLOT_DONE, i);
         const int n = s->n;
         const double t0 = now_s();
-        if (n > 0 && q->out && !q->stop) th_output(q->out, n, (const char *const *)s->names, (const char *const *)s->seqs, s->lens, s->ts, q->p);
+        /* the text was formatted by the batch's collecting threads, one buffer per thread in read order: nothing per record happens here */
+        if (n > 0 && q->out && !q->stop) for (int t = 0; t < s->fmt.n; ++t) if (s->fmt.buf[t].l) fwrite(s->fmt.buf[t].s, 1, s->fmt.buf[t].l, q->out);
+        s->fmt.n = 0;
         q->t_write += now_s() - t0;
         slot_set(q, s, SLOT_EMPTY);
-        if (n == 0) return NULL;
+        if (n == 0) { cpu_account(CPU_WRITER, thread_cpu_s()); return NULL; }
     }
 }
 /* the collecting thread of a device pipeline has finished a batch: its slot goes to the writer */
@@ -1152,10 +1425,26 @@ static void *pipe_device(void *arg)
         pthread_mutex_unlock(&q->mu);
         if (q->trace) fprintf(stderr, "[th_run_file]   pipeline %d: %s at %.3f s\n", w->dev_index, retired ? "retired (one pipeline is enough for this input / device memory)" : "buffers reserved", now_s() - q->t_start);
     }
-    if (retired) { st3_init(&w->st, NULL); if (h) th_destroy(h); return NULL; }
+    if (retired) { st3_init(&w->st, NULL); if (h) th_destroy(h); cpu_account(CPU_UPLOAD, thread_cpu_s()); return NULL; }
     st3_init(&w->st, h); w->st.on_done = pipe_batch_done; w->st.failed = h ? 0 : 1;
     pthread_t t_run, t_col;
-    pthread_create(&t_run, NULL, st3_runner, &w->st); pthread_create(&t_col, NULL, st3_collector, &w->st);
+    int have_threads = pthread_create(&t_run, NULL, st3_runner, &w->st) == 0;
+    if (have_threads && pthread_create(&t_col, NULL, st3_collector, &w->st) != 0) { st3_finish(&w->st, 0); pthread_join(t_run, NULL); have_threads = 0; }
+    if (!have_threads) {
+        /* no pipeline without its threads: the run fails, and the batches this pipeline draws go to the writer untouched (it prints
+         * nothing once `stop` is set) so that reader, writer and the other pipelines still come to an end */
+        host_fail("pthread_create failed"); w->rc = -1; q->stop = 1;
+        for (;;) {
+            const int i = __atomic_fetch_add(&q->next_batch, 1, __ATOMIC_RELAXED);
+            th_slot_t *s = &q->slot[i % q->n_slot];
+            if (!slot_wait(q, s, SLOT_FILLED, i)) break;
+            const int last = s->n == 0;
+            s->fmt.n = 0; slot_set(q, s, SLOT_DONE);
+            if (last) break;
+        }
+        if (h) th_destroy(h);
+        return NULL;
+    }
     int k = 0;
     for (;; ++k) {
         if (k >= 2) st3_wait(&w->st, &w->st.run_done, k - 2);       /* take a ticket only when an input set is free: an idle device gets the batch instead */
@@ -1163,7 +1452,7 @@ static void *pipe_device(void *arg)
         th_slot_t *s = &q->slot[i % q->n_slot];
         if (!slot_wait(q, s, SLOT_FILLED, i)) break;
         if (q->stop) w->st.failed = 1;
-        st3_upload(&w->st, k, (const char *const *)s->seqs, s->lens, s->n, s->ts, s);
+        st3_upload(&w->st, k, (const char *const *)s->seqs, s->lens, s->n, s->ts, s, (const char *const *)s->names, &s->fmt);
         ++w->batches;
         if (s->n == 0) { ++k; break; }                              /* the empty batch that ends the input went through (the writer stops on it) */
     }
@@ -1171,6 +1460,7 @@ static void *pipe_device(void *arg)
     pthread_join(t_run, NULL); pthread_join(t_col, NULL);
     if (w->st.failed) w->rc = -1;
     if (h) th_destroy(h);
+    cpu_account(CPU_UPLOAD, thread_cpu_s());
     return NULL;
 }
 
@@ -1203,11 +1493,45 @@ int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *d
     pthread_t t_rd, t_wr, t_dev[TH_MAX_WORKER]; th_dev_worker_t *w = (th_dev_worker_t *)calloc(TH_MAX_WORKER, sizeof(th_dev_worker_t));
     const double t_start = now_s();
     q->t_start = t_start; q->trace = getenv("TH_TRACE") != NULL;
-    pthread_create(&t_rd, NULL, pipe_reader, q); pthread_create(&t_wr, NULL, pipe_writer, q);
-    for (int d = 0; d < n_dev; ++d) { w[d].q = q; w[d].dev_index = d; w[d].device = devices[d]; pthread_create(&t_dev[d], NULL, pipe_device, &w[d]); }
+    double cpu0[CPU_N]; th_host_cpu_seconds(cpu0, CPU_N);
+    struct rusage ru0; getrusage(RUSAGE_SELF, &ru0);
     int total = 0, rc = 0; double busy_up = 0, busy_run = 0, busy_col = 0;
-    for (int d = 0; d < n_dev; ++d) { pthread_join(t_dev[d], NULL); total += w[d].total; rc |= w[d].rc; busy_up += w[d].st.busy_up; busy_run += w[d].st.busy_run; busy_col += w[d].st.busy_col; }
-    pthread_join(t_rd, NULL); pthread_join(t_wr, NULL);
+    int dev_on[TH_MAX_WORKER]; memset(dev_on, 0, sizeof(dev_on));
+    /* the writer first, then the reader: whichever cannot be started, the other is not left waiting */
+    const int wr_on = pthread_create(&t_wr, NULL, pipe_writer, q) == 0;
+    int rd_on = 0;
+    if (wr_on && !(rd_on = pthread_create(&t_rd, NULL, pipe_reader, q) == 0)) {
+        q->stop = 1; q->slot[0].n = 0; q->slot[0].batch = 0; q->slot[0].fmt.n = 0;
+        pthread_mutex_lock(&q->mu); q->eof_batch = 0; pthread_mutex_unlock(&q->mu);
+        slot_set(q, &q->slot[0], SLOT_DONE);          /* the empty batch that ends the writer */
+    }
+    if (!rd_on || !wr_on) { rc = -1; host_fail("pthread_create failed"); }
+    int n_started = 0;
+    if (rd_on && wr_on)
+        for (int d = 0; d < n_dev; ++d) {
+            w[d].q = q; w[d].dev_index = d; w[d].device = devices[d];
+            dev_on[d] = pthread_create(&t_dev[d], NULL, pipe_device, &w[d]) == 0;
+            n_started += dev_on[d];
+        }
+    if (rd_on && wr_on && n_started < n_dev) {
+        /* a pipeline thread that could not be started: the pipelines that did start wait for n_dev reservations, so the run is stopped
+         * (which also ends those waits) and fails; with no pipeline at all the calling thread draws the batches, as a pipeline without
+         * threads does (pipe_device), so that reader and writer come to an end */
+        rc = -1; host_fail("pthread_create failed");
+        pthread_mutex_lock(&q->mu); q->stop = 1; q->n_reserved += n_dev - n_started; pthread_cond_broadcast(&q->cv); pthread_mutex_unlock(&q->mu);
+        if (n_started == 0)
+            for (;;) {
+                const int i = __atomic_fetch_add(&q->next_batch, 1, __ATOMIC_RELAXED);
+                th_slot_t *sl = &q->slot[i % q->n_slot];
+                if (!slot_wait(q, sl, SLOT_FILLED, i)) break;
+                const int last = sl->n == 0;
+                sl->fmt.n = 0; slot_set(q, sl, SLOT_DONE);
+                if (last) break;
+            }
+    }
+    for (int d = 0; d < n_dev; ++d) if (dev_on[d]) { pthread_join(t_dev[d], NULL); total += w[d].total; rc |= w[d].rc; busy_up += w[d].st.busy_up; busy_run += w[d].st.busy_run; busy_col += w[d].st.busy_col; }
+    if (rd_on) pthread_join(t_rd, NULL);
+    if (wr_on) pthread_join(t_wr, NULL);
     if (getenv("TH_TRACE")) {
         const double t_end = now_s();
         /* steady: per pipeline, the reads completed after its first full-size batch over the time from then to its last batch; the
@@ -1221,9 +1545,16 @@ int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *d
         fprintf(stderr, "[th_run_file] %d reads on %d device pipeline(s): wall %.3f s; busy: reader %.3f s, upload %.3f s, device runs %.3f s, record arithmetic %.3f s, writer %.3f s; steady %.1f reads/s over the last %.3f s\n",
                 total, n_dev, t_end - t_start, q->t_read, busy_up, busy_run, busy_col, q->t_write, steady, window);
         if (n_dev > 1) for (int d = 0; d < n_dev; ++d) fprintf(stderr, "[th_run_file]   pipeline %d (device %d): %d batches, %d reads, device busy %.3f s\n", d, devices[d], w[d].batches, w[d].total, w[d].st.busy_run);
+        /* host CPU seconds by role (thread CPU clocks) and in all (getrusage); the rest is the HIP runtime's own threads */
+        double cpu1[CPU_N], sum = 0; th_host_cpu_seconds(cpu1, CPU_N);
+        struct rusage ru1; getrusage(RUSAGE_SELF, &ru1);
+        for (int i = 0; i < CPU_N; ++i) { cpu1[i] -= cpu0[i]; sum += cpu1[i]; }
+        const double all = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + 1e-6 * ((ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec));
+        fprintf(stderr, "[th_run_file] host CPU %.3f s (%.2f per 10^6 reads; %d usable CPUs): reader %.3f, inflate %.3f, upload threads %.3f, run threads %.3f, record arithmetic + formatting %.3f, writer %.3f, runtime and the rest %.3f\n",
+                all, total > 0 ? all * 1e6 / total : 0.0, th_effective_cpus(), cpu1[CPU_READER], cpu1[CPU_INFLATE], cpu1[CPU_UPLOAD], cpu1[CPU_RUN], cpu1[CPU_COLLECT], cpu1[CPU_WRITER], all - sum);
     }
     for (int d = 0; d < n_dev; ++d) st3_destroy(&w[d].st);
-    for (int i = 0; i < q->n_slot; ++i) { th_free_tandem_seq(q->slot[i].ts, batch_reads); free(q->slot[i].names); free(q->slot[i].seqs); free(q->slot[i].lens); free(q->slot[i].noff); free(q->slot[i].soff); free(q->slot[i].arena.s); }
+    for (int i = 0; i < q->n_slot; ++i) { th_free_tandem_seq(q->slot[i].ts, batch_reads); free(q->slot[i].names); free(q->slot[i].seqs); free(q->slot[i].lens); free(q->slot[i].noff); free(q->slot[i].soff); free(q->slot[i].arena.s); for (int t = 0; t < TH_MAX_COLLECT; ++t) free(q->slot[i].fmt.buf[t].s); }
     pthread_mutex_destroy(&q->mu); pthread_cond_destroy(&q->cv);
     if (r->failed && !rc) { rc = -1; host_fail("the input is corrupt or truncated: the output holds only the reads before the damage"); }
     free(q); free(w); rd_close(r);

@@ -72,6 +72,11 @@ long long th_gpu_debug(th_gpu_t *g, int what, void *dst, long long cap);
 struct th_handle;
 long long th_debug_stage(struct th_handle *h, int what, void *dst, long long cap);
 
+
+/* host CPU budget (th_host.c; exported for bench.py and the tests, not part of the public header) */
+int th_effective_cpus(void);                       /* CPUs the process may really use: affinity mask cut down to the cgroup quota */
+int th_host_cpu_seconds(double *out, int n);       /* CPU seconds so far by role: [0] reader [1] inflate [2] upload [3] run [4] record arithmetic + formatting [5] writer; returns 6 */
+
 #ifdef __cplusplus
 }
 #endif

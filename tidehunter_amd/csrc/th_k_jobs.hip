@@ -123,7 +123,9 @@ th_k_jobs_count(int n_reads, ThJobTables J, ThDevPara P, int only_unit, int *__r
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     int c[TH_JOB_COLS] = { 0, 0, 0, 0, 0, 0, 0 };
-    th_jobs_walk<false>(J, P, r, only_unit, c, C);
+    // the record arena overflowed: th_k_partition returned at entry, so par_n[] / par_off[] hold whatever the batch before left there
+    // (or nothing at all on a handle's first batch) -- zero rows, nothing is walked; the host reruns extraction, partition and this build
+    if (!(C->err & TH_E_REC_OVERFLOW)) th_jobs_walk<false>(J, P, r, only_unit, c, C);
 #pragma unroll
     for (int k = 0; k < TH_JOB_COLS; ++k) rows[(long long)r * TH_JOB_COLS + k] = c[k];
 }
@@ -133,7 +135,7 @@ th_k_jobs_emit(int n_reads, ThJobTables J, ThDevPara P, int only_unit, const int
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
-    if (C->err & TH_E_JOB_CAP) return;              // the tables are too small: nothing is written, the host reruns the build
+    if (C->err & (TH_E_JOB_CAP | TH_E_REC_OVERFLOW)) return;      // the tables are too small, or the partition did not run (see th_k_jobs_count): nothing is written, the host reruns the build
     int c[TH_JOB_COLS];
 #pragma unroll
     for (int k = 0; k < TH_JOB_COLS; ++k) c[k] = rows[(long long)r * TH_JOB_COLS + k];

@@ -133,9 +133,11 @@ __device__ int th_ksw_global_wave(const uint8_t *__restrict__ q, int qlen, const
 //
 // slb > TH_NEG: a LOWER BOUND of the optimum (the banded score of an earlier pass).  Inside the band, every cell that no path of
 // score >= slb can pass through is minus infinity as well: once the top border has left the band, paths enter a strip through the
-// parked column only; a parked cell (i, j0 - 1) with H + min(a, b) - (|a - b| + 1) e < slb where a != b (a = tlen - 1 - i, b = qlen - j0:
-// what is left to the end corner; the path may cross in an open horizontal gap, at most H - e, and then closes the difference without a
-// new opening) is dead, and a live one reaches nothing that matters below row i + 64 + min(H + b - slb, (H + a - slb) / 2).
+// parked column only; a parked cell (i, j0 - 1) with H + min(a, b) - |a - b| e < slb (a = tlen - 1 - i, b = qlen - j0: what is left to
+// the end corner; the path may cross INSIDE an open horizontal gap -- F == H at the parked cell -- and then closes the difference with
+// |a - b| further extension bases and no new opening, so neither the opening nor an extra base may be charged: round 3 charged
+// (|a - b| + 1) e and pruned the optimal path's own cell when slb was the optimum and the rest of the path all matches) is dead, and a
+// live one reaches nothing that matters below row i + 64 + min(H + b - slb, (H + a - slb) / 2).
 // Every optimal path, and every candidate that ties with one at a cell of the traceback, consists of live cells, so the result is
 // the band's (th_ksw_ext_band_wave has the argument in full); the live region is a lens around the path, not a band.
 __device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, int W, int *__restrict__ bnd, int (*s_in)[TH_WAVE][8], int *band_score, int slb = TH_NEG)
@@ -160,7 +162,7 @@ __device__ int th_ksw_global_band_wave(const uint8_t *__restrict__ q, int qlen, 
                 const int row = r0 + lane;
                 if (row <= ppre) {
                     const int H = bnd4[row].x, a = tlen - 1 - row, dab = a > b ? a - b : b - a;
-                    if (H + min(a, b) - (dab ? (dab + 1) * TH_KE : 0) >= slb) { vmin = min(vmin, row); vmax = max(vmax, row + 64 + min(H + b - slb, (H + a - slb) >> 1)); }
+                    if (H + min(a, b) - dab * TH_KE >= slb) { vmin = min(vmin, row); vmax = max(vmax, row + 64 + min(H + b - slb, (H + a - slb) >> 1)); }
                 }
             }
 #pragma unroll
@@ -606,7 +608,8 @@ __device__ void th_ksw_ext_wave(const uint8_t *__restrict__ q, int qs, int qlen,
         }
         // across strips the lane's columns grow by 64 while the rows start over: an equal score on an EARLIER anti-diagonal may turn up in
         // a later strip, and ksw2 reports the earliest
-        if (lbT >= 0 && (lbH > bestH || lbT + j < bestR)) { bestH = lbH; bestR = lbT + j; bestT = lbT; }
+        // (the same score on the SAME anti-diagonal, 64 k columns apart: ksw2's visiting order decides, as in the final reduction)
+        if (lbT >= 0 && (lbH > bestH || lbT + j < bestR || (lbT + j == bestR && th_ext_rank(bestR, lbT, qlen, tlen) < th_ext_rank(bestR, bestT, qlen, tlen)))) { bestH = lbH; bestR = lbT + j; bestT = lbT; }
         TH_WAVE_FENCE();
     }
     // wave arg-max by (H desc, anti-diagonal asc, SSE visiting rank asc)
@@ -715,7 +718,7 @@ __device__ void th_ksw_ext_band_wave(const uint8_t *__restrict__ q, int qs, int 
             for (; k + 1 < kend; k += 2) { step(k, in, in2); step(k + 1, in2, in); }
             if (k < kend) step(k, in, in2);
         }
-        if (lbT >= 0 && (lbH > bestH || lbT + j < bestR)) { bestH = lbH; bestR = lbT + j; bestT = lbT; }      // (as th_ksw_ext_wave)
+        if (lbT >= 0 && (lbH > bestH || lbT + j < bestR || (lbT + j == bestR && th_ext_rank(bestR, lbT, qlen, tlen) < th_ext_rank(bestR, bestT, qlen, tlen)))) { bestH = lbH; bestR = lbT + j; bestT = lbT; }      // (as th_ksw_ext_wave)
         prs = rs; ppre = re;
         TH_WAVE_FENCE();
     }

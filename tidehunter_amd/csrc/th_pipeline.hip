@@ -84,6 +84,7 @@ struct ThOut {
 
 struct th_gpu {
     th_gpu_para_t para; ThDevPara dp; int device; th_stream_t stream, cstream;
+    th_event_t sync_ev; bool sync_ev_ok = false;      // the blocking event every host wait of this pipeline goes through (th_rt.h)
     ThIn in[2]; ThOut out[2]; int last_in = 0;
     uint8_t *h_stage[2] = { nullptr, nullptr }; th_event_t stage_ev[2]; bool stage_ok = false, stage_used[2] = { false, false }; int stage_cur = 0;   // pinned staging for the upload (2 x TH_STAGE_BYTES)
     DBuf<uint8_t> d_bseq, d_tracked, d_cons, d_cons_c;
@@ -149,6 +150,9 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
     int ndev = 0;
     if (th_rt_device_count(&ndev) || ndev <= 0) { th_fail("no HIP device: the TideHunter HIP path needs an AMD GPU (no CPU fallback)"); delete g; return nullptr; }
     if (th_rt_set_device(device)) { th_fail("hipSetDevice failed"); delete g; return nullptr; }
+    th_rt_prefer_blocking();
+    if (th_rt_event_create(&g->sync_ev)) { th_fail("hipEventCreate failed"); delete g; return nullptr; }
+    g->sync_ev_ok = true;
     if (th_rt_stream_create(&g->stream) || th_rt_stream_create(&g->cstream)) { th_fail("hipStreamCreate failed"); delete g; return nullptr; }
     g->waves_part = env_int("TH_WAVES_PART", TH_PERSISTENT_WAVES(g->waves_part));
     g->waves_poa = env_int("TH_WAVES_POA", TH_PERSISTENT_WAVES(g->waves_poa));
@@ -164,6 +168,7 @@ extern "C" void th_gpu_destroy(th_gpu_t *g)
     if (!g) return;
     (void)th_rt_set_device(g->device);
     (void)th_rt_sync(g->stream); (void)th_rt_sync(g->cstream);
+    if (g->sync_ev_ok) th_rt_event_destroy(g->sync_ev);
     g_arena = nullptr;
     for (int s = 0; s < 2; ++s) { g->in[s].d_seq.release(); g->in[s].d_roff.release(); g->in[s].d_gsort_off.release(); if (g->in[s].ev_ok) th_rt_event_destroy(g->in[s].ev); }
     g->d_bseq.release(); g->d_tracked.release(); g->d_cons.release(); g->d_cons_c.release(); g->d_tmp.release(); g->d_xorder.release(); g->d_xstart.release(); g->d_xend.release(); g->d_xovf.release();
@@ -342,7 +347,7 @@ static int th_fetch_cnt(th_gpu *g, ThCnt **out)
 {
     g->h_cnt.resize(1);
     TRY(th_rt_d2h(g->h_cnt.data(), g->d_cnt.p, sizeof(ThCnt), g->stream));
-    TRY(th_rt_sync(g->stream));
+    TRY(th_rt_sync_event(g->stream, g->sync_ev));
     ++g->n_sync;
     *out = g->h_cnt.data();
     return 0;
@@ -376,7 +381,7 @@ static int th_poa_retries(th_gpu *g, KTimer &kt, const ThIn &in, int nt, int poa
     th_room(g->h_tasks, (size_t)nt); g->h_tasks.resize(nt); th_room(g->h_status, (size_t)nt); g->h_status.resize(nt);
     TRY(th_rt_d2h(g->h_tasks.data(), g->d_tasks.p, (size_t)nt * sizeof(ThTask), g->stream));
     TRY(th_rt_d2h(g->h_status.data(), g->d_status.p, (size_t)nt * 4, g->stream));
-    TRY(th_rt_sync(g->stream));
+    TRY(th_rt_sync_event(g->stream, g->sync_ev));
     auto run_list = [&](const std::vector<int> &grp, int cls, bool noband, double factor, bool *ran) -> int {
         const bool wide = cls == 0;
         *ran = false;
@@ -392,7 +397,7 @@ static int th_poa_retries(th_gpu *g, KTimer &kt, const ThIn &in, int nt, int poa
         TH_LAUNCH(th_k_cnt_set, 1, 64, g->stream, &g->d_cnt.p->q_poa_w, 0, (int *)nullptr, 0, (int *)nullptr, 0, (int *)nullptr, 0);
         TRY(th_poa_launch(g, kt, in, g->d_sublist.p, (int)grp.size(), cls, max_unit, need, wv, &g->d_cnt.p->q_poa_w, (noband ? 1 : 0) | poa_test_fail << 8));
         TRY(th_rt_d2h(g->h_status.data(), g->d_status.p, (size_t)nt * 4, g->stream));
-        TRY(th_rt_sync(g->stream));
+        TRY(th_rt_sync_event(g->stream, g->sync_ev));
         *ran = true;
         return 0;
     };
@@ -431,7 +436,7 @@ static int th_poa_retries(th_gpu *g, KTimer &kt, const ThIn &in, int nt, int poa
         // whatever is left stays without a consensus: status 5 tells the item build so (it only counts 1-4 and 7 as "retry")
         for (int t = 0; t < nt; ++t) if (g->h_status[t] != 0 && g->h_status[t] != 5 && g->h_status[t] != 6) g->h_status[t] = 5;
         TRY(th_rt_h2d(g->d_status.p, g->h_status.data(), (size_t)nt * 4, g->stream));
-        TRY(th_rt_sync(g->stream));
+        TRY(th_rt_sync_event(g->stream, g->sync_ev));
     }
     return 0;
 }
@@ -613,7 +618,7 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
         TRY(th_poa_launch(g, kt, in, g->d_list_l.p, n_task_l, 2, cnt->max_unit, need_l, wv_l, &dc->q_poa_l, poa_test_fail << 8));       // (the long jobs first: the short ones fill the tail)
         TRY(th_poa_launch(g, kt, in, g->d_list_n.p, n_task_n, 1, cnt->max_unit, need_n, wv_n, &dc->q_poa_n, poa_test_fail << 8));
         TRY(th_poa_launch(g, kt, in, g->d_list_w.p, n_task_w, 0, cnt->max_unit, need_w, wv_w, &dc->q_poa_w, poa_test_fail << 8));
-        if (trace) { th_rt_sync(g->stream); fprintf(stderr, "[th] %.3f s: poa done (%d + %d + %d jobs, %d / %d / %d waves, %lld MB scratch)\n", th_wall_s() - t_run0, n_task_n, n_task_l, n_task_w, wv_n, wv_l, wv_w, (long long)(std::max(std::max(need_n * wv_n, need_w * wv_w), need_l * wv_l) * 4 >> 20)); }
+        if (trace) { th_rt_sync_event(g->stream, g->sync_ev); fprintf(stderr, "[th] %.3f s: poa done (%d + %d + %d jobs, %d / %d / %d waves, %lld MB scratch)\n", th_wall_s() - t_run0, n_task_n, n_task_l, n_task_w, wv_n, wv_l, wv_w, (long long)(std::max(std::max(need_n * wv_n, need_w * wv_w), need_l * wv_l) * 4 >> 20)); }
         for (int pass = 0;; ++pass) {
             // ---- item lists of the alignment kernels and the compacted consensus offsets, per job, on the device ----
             KT_BEGIN(TK_ALIGN);
@@ -671,7 +676,7 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
 #undef TH_ALN_ARGS
         }
         KT_END(TK_ALIGN);
-        if (trace) { th_rt_sync(g->stream); fprintf(stderr, "[th] %.3f s: align done (%d items)\n", th_wall_s() - t_run0, ni); }
+        if (trace) { th_rt_sync_event(g->stream, g->sync_ev); fprintf(stderr, "[th] %.3f s: align done (%d items)\n", th_wall_s() - t_run0, ni); }
         // ---- adapter searches on the doubled consensus (src/gen_cons.c:226-291), four per job, one per lane ----
         if (g->ad_on) {
             TRY(g->d_adp.ensure(1)); TRY(g->d_ad.ensure((size_t)nt * 12));

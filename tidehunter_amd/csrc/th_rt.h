@@ -20,10 +20,20 @@ static inline int th_rt_sync(th_stream_t s) { TH_CHECK(hipStreamSynchronize(s));
 static inline int th_rt_host_alloc(void **p, size_t n) { TH_CHECK(hipHostMalloc(p, n ? n : 1, hipHostMallocDefault)); return 0; }
 static inline int th_rt_host_free(void *p) { if (p) TH_CHECK(hipHostFree(p)); return 0; }
 typedef hipEvent_t th_event_t;
-static inline int th_rt_event_create(th_event_t *e) { TH_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming)); return 0; }
+// Every event the host waits on is a BLOCKING one: hipEventSynchronize then sleeps on the completion signal's interrupt instead of
+// spinning on it.  hipStreamSynchronize spins (with the default device schedule) for as long as the kernels run -- one core per
+// pipeline thread, 16 of the 30 CPU-seconds round 3 spent per million reads -- so the pipeline never calls it on its hot path: it
+// records such an event behind the work and waits for that (th_rt_sync_event).  TH_SPIN_SYNC=1 restores the spinning waits (A/B runs).
+static inline bool th_rt_spin() { static const bool on = getenv("TH_SPIN_SYNC") && atoi(getenv("TH_SPIN_SYNC")); return on; }
+static inline int th_rt_event_create(th_event_t *e) { TH_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming | (th_rt_spin() ? 0 : hipEventBlockingSync))); return 0; }
 static inline int th_rt_event_record(th_event_t e, th_stream_t s) { TH_CHECK(hipEventRecord(e, s)); return 0; }
 static inline int th_rt_event_wait(th_event_t e) { TH_CHECK(hipEventSynchronize(e)); return 0; }
 static inline int th_rt_event_destroy(th_event_t e) { TH_CHECK(hipEventDestroy(e)); return 0; }
+// drains stream s without spinning: a blocking event behind everything enqueued so far
+static inline int th_rt_sync_event(th_stream_t s, th_event_t e) { if (th_rt_spin()) { TH_CHECK(hipStreamSynchronize(s)); return 0; } TH_CHECK(hipEventRecord(e, s)); TH_CHECK(hipEventSynchronize(e)); return 0; }
+// asks the runtime for blocking waits everywhere else too (hipStreamSynchronize in slow paths, hipFree, ...).  Only honoured before the
+// device's context exists; afterwards it fails harmlessly (torch or another handle got there first) -- the events above do not depend on it.
+static inline void th_rt_prefer_blocking() { if (!th_rt_spin()) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); } }
 // a launch the runtime rejects (resource limits, wrong device, ...) must not pass silently: the enclosing function returns
 // th_launch_failed(...) (an int, defined by the pipeline before its first launch)
 #define TH_LAUNCH(kernel, grid, block, stream, ...) do { hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__); \

@@ -1,7 +1,7 @@
 #!/bin/bash
-# development helper (GPU box): the command line on N x the 100 000-read headline set, TH_TRACE timeline kept.
-#   usage: tools/r3_e2e.sh outdir [copies=10] [cases="workers:batch ..."]
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r3e2e}; mkdir -p $O; cd $R
+# GPU box: the command line on N x the 100 000-read headline set, TH_TRACE timeline (incl. the host-CPU table) kept.
+#   usage: tools/e2e.sh outdir [copies=10] [cases="workers:batch ..."]
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-e2e}; mkdir -p $O; cd $R
 COPIES=${2:-10}
 D=/dev/shm; [ -d $D ] || D=/tmp
 python3 - <<PY
