@@ -1,0 +1,245 @@
+"""Reference-generated vectors (tests/golden/ref_ksw2_vectors.npz, ref_edlib_vectors.npz: written by tests/golden/make_ref_vectors.py
+from the reference's OWN ksw2 / edlib code, oracle/_ref/libthref.so) against
+
+  * the oracle (CPU, any box -- the files travel, /root/reference does not),
+  * the kernel sources under the CPU emulation, through the raw-pair hooks (a subset: the emulation is slow),
+  * the HIP kernels on the GPU (`-m gpu`), every engine the alignment kernel has: strip engine, pruned second band, anti-diagonal band
+    engine at one to six registers per lane, the deferred strip launch, flank extensions on the anti-diagonal engine / pruned strips /
+    full matrix, the partition's full-matrix engine with the CIGAR functionals, and both adapter searches.
+
+src/ksw2_align.c:88-173 (ksw2_backtrack_left_end, ksw2_global, ksw2_global_with_cigar, ksw2_right_ext, ksw2_left_ext),
+src/edlib_align.c:73-85 (edlib_align_HW)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import th_util as U
+
+GOLD = os.path.join(U.ROOT, "tests", "golden")
+CLS = {"short": 0, "strip": 1, "kb": 2, "long": 3}
+
+
+@pytest.fixture(scope="module")
+def kv():
+    return np.load(os.path.join(GOLD, "ref_ksw2_vectors.npz"))
+
+
+@pytest.fixture(scope="module")
+def ev():
+    return np.load(os.path.join(GOLD, "ref_edlib_vectors.npz"))
+
+
+def _pair(v, i):
+    return v["q_cat"][v["q_off"][i]:v["q_off"][i + 1]], v["t_cat"][v["t_off"][i]:v["t_off"][i + 1]]
+
+
+# ------------------------------------------------------------------------------------------------ the oracle
+def test_oracle_ksw2_matches_reference_vectors(kv):
+    lib = O.load()
+    n = len(kv["iden"])
+    assert n > 2500
+    for i in range(n):
+        q, t = _pair(kv, i)
+        if kv["cls"][i] == CLS["long"] and i % 4:
+            continue                                  # (a quarter of the 5000-base pairs: the scalar oracle keeps a traceback matrix)
+        iden, cigar, _ = O.ksw2_global_cigar(q, t)
+        assert iden == kv["iden"][i], i
+        arr = (C.c_uint32 * len(cigar))(*cigar)
+        for x, want in zip(kv["q_left_ext"][i], kv["t_back"][i]):
+            assert lib.tho_ksw2_backtrack_left_end(len(cigar), arr, len(q), len(t), int(x)) == want, (i, x)
+        assert O.ksw2_ext(q, t, True) == tuple(kv["left_ext"][i]), i
+        assert O.ksw2_ext(q, t, False) == tuple(kv["right_ext"][i]), i
+
+
+def _queries(ev):
+    qo = ev["q_off"]
+    return [bytes(ev["queries"][qo[j]:qo[j + 1]]) for j in range(len(qo) - 1)]
+
+
+def test_oracle_edlib_matches_reference_vectors(ev):
+    qs, ks = _queries(ev), ev["k"]
+    to, co = ev["t_off"], ev["c_off"]
+    n_hit = 0
+    for i in range(len(to) - 1):
+        t = bytes(ev["t_cat"][to[i]:to[i + 1]])
+        for j, q in enumerate(qs):
+            got = O.edlib_hw(q, t, int(ks[j]))
+            want = tuple(ev["res"][i, j])
+            assert (got if got[0] != -1 else (-1, -1, -1)) == want, (i, j)
+            n_hit += want[0] >= 0
+    for i in range(len(co) - 1):
+        t = bytes(b"ACGTN"[c] for c in ev["c_cat"][co[i]:co[i + 1]]) * 2
+        for j, q in enumerate(qs):
+            got = O.edlib_hw(q, t, int(ks[j]))
+            assert (got if got[0] != -1 else (-1, -1, -1)) == tuple(ev["res_doubled"][i, j]), (i, j)
+    assert n_hit > 1000
+
+
+# ------------------------------------------------------------------------------------------------ the device engines, through the hooks
+def _bind(lib):
+    u8p, ip = C.POINTER(C.c_uint8), C.POINTER(C.c_int)
+    lib.th_debug_align_pairs.argtypes = [C.c_int, C.c_int, C.c_int, u8p, ip, u8p, ip, ip, ip, ip]
+    lib.th_debug_global_pairs.argtypes = [C.c_int, C.c_int, u8p, ip, u8p, ip, ip, C.c_int, ip, ip]
+    lib.th_debug_adapter.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_char_p), ip, ip, C.c_int, u8p, ip, ip]
+    return lib
+
+
+def _subset(v, idx):
+    """the pairs idx of a vector file, concatenated again"""
+    qs = [v["q_cat"][v["q_off"][i]:v["q_off"][i + 1]] for i in idx]
+    ts = [v["t_cat"][v["t_off"][i]:v["t_off"][i + 1]] for i in idx]
+    qc = np.ascontiguousarray(np.concatenate(qs), dtype=np.uint8); tc = np.ascontiguousarray(np.concatenate(ts), dtype=np.uint8)
+    qo = np.concatenate([[0], np.cumsum([len(a) for a in qs])]).astype(np.int32); to = np.concatenate([[0], np.cumsum([len(a) for a in ts])]).astype(np.int32)
+    return qc, qo, tc, to
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+def align_pairs(lib, v, idx, kind, cfg):
+    """cfg: dict(variant, mode, wdiv, wadd, wtol, xpct, defer) -> (results, stats)"""
+    qc, qo, tc, to = _subset(v, idx)
+    n = len(idx)
+    c = np.array([cfg.get("variant", 0), cfg.get("mode", 1), cfg.get("wdiv", 10), cfg.get("wadd", 24), cfg.get("wtol", 16), cfg.get("xpct", 36), cfg.get("defer", 0)], dtype=np.int32)
+    out = np.full(n if kind == 0 else 2 * n, -12345, dtype=np.int32); st = np.zeros(8, dtype=np.int32)
+    rc = lib.th_debug_align_pairs(0, kind, n, _p(qc, C.c_uint8), _p(qo, C.c_int), _p(tc, C.c_uint8), _p(to, C.c_int), _p(c, C.c_int), _p(out, C.c_int), _p(st, C.c_int))
+    assert rc == 0
+    return (out if kind == 0 else out.reshape(n, 2)), st
+
+
+def global_pairs(lib, v, idx):
+    qc, qo, tc, to = _subset(v, idx)
+    n = len(idx)
+    x = np.ascontiguousarray(v["q_left_ext"][idx], dtype=np.int32)
+    iden = np.full(n, -12345, dtype=np.int32); tb = np.full((n, x.shape[1]), -12345, dtype=np.int32)
+    rc = lib.th_debug_global_pairs(0, n, _p(qc, C.c_uint8), _p(qo, C.c_int), _p(tc, C.c_uint8), _p(to, C.c_int), _p(x, C.c_int), x.shape[1], _p(iden, C.c_int), _p(tb, C.c_int))
+    assert rc == 0
+    return iden, tb
+
+
+def adapter(lib, ev, group, doubled, rows):
+    """queries 4 * group .. 4 * group + 3 against the targets `rows` (byte targets, or consensus codes searched over the doubled text)"""
+    qs, ks = _queries(ev), ev["k"]
+    q4 = qs[4 * group:4 * group + 4]
+    arr = (C.c_char_p * 4)(*q4); ql = np.array([len(q) for q in q4], dtype=np.int32); kk = np.ascontiguousarray(ks[4 * group:4 * group + 4], dtype=np.int32)
+    cat, off = (ev["c_cat"], ev["c_off"]) if doubled else (ev["t_cat"], ev["t_off"])
+    ts = [cat[off[i]:off[i + 1]] for i in rows]
+    tc = np.ascontiguousarray(np.concatenate(ts), dtype=np.uint8); to = np.concatenate([[0], np.cumsum([len(t) for t in ts])]).astype(np.int32)
+    out = np.full((len(rows), 4, 3), -12345, dtype=np.int32)
+    rc = lib.th_debug_adapter(0, 1 if doubled else 0, arr, _p(ql, C.c_int), _p(kk, C.c_int), len(rows), _p(tc, C.c_uint8), _p(to, C.c_int), _p(out, C.c_int))
+    assert rc == 0
+    return out
+
+
+def _idx(v, names, step=1, maxlen=None):
+    sel = [i for i in range(len(v["iden"])) if v["cls"][i] in [CLS[c] for c in names]]
+    if maxlen:
+        sel = [i for i in sel if v["q_off"][i + 1] - v["q_off"][i] <= maxlen and v["t_off"][i + 1] - v["t_off"][i] <= maxlen]
+    return np.array(sel[::step], dtype=np.int64)
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    return _bind(C.CDLL(U.emul_lib_path()))
+
+
+def test_emul_engines_match_reference_vectors(emu_lib, kv, ev):
+    """the kernel sources under the CPU emulation (a thin sample: it runs every wave as 64 fibers)"""
+    idx = np.concatenate([_idx(kv, ["short"], step=40, maxlen=120), _idx(kv, ["strip"], step=30, maxlen=230)])
+    for cfg in (dict(mode=0, wdiv=100000, wadd=2), dict(mode=1), dict(mode=1, variant=1, defer=1, wdiv=100000, wadd=3)):
+        got, st = align_pairs(emu_lib, kv, idx, 0, cfg)
+        assert st[0] == 0 and (got == kv["iden"][idx]).all(), (cfg, np.nonzero(got != kv["iden"][idx]))
+    for kind, key in ((1, "left_ext"), (2, "right_ext")):
+        got, st = align_pairs(emu_lib, kv, idx[::2], kind, dict(mode=1))
+        assert st[0] == 0 and (got == kv[key][idx[::2]]).all(), kind
+    iden, tb = global_pairs(emu_lib, kv, idx[::3])
+    assert (iden == kv["iden"][idx[::3]]).all() and (tb == kv["t_back"][idx[::3]]).all()
+    rows = list(range(0, 40, 3))
+    for g in (0, 2):
+        assert (adapter(emu_lib, ev, g, False, rows) == ev["res"][rows][:, 4 * g:4 * g + 4]).all()
+        assert (adapter(emu_lib, ev, g, True, rows) == ev["res_doubled"][rows][:, 4 * g:4 * g + 4]).all()
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def gpu_lib():
+    import tidehunter_amd as TH
+    return _bind(TH.load_library())
+
+
+# unit-vs-consensus alignments (ksw2_global): which engine computes a pair never changes its result
+ALIGN_CFGS = [
+    ("strip engine only, default first band", dict(mode=0)),
+    ("strip engine only, first band of 2: nearly every pair goes through the pruned second band (slb)", dict(mode=0, wdiv=100000, wadd=2)),
+    ("strip engine only, first band of 6", dict(mode=0, wdiv=100000, wadd=6)),
+    ("anti-diagonal engine first, defaults, small-area variant (<= 2 registers)", dict(mode=1)),
+    ("anti-diagonal engine, verify every banded result on the device (TH_ALN_MODE=2)", dict(mode=2)),
+    ("anti-diagonal engine, one register, narrow request", dict(mode=1, wdiv=100000, wadd=20, wtol=0)),
+    ("anti-diagonal engine, two registers", dict(mode=1, wdiv=100000, wadd=190, wtol=0)),
+    ("big-area variant, three registers", dict(mode=1, variant=2, wdiv=100000, wadd=320, wtol=0)),
+    ("big-area variant, four registers", dict(mode=1, variant=2, wdiv=100000, wadd=440, wtol=0)),
+    ("big-area variant, five registers", dict(mode=1, variant=2, wdiv=100000, wadd=570, wtol=0)),
+    ("big-area variant, six registers", dict(mode=1, variant=2, wdiv=100000, wadd=700, wtol=0)),
+    ("16 KB variant, defaults, deferred strip launch", dict(mode=1, variant=1, defer=1)),
+    ("24 KB variant, tiny first band, everything uncertified is deferred to the strip launch", dict(mode=1, variant=2, defer=1, wdiv=100000, wadd=3, wtol=0)),
+    ("24 KB variant without the deferred launch: the strip engines run in place", dict(mode=1, variant=2, defer=0, wdiv=100000, wadd=3, wtol=0)),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("label,cfg", ALIGN_CFGS, ids=[c[0].split(",")[0].replace(" ", "_") + "_%d" % i for i, c in enumerate(ALIGN_CFGS)])
+def test_gpu_unit_alignments_match_reference_vectors(gpu_lib, kv, label, cfg):
+    idx = np.arange(len(kv["iden"]))
+    got, st = align_pairs(gpu_lib, kv, idx, 0, cfg)
+    bad = np.nonzero(got != kv["iden"])[0]
+    assert st[0] == 0, "%s: device error flags %d" % (label, st[0])
+    assert len(bad) == 0, "%s: %d pairs differ from the reference, first %s" % (label, len(bad), bad[:5])
+    if cfg.get("defer"):
+        assert st[1] > 0, "%s: nothing was deferred" % label
+
+
+EXT_CFGS = [
+    ("anti-diagonal engine / pruned strips / full matrix as the pipeline picks them", dict(mode=1)),
+    ("every engine verified against the full matrix on the device", dict(mode=2)),
+    ("full matrix only", dict(mode=0)),
+    ("expected score of 90 % of the flank: narrow first bands, retries through wider ones and the pruned strip engine", dict(mode=1, xpct=10)),
+    ("expected score of 5 %: the widest band first", dict(mode=1, xpct=95)),
+    ("big-area variant", dict(mode=1, variant=2)),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("label,cfg", EXT_CFGS, ids=["ext_%d" % i for i in range(len(EXT_CFGS))])
+def test_gpu_flank_extensions_match_reference_vectors(gpu_lib, kv, label, cfg):
+    idx = np.arange(len(kv["iden"]))
+    for kind, key in ((1, "left_ext"), (2, "right_ext")):
+        got, st = align_pairs(gpu_lib, kv, idx, kind, cfg)
+        bad = np.nonzero((got != kv[key]).any(axis=1))[0]
+        assert st[0] == 0, "%s: device error flags %d" % (label, st[0])
+        assert len(bad) == 0, "%s (%s): %d pairs differ from the reference, first %s: got %s want %s" % (label, key, len(bad), bad[:5], got[bad[:3]], kv[key][bad[:3]])
+
+
+@pytest.mark.gpu
+def test_gpu_global_with_cigar_backprojection_matches_reference_vectors(gpu_lib, kv):
+    """th_ksw_global_wave (the partition's engine): iden_n and ksw2_backtrack_left_end for four q_left_ext per pair"""
+    idx = np.arange(len(kv["iden"]))
+    iden, tb = global_pairs(gpu_lib, kv, idx)
+    assert (iden == kv["iden"]).all(), np.nonzero(iden != kv["iden"])[0][:5]
+    bad = np.nonzero((tb != kv["t_back"]).any(axis=1))[0]
+    assert len(bad) == 0, (bad[:5], tb[bad[:3]], kv["t_back"][bad[:3]], kv["q_left_ext"][bad[:3]])
+
+
+@pytest.mark.gpu
+def test_gpu_adapter_searches_match_reference_vectors(gpu_lib, ev):
+    n_t, n_c = len(ev["t_off"]) - 1, len(ev["c_off"]) - 1
+    for g in range(len(ev["k"]) // 4):
+        got = adapter(gpu_lib, ev, g, False, list(range(n_t)))
+        want = ev["res"][:, 4 * g:4 * g + 4]
+        assert (got == want).all(), ("th_k_adapter_reads", g, np.argwhere((got != want).any(axis=2))[:5])
+        got = adapter(gpu_lib, ev, g, True, list(range(n_c)))
+        want = ev["res_doubled"][:, 4 * g:4 * g + 4]
+        assert (got == want).all(), ("th_k_adapter", g, np.argwhere((got != want).any(axis=2))[:5])

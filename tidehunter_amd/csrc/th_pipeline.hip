@@ -771,3 +771,5 @@ extern "C" long long th_gpu_debug(th_gpu_t *g, int what, void *dst, long long ca
     if (th_rt_sync(g->stream)) return -1;
     return bytes;
 }
+
+#include "th_debug_hooks.h"
