@@ -167,11 +167,13 @@ def cli_e2e(set_reads, copies, cfg, batch_opt, n_runs=2, pause_s=6.0):
         subprocess.run([exe, *cfg.get("cli_opts", []), "-b", str(batch_opt), "-o", outp, wpath], check=True, capture_output=True)
         machine_warmup = {"reads": n_warm, "wall_s": time.time() - t0, "reads_per_s_with_process_startup": n_warm / (time.time() - t0)}
         os.unlink(wpath)
-        for _ in range(n_runs):
+        for run_i in range(n_runs + 1):
             # the driver is still clearing the HBM the previous process released (70-140 GB) for a few seconds after its exit, and a new
             # process's first allocation waits for that -- 1.5-4.5 s seen back to back (profiles/r03_e2e_pipelines.txt); it is the previous
-            # run's cost, not this one's, so each run starts after a pause
-            time.sleep(pause_s)
+            # run's cost, not this one's, so each of the n_runs runs behind `value` starts after a pause.  One more run follows WITHOUT a
+            # pause and is listed apart (`run_without_pause`): what a caller sees who starts the next file the moment the last one ended.
+            pause = pause_s if run_i < n_runs else 0.0
+            time.sleep(pause)
             t0 = time.time()
             err = subprocess.run([exe, *cfg.get("cli_opts", []), "-b", str(batch_opt), "-o", outp, path], check=True, capture_output=True, text=True,
                                  env=dict(os.environ, TH_TRACE="1")).stderr
@@ -180,6 +182,15 @@ def cli_e2e(set_reads, copies, cfg, batch_opt, n_runs=2, pause_s=6.0):
                           r"record arithmetic ([0-9.]+) s, writer ([0-9.]+) s; steady ([0-9.]+) reads/s over the last ([0-9.]+) s", err)
             inner = float(m.group(2))
             assert int(m.group(1)) == n_reads, (m.group(1), n_reads)
+            mc = re.search(r"\[th_run_file\] host CPU ([0-9.]+) s \(([0-9.]+) per 10\^6 reads; (\d+) usable CPUs\): reader ([0-9.]+), inflate ([0-9.]+), upload threads ([0-9.]+), "
+                           r"run threads ([0-9.]+), record arithmetic \+ formatting ([0-9.]+), writer ([0-9.]+), runtime and the rest (-?[0-9.]+)", err)
+            mp = re.search(r"\[main\] Real time: ([0-9.]+) sec; CPU: ([0-9.]+) sec", err)
+            host_cpu = None
+            if mc:
+                host_cpu = {"cpu_s": float(mc.group(1)), "cpu_s_per_1M_reads": float(mc.group(2)), "usable_cpus": int(mc.group(3)),
+                            "by_role_s": {"reader": float(mc.group(4)), "inflate": float(mc.group(5)), "upload_threads": float(mc.group(6)), "run_threads": float(mc.group(7)),
+                                          "record_arithmetic_and_formatting": float(mc.group(8)), "writer": float(mc.group(9)), "runtime_and_rest": float(mc.group(10))},
+                            "process_cpu_s_incl_startup": float(mp.group(2)) if mp else None, "cores_busy_mean": float(mc.group(1)) / inner}
             md5 = hashlib.md5()
             with open(outp, "rb") as f:
                 for chunk in iter(lambda: f.read(1 << 24), b""):
@@ -187,9 +198,17 @@ def cli_e2e(set_reads, copies, cfg, batch_opt, n_runs=2, pause_s=6.0):
             runs.append({"reads_per_s": n_reads / inner, "seconds_first_byte_to_last_byte": inner, "wall_with_startup_s": wall,
                          "steady_reads_per_s": float(m.group(8)), "steady_window_s": float(m.group(9)), "startup_s": inner - float(m.group(9)),
                          "mbases_per_s": nbytes / inner / 1e6, "reader_busy_s": float(m.group(3)), "upload_busy_s": float(m.group(4)), "device_busy_s": float(m.group(5)),
-                         "collect_busy_s": float(m.group(6)), "writer_busy_s": float(m.group(7)), "output_md5": md5.hexdigest()})
+                         "collect_busy_s": float(m.group(6)), "writer_busy_s": float(m.group(7)), "output_md5": md5.hexdigest(), "host_cpu": host_cpu,
+                         "paused_before_s": pause})
+        nopause = runs.pop()
         vals = [r["reads_per_s"] for r in runs]
+        cpus = [r["host_cpu"]["cpu_s_per_1M_reads"] for r in runs if r.get("host_cpu")]
         return {"value": sum(vals) / len(vals), "unit": "reads/s", "value_is": "mean of the whole-run rates of all runs (first byte parsed to last byte written), no run dropped",
+                "host_cpu_s_per_1M_reads": sum(cpus) / len(cpus) if cpus else None,
+                "host_cpu_note": "CPU seconds of the whole process between the first byte parsed and the last byte written (getrusage), per million reads, mean of the runs; "
+                                 "by role in runs[].host_cpu (thread CPU clocks; the remainder is the HIP runtime's own threads).  The seam this replaces keeps n_thread workers "
+                                 "and one writer busy (src/main.c:273-291,214-271); round 3 spent 29.9 here, 16 of them in spinning stream synchronisations",
+                "run_without_pause": nopause,
                 "reads": n_reads, "runs_reads_per_s": vals, "cold_reads_per_s": vals[0], "steady_reads_per_s": [r["steady_reads_per_s"] for r in runs],
                 "runs": runs, "batch_reads": batch_opt, "machine_warmup_run": machine_warmup, "pause_before_each_run_s": pause_s,
                 "what": "TideHunter-amd (reader -> H2D -> kernels -> record arithmetic -> writer) on a FASTA of %d x the read set in %s" % (copies, d)}
@@ -358,6 +377,12 @@ def main():
         else:
             th.upload(my_batch); th.run(); th.collect()
     t_total, n_cons, alg_bytes, kms, n_reads_mine, bases_mine, digests, blocks_mine, n_syncs = 0.0, 0, 0, {}, 0, 0, {}, 0, 0
+    import resource
+
+    def cpu_now():
+        ru = resource.getrusage(resource.RUSAGE_SELF)
+        return ru.ru_utime + ru.ru_stime
+    cpu_timed = 0.0
 
     def add_timing():
         for kname, v in th.timing().items():
@@ -380,7 +405,7 @@ def main():
         for b in range(a.warmup, n_batches):
             # dynamic: blocks from the shared ticket counter; the upload of a block cannot precede the timed region
             sync_all()
-            t0 = time.perf_counter()
+            t0 = time.perf_counter(); c0 = cpu_now()
             done = []
             while True:
                 k = lib.th_ticket_next(ticket, b)
@@ -393,7 +418,7 @@ def main():
                 blocks_mine += th.launches()
             if on_gpu:
                 torch.cuda.synchronize()
-            t_total += time.perf_counter() - t0
+            t_total += time.perf_counter() - t0; cpu_timed += cpu_now() - c0
             for k, batch, recs in done:
                 if recs is not None:
                     account(batch, recs, cuts[k])
@@ -405,11 +430,11 @@ def main():
         # (src/gen_cons.c:208-301, in C) of pass k fills the tandem_seq_t slots -- the last pass's arithmetic ends inside the region
         th.upload(my_batch)
         sync_all()
-        t0 = time.perf_counter()
+        t0 = time.perf_counter(); c0 = cpu_now()
         kstep = th.run_steps(a.steps)
         if on_gpu:
             torch.cuda.synchronize()
-        t_total += time.perf_counter() - t0
+        t_total += time.perf_counter() - t0; cpu_timed += cpu_now() - c0
         n_syncs = th.syncs()
         for kname, v in kstep.items():
             kms[kname] = kms.get(kname, 0.0) + v
@@ -420,7 +445,8 @@ def main():
     # the byte accounting ran on the last step (all steps process the same reads): scale it to the timed steps
     if (a.steal == 0 or not a.digest) and a.steps > 1:
         n_cons *= a.steps; alg_bytes *= a.steps
-    tot = torch.tensor([float(n_reads_mine), float(bases_mine), float(n_cons), float(alg_bytes)], dtype=torch.float64)
+    tot = torch.tensor([float(n_reads_mine), float(bases_mine), float(n_cons), float(alg_bytes), cpu_timed], dtype=torch.float64)
+    cpu_by_rank = [cpu_timed]
     if dist is not None:
         dev = "cuda" if backend == "nccl" else "cpu"
         t = torch.tensor([t_total], device=dev, dtype=torch.float64)
@@ -429,6 +455,8 @@ def main():
         tot = tot.to(dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         tot = tot.cpu()
+        cpu_by_rank = [None] * world
+        dist.all_gather_object(cpu_by_rank, cpu_timed)
         if a.digest:
             gathered = [None] * world
             dist.all_gather_object(gathered, digests)
@@ -447,9 +475,15 @@ def main():
                    "name": a.config, "reads_per_step_per_gpu": B,
                    "sharding": ("contiguous read blocks per rank balanced by cumulative bases, no data-path collective" if a.steal == 0 else
                                 "%d blocks per step (balanced by cumulative bases) taken by the ranks from a shared ticket counter; uploads inside the timed region" % n_blocks),
-                   "inputs_resident_before_timing": a.steal == 0},
+                   "inputs_resident_before_timing": a.steal == 0,
+                   "value_note": "`value` is the device path with the step's reads already in HBM, as the bench contract defines it; the same steps fed from HOST memory are "
+                                 "`value_upload_inclusive` (PCIe inside, N=1), and `value_e2e` is the command line from the first byte parsed to the last byte written"},
         "consensus_per_read": n_cons_all / float(reads),
         "host_syncs_per_step": n_syncs, "read_set_generation_s": t_gen,
+        # CPU seconds of each rank's process inside the timed region (getrusage; the record arithmetic threads and the runtime's own included), and
+        # the same per million reads of the whole job: the host budget at N ranks is effective_cpus() / N cores each
+        "host_cpu": {"cpu_s_per_1M_reads": float(tot[4].item()) * 1e6 / float(reads), "cpu_s_in_timed_region_by_rank": [round(float(x), 3) for x in cpu_by_rank],
+                     "cores_busy_mean_per_rank": float(tot[4].item()) / world / t_total, "usable_cpus": effective_cpus(), "host_threads_per_rank": int(os.environ.get("TH_HOST_THREADS", "0"))},
     }
     if a.digest:
         h = hashlib.md5()
@@ -467,12 +501,12 @@ def main():
         # (tools/round3_end.sh -> profiles/rNN_hbm_traffic.json); counters cannot be read from inside the process, so
         # the committed profile is quoted when it was taken at the same workload and batch size, else null
         traffic, traffic_src = None, None
-        for pf in ("r03_hbm_traffic.json",):
+        for pf in ("r04_hbm_traffic.json", "r03_hbm_traffic.json"):
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", pf)))
                 if prof.get("reads_per_launch") == B * a.steps // launches and prof.get("config", "c3") == a.config and a.steal == 0:
                     for kname, v in prof["kernels"].items():
-                        if kname.replace("void ", "").split("<")[0].split("::")[-1] == dom:
+                        if traffic is None and kname.replace("void ", "").split("<")[0].split("::")[-1] == dom:
                             traffic, traffic_src = v["hbm_bytes_per_launch_corrected"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % pf
             except (OSError, ValueError, KeyError):
                 pass
@@ -487,14 +521,17 @@ def main():
         # the same steps with the upload INSIDE: th_process_batches() pipelines H2D of batch i+1 and the record arithmetic of batch i-1
         # under the kernels of batch i (what th_run_file does with batches from the reader)
         if world == 1 and a.steal == 0 and a.streamed != 0:
-            ks = max(a.steps, 3)
-            t0 = time.perf_counter()
+            ks = max(a.steps, 8)                       # (fill and drain of the three-stage pipeline are ~0.15 s: eight batches keep them near 2 %)
+            t0 = time.perf_counter(); c0 = cpu_now()
             th.process_batches([my_batch] * ks)
             if on_gpu:
                 torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            out["value_streamed"] = {"value": ks * len(my_batch) / dt, "unit": "reads/s", "steps": ks, "ms_per_step": 1000.0 * dt / ks, "inputs_resident_before_timing": False,
-                                     "what": "th_process_batches(): %d batches back to back, each uploaded from host memory inside the timed region (pipeline fill and drain included)" % ks}
+            out["value_upload_inclusive"] = {"value": ks * len(my_batch) / dt, "unit": "reads/s", "steps": ks, "ms_per_step": 1000.0 * dt / ks, "inputs_resident_before_timing": False,
+                                             "ratio_to_value": ks * len(my_batch) / dt / value, "host_cpu_s_per_1M_reads": (cpu_now() - c0) * 1e6 / (ks * len(my_batch)),
+                                             "what": "th_process_batches(): %d batches back to back, each taken from HOST memory inside the timed region -- H2D of batch i+1 and the record arithmetic "
+                                                     "of batch i-1 under the kernels of batch i, pipeline fill and drain included (one pipeline; the command line of value_e2e runs two per device)" % ks}
+            out["value_streamed"] = out["value_upload_inclusive"]          # (round 3's name for it)
     th.close()
     if ticket:
         lib.th_ticket_close(ticket, 1 if rank == 0 else 0)

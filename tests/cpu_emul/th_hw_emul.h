@@ -50,6 +50,7 @@ __device__ __forceinline__ int th_wave_incl_sum(int v)
 
 #define TH_BALLOT(b) __ballot(b)
 #define TH_STORE_U32_SADDR(base, off, v) (*(uint32_t *)((char *)(base) + (uint32_t)(off)) = (v))
+#define TH_STORE_U16_SADDR(base, off, v) (*(uint16_t *)((char *)(base) + (uint32_t)(off)) = (uint16_t)(v))
 #define TH_LDS_READ64_ASYNC(p) (*(p))
 #define TH_LDS_ASYNC_WAIT(v) ((void)0)
 #define TH_LANE_OF_MASK(m, lane) (((m) >> (lane)) & 1ull)
@@ -69,6 +70,7 @@ static inline uint32_t th_cvt_pk_i16(int lo, int hi) { return TH_PK(th_sat16_(lo
 // v_perm_b32: result byte k is picked by selector byte k: 0..3 byte of s1, 4..7 byte of s0, 12 the constant 0 (the other codes are not used here)
 static inline int th_mbcnt(unsigned long long m) { return __builtin_popcountll(m & ((1ull << TH_LANE()) - 1)); }
 #define TH_PERM_SIGNS 0x0b090a08u
+#define TH_PERM_SIGNS8 0x09080b0au
 static inline uint32_t th_and_or(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | c; }
 static inline uint32_t th_perm(uint32_t s0, uint32_t s1, uint32_t sel)
 {

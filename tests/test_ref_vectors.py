@@ -24,12 +24,14 @@ CLS = {"short": 0, "strip": 1, "kb": 2, "long": 3}
 
 @pytest.fixture(scope="module")
 def kv():
-    return np.load(os.path.join(GOLD, "ref_ksw2_vectors.npz"))
+    with np.load(os.path.join(GOLD, "ref_ksw2_vectors.npz")) as z:
+        return {k: z[k] for k in z.files}          # (an NpzFile inflates an array at EVERY access)
 
 
 @pytest.fixture(scope="module")
 def ev():
-    return np.load(os.path.join(GOLD, "ref_edlib_vectors.npz"))
+    with np.load(os.path.join(GOLD, "ref_edlib_vectors.npz")) as z:
+        return {k: z[k] for k in z.files}
 
 
 def _pair(v, i):

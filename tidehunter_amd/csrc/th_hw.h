@@ -99,6 +99,12 @@ __device__ __forceinline__ void th_store_u32_saddr(const void *base, uint32_t of
     asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
 }
 #define TH_STORE_U32_SADDR(base, off, v) th_store_u32_saddr((base), (uint32_t)(off), (v))
+// the same for the low 16 bits of v
+__device__ __forceinline__ void th_store_u16_saddr(const void *base, uint32_t off, uint32_t v)
+{
+    asm volatile("global_store_short %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
+}
+#define TH_STORE_U16_SADDR(base, off, v) th_store_u16_saddr((base), (uint32_t)(off), (v))
 // An LDS read the compiler does not wait for: the value may be used only after TH_LDS_ASYNC_WAIT(value) -- which must come before
 // ANY use or copy of it, loop-carried copies included -- so that a whole loop trip can pass between request and use.
 __device__ __forceinline__ unsigned long long th_lds_read64_async(const void *p)
@@ -131,6 +137,8 @@ __device__ __forceinline__ uint32_t th_perm(uint32_t s0, uint32_t s1, uint32_t s
 // set bits of a ballot below this lane (v_mbcnt_lo / _hi: no per-lane 64-bit mask to keep alive)
 __device__ __forceinline__ int th_mbcnt(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 #define TH_PERM_SIGNS 0x0b090a08u
+// ... and ordered by source: (s1.hi, s1.lo, s0.hi, s0.lo) -- the two halves of one difference side by side (the 8-bit direction words)
+#define TH_PERM_SIGNS8 0x09080b0au
 __device__ __forceinline__ uint32_t th_and_or(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | c; }
 __device__ __forceinline__ uint32_t th_wave_incl_pkmax(uint32_t v)
 {

@@ -38,6 +38,10 @@
 //   bits 8, 0, 9, 1    "strictly better than everything before it" for E1, E2, F1, F2 in that order (the source is the last one set)
 //   bits 10, 2, 11, 3  XE1, XE2, XF1, XF2: the gap was extended rather than opened
 //   bits 13..12 / 15..14 / 5..4  edge index of the predecessor that gave the diagonal / the E1 / the E2 value
+// A row with exactly ONE predecessor (three rows in four at the headline shape) needs no edge indices: its cells are 8-BIT words --
+// bits 4, 0, 5, 1 for E1, E2, F1, F2, bits 6, 2, 7, 3 for XE1, XE2, XF1, XF2: the low nibble of either byte of the 16-bit word -- which the
+// packed row assembles from the same four permutes with the sign selectors in source order (TH_PERM_SIGNS8) and one shift-or, and
+// stores two per lane as one short.  (Round 3 wrote 16 bits for every cell: 383 GB per 100 000 headline reads.)
 // so the packed row spends one instruction per comparison (a permute and an and-or per pair; round 2: two per comparison) instead of
 // assembling a 32-bit word per cell, and the traffic of the direction matrix halves.  Rows with more than four predecessors
 // store whole cells (int4, the 32-bit word in .w); th_poa_dir() returns the register layout for either kind.
@@ -51,6 +55,10 @@ __device__ __forceinline__ uint32_t th_d16_expand(uint32_t w)
     return src | ((w >> TH_D16_PM_SHIFT) & 3u) << 3 | ((w >> TH_D16_PE1_SHIFT) & 3u) << 11 | ((w >> TH_D16_PE2_SHIFT) & 3u) << 19
          | ((w >> 10) & 1u) << 27 | ((w >> 2) & 1u) << 28 | ((w >> 11) & 1u) << 29 | ((w >> 3) & 1u) << 30;
 }
+__device__ __forceinline__ uint32_t th_d8_expand(uint32_t b) { return th_d16_expand((b & 0x0fu) | (b & 0xf0u) << 4); }
+__device__ __forceinline__ uint32_t th_d8_from16(uint32_t w) { return (w & 0x0fu) | ((w >> 4) & 0xf0u); }      // (a 16-bit word without edge indices)
+// 2-byte units a row of `span` cells (span even) takes among the direction words: 8-bit rows are rounded up to a whole dword
+__device__ __forceinline__ int th_d_units(int span, bool d8) { return d8 ? ((span >> 1) + 1) & ~1 : span; }
 // the 16-bit word from a source (0..4), the four extension flags and the three edge indices (the one-column-per-lane rows)
 __device__ __forceinline__ uint32_t th_d16_pack(int src, uint32_t xe1, uint32_t xe2, uint32_t xf1, uint32_t xf2, uint32_t pm, uint32_t pe1, uint32_t pe2)
 {

@@ -10,7 +10,7 @@ struct ThPoaG {
     int *order, *order2;
     // by row (order index)
     int *r_meta, *r_p, *r_s, *r_rem, *r_beg, *r_end, *r_mpl, *r_mpr;
-    int *r_off, *r_foff;       // offset of a row's band start among the direction words / among the full cells (rows that store them)
+    int *r_off, *r_foff;       // offset (2-byte units) of a row's direction words -- of its band start (16-bit rows) or of its even base column (8-bit rows: in-degree 1) -- / of its band start among the full cells (rows that store them)
     int *cntB, *headB, *aft;
     int *ops, *pv, *glo, *pth;
     int4 *cell; uint16_t *dcell; uint32_t cell_u2;     // cell_u2: size of the region in 2-byte units (clamped to 2^31: row offsets are ints); full cells (rows some far row will read, rows of in-degree > 4) / 16-bit direction words (all other rows)
@@ -323,7 +323,8 @@ __device__ unsigned long long th_poa_prof[24];    // 0..3 phase cycles; 4..7 tra
 // and is read from its full cells in HBM (far_row: its cell of column far_pb; band far_pb..far_pe), converted to int16 with saturation
 // (its values are exact 32-bit ones; minus infinity becomes -32768 like everything outside a ring row's band); full_row (or null):
 // the row's own full cells {H, E1', E2', -} are written for a far reader, minus infinity widened back to TH_NEG below neg_thr.
-template <int QCAP, typename RT, bool COMMON, bool FAR>
+// D8: the row's direction words are 8-bit ones (1), 16-bit ones (0), or 8-bit iff npk == 1 (2) -- the rule is "in-degree 1" everywhere
+template <int QCAP, typename RT, bool COMMON, bool FAR, int D8>
 __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[3][TH_POA_RS], uint16_t *drow, const int lane, const int b, const int e, const int B0,
                                                const int myslot, const uint32_t T, const int npk,
                                                const int q_slot0, const int q_slot1, const int q_slot2, const int q_slot3, const int q_pb0, const int q_pb1, const int q_pb2, const int q_pb3,
@@ -425,15 +426,26 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
         // selectors deliver 0xff / 0x00 per half), one bit position per pair (layout: th_k_poa.hip)
         const uint32_t hO1 = th_pk_sub(h, O1P), hO2 = th_pk_sub(h, O2P);
         const uint32_t xf1 = th_pk_sub(hO1, f1), xf2 = th_pk_sub(hO2, f2);
-        uint32_t code = th_perm(dg1, dg2, TH_PERM_SIGNS) & 0x01010101u;
-        code = th_and_or(th_perm(dg3, dg4, TH_PERM_SIGNS), 0x02020202u, code);
-        code = th_and_or(th_perm(th_pk_sub(hO1, e1v), th_pk_sub(hO2, e2v), TH_PERM_SIGNS), 0x04040404u, code);
-        code = th_and_or(th_perm(xf1, xf2, TH_PERM_SIGNS), 0x08080808u, code);
-        if (npk > 1) code |= PMV | PE1V | PE2V;
         const uint32_t n1 = th_pk_sub(th_pk_max(hO1, e1v), E1P), n2 = th_pk_sub(th_pk_max(hO2, e2v), E2P);
         // column b-1 / e+1 of an odd edge land in the row's own padding.  drow is the word of column B0 (the row's even base): a
         // wave-uniform pointer + the lane's constant byte offset (+ the trip's): no 64-bit address arithmetic per trip on the scalar unit
-        if (j0 <= e) TH_STORE_U32_SADDR(drow, (uint32_t)(4 * lane + 2 * t0), code);
+        if (D8 == 1 || (D8 == 2 && npk == 1)) {
+            // one predecessor: no edge indices, eight bits per cell (layout: th_k_poa.hip) -- a difference's two signs land side by side
+            // (bytes 0, 1 for the first of a pair, 2, 3 for the second), the halves are folded, the lane stores its two cells as one short
+            uint32_t y = th_perm(dg1, dg2, TH_PERM_SIGNS8) & 0x01011010u;
+            y = th_and_or(th_perm(dg3, dg4, TH_PERM_SIGNS8), 0x02022020u, y);
+            y = th_and_or(th_perm(th_pk_sub(hO1, e1v), th_pk_sub(hO2, e2v), TH_PERM_SIGNS8), 0x04044040u, y);
+            y = th_and_or(th_perm(xf1, xf2, TH_PERM_SIGNS8), 0x08088080u, y);
+            y |= y >> 16;
+            if (j0 <= e) TH_STORE_U16_SADDR(drow, (uint32_t)(2 * lane + t0), y);
+        } else {
+            uint32_t code = th_perm(dg1, dg2, TH_PERM_SIGNS) & 0x01010101u;
+            code = th_and_or(th_perm(dg3, dg4, TH_PERM_SIGNS), 0x02020202u, code);
+            code = th_and_or(th_perm(th_pk_sub(hO1, e1v), th_pk_sub(hO2, e2v), TH_PERM_SIGNS), 0x04040404u, code);
+            code = th_and_or(th_perm(xf1, xf2, TH_PERM_SIGNS), 0x08080808u, code);
+            if (npk > 1) code |= PMV | PE1V | PE2V;
+            if (j0 <= e) TH_STORE_U32_SADDR(drow, (uint32_t)(4 * lane + 2 * t0), code);
+        }
         if (t0 == 0 || wi < TH_POA_RS / 2) {     // (every lane of the first trip is inside the slot)
 #if TH_POA_REL
             const uint32_t THRP = TH_PK_DUP(TH_POA_REL_THR);          // below the threshold: minus infinity, stored as exactly that
@@ -583,12 +595,12 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 const int b = max(max(0, min(L_l + 1, xd) - w), L_b), e = min(qlen, max(L_r + 1, xd) + w);
                 if (b > e) return -2;
                 if (e - b < TH_POA_RW) {
-                    const int B0 = b & ~1, span = (e | 1) - B0 + 1;
-                    if (ncell + (uint32_t)span + nfull * 8u > g.cell_u2) return -3;
-                    const int my_off = (int)ncell + (b - B0);
-                    ncell += span;
+                    const int B0 = b & ~1, span = (e | 1) - B0 + 1, units = th_d_units(span, true);
+                    if (ncell + (uint32_t)units + nfull * 8u > g.cell_u2) return -3;
+                    const int my_off = (int)ncell;                     // (8-bit words: the offset of the even base column)
+                    ncell += units;
                     int rmax = TH_NEG - 0x10000000, left = b, right = b;
-                    th_poa_pk_row<QCAP, RT, true, false>(s_qs, s_ring, g.dcell + (my_off - (b - B0)), lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), 1, (i - 1) & 3, 0, 0, 0, L_b & ~1, 0, 0, 0,
+                    th_poa_pk_row<QCAP, RT, true, false, 1>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), 1, (i - 1) & 3, 0, 0, 0, L_b & ~1, 0, 0, 0,
                                             E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
                     TH_POA_PK_ROW_DONE(0, 0);
                     continue;
@@ -624,16 +636,17 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                     const int b = max(max(0, min(mpl, xd) - w), mb), e = min(qlen, max(mpr, xd) + w);
                     if (b > e) return -2;
                     if (e - b < TH_POA_RW) {
-                        const int B0 = b & ~1, span = (e | 1) - B0 + 1;
-                        if (ncell + (uint32_t)span + nfull * 8u > g.cell_u2) return -3;
-                        const int my_off = (int)ncell + (b - B0);
-                        ncell += span;
+                        const int B0 = b & ~1, span = (e | 1) - B0 + 1, units = th_d_units(span, inn_ == 1);
+                        if (ncell + (uint32_t)units + nfull * 8u > g.cell_u2) return -3;
+                        const int my_off = (int)ncell + (inn_ == 1 ? 0 : b - B0);
+                        uint16_t *dbase = g.dcell + ncell;
+                        ncell += units;
                         int rmax = TH_NEG - 0x10000000, left = b, right = b;
                         const uint32_t T_ = (uint32_t)TH_READLANE((int)v_T, meta & 0xff);
                         // (one or two predecessors as compile-time constants: the body's per-predecessor tests disappear)
-                        if (inn_ == 1) th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, g.dcell + (my_off - (b - B0)), lane, b, e, B0, i & 3, T_, 1, qs0, 0, 0, 0, qb0, 0, 0, 0, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
-                        else if (inn_ == 2) th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, g.dcell + (my_off - (b - B0)), lane, b, e, B0, i & 3, T_, 2, qs0, qs1, 0, 0, qb0, qb1, 0, 0, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
-                        else th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, g.dcell + (my_off - (b - B0)), lane, b, e, B0, i & 3, T_, inn_, qs0, qs1, qs2, qs3, qb0, qb1, qb2, qb3, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
+                        if (inn_ == 1) th_poa_pk_row<QCAP, RT, false, false, 1>(s_qs, s_ring, dbase, lane, b, e, B0, i & 3, T_, 1, qs0, 0, 0, 0, qb0, 0, 0, 0, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
+                        else if (inn_ == 2) th_poa_pk_row<QCAP, RT, false, false, 0>(s_qs, s_ring, dbase, lane, b, e, B0, i & 3, T_, 2, qs0, qs1, 0, 0, qb0, qb1, 0, 0, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
+                        else th_poa_pk_row<QCAP, RT, false, false, 0>(s_qs, s_ring, dbase, lane, b, e, B0, i & 3, T_, inn_, qs0, qs1, qs2, qs3, qb0, qb1, qb2, qb3, E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
                         TH_POA_PK_ROW_DONE(inn_ == 1 ? 1 : inn_ == 2 ? 6 : 7, 0);
                         continue;
                     }
@@ -672,14 +685,15 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                     const int b = max(max(0, min(mpl, xd) - w), mb), e = min(qlen, max(mpr, xd) + w);
                     if (b > e) return -2;
                     if (e - b < TH_POA_RW) {
-                        const int B0 = b & ~1, span = (e | 1) - B0 + 1;
+                        const int B0 = b & ~1, span = (e | 1) - B0 + 1, units = th_d_units(span, inn_ == 1);
                         const int full = (meta >> 24) & 1;
                         if (full) nfull += span;
-                        if (ncell + (uint32_t)span + nfull * 8u > g.cell_u2) return -3;
-                        const int my_off = (int)ncell + (b - B0), my_foff = full ? -(int)nfull + (b - B0) : 0;
-                        ncell += span;
+                        if (ncell + (uint32_t)units + nfull * 8u > g.cell_u2) return -3;
+                        const int my_off = (int)ncell + (inn_ == 1 ? 0 : b - B0), my_foff = full ? -(int)nfull + (b - B0) : 0;
+                        uint16_t *dbase = g.dcell + ncell;
+                        ncell += units;
                         int rmax = TH_NEG - 0x10000000, left = b, right = b;
-                        th_poa_pk_row<QCAP, RT, false, true>(s_qs, s_ring, g.dcell + (my_off - (b - B0)), lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), inn_, qs0, qs1, qs2, qs3, qb0, qb1, qb2, qb3,
+                        th_poa_pk_row<QCAP, RT, false, true, 2>(s_qs, s_ring, dbase, lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), inn_, qs0, qs1, qs2, qs3, qb0, qb1, qb2, qb3,
                                                 E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right, far_o, far_pb, far_pe, g.cell + far_po, full ? g.cell + my_foff : nullptr, neg_thr, base);
                         TH_POA_PK_ROW_DONE(2, my_foff);
                         continue;
@@ -728,17 +742,19 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         // direction words (2 bytes per cell, every row) grow upwards from the start of the cell region; full cells (16 bytes, only the
         // rows that store them: g.cell points at the END of the region and their offsets are negative) grow downwards from its end.
         // A wave's scratch shrinks from ~18 to ~3-6 bytes per band cell, whatever the share of rows stored in full.
+        const bool d8 = inn == 1;                                // one predecessor: 8-bit direction words (every reader goes by the in-degree)
+        const int units = th_d_units(span, d8);
         if (store_full) nfull += span;
-        if (ncell + (uint32_t)span + nfull * 8u > g.cell_u2) return -3;
-        const int my_off = (int)ncell + (b - B0);                // offset of column b, as every reader expects
+        if (ncell + (uint32_t)units + nfull * 8u > g.cell_u2) return -3;
+        const int my_off = (int)ncell + (d8 ? 0 : b - B0);       // 16-bit rows: offset of column b; 8-bit rows: of the even base column
         const int my_foff = store_full ? -(int)nfull + (b - B0) : 0;
-        int4 *row = g.cell + my_foff; uint16_t *drow = g.dcell + my_off;
-        ncell += span;
+        int4 *row = g.cell + my_foff; uint16_t *dbase = g.dcell + ncell; uint16_t *drow = dbase + (b - B0); uint8_t *drow8 = (uint8_t *)dbase + (b - B0);
+        ncell += units;
         int rmax = TH_NEG - 0x10000000, left = b, right = b;
         const bool pk = !WIDE && LQ && ring_all && cache_me && !needfull;    // rows some far row will read take the 32-bit path (they store whole cells)
         const int npk = fast ? 1 : inn;
         if (pk) {
-            th_poa_pk_row<QCAP, RT, false, false>(s_qs, s_ring, drow - (b - B0), lane, b, e, B0, myslot, (uint32_t)TH_READLANE((int)v_T, nb), npk, q_slot0, q_slot1, q_slot2, q_slot3, q_pb0, q_pb1, q_pb2, q_pb3,
+            th_poa_pk_row<QCAP, RT, false, false, 2>(s_qs, s_ring, dbase, lane, b, e, B0, myslot, (uint32_t)TH_READLANE((int)v_T, nb), npk, q_slot0, q_slot1, q_slot2, q_slot3, q_pb0, q_pb1, q_pb2, q_pb3,
                                     E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
         } else {
         if (!WIDE && cache_me) {      // leave the slot clean for a packed successor: minus infinity wherever this row stores nothing
@@ -816,8 +832,10 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                     if (f2 > h - O2) d |= TH_D_XF2;
                 }
                 const int n1 = max(h - O1, e1v) - E1, n2 = max(h - O2, e2v) - E2;
-                if (inn <= TH_D16_WIDE_DEG)
-                    drow[j - b] = (uint16_t)th_d16_pack(src, d >> 27 & 1u, d >> 28 & 1u, d >> 29 & 1u, d >> 30 & 1u, (uint32_t)pm, (uint32_t)pe1, (uint32_t)pe2);
+                if (inn <= TH_D16_WIDE_DEG) {
+                    const uint32_t w16 = th_d16_pack(src, d >> 27 & 1u, d >> 28 & 1u, d >> 29 & 1u, d >> 30 & 1u, (uint32_t)pm, (uint32_t)pe1, (uint32_t)pe2);
+                    if (d8) drow8[j - b] = (uint8_t)th_d8_from16(w16); else drow[j - b] = (uint16_t)w16;
+                }
                 if (store_full) { int4 cv; cv.x = h; cv.y = n1; cv.z = n2; cv.w = (int)d; row[j - b] = cv; }
                 if (cache_me) { s_ring[myslot][0][TH_RIDX(j, b)] = TH_RING_ST(h); s_ring[myslot][1][TH_RIDX(j, b)] = TH_RING_ST(n1); s_ring[myslot][2][TH_RIDX(j, b)] = TH_RING_ST(n2); }
             }
@@ -864,7 +882,9 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
 __device__ __forceinline__ uint32_t th_poa_dir(const ThPoaG &g, int row, int o)
 {
     const int deg = (g.r_meta[row] >> 8) & 0xff;
-    return deg > TH_D16_WIDE_DEG ? (uint32_t)g.cell[g.r_foff[row] + o].w : th_d16_expand(g.dcell[g.r_off[row] + o]);
+    if (deg > TH_D16_WIDE_DEG) return (uint32_t)g.cell[g.r_foff[row] + o].w;
+    if (deg == 1) return th_d8_expand(((const uint8_t *)(g.dcell + g.r_off[row]))[o + (g.r_beg[row] & 1)]);
+    return th_d16_expand(g.dcell[g.r_off[row] + o]);
 }
 
 // ---- traceback: wave-uniform walk; direction words come from tiles of 16 rows x 4 diagonals ----
@@ -895,7 +915,9 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
                 t_p0 = g.r_p[row * 4]; t_p1 = g.r_p[row * 4 + 1]; t_p2 = g.r_p[row * 4 + 2]; t_p3 = g.r_p[row * 4 + 3];
                 TH_KEEP_V(rb); TH_KEEP_V(re); TH_KEEP_V(meta); TH_KEEP_V(roff); TH_KEEP_V(rfoff);     // (all five in flight together: the compiler would sink each load behind the test that needs it)
                 if (col >= rb && col <= re) {
-                    t_d = ((meta >> 8) & 0xff) > TH_D16_WIDE_DEG ? g.cell[rfoff + (col - rb)].w : (int)th_d16_expand(g.dcell[roff + (col - rb)]);
+                    const int deg_ = (meta >> 8) & 0xff;
+                    t_d = deg_ > TH_D16_WIDE_DEG ? g.cell[rfoff + (col - rb)].w
+                        : deg_ == 1 ? (int)th_d8_expand(((const uint8_t *)(g.dcell + roff))[col - (rb & ~1)]) : (int)th_d16_expand(g.dcell[roff + (col - rb)]);
                     t_ok = 1;
                 }
             }
