@@ -238,6 +238,18 @@ def test_emul_poa_band_failure_is_rerun_without_a_band(emu, monkeypatch):
     th.close()
 
 
+def test_emul_poa_node_capacity_overflow_is_rerun(emu, monkeypatch):
+    """round 4: a job's node arrays are carved for an estimate of its graph (1.5 x the longest unit plus 9 % per further unit), not for
+    one node per base of every unit; TH_POA_TEST_SMALLCAP carves them just above the longest unit on the first attempt, so every graph
+    outgrows them at its first merge: status 1, the rerun with twice the factor must reach the same records"""
+    monkeypatch.setenv("TH_POA_TEST_SMALLCAP", "1")
+    th = TH.TideHunter(lib_path=emu)
+    seqs = _reads(th.lib, [(60, 8, 0.10), (120, 5, 0.08), (35, 12, 0.12), (200, 4, 0.15)])
+    got = th.process(seqs)
+    assert U.assert_records_equal(seqs, got, O.default_para(), "node capacity rerun") >= 4
+    th.close()
+
+
 def test_emul_file_driver_pipeline(emu, tmp_path):
     """th_run_file_multi on the emulation library: reader -> device pipelines (upload / run / collect threads each; one or two per
     device, batches taken from the shared ticket counter, ramped batch sizes) -> writer; several batches, output order = input order, bytes equal to the oracle's command line"""
@@ -430,6 +442,12 @@ def test_emul_poa_relative_score_variant(monkeypatch):
     th = TH.TideHunter(lib_path=lib, match=5, mismatch=9, gap_open1=8, gap_ext1=4, gap_open2=30, gap_ext2=2)
     got = th.process(seqs)
     assert U.assert_records_equal(seqs, got, O.default_para(match=5, mismatch=9, gap_open1=8, gap_ext1=4, gap_open2=30, gap_ext2=2), "relative-score POA, other scoring") >= 6
+    th.close()
+    # the same build carries the opt-in 8-bit direction words (TH_POA_D8=1: rows with one predecessor): the ordinary int16 variant with them
+    monkeypatch.delenv("TH_POA_FORCE_LONG")
+    th = TH.TideHunter(lib_path=lib)
+    got = th.process(seqs)
+    assert U.assert_records_equal(seqs, got, O.default_para(), "8-bit direction words") >= 6
     th.close()
 
 

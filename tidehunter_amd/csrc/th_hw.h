@@ -94,15 +94,18 @@ __device__ __forceinline__ int th_wave_incl_sum(int v)
 // 32-bit store to a wave-uniform base (scalar register pair) plus a 32-bit per-lane byte offset: the addressing mode the compiler does
 // not pick when it can hoist `base + offset` into a loop-invariant 64-bit register pair per lane (two VGPRs that the POA row loop does
 // not have to spare)
+#ifndef TH_ASM_STORE_PRE
+#define TH_ASM_STORE_PRE ""
+#endif
 __device__ __forceinline__ void th_store_u32_saddr(const void *base, uint32_t off, uint32_t v)
 {
-    asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
+    asm volatile(TH_ASM_STORE_PRE "global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
 }
 #define TH_STORE_U32_SADDR(base, off, v) th_store_u32_saddr((base), (uint32_t)(off), (v))
 // the same for the low 16 bits of v
 __device__ __forceinline__ void th_store_u16_saddr(const void *base, uint32_t off, uint32_t v)
 {
-    asm volatile("global_store_short %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
+    asm volatile(TH_ASM_STORE_PRE "global_store_short %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
 }
 #define TH_STORE_U16_SADDR(base, off, v) th_store_u16_saddr((base), (uint32_t)(off), (v))
 // An LDS read the compiler does not wait for: the value may be used only after TH_LDS_ASYNC_WAIT(value) -- which must come before

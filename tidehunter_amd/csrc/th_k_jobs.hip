@@ -22,19 +22,28 @@
 // variant on long units: measured band ~ 2w + 1 + len / 30 at 15 % error).  Graph rows grow by ~9 % of the unit length per unit
 // (measured: 1.27 x at 4 units of 5000, ~1.5 x at 9 units of 1000, ~2.6 x at 20 units of 200).  cell_factor is the attempt's
 // safety factor (1.5 at first, doubled for the jobs that come back with "scratch too small").
+#ifndef TH_POA_CELL_INTS
+#define TH_POA_CELL_INTS (TH_POA_D8 ? 1.25 : 1.5)     // ints reserved per estimated band cell (x the attempt's factor); 1.0 sent 329 of 100 000 headline jobs to the rerun
+#endif
 __host__ __device__ static inline long long th_poa_need_ints(int n_units, int sum_len, int max_len, double cell_factor, bool noband, bool wide /* class 0: rows wider than the ring store full cells */)
 {
     if (n_units <= 2) return 0;
-    const long long cap = sum_len + 2, ocap = 2LL * (sum_len + n_units + 8), opn = cap + max_len + 2;
+    int fexp = 0; for (double f = 1.5; f * 1.99 < cell_factor; f *= 2) ++fexp;        // the attempt's factor as the kernel is told it: 1.5 * 2^fexp
+    const ThPoaCaps K = th_poa_caps(n_units, sum_len, max_len, fexp, noband);
+    const long long cap = K.cap, ocap = K.ocap, opn = K.opn;
     const long long graph = 39 * cap + 2 * ocap + 5 * opn + 512;
     if (noband) return (graph + (long long)(cap * ((long long)max_len + 4) * (cell_factor > 1.5 ? 1.25 : 1.0) * 4.5) + 63) & ~63LL;   // full rows, all stored in full
     const long long w = TH_POA_WB + max_len / 100;
     const long long span = 2 * w + 1 + 48 + max_len / 30;
     long long rows = (long long)(max_len * (1.0 + 0.09 * (n_units - 1))) + 64;
-    if (rows > cap) rows = cap;
+    if (rows > sum_len + 2) rows = sum_len + 2;
     const bool all_full = wide && span + 16 >= TH_POA_RW_N;
-    return (graph + (long long)(rows * span * cell_factor * (all_full ? 4.5 : 1.5)) + 63) & ~63LL;
+    // ints per band cell: a direction word of two bytes (one for three rows in four with TH_POA_D8) plus the full cells of the few rows a
+    // far row will read -- ~3.3 bytes on average (2.3 with TH_POA_D8); TH_POA_CELL_INTS x 4 bytes (x the attempt's factor) are reserved
+    return (graph + (long long)(rows * span * cell_factor * (all_full ? 4.5 : TH_POA_CELL_INTS)) + 63) & ~63LL;
 }
+// the factor exponent of a POA launch's flags (bits 1..4) from the attempt's factor
+static inline int th_poa_fexp(double cell_factor) { int fexp = 0; for (double f = 1.5; f * 1.99 < cell_factor; f *= 2) ++fexp; return fexp > 15 ? 15 : fexp; }
 // Which POA variant a job starts on.  The int16 variant gives a job back (status 7) when an alignment's scores may not fit
 // (th_poa_dp: cache16_ok, evaluated with the graph's row count at that alignment); with the row estimate above the same test
 // tells beforehand, for nearly every job, that it would -- those start on the 32-bit variant (both are exact: same results).

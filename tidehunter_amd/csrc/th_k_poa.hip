@@ -38,13 +38,19 @@
 //   bits 8, 0, 9, 1    "strictly better than everything before it" for E1, E2, F1, F2 in that order (the source is the last one set)
 //   bits 10, 2, 11, 3  XE1, XE2, XF1, XF2: the gap was extended rather than opened
 //   bits 13..12 / 15..14 / 5..4  edge index of the predecessor that gave the diagonal / the E1 / the E2 value
-// A row with exactly ONE predecessor (three rows in four at the headline shape) needs no edge indices: its cells are 8-BIT words --
+// TH_POA_D8 = 1: a row with exactly ONE predecessor (three rows in four at the headline shape) needs no edge indices: its cells are 8-BIT words --
 // bits 4, 0, 5, 1 for E1, E2, F1, F2, bits 6, 2, 7, 3 for XE1, XE2, XF1, XF2: the low nibble of either byte of the 16-bit word -- which the
 // packed row assembles from the same four permutes with the sign selectors in source order (TH_PERM_SIGNS8) and one shift-or, and
-// stores two per lane as one short.  (Round 3 wrote 16 bits for every cell: 383 GB per 100 000 headline reads.)
+// stores two per lane as one short.
 // so the packed row spends one instruction per comparison (a permute and an and-or per pair; round 2: two per comparison) instead of
 // assembling a 32-bit word per cell, and the traffic of the direction matrix halves.  Rows with more than four predecessors
 // store whole cells (int4, the 32-bit word in .w); th_poa_dir() returns the register layout for either kind.
+#ifndef TH_POA_D8
+#define TH_POA_D8 0             // 1: 8-bit direction words for rows with one predecessor (below).  Measured on the GPU in round 4 at the headline shape and
+                                // NOT the default: it takes 11 % off the kernel's HBM traffic (write 383 -> 320 GB per 100 000 reads: the rows are not line-aligned, so
+                                // the partial sectors at either end of a 65-byte row are counted whole) and 0.35 MB off a wave's scratch, and costs 13 ms of 459 (the fold of
+                                // the two halves, a short store per trip, 16 bytes more register scratch).  The CPU emulation's second build (libth_emul_rel.so) keeps it compiled and tested.
+#endif
 #define TH_D16_WIDE_DEG 4
 #define TH_D16_PM_SHIFT 12
 #define TH_D16_PE1_SHIFT 14
@@ -58,7 +64,7 @@ __device__ __forceinline__ uint32_t th_d16_expand(uint32_t w)
 __device__ __forceinline__ uint32_t th_d8_expand(uint32_t b) { return th_d16_expand((b & 0x0fu) | (b & 0xf0u) << 4); }
 __device__ __forceinline__ uint32_t th_d8_from16(uint32_t w) { return (w & 0x0fu) | ((w >> 4) & 0xf0u); }      // (a 16-bit word without edge indices)
 // 2-byte units a row of `span` cells (span even) takes among the direction words: 8-bit rows are rounded up to a whole dword
-__device__ __forceinline__ int th_d_units(int span, bool d8) { return d8 ? ((span >> 1) + 1) & ~1 : span; }
+__device__ __forceinline__ int th_d_units(int span, bool d8) { return (TH_POA_D8 && d8) ? ((span >> 1) + 1) & ~1 : span; }
 // the 16-bit word from a source (0..4), the four extension flags and the three edge indices (the one-column-per-lane rows)
 __device__ __forceinline__ uint32_t th_d16_pack(int src, uint32_t xe1, uint32_t xe2, uint32_t xf1, uint32_t xf2, uint32_t pm, uint32_t pe1, uint32_t pe2)
 {
@@ -82,6 +88,26 @@ __device__ __forceinline__ uint32_t th_d16_pack(int src, uint32_t xe1, uint32_t 
 #define TH_POA_RING 4      // recent rows kept in LDS (a row can read the three before it)
 #define TH_POA_PAD 4       // minus-infinity shorts in front of every ring row (columns left of the band; clamp target)
 #define TH_BIG 0x3fffffff
+
+// Capacities of one job's graph arrays inside its wave's scratch (th_poa_carve), the same on the host (th_poa_need_ints) and in the
+// kernel.  `cap` bounds the NODES (= rows): the worst case is one node per base of every unit (sum_len + 2, what rounds 1-3 carved: 39
+// arrays of it, 1.75 MB of a headline job's 3.8 MB), the usual case is the longest unit plus ~9 % per further unit; the arrays are sized
+// for `factor` times that estimate (1.5 on the first attempt), a job whose graph outgrows them is given back with status 1 and rerun with
+// twice the factor -- up to the worst case, which every no-band rerun uses.  fexp: factor = 1.5 * 2^fexp.
+struct ThPoaCaps { long long cap, ocap, opn; };
+__host__ __device__ static inline ThPoaCaps th_poa_caps(int n_units, int sum_len, int max_len, int fexp, bool full)
+{
+    ThPoaCaps c;
+    const long long worst = (long long)sum_len + 2;
+    long long est = (long long)((max_len * (1.0 + 0.09 * (n_units - 1)) + 64) * 1.5) << (fexp < 0 ? 0 : fexp > 20 ? 20 : fexp);
+#ifdef TH_POA_NOCAPS
+    full = true;
+#endif
+    c.cap = (full || est > worst) ? worst : est;
+    c.ocap = 2LL * (sum_len + n_units + 8);                 // overflow edges (beyond four in / out per node): by edges, not by nodes -- 2 small arrays
+    c.opn = c.cap + max_len + 2;                            // alignment operations: a path visits every row and every query base at most once
+    return c;
+}
 
 // The kernels are compiled in two configurations (th_k_poa_body.h, once per namespace):
 //   thpoa_n  ring rows of up to 192 columns (two trips of 128), absolute int16 scores: units of up to ~1500 bases (TH_POA_QCAP staged

@@ -429,7 +429,7 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
         const uint32_t n1 = th_pk_sub(th_pk_max(hO1, e1v), E1P), n2 = th_pk_sub(th_pk_max(hO2, e2v), E2P);
         // column b-1 / e+1 of an odd edge land in the row's own padding.  drow is the word of column B0 (the row's even base): a
         // wave-uniform pointer + the lane's constant byte offset (+ the trip's): no 64-bit address arithmetic per trip on the scalar unit
-        if (D8 == 1 || (D8 == 2 && npk == 1)) {
+        if (TH_POA_D8 && (D8 == 1 || (D8 == 2 && npk == 1))) {
             // one predecessor: no edge indices, eight bits per cell (layout: th_k_poa.hip) -- a difference's two signs land side by side
             // (bytes 0, 1 for the first of a pair, 2, 3 for the second), the halves are folded, the lane stores its two cells as one short
             uint32_t y = th_perm(dg1, dg2, TH_PERM_SIGNS8) & 0x01011010u;
@@ -597,10 +597,10 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 if (e - b < TH_POA_RW) {
                     const int B0 = b & ~1, span = (e | 1) - B0 + 1, units = th_d_units(span, true);
                     if (ncell + (uint32_t)units + nfull * 8u > g.cell_u2) return -3;
-                    const int my_off = (int)ncell;                     // (8-bit words: the offset of the even base column)
+                    const int my_off = (int)ncell + (TH_POA_D8 ? 0 : b - B0);      // (8-bit words: the offset of the even base column)
                     ncell += units;
                     int rmax = TH_NEG - 0x10000000, left = b, right = b;
-                    th_poa_pk_row<QCAP, RT, true, false, 1>(s_qs, s_ring, g.dcell + my_off, lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), 1, (i - 1) & 3, 0, 0, 0, L_b & ~1, 0, 0, 0,
+                    th_poa_pk_row<QCAP, RT, true, false, 1>(s_qs, s_ring, g.dcell + (my_off - (TH_POA_D8 ? 0 : b - B0)), lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), 1, (i - 1) & 3, 0, 0, 0, L_b & ~1, 0, 0, 0,
                                             E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right);
                     TH_POA_PK_ROW_DONE(0, 0);
                     continue;
@@ -638,7 +638,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                     if (e - b < TH_POA_RW) {
                         const int B0 = b & ~1, span = (e | 1) - B0 + 1, units = th_d_units(span, inn_ == 1);
                         if (ncell + (uint32_t)units + nfull * 8u > g.cell_u2) return -3;
-                        const int my_off = (int)ncell + (inn_ == 1 ? 0 : b - B0);
+                        const int my_off = (int)ncell + ((TH_POA_D8 && inn_ == 1) ? 0 : b - B0);
                         uint16_t *dbase = g.dcell + ncell;
                         ncell += units;
                         int rmax = TH_NEG - 0x10000000, left = b, right = b;
@@ -689,7 +689,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                         const int full = (meta >> 24) & 1;
                         if (full) nfull += span;
                         if (ncell + (uint32_t)units + nfull * 8u > g.cell_u2) return -3;
-                        const int my_off = (int)ncell + (inn_ == 1 ? 0 : b - B0), my_foff = full ? -(int)nfull + (b - B0) : 0;
+                        const int my_off = (int)ncell + ((TH_POA_D8 && inn_ == 1) ? 0 : b - B0), my_foff = full ? -(int)nfull + (b - B0) : 0;
                         uint16_t *dbase = g.dcell + ncell;
                         ncell += units;
                         int rmax = TH_NEG - 0x10000000, left = b, right = b;
@@ -742,7 +742,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         // direction words (2 bytes per cell, every row) grow upwards from the start of the cell region; full cells (16 bytes, only the
         // rows that store them: g.cell points at the END of the region and their offsets are negative) grow downwards from its end.
         // A wave's scratch shrinks from ~18 to ~3-6 bytes per band cell, whatever the share of rows stored in full.
-        const bool d8 = inn == 1;                                // one predecessor: 8-bit direction words (every reader goes by the in-degree)
+        const bool d8 = TH_POA_D8 && inn == 1;                   // one predecessor: 8-bit direction words (every reader goes by the in-degree)
         const int units = th_d_units(span, d8);
         if (store_full) nfull += span;
         if (ncell + (uint32_t)units + nfull * 8u > g.cell_u2) return -3;
@@ -883,7 +883,7 @@ __device__ __forceinline__ uint32_t th_poa_dir(const ThPoaG &g, int row, int o)
 {
     const int deg = (g.r_meta[row] >> 8) & 0xff;
     if (deg > TH_D16_WIDE_DEG) return (uint32_t)g.cell[g.r_foff[row] + o].w;
-    if (deg == 1) return th_d8_expand(((const uint8_t *)(g.dcell + g.r_off[row]))[o + (g.r_beg[row] & 1)]);
+    if (TH_POA_D8 && deg == 1) return th_d8_expand(((const uint8_t *)(g.dcell + g.r_off[row]))[o + (g.r_beg[row] & 1)]);
     return th_d16_expand(g.dcell[g.r_off[row] + o]);
 }
 
@@ -917,7 +917,7 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
                 if (col >= rb && col <= re) {
                     const int deg_ = (meta >> 8) & 0xff;
                     t_d = deg_ > TH_D16_WIDE_DEG ? g.cell[rfoff + (col - rb)].w
-                        : deg_ == 1 ? (int)th_d8_expand(((const uint8_t *)(g.dcell + roff))[col - (rb & ~1)]) : (int)th_d16_expand(g.dcell[roff + (col - rb)]);
+                        : (TH_POA_D8 && deg_ == 1) ? (int)th_d8_expand(((const uint8_t *)(g.dcell + roff))[col - (rb & ~1)]) : (int)th_d16_expand(g.dcell[roff + (col - rb)]);
                     t_ok = 1;
                 }
             }
@@ -988,7 +988,8 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
 }
 
 // ---- merge the alignment (ops were written backwards; rows refer to the CURRENT order) ----
-__device__ void th_poa_merge(ThPoaG &g, const uint8_t *__restrict__ q, int n_ops)
+// returns 1 (graph abandoned) when the new nodes would not fit the job's node capacity
+__device__ int th_poa_merge(ThPoaG &g, const uint8_t *__restrict__ q, int n_ops)
 {
     const int lane = TH_LANE(), n_old = g.n_node;
     for (int p = lane; p < n_old; p += TH_WAVE) { g.cntB[p] = 0; g.headB[p] = 0x7fffffff; g.aft[p] = -1; }
@@ -1014,6 +1015,7 @@ __device__ void th_poa_merge(ThPoaG &g, const uint8_t *__restrict__ q, int n_ops
         } else if (ok && op == 1) kind = 2;
         const bool isnew = kind != 0;
         const unsigned long long nm = __ballot(isnew);
+        if (n_old + new_cnt + (int)__popcll(nm) > g.cap) return 1;          // (wave-uniform)
         if (isnew) {
             v = n_old + new_cnt + th_mbcnt(nm);
             th_poa_init_node(g, v, b, 0);
@@ -1070,6 +1072,7 @@ __device__ void th_poa_merge(ThPoaG &g, const uint8_t *__restrict__ q, int n_ops
     }
     int *t = g.order; g.order = g.order2; g.order2 = t;
     TH_WAVE_FENCE();
+    return 0;
 }
 
 // ---- row-column consensus: one column = one aligned ring (its members are adjacent in the order) ----
@@ -1126,7 +1129,7 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
     // flags: bit 0 = no adaptive band (the rerun of a job whose band failed); bits 8.. = test knob TH_POA_TEST_FAIL: jobs whose
     // index is a multiple of it report status 4 on the banded pass, so the tests can drive the rerun path
     constexpr bool LQ = QCAP > 0;
-    const bool noband = flags & 1; const int test_fail = flags >> 8;
+    const bool noband = flags & 1; const int fexp = (flags >> 1) & 15, test_fail = flags >> 8;
     __shared__ __attribute__((aligned(4))) uint8_t s_qs[QCAP / 2 + 4]; // column j's query code (0..4, code of q[j-1]; 4 for j = 0 and j > qlen) in nibble j & 1 of byte j >> 1
     __shared__ __attribute__((aligned(4))) RT s_ring[TH_POA_RING][3][TH_POA_RS];
     __shared__ int s_rmeta[TH_POA_RING][8];
@@ -1149,7 +1152,9 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
             continue;
         }
         ThPoaG g;
-        const long long cap = T.sum_len + 2, ocap = 2LL * (T.sum_len + T.n_units + 8), opn = cap + T.max_len + 2;
+        const ThPoaCaps K = th_poa_caps(T.n_units, T.sum_len, T.max_len, fexp, noband);      // (node capacity: an estimate, not the worst case -- th_k_poa.hip)
+        // (flags bit 5, test knob TH_POA_TEST_SMALLCAP: the first attempt carves node arrays just above the longest unit, so that the tests drive the status-1 rerun)
+        const long long cap = (flags & 32) ? min(K.cap, (long long)T.max_len + 8) : K.cap, ocap = K.ocap, opn = cap + T.max_len + 2;
         g.cap = (int)cap; g.n_node = 0;
         int *p = th_poa_carve(g, my, cap, ocap, opn);
         const int *order0 = g.order;       // (th_poa_merge swaps order / order2)
@@ -1158,7 +1163,7 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
             g.cell_u2 = (uint32_t)min(avail * 2, 0x7ff00000LL); g.dcell = (uint16_t *)p; g.cell = (int4 *)(p + avail);
         }
         int st = 0;
-        if (p - my > scratch_ints || g.cell_u2 < 2048) st = 1;
+        if (p - my > scratch_ints || g.cell_u2 < 2048 || U[0].len + 2 > cap) st = 1;
         if (!st) th_poa_seed(g, rb + U[0].start, U[0].len);
         for (int s = 1; s < T.n_units && !st; ++s) {
             const uint8_t *q = rb + U[s].start; const int qlen = U[s].len;
@@ -1185,7 +1190,7 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
 #endif
             const int no = th_poa_traceback(g, bi, qlen);
             TH_PROF(2);
-            th_poa_merge(g, q, no);
+            if (th_poa_merge(g, q, no)) { st = 1; break; }          // the graph outgrew its node capacity: rerun with twice the factor
             TH_PROF(3);
         }
         int cl = 0;

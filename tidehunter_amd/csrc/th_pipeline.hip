@@ -382,6 +382,11 @@ static int th_poa_retries(th_gpu *g, KTimer &kt, const ThIn &in, int nt, int poa
     TRY(th_rt_d2h(g->h_tasks.data(), g->d_tasks.p, (size_t)nt * sizeof(ThTask), g->stream));
     TRY(th_rt_d2h(g->h_status.data(), g->d_status.p, (size_t)nt * 4, g->stream));
     TRY(th_rt_sync_event(g->stream, g->sync_ev));
+    if (getenv("TH_TRACE")) {
+        int c[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (int t = 0; t < nt; ++t) ++c[g->h_status[t] & 7];
+        fprintf(stderr, "[th] poa gave back: %d graph / scratch too small (1), %d band cells overflow (2), %d empty band (3), %d band lost the path (4), %d int16 range (7); failed for good: %d + %d\n", c[1], c[2], c[3], c[4], c[7], c[5], c[6]);
+    }
     auto run_list = [&](const std::vector<int> &grp, int cls, bool noband, double factor, bool *ran) -> int {
         const bool wide = cls == 0;
         *ran = false;
@@ -395,7 +400,7 @@ static int th_poa_retries(th_gpu *g, KTimer &kt, const ThIn &in, int nt, int poa
         TRY(g->d_sublist.ensure(grp.size()));
         TRY(th_rt_h2d(g->d_sublist.p, g->h_sublist.data(), grp.size() * 4, g->stream));
         TH_LAUNCH(th_k_cnt_set, 1, 64, g->stream, &g->d_cnt.p->q_poa_w, 0, (int *)nullptr, 0, (int *)nullptr, 0, (int *)nullptr, 0);
-        TRY(th_poa_launch(g, kt, in, g->d_sublist.p, (int)grp.size(), cls, max_unit, need, wv, &g->d_cnt.p->q_poa_w, (noband ? 1 : 0) | poa_test_fail << 8));
+        TRY(th_poa_launch(g, kt, in, g->d_sublist.p, (int)grp.size(), cls, max_unit, need, wv, &g->d_cnt.p->q_poa_w, (noband ? 1 : 0) | th_poa_fexp(factor) << 1 | poa_test_fail << 8));
         TRY(th_rt_d2h(g->h_status.data(), g->d_status.p, (size_t)nt * 4, g->stream));
         TRY(th_rt_sync_event(g->stream, g->sync_ev));
         *ran = true;
@@ -609,15 +614,16 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
         // recent rows as int16 in LDS (packed rows, 6 waves per SIMD); jobs whose scores may not fit int16 (long units, unusual scoring)
         // or whose units exceed its query staging buffer run on the 32-bit-ring variant.
         const int poa_test_fail = std::max(0, env_int("TH_POA_TEST_FAIL", 0));   // test knob, see th_k_poa
+        const int poa_small_cap = env_int("TH_POA_TEST_SMALLCAP", 0) ? 32 : 0;  // test knob: node arrays too small on the first attempt (th_k_poa)
         const long long need_n = std::max<long long>(1024, (long long)cnt->need_n), need_w = std::max<long long>(1024, (long long)cnt->need_w), need_l = std::max<long long>(1024, (long long)cnt->need_l);
         const int wv_n = n_task_n ? th_poa_waves(g, n_task_n, need_n) : 0, wv_w = n_task_w ? th_poa_waves(g, n_task_w, need_w) : 0;
         const int wv_l = n_task_l ? std::min(th_poa_waves(g, n_task_l, need_l), g->waves_poa / 2) : 0;       // (three waves per SIMD)
         // a handle reserved for larger batches takes the scratch of the full persistent grid at once (with slack for longer units)
         const long long wv_alloc = g->reserve_n > n ? th_poa_waves(g, std::max(g->reserve_n, n_task_n), need_n) : wv_n;
         TRY(g->d_scratch.ensure((size_t)std::max<long long>(std::max<long long>(std::max<long long>(need_n * std::max<long long>(wv_n, wv_alloc), need_w * wv_w), need_l * wv_l), 1024)));
-        TRY(th_poa_launch(g, kt, in, g->d_list_l.p, n_task_l, 2, cnt->max_unit, need_l, wv_l, &dc->q_poa_l, poa_test_fail << 8));       // (the long jobs first: the short ones fill the tail)
-        TRY(th_poa_launch(g, kt, in, g->d_list_n.p, n_task_n, 1, cnt->max_unit, need_n, wv_n, &dc->q_poa_n, poa_test_fail << 8));
-        TRY(th_poa_launch(g, kt, in, g->d_list_w.p, n_task_w, 0, cnt->max_unit, need_w, wv_w, &dc->q_poa_w, poa_test_fail << 8));
+        TRY(th_poa_launch(g, kt, in, g->d_list_l.p, n_task_l, 2, cnt->max_unit, need_l, wv_l, &dc->q_poa_l, poa_small_cap | poa_test_fail << 8));       // (the long jobs first: the short ones fill the tail)
+        TRY(th_poa_launch(g, kt, in, g->d_list_n.p, n_task_n, 1, cnt->max_unit, need_n, wv_n, &dc->q_poa_n, poa_small_cap | poa_test_fail << 8));
+        TRY(th_poa_launch(g, kt, in, g->d_list_w.p, n_task_w, 0, cnt->max_unit, need_w, wv_w, &dc->q_poa_w, poa_small_cap | poa_test_fail << 8));
         if (trace) { th_rt_sync_event(g->stream, g->sync_ev); fprintf(stderr, "[th] %.3f s: poa done (%d + %d + %d jobs, %d / %d / %d waves, %lld MB scratch)\n", th_wall_s() - t_run0, n_task_n, n_task_l, n_task_w, wv_n, wv_l, wv_w, (long long)(std::max(std::max(need_n * wv_n, need_w * wv_w), need_l * wv_l) * 4 >> 20)); }
         for (int pass = 0;; ++pass) {
             // ---- item lists of the alignment kernels and the compacted consensus offsets, per job, on the device ----
