@@ -377,6 +377,7 @@ def main():
         else:
             th.upload(my_batch); th.run(); th.collect()
     t_total, n_cons, alg_bytes, kms, n_reads_mine, bases_mine, digests, blocks_mine, n_syncs = 0.0, 0, 0, {}, 0, 0, {}, 0, 0
+    gather_info = None
     import resource
 
     def cpu_now():
@@ -441,6 +442,33 @@ def main():
         blocks_mine += th.launches() * a.steps              # TH_SUBBATCH > 1: several concurrent parts, that many launches of every kernel
         account(my_batch, th.records(), cuts[rank])         # Python dict view for the byte accounting (every pass has the same records): not part of the path
         n_reads_mine += len(my_batch) * (a.steps - 1); bases_mine += sum(len(s) for s in my_batch) * (a.steps - 1)
+        # ---- ordered result gather (outside the timed region): every rank formats the records of its block as the command line would print
+        # them (th_format_output = mini_tandem_output, src/main.c:214-271, into memory) and the blocks go to rank 0 in rank order = input
+        # order (src/main.c:217) -- torch.distributed gather of byte tensors: RCCL over xGMI at N > 1 on the GPUs, gloo in the rehearsals
+        my_text = th.format_output([b"syn_%d" % gi for gi in range(cuts[rank], cuts[rank + 1])])
+        sync_all()
+        tg0 = time.perf_counter()
+        if dist is not None:
+            import numpy as np
+            dev = "cuda" if backend == "nccl" else "cpu"
+            sizes = torch.zeros(world, dtype=torch.int64, device=dev); sizes[rank] = len(my_text)
+            dist.all_reduce(sizes, op=dist.ReduceOp.SUM)
+            sizes = [int(x) for x in sizes.cpu()]
+            cap = max(max(sizes), 1)
+            buf = torch.zeros(cap, dtype=torch.uint8)
+            buf[: len(my_text)] = torch.from_numpy(np.frombuffer(my_text, dtype=np.uint8).copy()) if my_text else buf[:0]
+            buf = buf.to(dev)
+            parts = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+            dist.gather(buf, parts, dst=0)
+            if on_gpu:
+                torch.cuda.synchronize()
+            gathered = b"".join(bytes(parts[r][: sizes[r]].cpu().numpy()) for r in range(world)) if rank == 0 else b""
+        else:
+            sizes, gathered = [len(my_text)], my_text
+        gather_s = time.perf_counter() - tg0
+        gather_info = {"bytes": sum(sizes), "bytes_by_rank": sizes, "seconds": gather_s, "backend": (backend if dist is not None else "none (one rank)"),
+                       "order": "contiguous blocks in rank order = input order", "output_md5": hashlib.md5(gathered).hexdigest() if rank == 0 else None,
+                       "what": "the FASTA text of the last step's records of every rank (th_format_output), gathered to rank 0 with torch.distributed.gather; outside the timed region"}
     sync_all()
     # the byte accounting ran on the last step (all steps process the same reads): scale it to the timed steps
     if (a.steal == 0 or not a.digest) and a.steps > 1:
@@ -485,6 +513,8 @@ def main():
         "host_cpu": {"cpu_s_per_1M_reads": float(tot[4].item()) * 1e6 / float(reads), "cpu_s_in_timed_region_by_rank": [round(float(x), 3) for x in cpu_by_rank],
                      "cores_busy_mean_per_rank": float(tot[4].item()) / world / t_total, "usable_cpus": effective_cpus(), "host_threads_per_rank": int(os.environ.get("TH_HOST_THREADS", "0"))},
     }
+    if gather_info is not None:
+        out["result_gather"] = gather_info
     if a.digest:
         h = hashlib.md5()
         for k in sorted(digests):

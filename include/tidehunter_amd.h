@@ -115,6 +115,11 @@ int th_batch_run_steps(th_handle_t *h, int steps, th_tandem_seq_t *out, double *
 void th_output(FILE *fp, int n, const char *const *names, const char *const *seqs, const int *lens,
                th_tandem_seq_t *tseq, const th_para_t *p);
 
+/* the same text into memory (malloc'ed, NUL-terminated, *len bytes; release with th_free_buffer): a rank of a one-process-per-GPU launch
+ * formats its block and the blocks are gathered in rank order = input order (src/main.c:214-217) */
+char *th_format_output(int n, const char *const *names, const char *const *seqs, const int *lens, th_tandem_seq_t *tseq, const th_para_t *p, size_t *len);
+void th_free_buffer(void *p);
+
 /* mini_tandem(), src/main.c:375-436: whole-file driver (FASTA/FASTQ, optionally gzipped) */
 int th_run_file(const char *read_fn, th_para_t *p, FILE *out, int device, int batch_reads);
 /* the same over several devices of one node: one worker per device takes the next batch from a shared ticket counter -- the

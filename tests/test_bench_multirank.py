@@ -40,6 +40,10 @@ def test_bench_two_ranks_match_one_rank(tmp_path):
         assert "roofline" in j and j["roofline"]["bound"] == "hbm"
     assert one["records_digest"] == two["records_digest"] == steal["records_digest"]
     assert two["config"]["inputs_resident_before_timing"] and not steal["config"]["inputs_resident_before_timing"]
+    # the ordered result gather: the text of the two ranks' blocks, gathered to rank 0 in rank order, is the text of the one-rank run
+    assert two["result_gather"]["backend"] == "gloo" and len(two["result_gather"]["bytes_by_rank"]) == 2 and all(b > 0 for b in two["result_gather"]["bytes_by_rank"])
+    assert two["result_gather"]["output_md5"] == one["result_gather"]["output_md5"] == spawned["result_gather"]["output_md5"]
+    assert two["result_gather"]["bytes"] == one["result_gather"]["bytes"] > 100
 
 
 def test_bench_eight_ranks_rehearsal(tmp_path):
@@ -51,6 +55,7 @@ def test_bench_eight_ranks_rehearsal(tmp_path):
     assert eight["n_gpus"] == 8 and steal["n_gpus"] == 8
     assert one["records_digest"] == eight["records_digest"] == steal["records_digest"]
     assert eight["records_digest_reads"] == 16 and steal["records_digest_reads"] == 16
+    assert eight["result_gather"]["output_md5"] == one["result_gather"]["output_md5"] and len(eight["result_gather"]["bytes_by_rank"]) == 8
     sys.path.insert(0, ROOT)
     import bench
     lens = [100 + 7 * (i % 5) for i in range(16)]

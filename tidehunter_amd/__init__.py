@@ -231,6 +231,22 @@ class TideHunter:
             cs += L
         return out
 
+    def format_output(self, names):
+        """th_format_output(): the text mini_tandem_output() would print for the resident batch's records (names: one bytes per read);
+        the slots are reset, as th_output() does"""
+        n = self._n
+        assert len(names) == n
+        arr_n = (C.c_char_p * n)(*names)
+        ln = C.c_size_t(0)
+        self.lib.th_format_output.restype = C.c_void_p
+        self.lib.th_format_output.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(TandemSeq), C.POINTER(Para), C.POINTER(C.c_size_t)]
+        self.lib.th_free_buffer.argtypes = [C.c_void_p]
+        p = self.lib.th_format_output(n, arr_n, self._keep[0], self._keep[1], self._ts, self.para, C.byref(ln))
+        try:
+            return C.string_at(p, ln.value)
+        finally:
+            self.lib.th_free_buffer(p)
+
     def debug_stage(self, what, nbytes, dtype):
         import numpy as np
         buf = np.zeros(max(1, nbytes // np.dtype(dtype).itemsize + 8), dtype=dtype)

@@ -1079,6 +1079,18 @@ static void fmt_read(th_str_t *b, const char *name, const char *seq, int len, th
     }
     t->cons_n = 0; t->cons_seq->seq.l = 0; t->cons_seq->qual.l = 0;          /* src/main.c:266-268 (and the quality buffer: DESIGN.md) */
 }
+/* th_output into memory: what mini_tandem_output() would print for the n reads (slots reset, as there); the buffer is malloc'ed, *len its size */
+char *th_format_output(int n, const char *const *names, const char *const *seqs, const int *lens, th_tandem_seq_t *tseq, const th_para_t *p, size_t *len)
+{
+    th_str_t b = { 0, 0, 0 };
+    sb_reserve(&b, 64);
+    for (int si = 0; si < n; ++si) fmt_read(&b, names[si], seqs[si], lens[si], tseq + si, p);
+    b.s[b.l] = 0;
+    *len = b.l;
+    return b.s;
+}
+void th_free_buffer(void *p) { free(p); }
+
 void th_output(FILE *fp, int n, const char *const *names, const char *const *seqs, const int *lens, th_tandem_seq_t *tseq, const th_para_t *p)
 {
     th_str_t b = { 0, 0, 0 };
