@@ -1,6 +1,6 @@
 #!/bin/bash
-# development helper (GPU box): rocprofv3 kernel statistics of one bench step of another shape (c2 / c4 / c5): which launches the time goes to
-#   usage: tools/r3_shape_stats.sh "c4 c5"
+# GPU box: rocprofv3 kernel statistics of one bench step of another shape (c2 / c4 / c5): which launches the time goes to
+#   usage: tools/shape_stats.sh "c4 c5"
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/shape_stats; mkdir -p $O; cd /tmp && export TMPDIR=/tmp
 for c in ${1:-c4 c5}; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$c -o run -- python3 $R/bench.py --config $c --steps 2 --warmup 1 --quick > $O/$c.log 2>&1
