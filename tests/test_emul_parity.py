@@ -250,6 +250,35 @@ def test_emul_poa_node_capacity_overflow_is_rerun(emu, monkeypatch):
     th.close()
 
 
+def test_emul_radix_sort_of_the_kmer_words(emu, monkeypatch):
+    """round 4: th_k_hits sorts its 32-bit words (key << 14 | position, written in position order) with a stable LSD radix sort of the
+    key field -- two passes of 8-bit digits, per-wave counters, lanes of a step ranked with ballots -- instead of the bitonic network.
+    Hits must equal the oracle's (src/tandem_hit.c:171-225) and the bitonic path's (TH_SORT_BITONIC=1) on reads that fill 2, 8 and 32
+    steps per wave, with N bases (sentinel words inside the array), homopolymer stretches (many equal keys) and -k 9 (a third pass of
+    two bits) and -k 6 (a second pass of four)"""
+    import numpy as np
+    lib = TH.load_library(emu)
+    rng = np.random.default_rng(3)
+    seqs = [TH.synth_read(lib, 21, 0, 700, 14, 0.08), TH.synth_read(lib, 21, 1, 300, 7, 0.10), TH.synth_read(lib, 21, 2, 97, 9, 0.05)]
+    s = bytearray(TH.synth_read(lib, 21, 3, 450, 9, 0.10))
+    for x in rng.integers(0, len(s), 60):
+        s[int(x)] = ord("N")
+    s[1000:1300] = b"A" * 300
+    s[2000:2200] = b"AC" * 100
+    seqs.append(bytes(s))
+    for kw in ({}, {"k": 9}, {"k": 6}, {"hpc": 1}):
+        got = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("TH_SORT_BITONIC", mode)
+            th = TH.TideHunter(lib_path=emu, only_unit=1, **kw)
+            th.process(seqs)
+            U.stage_compare(th, seqs, O.default_para(only_unit=1, **kw))
+            T = sum(len(x) for x in seqs)
+            got[mode] = (th.debug_stage(1, 4 * len(seqs), np.int32).copy(), th.debug_stage(2, 4 * T, np.int32).copy(), th.debug_stage(3, 4 * T, np.int32).copy())
+            th.close()
+        assert all(np.array_equal(a, b) for a, b in zip(got["0"], got["1"])), kw
+
+
 def test_emul_file_driver_pipeline(emu, tmp_path):
     """th_run_file_multi on the emulation library: reader -> device pipelines (upload / run / collect threads each; one or two per
     device, batches taken from the shared ticket counter, ramped batch sizes) -> writer; several batches, output order = input order, bytes equal to the oracle's command line"""

@@ -10,6 +10,7 @@ struct ThDevPara {
     int k;                       // k-mer length (-k)
     int w;                       // -w: minimizer window (1 = every k-mer)
     int w_seq;                   // TH_MINIMIZER_SEQ=1: minimizer selection by the sequential replay only (the tests' cross-check)
+    int sort_bitonic;            // TH_SORT_BITONIC=1: th_k_hits sorts with the bitonic network everywhere (no radix passes)
     int hpc;                     // -H: homopolymer-compressed k-mers (src/tandem_hit.c:46)
     uint32_t min_p, max_p;       // period limits, cast as at src/tandem_hit.c:235
     double one_minus_div;        // 1 - max_div (src/partition.c:202,252: the one double product on the path)
@@ -163,6 +164,81 @@ __device__ __forceinline__ void th_bitonic_sort(W *buf, int N, int tid)
         }
         if (N >= 1024 && stride >= 32) { reg_pass(32, size, stride); stride = 16; }
         if (N >= 32 && stride >= 1) reg_pass(1, size, stride);
+    }
+}
+
+// ---- workgroup LSD radix sort of 32-bit words in LDS by a key field, stable; ends with a barrier ----
+// For words whose order among equal keys is already right (th_k_hits: key << PB | position, written in position order), sorting by the key
+// FIELD alone with a stable sort gives the fully sorted sequence -- at 2 passes of 8-bit digits for 16 key bits, where the bitonic network
+// above makes 33 passes over the same buffer (105 compare-exchange stages at 16384 words) and fights the LDS banks at every stride.
+// Per pass: every wave owns a contiguous 1/WAVES of the array and walks it 64 words at a time (word = chunk base + step * 64 + lane: the
+// loads are conflict-free and land in registers, so the scatter can go back into the same buffer); the digits are counted per wave
+// (LDS atomics), a bin-major scan over (digit, wave) turns the counts into start offsets, and the scatter ranks the lanes of a step that
+// share a digit among themselves with eight ballots (match-any) -- lane order = array order, which is what keeps the sort stable.
+// Words equal to `none` sink to the end (an extra bin of the last pass).  N: a power of two, 64 * WAVES <= N <= 32 * 64 * WAVES.
+// hist: WAVES x (TH_RDX_BINS + 1) words of LDS; tot: 16 words.
+#define TH_RDX_BINS 256
+#define TH_RDX_STEPS 32
+template <int BLOCK>
+__device__ __forceinline__ void th_radix_sort_field(uint32_t *buf, int N, int shift, int kbits, uint32_t none, uint32_t (*hist)[TH_RDX_BINS + 1], int *tot, int tid)
+{
+    constexpr int WAVES = BLOCK / TH_WAVE;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int chunk = N / WAVES, steps = chunk >> 6;
+    uint32_t *my = buf + wave * chunk + lane;
+    const int passes = (kbits + 7) >> 3;
+    for (int p = 0; p < passes; ++p) {
+        const int sh = shift + 8 * p; const bool lastp = p == passes - 1;
+        const uint32_t dmask = lastp ? (1u << (kbits - 8 * p)) - 1u : 0xffu;
+        for (int x = tid; x < WAVES * (TH_RDX_BINS + 1); x += BLOCK) hist[0][x] = 0;
+        __syncthreads();
+        uint32_t v[TH_RDX_STEPS];
+#pragma unroll
+        for (int s_ = 0; s_ < TH_RDX_STEPS; ++s_) {
+            v[s_] = none;
+            if (s_ < steps) {
+                v[s_] = my[s_ << 6];
+                const uint32_t d = (lastp && v[s_] == none) ? TH_RDX_BINS : ((v[s_] >> sh) & dmask);
+                atomicAdd(&hist[wave][d], 1u);
+            }
+        }
+        __syncthreads();
+        {   // counts -> start offsets, bin-major over (digit, wave); the waves that hold bins 0 .. 255 scan their totals, bin 256 follows all of them
+            uint32_t t_ = 0;
+            if (tid < TH_RDX_BINS) for (int w = 0; w < WAVES; ++w) t_ += hist[w][tid];
+            const int inc = th_wave_incl_sum((int)t_);
+            if (tid < TH_RDX_BINS && lane == 63) tot[wave] = inc;
+            __syncthreads();
+            if (tid <= TH_RDX_BINS) {
+                uint32_t acc = 0;
+                if (tid < TH_RDX_BINS) { acc = (uint32_t)inc - t_; for (int w = 0; w < wave; ++w) acc += (uint32_t)tot[w]; }
+                else for (int w = 0; w < TH_RDX_BINS / TH_WAVE; ++w) acc += (uint32_t)tot[w];
+                for (int w = 0; w < WAVES; ++w) { const uint32_t c = hist[w][tid]; hist[w][tid] = acc; acc += c; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s_ = 0; s_ < TH_RDX_STEPS; ++s_) {
+            if (s_ < steps) {
+                const uint32_t d = (lastp && v[s_] == none) ? TH_RDX_BINS : ((v[s_] >> sh) & dmask);
+                unsigned long long mm = ~0ull;                      // lanes of this step with my digit
+#pragma unroll
+                for (int b = 0; b < 9; ++b) {
+                    if (b < 8 || lastp) {
+                        const bool bit = (d >> b) & 1u;
+                        const unsigned long long m = __ballot(bit);
+                        mm &= bit ? m : ~m;
+                    }
+                }
+                const int rank = th_mbcnt(mm), cnt = __popcll(mm);
+                const uint32_t base = hist[wave][d];
+                TH_WAVE_FENCE();                                    // every lane has read its group's offset before the group's last lane moves it on
+                if (rank == cnt - 1) hist[wave][d] = base + (uint32_t)cnt;
+                buf[base + (uint32_t)rank] = v[s_];
+                TH_WAVE_FENCE();
+            }
+        }
+        __syncthreads();
     }
 }
 

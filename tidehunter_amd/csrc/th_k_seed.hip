@@ -55,6 +55,7 @@ __global__ void th_k_encode(const uint8_t *__restrict__ seq, uint8_t *__restrict
 // W = uint32_t:           words key<<PB | pos when every word of the batch fits 32 bits and every read fits the LDS buffer:
 //                         PB 14 / CAP 16384 (k <= 9, reads < 16384 bases: 64 KiB, two workgroups per CU) or
 //                         PB 15 / CAP 32768 (k <= 8, reads < 32768 bases: 128 KiB); half the LDS traffic of the 64-bit sort.
+__device__ __forceinline__ bool th_env_bitonic(const ThDevPara &P) { return P.sort_bitonic != 0; }     // TH_SORT_BITONIC=1: the bitonic sort everywhere (A/B runs, the tests' cross-check)
 template <typename W, int PB, int CAP>
 __global__ void __launch_bounds__(TH_SEED_BLOCK)
 th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, ThDevPara P,
@@ -65,6 +66,7 @@ th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, T
     __shared__ W lds[CAP];
     const W NONE_W = (W)~(W)0;
     __shared__ int s_cnt[TH_SEED_BLOCK + 1];
+    __shared__ uint32_t s_hist[sizeof(W) == 4 ? TH_SEED_BLOCK / TH_WAVE : 1][TH_RDX_BINS + 1];     // the radix sort's digit counters (32-bit words only)
     __shared__ uint32_t s_wkey[256], s_wpos[256]; // -w > 1: the minimizer window (key, pos)
     __shared__ int s_runs[32];                    // -w > 1 with -H: lengths of the last k runs
     const int tid = threadIdx.x, r = blockIdx.x;
@@ -202,8 +204,14 @@ th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, T
     for (int p = tid; p < L; p += TH_SEED_BLOCK) tmp[off + p] = 0;
     __syncthreads();
 
-    // 2. bitonic sort, ascending on the full 64-bit word (key major, pos minor); sentinels sink to the end
-    th_bitonic_sort<W, false, TH_SEED_BLOCK>(buf, N, tid);
+    // 2. sort, ascending on the full word (key major, pos minor); sentinels sink to the end.  The 32-bit words of step 1 were written in
+    // position order, so a STABLE sort by the key field is the full sort: two radix passes (k = 8) instead of the bitonic network's 33
+    // passes over the buffer (round 4; 34 -> ms per 100 000 headline reads in profiles/r04_*).  The minimizer words (-w > 1) arrive in no
+    // particular order, 64-bit words and reads beyond 32 words per lane keep the bitonic sort.
+    if (sizeof(W) == 4 && P.w == 1 && N <= TH_RDX_STEPS * TH_SEED_BLOCK && N >= TH_SEED_BLOCK && buf == (W *)lds && !th_env_bitonic(P))
+        th_radix_sort_field<TH_SEED_BLOCK>((uint32_t *)lds, N, PB, 2 * k, 0xffffffffu, s_hist, s_cnt, tid);
+    else
+        th_bitonic_sort<W, false, TH_SEED_BLOCK>(buf, N, tid);
 
     // 3. nearest earlier occurrence at distance >= min_p (src/tandem_hit.c:192-196)
     for (int x = tid; x < ne; x += TH_SEED_BLOCK) {
