@@ -209,11 +209,15 @@ __device__ __forceinline__ void th_radix_sort_field(uint32_t *buf, int N, int sh
             const int inc = th_wave_incl_sum((int)t_);
             if (tid < TH_RDX_BINS && lane == 63) tot[wave] = inc;
             __syncthreads();
-            if (tid <= TH_RDX_BINS) {
-                uint32_t acc = 0;
-                if (tid < TH_RDX_BINS) { acc = (uint32_t)inc - t_; for (int w = 0; w < wave; ++w) acc += (uint32_t)tot[w]; }
-                else for (int w = 0; w < TH_RDX_BINS / TH_WAVE; ++w) acc += (uint32_t)tot[w];
+            if (tid < TH_RDX_BINS) {
+                uint32_t acc = (uint32_t)inc - t_;
+                for (int w = 0; w < wave; ++w) acc += (uint32_t)tot[w];
                 for (int w = 0; w < WAVES; ++w) { const uint32_t c = hist[w][tid]; hist[w][tid] = acc; acc += c; }
+            }
+            if (tid == TH_RDX_BINS % BLOCK) {          // the sentinels' bin: behind every word (a thread of its own in a block of 512, thread 0's second bin in one of 256)
+                uint32_t acc = 0;
+                for (int w = 0; w < TH_RDX_BINS / TH_WAVE; ++w) acc += (uint32_t)tot[w];
+                for (int w = 0; w < WAVES; ++w) { const uint32_t c = hist[w][TH_RDX_BINS]; hist[w][TH_RDX_BINS] = acc; acc += c; }
             }
         }
         __syncthreads();

@@ -355,15 +355,26 @@ th_k_chain_sort(const uint32_t *__restrict__ roff, ThDevPara P,
                 const int *__restrict__ score, uint16_t *__restrict__ xorder, int *__restrict__ xstart, int *__restrict__ xend)
 {
     __shared__ uint32_t s_key[TH_XFAST_MAX];
+    __shared__ uint32_t s_hist[TH_XS_BLOCK / TH_WAVE][TH_RDX_BINS + 1];
+    __shared__ int s_tot[16];
     const int tid = threadIdx.x, r = blockIdx.x;
     const uint32_t off = roff[r];
     const int n = hit_n[r];
     if (n > TH_XFAST_MAX || n < 2) return;
     const int *E = hit_end + off, *Pd = hit_per + off, *S = score + off;
     int N = 1; while (N < n) N <<= 1;
-    for (int i = tid; i < N; i += TH_XS_BLOCK) s_key[i] = i < n ? ((uint32_t)S[i] << 13 | (uint32_t)i) : 0u;
-    __syncthreads();
-    th_bitonic_sort<uint32_t, true, TH_XS_BLOCK>(s_key, N, tid);      // descending: best score first, ties keep the larger index first
+    if (N >= TH_XS_BLOCK && N <= TH_RDX_STEPS * TH_XS_BLOCK && !P.sort_bitonic) {
+        // round 4: the same order from a stable radix sort (th_dev.h).  Slot x holds hit n - 1 - x with the COMPLEMENT of its score in the key
+        // field: ascending by that field is best score first, and stability keeps slot order among equal scores = the larger index first.
+        // (A score is at least k + 1, so no word equals the all-ones sentinel of the empty slots, which sink to the end.)
+        for (int x = tid; x < N; x += TH_XS_BLOCK) { const int i = n - 1 - x; s_key[x] = x < n ? ((~(uint32_t)S[i] & 0x7ffffu) << 13 | (uint32_t)i) : 0xffffffffu; }
+        __syncthreads();
+        th_radix_sort_field<TH_XS_BLOCK>(s_key, N, 13, 19, 0xffffffffu, s_hist, s_tot, tid);
+    } else {
+        for (int i = tid; i < N; i += TH_XS_BLOCK) s_key[i] = i < n ? ((uint32_t)S[i] << 13 | (uint32_t)i) : 0u;
+        __syncthreads();
+        th_bitonic_sort<uint32_t, true, TH_XS_BLOCK>(s_key, N, tid);      // descending: best score first, ties keep the larger index first
+    }
     for (int x = tid; x < n; x += TH_XS_BLOCK) {
         const int cand = (int)(s_key[x] & 0x1fff);
         const int e = E[cand];
