@@ -399,8 +399,10 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
                         ThChainRec *__restrict__ rec, int rec_cap, int *__restrict__ rec_count,
                         int *__restrict__ read_ch_base, int *__restrict__ read_ch_n, int *__restrict__ err, int *__restrict__ queue)
 {
-    __shared__ short s_from[TH_XFAST_MAX];
-    __shared__ uint32_t s_trk[TH_XFAST_MAX / 32];
+    // from[] and the tracked flags in ONE 16-bit word per hit: bits 0..13 = predecessor + 1 (0: none), bit 15 = tracked.  The backtrack's test
+    // of the predecessor then reads the very word its next step needs (one dependent LDS read per cell instead of two: the walk is what
+    // this kernel waits for), and a window's tracked test comes with the candidates' predecessors (round 4; 34.8 -> ms in profiles/r04_*)
+    __shared__ unsigned short s_ft[TH_XFAST_MAX];
     // chain table: the first TH_TOPL slots in LDS, the rest (up to the reference's cap of 1000 chains) in the wave's HBM
     // overflow segment -- a read rarely keeps more than a few dozen chains, and 22 KB of LDS per wave for the full table
     // held the kernel at 4 waves per CU (157 -> 84 -> 52 ms per 100 000 reads with the sort split off and 8 waves) (it is bound by the latency of its sequential attempts)
@@ -423,8 +425,7 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
         const int *E = hit_end + off, *Pd = hit_per + off, *S = score + off, *F = from + off;
         int *CL = cells + off;
         const uint16_t *XO = xorder + off; const int *XS = xstart + off, *XE = xend + off;
-        for (int i = lane; i < n; i += TH_WAVE) s_from[i] = (short)F[i];
-        for (int i = lane; i < (n + 31) / 32; i += TH_WAVE) s_trk[i] = 0;
+        for (int i = lane; i < n; i += TH_WAVE) s_ft[i] = (unsigned short)(F[i] + 1);
         for (int i = lane; i < TH_TOPN; i += TH_WAVE) ch_idx.set(i, i);
         TH_WAVE_FENCE();
         int ch_n = 0, top = 0, ci = 0;
@@ -434,7 +435,8 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
             const bool valid = x < n;
             const int cand = valid ? (int)XO[x] : 0;
             const int cell_end = valid ? XE[x] : 0, cell_start = valid ? XS[x] : 0;
-            bool skip = !valid || ((s_trk[cand >> 5] >> (cand & 31)) & 1);
+            const int w0 = valid ? (int)s_ft[cand] : 0x8000;
+            bool skip = !valid || (w0 >> 15);
             bool open = !skip;                       // is_in_chain's scan is still running for this lane
             for (int q = 0; q < ch_n; ++q) {
                 const int c = ch_idx.get(q);
@@ -452,8 +454,8 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
             // has one cell, is rejected (:107) and the sort_chain that follows changes nothing.  They are
             // committed together up to the first candidate that needs a real walk.
             const bool nonskip = valid && !skip;
-            const int pre0 = nonskip ? (int)s_from[cand] : -1;
-            bool trivial = nonskip && (pre0 == -1 || ((s_trk[pre0 >> 5] >> (pre0 & 31)) & 1));
+            const int pre0 = nonskip ? (w0 & 0x3fff) - 1 : -1;
+            bool trivial = nonskip && (pre0 == -1 || (s_ft[pre0] >> 15));
             const unsigned long long nsm = __ballot(nonskip);
             if (nsm & (nsm - 1)) {                    // two or more live candidates: one may track another's predecessor
                 for (unsigned long long w = nsm; w; w &= w - 1) {
@@ -464,23 +466,26 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
             }
             const unsigned long long m = __ballot(nonskip && !trivial);
             const int f = th_ctz64(m);               // 64 when every live candidate of the window is trivial
-            if (nonskip && trivial && lane < f) atomicOr(&s_trk[cand >> 5], 1u << (cand & 31));
+            if (nonskip && trivial && lane < f) s_ft[cand] = (unsigned short)(w0 | 0x8000);      // (one 16-bit store per lane: the candidates of a window are distinct hits)
             TH_WAVE_FENCE();
             if (!m) { ci += TH_WAVE; continue; }
             const int c0 = TH_READLANE(cand, f);
             ci += f + 1;
             // ---- attempt: backtrack_dp into slot ch_n (wave-uniform scalar walk; cells written by lane 0) ----
             int sc = S[c0], cur = c0, len = 0;
+            int wc = TH_READLANE(w0, f);             // the word of `cur`: it is not tracked yet
             for (;;) {
-                if (lane == 0) { s_trk[cur >> 5] |= 1u << (cur & 31); CL[top + len] = cur; }
+                if (lane == 0) { s_ft[cur] = (unsigned short)(wc | 0x8000); CL[top + len] = cur; }
                 ++len;
-                TH_WAVE_FENCE();
-                const int pre = s_from[cur];
+                const int pre = (wc & 0x3fff) - 1;
                 if (pre == -1) break;
-                if ((s_trk[pre >> 5] >> (pre & 31)) & 1) { sc -= S[pre]; break; }
-                cur = pre;
-                TH_WAVE_FENCE();     // every lane has tested `pre` before lane 0 marks it in the next trip
+                TH_WAVE_FENCE();
+                const int wp = (int)s_ft[pre];       // the predecessor's flag AND its own predecessor: the only dependent read of the step
+                if (wp >> 15) { sc -= S[pre]; break; }
+                cur = pre; wc = wp;
+                TH_WAVE_FENCE();     // every lane has read the word of `pre` before lane 0 rewrites it in the next trip
             }
+            TH_WAVE_FENCE();
             const int nw = ch_n;
             const int cfirst = cur, clast = c0;      // the walk ran from the chain's last cell to its first
             int ok = 0;
