@@ -50,7 +50,8 @@ struct ThCnt {
     int n_retry;             // jobs the POA gave back (status 1-4, 7): the host takes the slow path when this is not 0
     int n_failed;            // jobs that stay without a consensus (status 5, 6)
     int q_poa_l;             // ... POA relative-int16 variant (long units)
-    int pad0[2];
+    int q_xw2;               // ... reads of the extraction waves, second instantiation (more than TH_XFAST_SMALL hits)
+    int pad0[1];
     // job build (the first seven in the column order of th_k_jobs_count: the scan writes them in one go)
     int par_total, n_task, n_unit, cons_total, aln_total, n_task_n, n_task_l;
     int max_unit, max_cons_cap, pad1;

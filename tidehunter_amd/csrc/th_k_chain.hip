@@ -12,6 +12,7 @@
 #define TH_XSORT_LDS 8192       // candidates sorted in LDS up to this many hits, else in HBM scratch
 #define TH_XBLOCK 256
 #define TH_XFAST_MAX 8192       // reads with at most this many hits take the one-wave-per-read extraction kernel
+#define TH_XFAST_SMALL 4608     // ... and those with at most this many its low-LDS instantiation
 
 enum { TH_NO_CON = 0, TH_REG_CON = 1, TH_SAME_CON = 2, TH_OVL_CON = 3 };
 
@@ -391,6 +392,11 @@ template <class T> struct ThTier {
     __device__ __forceinline__ int get(int i) const { return i < TH_TOPL ? (int)lds[i] : TH_LOAD_L2(ovf + (i - TH_TOPL)); }
     __device__ __forceinline__ void set(int i, int v) const { if (i < TH_TOPL) lds[i] = (T)v; else ovf[i - TH_TOPL] = v; }
 };
+// FMAX / FMIN: the kernel takes the reads with FMIN < hits <= FMAX (and, with FMIN = 0, the reads with fewer than two hits).  Two
+// instantiations share a batch: <TH_XFAST_SMALL, 0> keeps 9 KB of predecessor words per wave (14 waves per CU: the kernel is bound by
+// the latency of its sequential walks, so resident waves are what it needs) and serves every read of the headline shape (4230 hits on
+// average, 4521 at most), <TH_XFAST_MAX, TH_XFAST_SMALL> the reads beyond (8 waves per CU, as round 3 ran all of them).
+template <int FMAX, int FMIN>
 __global__ void __launch_bounds__(TH_XW_BLOCK)
 th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
                         const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ hit_n,
@@ -402,7 +408,7 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
     // from[] and the tracked flags in ONE 16-bit word per hit: bits 0..13 = predecessor + 1 (0: none), bit 15 = tracked.  The backtrack's test
     // of the predecessor then reads the very word its next step needs (one dependent LDS read per cell instead of two: the walk is what
     // this kernel waits for), and a window's tracked test comes with the candidates' predecessors (round 4; 34.8 -> ms in profiles/r04_*)
-    __shared__ unsigned short s_ft[TH_XFAST_MAX];
+    __shared__ unsigned short s_ft[FMAX];
     // chain table: the first TH_TOPL slots in LDS, the rest (up to the reference's cap of 1000 chains) in the wave's HBM
     // overflow segment -- a read rarely keeps more than a few dozen chains, and 22 KB of LDS per wave for the full table
     // held the kernel at 4 waves per CU (157 -> 84 -> 52 ms per 100 000 reads with the sort split off and 8 waves) (it is bound by the latency of its sequential attempts)
@@ -420,7 +426,7 @@ th_k_chain_extract_wave(const uint32_t *__restrict__ roff, int n_reads, ThDevPar
         if (r >= n_reads) break;
         const uint32_t off = roff[r];
         const int n = hit_n[r];
-        if (n > TH_XFAST_MAX) continue;
+        if (n > FMAX || (FMIN > 0 && n <= FMIN)) continue;
         if (n < 2) { if (lane == 0) { read_ch_base[r] = 0; read_ch_n[r] = 0; } continue; }     // src/tandem_chain.c:291
         const int *E = hit_end + off, *Pd = hit_per + off, *S = score + off, *F = from + off;
         int *CL = cells + off;

@@ -253,7 +253,7 @@ __global__ void th_k_cnt_rerun(ThCnt *C, int redo_extract, int redo_part)
 {
     if (threadIdx.x || blockIdx.x) return;
     C->err &= ~(TH_E_REC_OVERFLOW | TH_E_PART_OVERFLOW | TH_E_JOB_CAP);
-    if (redo_extract) { C->rec = 0; C->q_xw = 0; }
+    if (redo_extract) { C->rec = 0; C->q_xw = 0; C->q_xw2 = 0; }
     if (redo_part) { C->par_top = 0; C->q_part = 0; }
     C->need_n = 0; C->need_w = 0; C->need_l = 0; C->max_unit = 0; C->max_cons_cap = 0;
 }

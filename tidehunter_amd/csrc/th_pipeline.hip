@@ -107,7 +107,7 @@ struct th_gpu {
     int aln_wdiv = 10, aln_wadd = 24;     // first certified band of the unit alignments: half-width cons_len / wdiv + wadd
     int aln_xpct = 36;                    // flank extensions: band half-width requested from the anti-diagonal engine, percent of min(consensus, flank) (+ 8)
     int aln_wtol = 16, aln_mode = 1;      // anti-diagonal engine: accepted shortfall of its band against that half-width; 0 = strip engine only, 2 = verify against the full matrix
-    int waves_part = 8192, waves_poa = 6144, waves_aln = 8192, waves_xw = 2048;   // persistent grids: 256 CUs x 4 SIMDs x resident waves
+    int waves_part = 8192, waves_poa = 6144, waves_aln = 8192, waves_xw = 2048, waves_xw_small = 3584;   // persistent grids: 256 CUs x 4 SIMDs x resident waves (extraction: 256 CUs x 8 / x 14 waves by their LDS)
 };
 
 static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
@@ -158,6 +158,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
     g->waves_poa = env_int("TH_WAVES_POA", TH_PERSISTENT_WAVES(g->waves_poa));
     g->waves_aln = env_int("TH_WAVES_ALN", TH_PERSISTENT_WAVES(g->waves_aln));
     g->waves_xw = env_int("TH_WAVES_XW", TH_PERSISTENT_WAVES(g->waves_xw));
+    g->waves_xw_small = env_int("TH_WAVES_XW_SMALL", TH_PERSISTENT_WAVES(g->waves_xw_small));
     g->aln_wdiv = std::max(1, env_int("TH_ALN_WDIV", g->aln_wdiv)); g->aln_wadd = std::max(0, env_int("TH_ALN_WADD", g->aln_wadd));
     g->aln_wtol = std::max(0, env_int("TH_ALN_WTOL", g->aln_wtol)); g->aln_mode = env_int("TH_ALN_MODE", g->aln_mode); g->aln_xpct = std::max(0, env_int("TH_ALN_XPCT", g->aln_xpct));
     return g;
@@ -463,7 +464,7 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
     if (getenv("TH_REC_CAP")) rec_cap = std::max(1, atoi(getenv("TH_REC_CAP")));      // test knob: forces the arena-growth path
     TRY(th_ensure_work(g, n, padT));
     TRY(g->d_gsort.ensure((size_t)in.gsort_total));
-    TRY(g->d_xovf.ensure((size_t)std::min(n, g->waves_xw) * 7 * (TH_TOPN - TH_TOPL)));
+    TRY(g->d_xovf.ensure((size_t)std::min(n, std::max(g->waves_xw, g->waves_xw_small)) * 7 * (TH_TOPN - TH_TOPL)));
     TRY(g->d_rec.ensure(rec_cap));
     ThCnt *dc = g->d_cnt.p, *cnt = nullptr;
     if (in.ev_ok) TRY(th_rt_stream_wait_event(g->stream, in.ev));       // the batch's H2D copies (copy stream) before the first kernel
@@ -529,11 +530,15 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
                       (const int *)g->d_score.p, (const int *)g->d_from.p, g->d_tracked.p, g->d_cells.p,
                       g->d_gsort.p, (const long long *)in.d_gsort_off.p, g->d_rec.p, rec_cap, &dc->rec,
                       g->d_read_ch_base.p, g->d_read_ch_n.p, &dc->err);
-            TH_LAUNCH(th_k_chain_extract_wave, std::min(n, g->waves_xw), TH_XW_BLOCK, g->stream, (const uint32_t *)in.d_roff.p, n, g->dp,
-                      (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p,
-                      (const int *)g->d_score.p, (const int *)g->d_from.p, g->d_cells.p,
-                      (const uint16_t *)g->d_xorder.p, (const int *)g->d_xstart.p, (const int *)g->d_xend.p, g->d_xovf.p, g->d_rec.p, rec_cap, &dc->rec,
-                      g->d_read_ch_base.p, g->d_read_ch_n.p, &dc->err, &dc->q_xw);
+#define XW_LAUNCH(FMAX, FMIN, WV, Q) TH_LAUNCH((th_k_chain_extract_wave<FMAX, FMIN>), std::min(n, (WV)), TH_XW_BLOCK, g->stream, (const uint32_t *)in.d_roff.p, n, g->dp, \
+                      (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, \
+                      (const int *)g->d_score.p, (const int *)g->d_from.p, g->d_cells.p, \
+                      (const uint16_t *)g->d_xorder.p, (const int *)g->d_xstart.p, (const int *)g->d_xend.p, g->d_xovf.p, g->d_rec.p, rec_cap, &dc->rec, \
+                      g->d_read_ch_base.p, g->d_read_ch_n.p, &dc->err, (Q))
+            // (two instantiations, one after the other on the stream: they share the overflow segments, which are indexed by the wave)
+            XW_LAUNCH(TH_XFAST_SMALL, 0, g->waves_xw_small, &dc->q_xw);
+            XW_LAUNCH(TH_XFAST_MAX, TH_XFAST_SMALL, g->waves_xw, &dc->q_xw2);
+#undef XW_LAUNCH
             KT_END(TK_CHAIN_X);
         }
         if (redo_part) {
