@@ -93,7 +93,7 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
            const uint8_t *__restrict__ cons, const int *__restrict__ cons_len,
            int *__restrict__ bnd, long long bnd_stride, int *__restrict__ iden, int *__restrict__ ext, int *__restrict__ err, int *__restrict__ queue,
            int wdiv, int wadd, int wtol, int mode, int xpct, const int *__restrict__ n_items_ptr, ThAlnItem *__restrict__ defer, int *__restrict__ defer_n, int *__restrict__ wide_stat,
-           const int *__restrict__ item_s1, int *__restrict__ defer_s1)
+           const int *__restrict__ item_s1, int *__restrict__ defer_s1, int *__restrict__ aln_stat = nullptr)
 {
     // one LDS area, used either as the left-border inbox of the strip sweep (two 64-row blocks, 4 KB) or as the staged bases
     // of the anti-diagonal engine (never both at once)
@@ -145,6 +145,7 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                     while (np) {
                         v = th_ad_align<NPMAX>(np, qp, len, cs, cl, s_seq, &s1); have_s1 = true;
                         if (wide_first && np == np_first && np >= 3 && lane == 0) { atomicAdd(&wide_stat[0], 1); if (v < 0) atomicAdd(&wide_stat[1], 1); }
+                        if (aln_stat && lane == 0) { const int o_ = np == np_first ? 0 : 2; atomicAdd(&aln_stat[o_], 1); if (v < 0) atomicAdd(&aln_stat[o_ + 1], 1); }
                         if (v >= 0) break;
                         // not certified: the banded score s1 bounds the optimum from below, and a band whose Gmin exceeds
                         // (m + n - 2 s1 - 4q) / (1 + 2e) is certified for any optimum >= s1

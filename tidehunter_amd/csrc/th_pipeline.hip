@@ -670,7 +670,8 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
                   g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, &dc->err, (q), g->aln_wdiv, g->aln_wadd, g->aln_wtol
             const int big_first = nm, big_n = ni - big_first;           // (the second list is empty since round 3: th_aln_class)
             const int *no_n = nullptr, *no_s1 = nullptr; ThAlnItem *no_defer = nullptr; int *no_dn = nullptr, *no_ws = nullptr, *no_ds1 = nullptr;
-            if (nm) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(nm, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(0, nm, &dc->q_aln_s), g->aln_mode, g->aln_xpct, no_n, no_defer, no_dn, no_ws, no_s1, no_ds1);
+            int *aln_stat = trace ? dc->aln_first : (int *)nullptr;          // (TH_TRACE: first / second bands tried and not certified)
+            if (nm) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(nm, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(0, nm, &dc->q_aln_s), g->aln_mode, g->aln_xpct, no_n, no_defer, no_dn, no_ws, no_s1, no_ds1, aln_stat);
             if (big_n && big_first < ni) {
                 // the big-area variant hands the alignments its anti-diagonal engine could not certify on to a second launch of the small-area one
                 // (mode 3): same results, but their strip-engine work then runs at three waves per SIMD instead of one or two
@@ -717,6 +718,7 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
     if (cnt->err & TH_E_ALN_VERIFY) return th_fail("TH_ALN_MODE=2: a banded alignment differs from the full matrix");
     if (cnt->err) return th_fail("alignment boundary buffer overflow");
     out.n_jobs = nt;
+    if (trace) fprintf(stderr, "[th] unit alignments of the small-area launch: %d first bands, %d not certified; %d second bands, %d not certified\n", cnt->aln_first[0], cnt->aln_first[1], cnt->aln_first[2], cnt->aln_first[3]);
     if (trace) fprintf(stderr, "[th] %.3f s: run done, %d host synchronisations (this thread so far: device malloc %.3f s for %.2f GB in %d calls, free %.3f s)\n", th_wall_s() - t_run0, g->n_sync, g_alloc_s, g_alloc_bytes / 1e9, g_alloc_n, g_free_s);
     kt.collect(out.ms_k);
     out.ms_kernels = 0; out.ms_dominant = 0;
