@@ -18,9 +18,9 @@ the reference's THREAD_READ_I, src/main.c:277-281): then uploads happen inside t
 
 Prints ONE JSON line (rank 0) with `roofline` (the kernel with the largest device time, HIP-event timed on the
 kernel's own stream inside the library), `cpu_baseline` (the CPU oracle -- a scalar C port of the reference's algorithm,
-NOT the reference binary -- on the host cores, N=1 only), `value_streamed` (the same steps through th_process_batches(): H2D of
+NOT the reference binary -- on the host cores, N=1 only), `value_upload_inclusive` (the same steps through th_process_batches(): H2D of
 batch i+1 and the record arithmetic of batch i-1 overlap the kernels of batch i; inputs NOT resident), `value_e2e` (the command
-line on 10 x the read set, first byte parsed to last byte written, every run listed, cold and steady rates apart) and
+line on 20 x the read set, first byte parsed to last byte written, every run listed, cold and steady rates apart) and
 `other_shapes` (configs 2 / 4 / 5, three steps each, outside the headline's timed region) -- the last three at N=1 only.
 """
 import argparse
@@ -129,7 +129,7 @@ def cpu_baseline(read_at, n_reads, cfg):
 
 
 def cli_e2e(set_reads, copies, cfg, batch_opt, n_runs=2, pause_s=6.0):
-    """value_e2e: the command line on `copies` x the read set (>= 1 000 000 reads at the headline shape), wall-clock from the first byte
+    """value_e2e: the command line on `copies` x the read set (2 000 000 reads at the headline shape), wall-clock from the first byte
     parsed to the last byte written (th_run_file's own clock; process start and HIP initialisation are reported separately as
     `wall_with_startup_s`).  Every run is listed: the first is COLD (first GPU process of this bench: HIP initialisation, device
     allocation, page cache), `steady_reads_per_s` is the rate after the first full-size batch was complete (start-up excluded)."""
@@ -250,7 +250,7 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TH_BENCH_BATCH", "0")), help="reads per step per GPU (0: the config's default)")
     ap.add_argument("--steal", type=int, default=0, help="blocks per rank per step taken from a shared ticket counter (0: static partition by bases)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1: auto, 0: skip)")
-    ap.add_argument("--e2e", type=int, default=-1, help="copies of the read set in the end-to-end command-line run (-1: 10 for the headline workload, 0: skip)")
+    ap.add_argument("--e2e", type=int, default=-1, help="copies of the read set in the end-to-end command-line run (-1: 20 for the headline workload, 0: skip)")
     ap.add_argument("--streamed", type=int, default=-1, help="also time the steps through th_process_batches(), H2D inside (-1: at N=1, 0: skip)")
     ap.add_argument("--others", default=None, help="comma-separated configs for `other_shapes` (default: c2,c4,c5 with the headline workload at N=1; '' to skip)")
     ap.add_argument("--digest", action="store_true", help="add an md5 over all records of the timed steps in read order (tests)")
@@ -325,7 +325,7 @@ def main():
     e2e = None
     if rank == 0 and world == 1 and a.e2e != 0 and not (a.e2e < 0 and a.config != "c3") and "TH_BENCH_LIB" not in os.environ:      # (by default only for the headline workload)
         try:
-            e2e = cli_e2e(set_reads, a.e2e if a.e2e > 0 else 10, cfg, 32768)      # (32768 = the command line's default batch)
+            e2e = cli_e2e(set_reads, a.e2e if a.e2e > 0 else 20, cfg, 32768)      # (32768 = the command line's default batch; 20 x the set = 2 000 000 reads: start-up is ~0.2 s of each run)
         except Exception as ex:                       # reported, never fatal for the bench line
             e2e = {"error": repr(ex)[:400]}
     th = TH.TideHunter(device=local, lib_path=os.environ.get("TH_BENCH_LIB"), **kw)
@@ -552,13 +552,15 @@ def main():
         # under the kernels of batch i (what th_run_file does with batches from the reader)
         if world == 1 and a.steal == 0 and a.streamed != 0:
             ks = max(a.steps, 8)                       # (fill and drain of the three-stage pipeline are ~0.15 s: eight batches keep them near 2 %)
+            ctx = th.prepare_batches([my_batch] * ks)          # (argument arrays and result slots: what a C caller owns before the call)
             t0 = time.perf_counter(); c0 = cpu_now()
-            th.process_batches([my_batch] * ks)
+            th.run_prepared(ctx)
             if on_gpu:
                 torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            dt = time.perf_counter() - t0; c1 = cpu_now()
+            th.free_prepared(ctx)
             out["value_upload_inclusive"] = {"value": ks * len(my_batch) / dt, "unit": "reads/s", "steps": ks, "ms_per_step": 1000.0 * dt / ks, "inputs_resident_before_timing": False,
-                                             "ratio_to_value": ks * len(my_batch) / dt / value, "host_cpu_s_per_1M_reads": (cpu_now() - c0) * 1e6 / (ks * len(my_batch)),
+                                             "ratio_to_value": ks * len(my_batch) / dt / value, "host_cpu_s_per_1M_reads": (c1 - c0) * 1e6 / (ks * len(my_batch)),
                                              "what": "th_process_batches(): %d batches back to back, each taken from HOST memory inside the timed region -- H2D of batch i+1 and the record arithmetic "
                                                      "of batch i-1 under the kernels of batch i, pipeline fill and drain included (one pipeline; the command line of value_e2e runs two per device)" % ks}
             out["value_streamed"] = out["value_upload_inclusive"]          # (round 3's name for it)

@@ -186,9 +186,9 @@ class TideHunter:
         """host synchronisations (stream drains) of the last run()"""
         return self.lib.th_batch_syncs(self.h)
 
-    def process_batches(self, batches):
-        """th_process_batches(): the batches back to back through the upload / kernels / record-arithmetic pipeline; the result slots
-        stay with the library (use process() to look at records) -- this entry exists to time the pipelined seam"""
+    def prepare_batches(self, batches):
+        """marshals a list of batches for run_prepared(): the ctypes arrays and one tandem_seq_t array per batch (what a C caller has at hand
+        before it calls th_process_batches())"""
         nb = len(batches)
         uniq = {}
         for b in batches:                      # (the bench passes the same batch several times: marshal it once)
@@ -201,11 +201,25 @@ class TideHunter:
         a_lens = (ip * nb)(*[C.cast(uniq[id(b)][1], ip) for b in batches])
         a_n = (C.c_int * nb)(*[uniq[id(b)][2] for b in batches])
         a_out = (C.POINTER(TandemSeq) * nb)(*outs)
+        return dict(nb=nb, seqs=a_seqs, lens=a_lens, n=a_n, out=a_out, outs=outs, sizes=[max(len(b), 1) for b in batches], keep=(uniq, batches))
+
+    def run_prepared(self, ctx):
+        """th_process_batches() on prepared batches: upload, kernels and record arithmetic of neighbouring batches overlapped"""
+        self._check(self.lib.th_process_batches(self.h, ctx["nb"], ctx["seqs"], ctx["lens"], ctx["n"], ctx["out"]))
+
+    def free_prepared(self, ctx):
+        for o, n in zip(ctx["outs"], ctx["sizes"]):
+            self.lib.th_free_tandem_seq(o, n)
+        ctx["outs"] = []
+
+    def process_batches(self, batches):
+        """th_process_batches(): the batches back to back through the upload / kernels / record-arithmetic pipeline; the result slots
+        stay with the library (use process() to look at records) -- this entry exists to time the pipelined seam"""
+        ctx = self.prepare_batches(batches)
         try:
-            self._check(self.lib.th_process_batches(self.h, nb, a_seqs, a_lens, a_n, a_out))
+            self.run_prepared(ctx)
         finally:
-            for o, b in zip(outs, batches):
-                self.lib.th_free_tandem_seq(o, max(len(b), 1))
+            self.free_prepared(ctx)
 
     def process(self, seqs):
         """tidehunter_core() on every read of the batch; returns a list (per read) of record dicts."""
