@@ -28,7 +28,10 @@ __device__ __forceinline__ uint8_t th_code(uint8_t c)
     return r;
 }
 
-__global__ void th_k_encode(const uint8_t *__restrict__ seq, uint8_t *__restrict__ bseq, long long total)
+// total: a multiple of 16 (the upload pads the batch with 'N').  Besides the one-byte codes every later stage reads, the bases leave here
+// 2-BIT PACKED (pk2: base a in bits 2 (a & 15) .. of word a >> 4) with a mask of the positions that are not A/C/G/T (nmask: bit a & 31 of
+// word a >> 5): the k-mer words of th_k_hits are cut out of these streams, four dword loads per k-mer slot instead of k byte loads.
+__global__ void th_k_encode(const uint8_t *__restrict__ seq, uint8_t *__restrict__ bseq, long long total, uint32_t *__restrict__ pk2, uint16_t *__restrict__ nmask)
 {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
     // 16 bases per thread per trip: one dwordx4 load and store per lane (coalesced 1 KiB per wave)
@@ -36,17 +39,22 @@ __global__ void th_k_encode(const uint8_t *__restrict__ seq, uint8_t *__restrict
     const uint4 *s4 = (const uint4 *)seq; uint4 *d4 = (uint4 *)bseq;
     for (long long v = i; v < nvec; v += stride) {
         uint4 x = s4[v], y;
-        uint32_t in[4] = { x.x, x.y, x.z, x.w }, out[4];
+        uint32_t in[4] = { x.x, x.y, x.z, x.w }, out[4], pk = 0, nm = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             uint32_t o = 0;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) o |= (uint32_t)th_code((uint8_t)(in[w] >> (8 * b))) << (8 * b);
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t c = th_code((uint8_t)(in[w] >> (8 * b)));
+                o |= c << (8 * b); pk |= (c & 3u) << (2 * (4 * w + b)); nm |= (c >= 4u ? 1u : 0u) << (4 * w + b);
+            }
             out[w] = o;
         }
         y.x = out[0]; y.y = out[1]; y.z = out[2]; y.w = out[3];
         d4[v] = y;
+        pk2[v] = pk; nmask[v] = (uint16_t)nm;
     }
+    if (i == 0) { pk2[nvec] = 0; pk2[nvec + 1] = 0; nmask[nvec] = 0xffff; nmask[nvec + 1] = 0xffff; nmask[nvec + 2] = 0xffff; nmask[nvec + 3] = 0xffff; }      // (the words a window may reach beyond the last base)
     for (long long t = (nvec << 4) + i; t < total; t += stride) bseq[t] = th_code(seq[t]);
 }
 
@@ -61,7 +69,7 @@ __global__ void __launch_bounds__(TH_SEED_BLOCK)
 th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, ThDevPara P,
           int *__restrict__ hit_end, int *__restrict__ hit_per, int *__restrict__ hit_n,
           uint32_t *__restrict__ tmp, W *__restrict__ gsort, const long long *__restrict__ gsort_off,
-          int *__restrict__ err, int *__restrict__ n_seq_fallback)
+          int *__restrict__ err, int *__restrict__ n_seq_fallback, const uint32_t *__restrict__ pk2, const uint32_t *__restrict__ nmask)
 {
     __shared__ W lds[CAP];
     const W NONE_W = (W)~(W)0;
@@ -179,7 +187,17 @@ th_k_hits(const uint8_t *__restrict__ bseq, const uint32_t *__restrict__ roff, T
     // 1. words: key<<32 | pos of the k-mer's LAST base; any code >= 4 in the window kills the word
     for (int e = tid; e < N; e += TH_SEED_BLOCK) {
         W v = NONE_W;
-        if (e < ne && !P.hpc) {
+        if (e < ne && !P.hpc && pk2) {
+            // the k-mer of slot e cut out of the 2-bit stream (first base in the LOWEST bits: the reference shifts the first base to the top,
+            // src/tandem_hit.c:44 -- the self-hits depend on which words are EQUAL, not on their order, so any one-to-one key serves), and
+            // its k mask bits: any base that is not A/C/G/T kills the word (:41-43)
+            const unsigned long long a = (unsigned long long)off + (unsigned)e;
+            const uint32_t wi = (uint32_t)(a >> 4), sh = 2u * (uint32_t)(a & 15), mi = (uint32_t)(a >> 5), ms = (uint32_t)(a & 31);
+            const unsigned long long win = ((unsigned long long)pk2[wi + 1] << 32 | pk2[wi]) >> sh;
+            const unsigned long long mwin = ((unsigned long long)nmask[mi + 1] << 32 | nmask[mi]) >> ms;
+            const uint32_t key = (uint32_t)win & (k >= 16 ? 0xffffffffu : (1u << (2 * k)) - 1u);
+            if (((uint32_t)mwin & ((1u << k) - 1u)) == 0) v = (W)((W)key << PB | (uint32_t)(e + k - 1));
+        } else if (e < ne && !P.hpc) {
             uint32_t key = 0; bool ok = true;
             for (int x = 0; x < k; ++x) { uint8_t c = b[e + x]; ok = ok && c < 4; key = key << 2 | (c & 3); }
             if (ok) v = (W)((W)key << PB | (uint32_t)(e + k - 1));

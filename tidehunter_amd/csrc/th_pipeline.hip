@@ -88,7 +88,7 @@ struct th_gpu {
     ThIn in[2]; ThOut out[2]; int last_in = 0;
     uint8_t *h_stage[2] = { nullptr, nullptr }; th_event_t stage_ev[2]; bool stage_ok = false, stage_used[2] = { false, false }; int stage_cur = 0;   // pinned staging for the upload (2 x TH_STAGE_BYTES)
     DBuf<uint8_t> d_bseq, d_tracked, d_cons, d_cons_c;
-    DBuf<uint32_t> d_tmp;
+    DBuf<uint32_t> d_tmp, d_pk2, d_nmask;         // d_pk2 / d_nmask: the batch's bases 2-bit packed and the mask of the positions that are not A/C/G/T (th_k_encode)
     DBuf<uint16_t> d_xorder; DBuf<int> d_xstart, d_xend, d_xovf;
     DBuf<int> d_cov_c, d_cc_off;                           // compacted results
     DBuf<int> d_hit_end, d_hit_per, d_hit_n, d_score, d_from, d_cells, d_read_ch_base, d_read_ch_n;
@@ -172,7 +172,7 @@ extern "C" void th_gpu_destroy(th_gpu_t *g)
     if (g->sync_ev_ok) th_rt_event_destroy(g->sync_ev);
     g_arena = nullptr;
     for (int s = 0; s < 2; ++s) { g->in[s].d_seq.release(); g->in[s].d_roff.release(); g->in[s].d_gsort_off.release(); if (g->in[s].ev_ok) th_rt_event_destroy(g->in[s].ev); }
-    g->d_bseq.release(); g->d_tracked.release(); g->d_cons.release(); g->d_cons_c.release(); g->d_tmp.release(); g->d_xorder.release(); g->d_xstart.release(); g->d_xend.release(); g->d_xovf.release();
+    g->d_bseq.release(); g->d_tracked.release(); g->d_cons.release(); g->d_cons_c.release(); g->d_tmp.release(); g->d_pk2.release(); g->d_nmask.release(); g->d_xorder.release(); g->d_xstart.release(); g->d_xend.release(); g->d_xovf.release();
     g->d_cov_c.release(); g->d_cc_off.release(); g->d_hit_end.release(); g->d_hit_per.release(); g->d_hit_n.release(); g->d_score.release(); g->d_from.release(); g->d_cells.release();
     g->d_read_ch_base.release(); g->d_read_ch_n.release(); g->d_gsort.release(); g->d_eps.release(); g->d_cnt.release(); g->d_rec.release();
     g->d_par.release(); g->d_par_off.release(); g->d_par_n.release(); g->d_par_dst.release(); g->d_parc.release(); g->d_bnd.release(); g->d_scratch.release();
@@ -473,9 +473,11 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
     TH_LAUNCH(th_k_cnt_zero, 1, 64, g->stream, dc);
     const int enc_blocks = (int)std::min<long long>(2048, (T / 16 + 255) / 256 + 1);
     KT_BEGIN(TK_SEED);
-    TH_LAUNCH(th_k_encode, enc_blocks, 256, g->stream, (const uint8_t *)in.d_seq.p, g->d_bseq.p, (long long)T);
+    TRY(g->d_pk2.ensure(padT / 16 + 8)); TRY(g->d_nmask.ensure(padT / 32 + 8));
+    TH_LAUNCH(th_k_encode, enc_blocks, 256, g->stream, (const uint8_t *)in.d_seq.p, g->d_bseq.p, (long long)padT, g->d_pk2.p, (uint16_t *)g->d_nmask.p);
 #define HITS_LAUNCH(W, PB, CAP, GS) TH_LAUNCH((th_k_hits<W, PB, CAP>), n, TH_SEED_BLOCK, g->stream, (const uint8_t *)g->d_bseq.p, (const uint32_t *)in.d_roff.p, g->dp, \
-                  g->d_hit_end.p, g->d_hit_per.p, g->d_hit_n.p, g->d_tmp.p, GS, (const long long *)in.d_gsort_off.p, &dc->err, &dc->min_fb)
+                  g->d_hit_end.p, g->d_hit_per.p, g->d_hit_n.p, g->d_tmp.p, GS, (const long long *)in.d_gsort_off.p, &dc->err, &dc->min_fb, \
+                  (const uint32_t *)(env_int("TH_SEED_BYTES", 0) ? nullptr : g->d_pk2.p), (const uint32_t *)g->d_nmask.p)
     // 32-bit sort words when key << PB | pos stays below the all-ones sentinel and every read sorts in LDS
     if (g->dp.k <= 9 && in.max_len < 16384) HITS_LAUNCH(uint32_t, 14, 16384, (uint32_t *)nullptr);
     else if (g->dp.k <= 8 && in.max_len < 32768) HITS_LAUNCH(uint32_t, 15, 32768, (uint32_t *)nullptr);
