@@ -61,8 +61,9 @@ struct ThCnt {
     int n_defer, q_aln_d;    // unit alignments deferred to the strip-engine launch, and that launch's queue head
     int aln_wide[2];         // wide first bands (three registers per lane and more) tried / failed in the big-area alignment launch
     int max_need_big;        // bytes of staging area the largest item of the third alignment list could ask for
+    int n_item_long;         // unit alignments of jobs too long for a two-register first band (th_aln_class: probed on the small variant, or the big variant's)
     int aln_first[4];        // unit alignments: first bands tried / not certified on the anti-diagonal engine, second bands tried / not certified (TH_TRACE prints them)
-    int pad3[15];
+    int pad3[14];
 };
 static_assert(sizeof(ThCnt) == 256, "counter block");
 #define TH_E_REC_OVERFLOW 1       // chain record arena too small (rerun the extraction with a larger one)

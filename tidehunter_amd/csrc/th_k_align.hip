@@ -130,6 +130,9 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                     int s1 = 0; bool have_s1 = false;
                     // anti-diagonal engine: its band is as wide as its registers (>= W - wtol), so it also serves matrices narrower than the band
                     int np = (mode == 1 || mode == 2) ? th_ad_pick(len, cl, max(W - wtol, 0), LDSB, NPMAX) : 0;
+                    // no band of this variant's registers reaches the first band asked for (a long unit on the two-register variant: th_aln_class):
+                    // ONE register as a probe -- its banded score sizes the band that can be certified and prunes the strip sweep that follows
+                    if (np == 0 && (mode == 1 || mode == 2) && NPMAX <= 2 && th_ad_pick(len, cl, 0, LDSB, NPMAX) == 1) np = 1;
                     // A first band of three registers per lane or more (units of several thousand bases) that keeps failing its certificate in
                     // this launch -- pairs as divergent as config 4's, 15 % error: no band short of the matrix can be certified -- is probed
                     // with ONE register first: the probe's banded score sizes the band that could be certified, and the pair goes on to the

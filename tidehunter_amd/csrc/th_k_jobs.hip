@@ -200,11 +200,17 @@ struct ThAlnItem { int task, which; };   // which >= 0: unit index in the run; -
 // that variant runs at three waves per SIMD by its registers, which leaves 13 KB of LDS per wave) form the first list, the rest a
 // third one for the variant with a 16 / 24 KB area and up to 6 registers per lane (two waves per SIMD).  (Round 2 had a 4 KB and a 7 KB
 // list: the 4 KB one dated from a variant with five waves per SIMD.)  The two flank extensions of every job go to the first list.
+// Round 4: a job whose first band would want three registers per lane or more (units of several thousand bases) ALSO goes to the first list
+// when its sequences fit that variant's staging area with ONE register (up to ~5600 + 5600 bases): there it is probed with one register
+// and, where that cannot be certified, finished by the pruned strip engine in place -- at three waves per SIMD.  The six-register variant
+// ran those probes at two waves per SIMD, a launch of its own that was 162 of config 4's 966 ms (TH_ALN_PROBE_SMALL=0: round 3's routing).
 __device__ __forceinline__ int th_aln_class(const ThTask &T, int cl, int wdiv, int wadd, int wtol)
 {
-    const long long need2 = (long long)T.max_len + cl + 512 * 2 + 16;
+    const int probe_small = wtol >> 16; wtol &= 0xffff;                       // (the flag travels in the upper half of wtol)
+    const long long need2 = (long long)T.max_len + cl + 512 * 2 + 16, need1 = (long long)T.max_len + cl + 512 + 16;
     const bool two_regs = 2 * (cl / wdiv + wadd - wtol) + 2 + 64 <= 512;     // th_ad_pick would settle for NP <= 2
-    return (need2 <= TH_ALN_SMALL && two_regs) ? 0 : 2;
+    if (need2 <= TH_ALN_SMALL && two_regs) return 0;
+    return (probe_small && need1 <= TH_ALN_SMALL) ? (probe_small == 2 ? 1 : 0) : 2;      // (2: a list -- and a launch -- of their own on the same variant)
 }
 __global__ void __launch_bounds__(256)
 th_k_items_count(const int *__restrict__ n_tasks, const ThTask *__restrict__ tasks, int *__restrict__ cons_len, const int *__restrict__ status,
@@ -221,6 +227,7 @@ th_k_items_count(const int *__restrict__ n_tasks, const ThTask *__restrict__ tas
     const int cls = th_aln_class(T, cl, wdiv, wadd, wtol);
     c[cls] += T.pos_n - 1;
     if (cls == 2) atomicMax(&C->max_need_big, T.max_len + cl + 512 * 6 + 16);      // staging area the largest third-list item could ask for
+    if (cl > 0 && th_aln_class(T, cl, wdiv, wadd, wtol & 0xffff) == 2) atomicAdd(&C->n_item_long, T.pos_n - 1);     // (round 3's routing: what the long units add up to)
 #pragma unroll
     for (int k = 0; k < TH_ITEM_COLS; ++k) rows[(long long)t * TH_ITEM_COLS + k] = c[k];
     atomicMax(&C->max_cl, cl);

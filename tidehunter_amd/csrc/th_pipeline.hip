@@ -106,6 +106,8 @@ struct th_gpu {
     int n_sync = 0;
     int aln_wdiv = 10, aln_wadd = 24;     // first certified band of the unit alignments: half-width cons_len / wdiv + wadd
     int aln_xpct = 36;                    // flank extensions: band half-width requested from the anti-diagonal engine, percent of min(consensus, flank) (+ 8)
+    int aln_probe_small = 1;              // long units whose sequences fit the two-register variant's staging area are probed and finished there (th_aln_class)
+    int aln_probe_auto = 1;               // ... unless the batch BEFORE was mostly such units (config 4: there the dedicated launches of round 3 are faster, config 5 gains 6 %)
     int aln_wtol = 16, aln_mode = 1;      // anti-diagonal engine: accepted shortfall of its band against that half-width; 0 = strip engine only, 2 = verify against the full matrix
     int waves_part = 8192, waves_poa = 6144, waves_aln = 8192, waves_xw = 2048, waves_xw_small = 3584;   // persistent grids: 256 CUs x 4 SIMDs x resident waves (extraction: 256 CUs x 8 / x 14 waves by their LDS)
 };
@@ -160,7 +162,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
     g->waves_xw = env_int("TH_WAVES_XW", TH_PERSISTENT_WAVES(g->waves_xw));
     g->waves_xw_small = env_int("TH_WAVES_XW_SMALL", TH_PERSISTENT_WAVES(g->waves_xw_small));
     g->aln_wdiv = std::max(1, env_int("TH_ALN_WDIV", g->aln_wdiv)); g->aln_wadd = std::max(0, env_int("TH_ALN_WADD", g->aln_wadd));
-    g->aln_wtol = std::max(0, env_int("TH_ALN_WTOL", g->aln_wtol)); g->aln_mode = env_int("TH_ALN_MODE", g->aln_mode); g->aln_xpct = std::max(0, env_int("TH_ALN_XPCT", g->aln_xpct));
+    g->aln_wtol = std::max(0, env_int("TH_ALN_WTOL", g->aln_wtol)); g->aln_mode = env_int("TH_ALN_MODE", g->aln_mode); g->aln_xpct = std::max(0, env_int("TH_ALN_XPCT", g->aln_xpct)); g->aln_probe_small = std::min(3, std::max(0, env_int("TH_ALN_PROBE_SMALL", 1))); g->aln_probe_auto = getenv("TH_ALN_PROBE_SMALL") ? 0 : 1;
     return g;
 }
 
@@ -636,16 +638,17 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
             // ---- item lists of the alignment kernels and the compacted consensus offsets, per job, on the device ----
             KT_BEGIN(TK_ALIGN);
             TH_LAUNCH(th_k_items_count, (nt + 255) / 256, 256, g->stream, (const int *)&dc->n_task, (const ThTask *)g->d_tasks.p, g->d_cons_len.p, (const int *)g->d_status.p,
-                      g->aln_wdiv, g->aln_wadd, g->aln_wtol, g->d_rows.p, dc);
+                      g->aln_wdiv, g->aln_wadd, g->aln_wtol | g->aln_probe_small << 16, g->d_rows.p, dc);
             { ThScanCaps nocaps; nocaps.on = 0; for (int k = 0; k < 8; ++k) nocaps.v[k] = 0;
               TH_LAUNCH((th_k_scan_rows<TH_ITEM_COLS>), 1, 1024, g->stream, (const int *)&dc->n_task, 0, g->d_rows.p, &dc->n_item_s, nocaps, &dc->err); }
             TH_LAUNCH(th_k_items_emit, (nt + 255) / 256, 256, g->stream, (const int *)&dc->n_task, (const ThTask *)g->d_tasks.p, (const int *)g->d_cons_len.p, (const int *)g->d_status.p,
-                      g->aln_wdiv, g->aln_wadd, g->aln_wtol, (const int *)g->d_rows.p, (const ThCnt *)dc, g->d_items.p, g->d_cc_off.p, g->d_jobs.p);
+                      g->aln_wdiv, g->aln_wadd, g->aln_wtol | g->aln_probe_small << 16, (const int *)g->d_rows.p, (const ThCnt *)dc, g->d_items.p, g->d_cc_off.p, g->d_jobs.p);
             KT_END(TK_ALIGN);
             TRY(th_fetch_cnt(g, &cnt));                                                 // ---- host synchronisation 2 of 3 ----
             if (pass == 0 && cnt->n_retry) {
                 TRY(th_poa_retries(g, kt, in, nt, poa_test_fail));
                 TH_LAUNCH(th_k_cnt_set, 1, 64, g->stream, &dc->n_retry, 0, &dc->n_failed, 0, &dc->max_cl, 0, &dc->max_need_big, 0);
+                TH_LAUNCH(th_k_cnt_set, 1, 64, g->stream, &dc->n_item_long, 0, (int *)nullptr, 0, (int *)nullptr, 0, (int *)nullptr, 0);
                 continue;
             }
             break;
@@ -661,6 +664,9 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
 #endif
         // ---- unit-vs-consensus alignments and flank extensions: three item lists in one array, one kernel variant each ----
         const int ns = cnt->n_item_s, nm = ns + cnt->n_item_m, ni = nm + cnt->n_item_b, max_cl = cnt->max_cl;
+        // the routing of the NEXT batch's long units (th_aln_class): probed and finished on the small variant (measured: config 5 +6 %) unless they
+        // are most of the unit alignments (config 4: -5 % that way; its probes and strips keep the launches of their own)
+        if (g->aln_probe_auto && aln_total > 0) g->aln_probe_small = (long long)cnt->n_item_long * 2 > (long long)aln_total ? 0 : 1;
         const long long cc_total = cnt->cc_total;
         const long long bnd_aln = (std::max<long long>(((long long)max_cl + 128) * 4, ((long long)in.max_len + 128) * 2) + 3) & ~3LL;
         const int wa = std::min(ni, g->waves_aln);
@@ -673,20 +679,26 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
             const int big_first = nm, big_n = ni - big_first;           // (the second list is empty since round 3: th_aln_class)
             const int *no_n = nullptr, *no_s1 = nullptr; ThAlnItem *no_defer = nullptr; int *no_dn = nullptr, *no_ws = nullptr, *no_ds1 = nullptr;
             int *aln_stat = trace ? dc->aln_first : (int *)nullptr;          // (TH_TRACE: first / second bands tried and not certified)
-            if (nm) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(nm, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(0, nm, &dc->q_aln_s), g->aln_mode, g->aln_xpct, no_n, no_defer, no_dn, no_ws, no_s1, no_ds1, aln_stat);
+            // TH_ALN_PROBE_SMALL=3: the first launch, too, hands what its anti-diagonal engine cannot certify (long units after their one-register probe)
+            // on to the strip-engine launch at the end instead of finishing it in place
+            const bool defer_small = g->aln_probe_small == 3 && g->aln_mode == 1;
+            if (defer_small || (big_n && big_first < ni)) { TRY(g->d_defer.ensure((size_t)ni)); TRY(g->d_defer_s1.ensure((size_t)ni)); }
+            ThAlnItem *sd = defer_small ? g->d_defer.p : no_defer; int *sdn = defer_small ? &dc->n_defer : no_dn, *sds1 = defer_small ? g->d_defer_s1.p : no_ds1;
+            if (ns) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(0, ns, &dc->q_aln_s), g->aln_mode, g->aln_xpct, no_n, sd, sdn, no_ws, no_s1, sds1, aln_stat);
+            if (nm > ns) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(nm - ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(ns, nm - ns, &dc->q_aln_m), g->aln_mode, g->aln_xpct, no_n, sd, sdn, no_ws, no_s1, sds1, aln_stat);
             if (big_n && big_first < ni) {
                 // the big-area variant hands the alignments its anti-diagonal engine could not certify on to a second launch of the small-area one
                 // (mode 3): same results, but their strip-engine work then runs at three waves per SIMD instead of one or two
-                TRY(g->d_defer.ensure((size_t)big_n)); TRY(g->d_defer_s1.ensure((size_t)big_n));
                 // (16 KB of staging area when every item fits it -- units of up to ~6000 bases: eight waves per CU instead of six)
                 if (cnt->max_need_big <= TH_ALN_BIG16)
                     TH_LAUNCH((th_k_align<TH_ALN_BIG16, 6>), std::min(big_n, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(big_first, big_n, &dc->q_aln_b), g->aln_mode, g->aln_xpct, no_n, g->d_defer.p, &dc->n_defer, dc->aln_wide, no_s1, g->d_defer_s1.p);
                 else
                     TH_LAUNCH((th_k_align<TH_ALN_BIG, 6>), std::min(big_n, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(big_first, big_n, &dc->q_aln_b), g->aln_mode, g->aln_xpct, no_n, g->d_defer.p, &dc->n_defer, dc->aln_wide, no_s1, g->d_defer_s1.p);
-                if (g->aln_mode == 1) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(big_n, wa), TH_ALN_BLOCK, g->stream, (const ThAlnItem *)g->d_defer.p, 0, (const ThTask *)g->d_tasks.p, (const int *)g->d_parc.p,
-                              (const uint32_t *)in.d_roff.p, (const uint8_t *)g->d_bseq.p, (const uint8_t *)g->d_cons.p, (const int *)g->d_cons_len.p,
-                              g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, &dc->err, &dc->q_aln_d, g->aln_wdiv, g->aln_wadd, g->aln_wtol, 3, g->aln_xpct, (const int *)&dc->n_defer, no_defer, no_dn, no_ws, (const int *)g->d_defer_s1.p, no_ds1);
             }
+            if (g->aln_mode == 1 && (defer_small || (big_n && big_first < ni)))
+                TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(ni, wa), TH_ALN_BLOCK, g->stream, (const ThAlnItem *)g->d_defer.p, 0, (const ThTask *)g->d_tasks.p, (const int *)g->d_parc.p,
+                          (const uint32_t *)in.d_roff.p, (const uint8_t *)g->d_bseq.p, (const uint8_t *)g->d_cons.p, (const int *)g->d_cons_len.p,
+                          g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, &dc->err, &dc->q_aln_d, g->aln_wdiv, g->aln_wadd, g->aln_wtol, 3, g->aln_xpct, (const int *)&dc->n_defer, no_defer, no_dn, no_ws, (const int *)g->d_defer_s1.p, no_ds1);
 #undef TH_ALN_ARGS
         }
         KT_END(TK_ALIGN);
