@@ -211,6 +211,8 @@ EXT_CFGS = [
     ("expected score of 90 % of the flank: narrow first bands, retries through wider ones and the pruned strip engine", dict(mode=1, xpct=10)),
     ("expected score of 5 %: the widest band first", dict(mode=1, xpct=95)),
     ("big-area variant", dict(mode=1, variant=2)),
+    ("four-register probe for the long flanks (round 3's; the default is one: upper bits of xpct)", dict(mode=1, xpct=36 | 4 << 8)),
+    ("two-register probe, verified on the device", dict(mode=2, xpct=36 | 2 << 8)),
 ]
 
 

@@ -103,6 +103,10 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
     const int lane = TH_LANE();
     const int wave = blockIdx.x;
     int *mybnd = bnd + (long long)wave * bnd_stride;
+    // registers per lane of the flank extensions' PROBE (upper bits of xpct; 1 by default): a long flank no register band is expected to certify is
+    // probed for the lower bound that prunes its strip sweep -- the repeat's continuation hugs the main diagonal, so the narrowest band finds
+    // (nearly) the true maximum at a quarter of the four-register probe of round 3
+    const int xprobe = min(4, max(1, (xpct >> 8) ? (xpct >> 8) : 1)); xpct &= 0xff;
     if (n_items_ptr) n_items = TH_UNI(*n_items_ptr);
     for (;;) {
         const int it = th_queue_pop(queue);   // dynamic work queue: items range from a short extension to a full matrix
@@ -202,7 +206,7 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                             const int mn = min(cl, tlen), s_est = mn - (mn * xpct) / 100;
                             int np = 0;
                             for (int c = 1; c <= 4; ++c) if (th_adx_bound(c, cl, tlen) < s_est) { np = c; break; }
-                            if (!np && mn >= 1024) np = 4;
+                            if (!np && mn >= 1024) np = xprobe;
                             while (np && cl + tlen + 512 * np + 16 <= LDSB) {
                                 done = th_adx_align<4>(np, qp, st, cl, tp, st, tlen, s_seq, &mq, &mt, &bh);
                                 if (done || bh <= 0) break;
