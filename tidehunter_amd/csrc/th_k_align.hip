@@ -106,7 +106,9 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
     // registers per lane of the flank extensions' PROBE (upper bits of xpct; 1 by default): a long flank no register band is expected to certify is
     // probed for the lower bound that prunes its strip sweep -- the repeat's continuation hugs the main diagonal, so the narrowest band finds
     // (nearly) the true maximum at a quarter of the four-register probe of round 3
-    const int xprobe = min(4, max(1, (xpct >> 8) ? (xpct >> 8) : 1)); xpct &= 0xff;
+    const int xprobe = min(4, max(1, ((xpct >> 8) & 7) ? ((xpct >> 8) & 7) : 1));
+    const bool pkstrip = !((xpct >> 11) & 1);      // bit 11 of xpct (TH_ALN_PKSTRIP=0): the one-column strip engines only (A/B runs, the tests' cross-check)
+    xpct &= 0xff;
     if (n_items_ptr) n_items = TH_UNI(*n_items_ptr);
     for (;;) {
         const int it = th_queue_pop(queue);   // dynamic work queue: items range from a short extension to a full matrix
@@ -217,14 +219,30 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                             if (!done && bh > 0) {
                                 int W = 512;
                                 while (W < cl + tlen && th_ext_bound_w(W, cl, tlen) >= bh) W += 64;
-                                th_ksw_ext_band_wave(qp, st, cl, tp, st, tlen, W, bh, mybnd, s_in, &mq, &mt); done = true;        // exact for any lower bound bh (th_ksw.h)
+                                // exact for any lower bound bh (th_ksw.h); two columns per lane on packed int16 where the scores fit (round 4)
+                                if (pkstrip && cl + tlen <= TH_KSW_PK_MAXLEN) th_ksw_ext_band_pk_wave(qp, st, cl, tp, st, tlen, W, bh, mybnd, s_in, &mq, &mt);
+                                else th_ksw_ext_band_wave(qp, st, cl, tp, st, tlen, W, bh, mybnd, s_in, &mq, &mt);
+                                done = true;
                             }
                         }
                         if (!done) th_ksw_ext_wave(qp, st, cl, tp, st, tlen, mybnd, &mq, &mt);
-                        else if (mode == 2) {
+                        if (mode == 2) {
+                            // verification: the full matrix against whatever engine produced (mq, mt), and against BOTH pruned strip engines run with the
+                            // best lower bound at hand (the probe's banded maximum, or 1: any slb <= the true maximum must give the full matrix's cells)
                             int mq2 = -1, mt2 = -1;
                             th_ksw_ext_wave(qp, st, cl, tp, st, tlen, mybnd, &mq2, &mt2);
                             if ((mq2 != mq || mt2 != mt) && lane == 0) atomicOr(err, 64);
+                            const int slb2 = max(bh, 1);
+                            int W2 = 64;
+                            while (W2 < cl + tlen && th_ext_bound_w(W2, cl, tlen) >= slb2) W2 += 64;
+                            int a_ = -1, b_ = -1;
+                            th_ksw_ext_band_wave(qp, st, cl, tp, st, tlen, W2, slb2, mybnd, s_in, &a_, &b_);
+                            if ((a_ != mq2 || b_ != mt2) && lane == 0) atomicOr(err, 64);
+                            if (cl + tlen <= TH_KSW_PK_MAXLEN) {
+                                a_ = -1; b_ = -1;
+                                th_ksw_ext_band_pk_wave(qp, st, cl, tp, st, tlen, W2, slb2, mybnd, s_in, &a_, &b_);
+                                if ((a_ != mq2 || b_ != mt2) && lane == 0) atomicOr(err, 64);
+                            }
                         }
                     }
                 }

@@ -731,3 +731,122 @@ __device__ void th_ksw_ext_band_wave(const uint8_t *__restrict__ q, int qs, int 
     }
     if (bestH > 0) { *max_t = bestT; *max_q = bestR - bestT; } else { *max_t = -1; *max_q = -1; }
 }
+
+// ---- th_ksw_ext_band_wave on packed int16 pairs: TWO columns per lane (round 4) ----
+// Same cells, same pruning, same result as th_ksw_ext_band_wave above; strips of 128 columns.  Lane l owns columns j0 + 2l (low half) and
+// j0 + 2l + 1 (high half), the high half ONE ROW BEHIND the low one: at step s the low half is on row R - 2l, the high half on row R - 2l - 1
+// (R = rs + s), so that the high half's left neighbour is what the low half produced a step ago, and the low half's left neighbour is what
+// lane l - 1's high half produced a step ago.  Everything that flows to the right -- H, F' and the target base -- therefore moves by the same
+// two instructions per step: a DPP wave shift (lane 0 takes the strip's left border from the inbox, in the high half of the injected word) and
+// a v_alignbit that puts (own low half, left lane's high half) into (high, low).  The diagonal input is that left value one step later.
+// Rows outside a column's share of the sweep -- rs .. re, the band |i - j| <= W, columns beyond the query -- are two per-lane constants
+// (LOB, HIB); -32768 is minus infinity (the caller guarantees qlen + tlen <= TH_KSW_PK_MAXLEN: as in th_ksw_band_ad_wave every real value lies
+// within +-(qlen + tlen + 8), and an unreachable in-band cell can drift upwards by one per step from -32768, which stays below all of them).
+// Per step ~40 vector instructions for 128 cells where the one-column engine spends ~32 for 64.
+#define TH_KSW_PK_MAXLEN 24000
+__device__ void th_ksw_ext_band_pk_wave(const uint8_t *__restrict__ q, int qs, int qlen, const uint8_t *__restrict__ t, int ts, int tlen, int W, int slb,
+                                        int *__restrict__ bnd, int (*s_in)[TH_WAVE][8], int *max_q, int *max_t)
+{
+    const int lane = TH_LANE();
+    int2 *bnd2 = (int2 *)bnd;                 // {H, F'} of the parked column (ints; minus infinity = -32768 or below)
+    int bestH = 0, bestR = 0x7fffffff, bestT = -1;
+    int prs = 0, ppre = -1;
+    const uint32_t ONE2 = TH_AD_ONE, QQ = TH_PK_DUP(TH_KQ), EE = TH_PK_DUP(TH_KE);
+    for (int j0 = 0; j0 < qlen; j0 += 2 * TH_WAVE) {
+        const int c0 = j0 + 2 * lane, c1 = c0 + 1;
+        const bool ok0 = c0 < qlen, ok1 = c1 < qlen;
+        const uint32_t Qp = TH_PK(ok0 ? q[(long long)c0 * qs] : 4, ok1 ? q[(long long)c1 * qs] : 4);
+        const uint32_t NQ = th_ad_is4(Qp);
+        const bool first = j0 == 0, last = j0 + 2 * TH_WAVE >= qlen;
+        int rs = max(0, j0 - W), re = min(tlen - 1, j0 + 2 * TH_WAVE - 1 + W);
+        if (j0 > W) {                                                          // entries through the parked column only: the rows its live cells can reach
+            int vmin = 0x7fffffff, vmax = -1;
+            const int B = qlen - j0;
+            for (int r0 = prs; r0 <= ppre; r0 += TH_WAVE) {
+                const int row = r0 + lane;
+                if (row <= ppre) {
+                    const int H = bnd2[row].x, A = tlen - 1 - row;
+                    if (H + min(A, B) >= slb) { vmin = min(vmin, row); vmax = max(vmax, row + 2 * TH_WAVE + min(H + B - slb, (H + A - slb) >> 1)); }
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { vmin = min(vmin, __shfl_xor(vmin, d)); vmax = max(vmax, __shfl_xor(vmax, d)); }
+            rs = max(rs, vmin); re = min(re, vmax);
+        }
+        rs = TH_UNI(rs); re = TH_UNI(re);
+        if (rs > re) break;
+        const int nsteps = re - rs + 2 * TH_WAVE;
+        // rows of each half's column inside the sweep: [max(rs, c - W), min(re, c + W)]; nothing for a column beyond the query
+        const uint32_t LOB = TH_PK(ok0 ? max(rs, c0 - W) : 32767, ok1 ? max(rs, c1 - W) : 32767), HIB = TH_PK(ok0 ? min(re, c0 + W) : -32768, ok1 ? min(re, c1 + W) : -32768);
+        const uint32_t ETOP = TH_PK(-(TH_KQ + (c0 + 1) * TH_KE) - TH_KQ - TH_KE, -(TH_KQ + (c1 + 1) * TH_KE) - TH_KQ - TH_KE);        // E entering row 0
+        const uint32_t HDTOP = TH_PK(c0 == 0 ? 0 : -(TH_KQ + c0 * TH_KE), -(TH_KQ + c1 * TH_KE));                                  // H(-1, c - 1)
+        uint32_t rowv = TH_PK(rs - 2 * lane, rs - 2 * lane - 1);
+        uint32_t Hout = TH_PK_NEG, Fout = TH_PK_NEG, Tcur = 0x00040004u, Ecol = TH_PK_NEG, Hdiag = TH_PK_NEG;
+        uint32_t lbH = TH_PK_DUP(bestH - 1), lbT = TH_PK_DUP(-1);
+        int2 nb = { TH_NEG, TH_NEG }; int nt = 4;
+        { const int row = rs + lane; if (row < tlen) { nt = t[(long long)row * ts]; if (!first && row >= prs && row <= ppre) nb = bnd2[row]; } }
+        for (int s0 = 0; s0 < nsteps; s0 += TH_WAVE) {
+            int (*inbox)[8] = s_in[(s0 >> 6) & 1];
+            {
+                int4 ib;
+                // (the injected word's HIGH half is what lane 0's low half takes)
+                if (first) { const int hb = -(TH_KQ + (rs + s0 + lane + 1) * TH_KE); ib.x = (int)((uint32_t)hb << 16); ib.y = (int)((uint32_t)(hb - TH_KQ - TH_KE) << 16); }
+                else { ib.x = (int)((uint32_t)max(nb.x, -32768) << 16); ib.y = (int)((uint32_t)max(nb.y, -32768) << 16); }
+                ib.z = nt << 16; ib.w = 0;
+                *(int4 *)&inbox[lane][0] = ib;
+            }
+            TH_WAVE_FENCE();
+            {
+                const int row = rs + s0 + TH_WAVE + lane;
+                nt = 4; nb.x = TH_NEG; nb.y = TH_NEG;
+                if (row < tlen) { nt = t[(long long)row * ts]; if (!first && row >= prs && row <= ppre) nb = bnd2[row]; }
+            }
+            const int kend = min(TH_WAVE, nsteps - s0);
+            const bool top_ok = rs == 0 && s0 < 3 * TH_WAVE;      // a half meets row 0 within the first 128 steps of a sweep that starts at row 0
+            int4 in = *(const int4 *)&inbox[0][0];
+            auto step = [&](int k, int4 &cin, int4 &nin) {
+                const uint32_t L = th_alignbit16(Hout, (uint32_t)th_shr1_inject((int)Hout, cin.x));
+                const uint32_t Fl = th_alignbit16(Fout, (uint32_t)th_shr1_inject((int)Fout, cin.y));
+                Tcur = th_alignbit16(Tcur, (uint32_t)th_shr1_inject((int)Tcur, cin.z));
+                { const int kn = min(k + 1, TH_WAVE - 1); nin = *(const int4 *)&inbox[kn][0]; }
+                if (top_ok) { const uint32_t TOPM = th_pk_negmask_op(th_pk_sub(rowv, ONE2)); Ecol = th_sel(TOPM, ETOP, Ecol); Hdiag = th_sel(TOPM, HDTOP, Hdiag); }      // rows <= 0: the top border's values
+                const uint32_t EM = th_pk_negmask_op(th_pk_sub(Tcur ^ Qp, ONE2));
+                uint32_t sc = th_sel(EM, ONE2, 0xfffefffeu);
+                sc = th_sel(th_ad_is4(Tcur) | NQ, 0xffffffffu, sc);
+                const uint32_t h = th_pk_max(th_pk_max(th_pk_add(Hdiag, sc), Ecol), Fl);
+                Hdiag = L;
+                const uint32_t hq = th_pk_sub(h, QQ);
+                const uint32_t nE = th_pk_sub(th_pk_max(Ecol, hq), EE), nF = th_pk_sub(th_pk_max(Fl, hq), EE);
+                const uint32_t OUT = th_pk_negmask_op(th_pk_sub(rowv, LOB) | th_pk_sub(HIB, rowv));
+                Hout = th_sel(OUT, TH_PK_NEG, h); Ecol = th_sel(OUT, TH_PK_NEG, nE); Fout = th_sel(OUT, TH_PK_NEG, nF);
+                const uint32_t upd = th_pk_negmask_op(th_pk_sub(lbH, Hout));                    // a strictly greater H: within a strip a half's anti-diagonal only grows
+                lbH = th_pk_max(lbH, Hout); lbT = th_sel(upd, rowv, lbT);
+                if (!last && lane == 63) {
+                    const int row = rs + s0 + k - 2 * 63 - 1;
+                    if (row >= rs && row <= re) { int2 o; o.x = TH_PK_HI(Hout); o.y = TH_PK_HI(Fout); bnd2[row] = o; }
+                }
+                rowv = th_pk_add(rowv, ONE2);
+            };
+            int4 in2;
+            int k = 0;
+            for (; k + 1 < kend; k += 2) { step(k, in, in2); step(k + 1, in2, in); }
+            if (k < kend) step(k, in, in2);
+        }
+        // this strip's two columns into the lane's running best (as th_ksw_ext_wave does per strip)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int lH = hh ? TH_PK_HI(lbH) : TH_PK_LO(lbH), lT = hh ? TH_PK_HI(lbT) : TH_PK_LO(lbT), jc = hh ? c1 : c0;
+            if (lT >= 0 && (lH > bestH || (lH == bestH && (lT + jc < bestR || (lT + jc == bestR && th_ext_rank(bestR, lT, qlen, tlen) < th_ext_rank(bestR, bestT, qlen, tlen)))))) { bestH = lH; bestR = lT + jc; bestT = lT; }
+        }
+        prs = rs; ppre = re;
+        TH_WAVE_FENCE();
+    }
+    int bestRank = bestT >= 0 ? th_ext_rank(bestR, bestT, qlen, tlen) : 0x7fffffff;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int oH2 = __shfl_xor(bestH, d), oR = __shfl_xor(bestR, d), oK = __shfl_xor(bestRank, d), oT = __shfl_xor(bestT, d);
+        const bool take = oH2 > bestH || (oH2 == bestH && (oR < bestR || (oR == bestR && oK < bestRank)));
+        if (take) { bestH = oH2; bestR = oR; bestRank = oK; bestT = oT; }
+    }
+    if (bestH > 0) { *max_t = bestT; *max_q = bestR - bestT; } else { *max_t = -1; *max_q = -1; }
+}
