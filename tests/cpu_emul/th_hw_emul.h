@@ -69,6 +69,7 @@ static inline uint32_t th_ubfe(uint32_t v, uint32_t off, uint32_t w) { return (v
 static inline uint32_t th_cvt_pk_i16(int lo, int hi) { return TH_PK(th_sat16_(lo), th_sat16_(hi)); }     // two ints to a saturated int16 pair
 // v_perm_b32: result byte k is picked by selector byte k: 0..3 byte of s1, 4..7 byte of s0, 12 the constant 0 (the other codes are not used here)
 static inline int th_mbcnt(unsigned long long m) { return __builtin_popcountll(m & ((1ull << TH_LANE()) - 1)); }
+#define TH_ALN_OCC              // (th_k_align.hip: an occupancy attribute of the device build)
 #define TH_PERM_SIGNS 0x0b090a08u
 #define TH_PERM_SIGNS8 0x09080b0au
 static inline uint32_t th_and_or(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | c; }

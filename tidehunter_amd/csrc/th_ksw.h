@@ -850,3 +850,128 @@ __device__ void th_ksw_ext_band_pk_wave(const uint8_t *__restrict__ q, int qs, i
     }
     if (bestH > 0) { *max_t = bestT; *max_q = bestR - bestT; } else { *max_t = -1; *max_q = -1; }
 }
+
+// ---- th_ksw_global_band_wave on packed int16 pairs: two columns per lane (round 4; geometry as th_ksw_ext_band_pk_wave) ----
+// Same band [lo, hi], same pruning with a lower bound slb, same tie rules and path functional (CH / T1 / T2: the '=' columns along ksw_backtrack's
+// path), same certificate -- interchangeable with th_ksw_global_band_wave bit for bit.  Five quantities flow to the right (H, F', CH, T2 and the
+// target base), two instructions each; comparisons are sign bits of saturating differences, selections are v_bfi.  The caller guarantees
+// qlen + tlen <= TH_KSW_PK_MAXLEN ('=' counts are at most min(qlen, tlen)).  bnd: ((tlen + 63) & ~63) * 4 ints; s_in: two 64-row inbox blocks.
+__device__ int th_ksw_global_band_pk_wave(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, int W, int *__restrict__ bnd, int (*s_in)[TH_WAVE][8], int *band_score, int slb = TH_NEG)
+{
+    const int lane = TH_LANE();
+    const int D = tlen - qlen;
+    const int lo = min(0, D) - W, hi = max(0, D) + W;
+    int4 *bnd4 = (int4 *)bnd;
+    const uint32_t ONE2 = TH_AD_ONE, QQ = TH_PK_DUP(TH_KQ), EE = TH_PK_DUP(TH_KE);
+    uint32_t res_c = 0, res_h = TH_PK_NEG;
+    int prs = 0, ppre = -1;
+    for (int j0 = 0; j0 < qlen; j0 += 2 * TH_WAVE) {
+        const int c0 = j0 + 2 * lane, c1 = c0 + 1;
+        const bool ok0 = c0 < qlen, ok1 = c1 < qlen;
+        const uint32_t Qp = TH_PK(ok0 ? q[c0] : 4, ok1 ? q[c1] : 4);
+        const uint32_t NQ = th_ad_is4(Qp);
+        const bool first = j0 == 0, last = j0 + 2 * TH_WAVE >= qlen;
+        int rs = max(0, j0 + lo), re = min(tlen - 1, j0 + 2 * TH_WAVE - 1 + hi);
+        if (slb > TH_NEG && j0 + lo > 0) {
+            int vmin = 0x7fffffff, vmax = -1;
+            const int b = qlen - j0;
+            for (int r0 = prs; r0 <= ppre; r0 += TH_WAVE) {
+                const int row = r0 + lane;
+                if (row <= ppre) {
+                    const int H = bnd4[row].x, a = tlen - 1 - row, dab = a > b ? a - b : b - a;
+                    if (H + min(a, b) - dab * TH_KE >= slb) { vmin = min(vmin, row); vmax = max(vmax, row + 2 * TH_WAVE + min(H + b - slb, (H + a - slb) >> 1)); }
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { vmin = min(vmin, __shfl_xor(vmin, d)); vmax = max(vmax, __shfl_xor(vmax, d)); }
+            rs = max(rs, vmin); re = min(re, vmax);
+        }
+        rs = TH_UNI(rs); re = TH_UNI(re);
+        if (rs > re) { *band_score = TH_NEG; return -1; }
+        const int nsteps = re - rs + 2 * TH_WAVE;
+        const uint32_t LOB = TH_PK(ok0 ? max(rs, c0 + lo) : 32767, ok1 ? max(rs, c1 + lo) : 32767), HIB = TH_PK(ok0 ? min(re, c0 + hi) : -32768, ok1 ? min(re, c1 + hi) : -32768);
+        // the top border (row -1) where it lies inside the band: cell (-1, c) has d = -1 - c, cell (-1, c - 1) has d = -c
+        const int et0 = (-1 - c0 >= lo) ? -(TH_KQ + (c0 + 1) * TH_KE) - TH_KQ - TH_KE : -32768, et1 = (-1 - c1 >= lo) ? -(TH_KQ + (c1 + 1) * TH_KE) - TH_KQ - TH_KE : -32768;
+        const int hd0 = c0 == 0 ? 0 : ((-c0 >= lo) ? -(TH_KQ + c0 * TH_KE) : -32768), hd1 = (-c1 >= lo) ? -(TH_KQ + c1 * TH_KE) : -32768;
+        const uint32_t ETOP = TH_PK(et0, et1), HDTOP = TH_PK(hd0, hd1);
+        // the step at which the owner of cell (tlen - 1, qlen - 1) computes it (last strip): row R - 2 l - half = tlen - 1
+        const int own_l = ((qlen - 1) - j0) >> 1, own_h = ((qlen - 1) - j0) & 1;
+        const int rstar = tlen - 1 + 2 * own_l + own_h;
+        uint32_t rowv = TH_PK(rs - 2 * lane, rs - 2 * lane - 1);
+        uint32_t Hout = TH_PK_NEG, Fout = TH_PK_NEG, Cout = 0, T2out = 0, Tcur = 0x00040004u, Ecol = TH_PK_NEG, T1 = 0, Hdiag = TH_PK_NEG, Cdiag = 0;
+        int4 nb = { TH_NEG, TH_NEG, 0, 0 }; int nt = 4;
+        { const int row = rs + lane; if (row < tlen) { nt = t[row]; if (!first && row >= prs && row <= ppre) nb = bnd4[row]; } }
+        for (int s0 = 0; s0 < nsteps; s0 += TH_WAVE) {
+            int (*inbox)[8] = s_in[(s0 >> 6) & 1];
+            {
+                int4 ib; int ibT = nt << 16;
+                if (first) {
+                    const int row = rs + s0 + lane;
+                    const bool inb = row + 1 <= hi;                     // border column -1 has d = row + 1
+                    const int hb = inb ? -(TH_KQ + (row + 1) * TH_KE) : -32768, fb = inb ? hb - TH_KQ - TH_KE : -32768;
+                    ib.x = (int)((uint32_t)hb << 16); ib.y = (int)((uint32_t)fb << 16); ib.z = 0; ib.w = 0;
+                } else { ib.x = (int)((uint32_t)max(nb.x, -32768) << 16); ib.y = (int)((uint32_t)max(nb.y, -32768) << 16); ib.z = (int)((uint32_t)nb.z << 16); ib.w = (int)((uint32_t)nb.w << 16); }
+                *(int4 *)&inbox[lane][0] = ib; inbox[lane][4] = ibT;
+            }
+            TH_WAVE_FENCE();
+            {
+                const int row = rs + s0 + TH_WAVE + lane;
+                nt = 4; nb.x = TH_NEG; nb.y = TH_NEG; nb.z = 0; nb.w = 0;
+                if (row < tlen) { nt = t[row]; if (!first && row >= prs && row <= ppre) nb = bnd4[row]; }
+            }
+            const int kend = min(TH_WAVE, nsteps - s0);
+            const bool top_ok = rs == 0 && s0 < 3 * TH_WAVE;
+            int4 in = *(const int4 *)&inbox[0][0]; int inT = inbox[0][4];
+            auto step = [&](int k, int4 &cin, int &cinT, int4 &nin, int &ninT) {
+                const uint32_t L = th_alignbit16(Hout, (uint32_t)th_shr1_inject((int)Hout, cin.x));
+                const uint32_t Fl = th_alignbit16(Fout, (uint32_t)th_shr1_inject((int)Fout, cin.y));
+                const uint32_t Cl = th_alignbit16(Cout, (uint32_t)th_shr1_inject((int)Cout, cin.z));
+                const uint32_t T2l = th_alignbit16(T2out, (uint32_t)th_shr1_inject((int)T2out, cin.w));
+                Tcur = th_alignbit16(Tcur, (uint32_t)th_shr1_inject((int)Tcur, cinT));
+                { const int kn = min(k + 1, TH_WAVE - 1); nin = *(const int4 *)&inbox[kn][0]; ninT = inbox[kn][4]; }
+                if (top_ok) {
+                    const uint32_t TOPM = th_pk_negmask_op(th_pk_sub(rowv, ONE2));      // rows <= 0
+                    Ecol = th_sel(TOPM, ETOP, Ecol); T1 &= ~TOPM; Hdiag = th_sel(TOPM, HDTOP, Hdiag); Cdiag &= ~TOPM;
+                }
+                const uint32_t EM = th_pk_negmask_op(th_pk_sub(Tcur ^ Qp, ONE2));
+                uint32_t sc = th_sel(EM, ONE2, 0xfffefffeu);
+                sc = th_sel(th_ad_is4(Tcur) | NQ, 0xffffffffu, sc);
+                // ties prefer the diagonal over E over F (ksw2_extz2_sse.c:177-195)
+                const uint32_t diag = th_pk_add(Hdiag, sc);
+                const uint32_t g_e = th_pk_negmask_op(th_pk_sub(diag, Ecol));                 // E > diagonal
+                const uint32_t h1 = th_pk_max(diag, Ecol);
+                const uint32_t g_f = th_pk_negmask_op(th_pk_sub(h1, Fl));                     // F > both
+                const uint32_t h = th_pk_max(h1, Fl);
+                const uint32_t hq = th_pk_sub(h, QQ);
+                const uint32_t xe = th_pk_negmask_op(th_pk_sub(hq, Ecol)), xf = th_pk_negmask_op(th_pk_sub(hq, Fl));
+                const uint32_t ch = th_sel(g_f, T2l, th_sel(g_e, T1, th_pk_sub(Cdiag, EM)));
+                const uint32_t t1 = th_sel(xe, T1, ch), t2 = th_sel(xf, T2l, ch);
+                Hdiag = L; Cdiag = Cl; T1 = t1;
+                const uint32_t nE = th_pk_sub(th_pk_max(Ecol, hq), EE), nF = th_pk_sub(th_pk_max(Fl, hq), EE);
+                const uint32_t OUT = th_pk_negmask_op(th_pk_sub(rowv, LOB) | th_pk_sub(HIB, rowv));
+                Hout = th_sel(OUT, TH_PK_NEG, h); Ecol = th_sel(OUT, TH_PK_NEG, nE); Fout = th_sel(OUT, TH_PK_NEG, nF); Cout = ch; T2out = t2;
+                if (last && rs + s0 + k == rstar) { res_c = ch; res_h = h; }          // (wave-uniform test; the owner's lane and half are picked below)
+                if (!last && lane == 63) {
+                    const int row = rs + s0 + k - 2 * 63 - 1;
+                    if (row >= rs && row <= re) { int4 o; o.x = TH_PK_HI(Hout); o.y = TH_PK_HI(Fout); o.z = TH_PK_HI(Cout); o.w = TH_PK_HI(T2out); bnd4[row] = o; }
+                }
+                rowv = th_pk_add(rowv, ONE2);
+            };
+            int4 in2; int in2T;
+            int k = 0;
+            for (; k + 1 < kend; k += 2) { step(k, in, inT, in2, in2T); step(k + 1, in2, in2T, in, inT); }
+            if (k < kend) step(k, in, inT, in2, in2T);
+        }
+        if (last) {
+            const uint32_t rc = (uint32_t)TH_READLANE((int)res_c, own_l), rh = (uint32_t)TH_READLANE((int)res_h, own_l);
+            res_c = (uint32_t)(own_h ? TH_PK_HI(rc) : TH_PK_LO(rc)); res_h = (uint32_t)(own_h ? TH_PK_HI(rh) : TH_PK_LO(rh));
+        }
+        prs = rs; ppre = re;
+        TH_WAVE_FENCE();
+    }
+    const int iden = (int)res_c, hsc = (int)res_h <= -32768 ? TH_NEG : (int)res_h;
+    const int gmin = 2 * W + 2 + (D < 0 ? -D : D);
+    *band_score = hsc;
+    if (2LL * hsc > (long long)(qlen + tlen - gmin) - 4 * TH_KQ - 2LL * gmin * TH_KE) return iden;
+    return -1;
+}
