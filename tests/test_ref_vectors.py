@@ -84,7 +84,7 @@ def test_oracle_edlib_matches_reference_vectors(ev):
 def _bind(lib):
     u8p, ip = C.POINTER(C.c_uint8), C.POINTER(C.c_int)
     lib.th_debug_align_pairs.argtypes = [C.c_int, C.c_int, C.c_int, u8p, ip, u8p, ip, ip, ip, ip]
-    lib.th_debug_global_pairs.argtypes = [C.c_int, C.c_int, u8p, ip, u8p, ip, ip, C.c_int, ip, ip]
+    lib.th_debug_global_pairs.argtypes = [C.c_int, C.c_int, u8p, ip, u8p, ip, ip, C.c_int, ip, ip, C.c_int]
     lib.th_debug_adapter.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_char_p), ip, ip, C.c_int, u8p, ip, ip]
     return lib
 
@@ -113,12 +113,12 @@ def align_pairs(lib, v, idx, kind, cfg):
     return (out if kind == 0 else out.reshape(n, 2)), st
 
 
-def global_pairs(lib, v, idx):
+def global_pairs(lib, v, idx, banded=0):
     qc, qo, tc, to = _subset(v, idx)
     n = len(idx)
     x = np.ascontiguousarray(v["q_left_ext"][idx], dtype=np.int32)
     iden = np.full(n, -12345, dtype=np.int32); tb = np.full((n, x.shape[1]), -12345, dtype=np.int32)
-    rc = lib.th_debug_global_pairs(0, n, _p(qc, C.c_uint8), _p(qo, C.c_int), _p(tc, C.c_uint8), _p(to, C.c_int), _p(x, C.c_int), x.shape[1], _p(iden, C.c_int), _p(tb, C.c_int))
+    rc = lib.th_debug_global_pairs(0, n, _p(qc, C.c_uint8), _p(qo, C.c_int), _p(tc, C.c_uint8), _p(to, C.c_int), _p(x, C.c_int), x.shape[1], _p(iden, C.c_int), _p(tb, C.c_int), banded)
     assert rc == 0
     return iden, tb
 
@@ -158,8 +158,9 @@ def test_emul_engines_match_reference_vectors(emu_lib, kv, ev):
     for kind, key in ((1, "left_ext"), (2, "right_ext")):
         got, st = align_pairs(emu_lib, kv, idx[::2], kind, dict(mode=1))
         assert st[0] == 0 and (got == kv[key][idx[::2]]).all(), kind
-    iden, tb = global_pairs(emu_lib, kv, idx[::3])
-    assert (iden == kv["iden"][idx[::3]]).all() and (tb == kv["t_back"][idx[::3]]).all()
+    for banded in (0, 1):
+        iden, tb = global_pairs(emu_lib, kv, idx[::3], banded)
+        assert (iden == kv["iden"][idx[::3]]).all() and (tb == kv["t_back"][idx[::3]]).all(), banded
     rows = list(range(0, 40, 3))
     for g in (0, 2):
         assert (adapter(emu_lib, ev, g, False, rows) == ev["res"][rows][:, 4 * g:4 * g + 4]).all()
@@ -228,10 +229,12 @@ def test_gpu_flank_extensions_match_reference_vectors(gpu_lib, kv, label, cfg):
 
 
 @pytest.mark.gpu
-def test_gpu_global_with_cigar_backprojection_matches_reference_vectors(gpu_lib, kv):
-    """th_ksw_global_wave (the partition's engine): iden_n and ksw2_backtrack_left_end for four q_left_ext per pair"""
+@pytest.mark.parametrize("banded", [0, 1], ids=["full_matrix", "certified_band_then_pruned_band"])
+def test_gpu_global_with_cigar_backprojection_matches_reference_vectors(gpu_lib, kv, banded):
+    """the partition's engines (th_ksw_global_wave; th_ksw_global_r_wave: the packed strip engine with the back-projection functional): iden_n and
+    ksw2_backtrack_left_end for four q_left_ext per pair"""
     idx = np.arange(len(kv["iden"]))
-    iden, tb = global_pairs(gpu_lib, kv, idx)
+    iden, tb = global_pairs(gpu_lib, kv, idx, banded)
     assert (iden == kv["iden"]).all(), np.nonzero(iden != kv["iden"])[0][:5]
     bad = np.nonzero((tb != kv["t_back"]).any(axis=1))[0]
     assert len(bad) == 0, (bad[:5], tb[bad[:3]], kv["t_back"][bad[:3]], kv["q_left_ext"][bad[:3]])

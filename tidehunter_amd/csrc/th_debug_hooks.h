@@ -12,8 +12,9 @@
 // the full-matrix engine with the CIGAR functionals (the partition's engine), one pair per wave
 __global__ void __launch_bounds__(64)
 th_k_debug_global(int n, const uint8_t *__restrict__ q, const int *__restrict__ qo, const uint8_t *__restrict__ t, const int *__restrict__ to,
-                  const int *__restrict__ q_left_ext, int n_ext, int *__restrict__ bnd, long long bnd_stride, int *__restrict__ iden, int *__restrict__ tback, int *__restrict__ queue)
+                  const int *__restrict__ q_left_ext, int n_ext, int *__restrict__ bnd, long long bnd_stride, int *__restrict__ iden, int *__restrict__ tback, int *__restrict__ queue, int banded)
 {
+    __shared__ int s_in[2][TH_WAVE][8];
     int *mybnd = bnd + (long long)blockIdx.x * bnd_stride;
     for (;;) {
         const int i = th_queue_pop(queue);
@@ -24,7 +25,7 @@ th_k_debug_global(int n, const uint8_t *__restrict__ q, const int *__restrict__ 
         for (int e = 0; e < n_ext; ++e) {
             const int x = q_left_ext[(long long)i * n_ext + e];
             int tb = -1;
-            const int v = x >= 0 && x <= ql ? th_ksw_global_wave<true>(q + qo[i], ql, t + to[i], tl, x, mybnd, &tb) : -1;
+            const int v = x >= 0 && x <= ql ? th_ksw_global_r_wave(q + qo[i], ql, t + to[i], tl, x, mybnd, s_in, &tb, banded != 0) : -1;      // (banded: the partition's flow -- certified band, pruned wider band, full matrix)
             if (TH_LANE() == 0) tback[(long long)i * n_ext + e] = (x >= 0 && x <= ql && v == v0) ? tb : -0x7fffffff;      // (both instantiations must agree on iden_n)
         }
     }
@@ -103,7 +104,7 @@ extern "C" int th_debug_align_pairs(int device, int kind, int n, const uint8_t *
 
 // ksw2_global_with_cigar + ksw2_backtrack_left_end on the partition's engine (th_ksw_global_wave): iden[i], and tback[i * n_ext + e] for
 // q_left_ext[i * n_ext + e] (-0x7fffffff where the value is outside 0 .. qlen)
-extern "C" int th_debug_global_pairs(int device, int n, const uint8_t *q_cat, const int *q_off, const uint8_t *t_cat, const int *t_off, const int *q_left_ext, int n_ext, int *iden, int *tback)
+extern "C" int th_debug_global_pairs(int device, int n, const uint8_t *q_cat, const int *q_off, const uint8_t *t_cat, const int *t_off, const int *q_left_ext, int n_ext, int *iden, int *tback, int banded)
 {
     if (th_rt_set_device(device)) return th_fail("hipSetDevice failed");
     if (n <= 0) return 0;
@@ -121,7 +122,7 @@ extern "C" int th_debug_global_pairs(int device, int n, const uint8_t *q_cat, co
     TH_LAUNCH(th_k_cnt_zero, 1, 64, s, dc);
     const uint8_t *p_q = (const uint8_t *)d_q.p, *p_t = (const uint8_t *)d_t.p; const int *p_qo = (const int *)d_qo.p, *p_to = (const int *)d_to.p, *p_x = (const int *)d_x.p;
     int *p_bnd = (int *)d_bnd.p, *p_iden = (int *)d_iden.p, *p_tb = (int *)d_tb.p;
-    TH_LAUNCH(th_k_debug_global, waves, 64, s, n, p_q, p_qo, p_t, p_to, p_x, n_ext, p_bnd, stride, p_iden, p_tb, &dc->q_part);
+    TH_LAUNCH(th_k_debug_global, waves, 64, s, n, p_q, p_qo, p_t, p_to, p_x, n_ext, p_bnd, stride, p_iden, p_tb, &dc->q_part, banded);
     TRY(th_rt_d2h(iden, d_iden.p, (size_t)n * 4, s));
     if (n_ext > 0) TRY(th_rt_d2h(tback, d_tb.p, (size_t)n * n_ext * 4, s));
     TRY(th_rt_sync(s));

@@ -10,6 +10,7 @@ struct ThDevPara {
     int k;                       // k-mer length (-k)
     int w;                       // -w: minimizer window (1 = every k-mer)
     int w_seq;                   // TH_MINIMIZER_SEQ=1: minimizer selection by the sequential replay only (the tests' cross-check)
+    int part_full;               // TH_PART_FULL=1: the partition's bridging alignments on the full matrix only (round 3; A/B runs and the tests' cross-check)
     int sort_bitonic;            // TH_SORT_BITONIC=1: th_k_hits sorts with the bitonic network everywhere (no radix passes)
     int hpc;                     // -H: homopolymer-compressed k-mers (src/tandem_hit.c:46)
     uint32_t min_p, max_p;       // period limits, cast as at src/tandem_hit.c:235

@@ -78,10 +78,11 @@ long long th_debug_stage(struct th_handle *h, int what, void *dst, long long cap
  * th_debug_align_pairs: kind 0 ksw2_global -> out[i] = iden_n; kind 1 / 2 ksw2_left_ext / ksw2_right_ext -> out[2i], out[2i+1] = (max_q, max_t), all through
  * th_k_align; cfg = { variant 0 <12288,2> / 1 <16384,6> / 2 <24576,6>, TH_ALN_MODE, wdiv, wadd, wtol, xpct, defer }; stats (8 ints, may be NULL):
  * error flags, deferred items, wide first bands tried / failed.
- * th_debug_global_pairs: ksw2_global_with_cigar + ksw2_backtrack_left_end on the partition's engine.
+ * th_debug_global_pairs: ksw2_global_with_cigar + ksw2_backtrack_left_end on the partition's engines (banded 0: the full matrix; 1: its flow of round 4 --
+ * certified band on the packed strip engine, pruned wider band, full matrix).
  * th_debug_adapter: edlib_align_HW of four queries against every target (doubled 0: raw bytes, th_k_adapter_reads; 1: codes, searched over target + target, th_k_adapter). */
 int th_debug_align_pairs(int device, int kind, int n, const uint8_t *q_cat, const int *q_off, const uint8_t *t_cat, const int *t_off, const int *cfg, int *out, int *stats);
-int th_debug_global_pairs(int device, int n, const uint8_t *q_cat, const int *q_off, const uint8_t *t_cat, const int *t_off, const int *q_left_ext, int n_ext, int *iden, int *tback);
+int th_debug_global_pairs(int device, int n, const uint8_t *q_cat, const int *q_off, const uint8_t *t_cat, const int *t_off, const int *q_left_ext, int n_ext, int *iden, int *tback, int banded);
 int th_debug_adapter(int device, int doubled, const char *const queries[4], const int qlen[4], const int k[4], int n, const uint8_t *t_cat, const int *t_off, int *out);
 
 /* host CPU budget (th_host.c; exported for bench.py and the tests, not part of the public header) */

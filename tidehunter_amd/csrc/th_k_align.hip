@@ -168,7 +168,7 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                     }
                     // (the strip engines: two columns per lane on packed int16 where the scores fit -- round 4 -- else one column per lane in 32 bits)
                     const bool pkg = pkstrip && len + cl <= TH_KSW_PK_MAXLEN;
-                    if (!ad_first && mode != 3 && 64 + 2 * W + aD < (cl * 3) / 4) { v = pkg ? th_ksw_global_band_pk_wave(qp, len, cs, cl, W, mybnd, s_in, &s1) : th_ksw_global_band_wave(qp, len, cs, cl, W, mybnd, s_in, &s1); have_s1 = true; }
+                    if (!ad_first && mode != 3 && 64 + 2 * W + aD < (cl * 3) / 4) { v = pkg ? th_ksw_global_band_pk_wave<false>(qp, len, cs, cl, W, mybnd, s_in, &s1) : th_ksw_global_band_wave(qp, len, cs, cl, W, mybnd, s_in, &s1); have_s1 = true; }
                     if (mode == 3) { s1 = item_s1[it]; have_s1 = s1 != TH_ALN_NO_S1; }       // deferred by the launch before, with its banded score
                     if (v < 0 && defer && mode == 1) {          // what is left is strip-engine work (a wider certified band, the full matrix): on that engine's own launch
                         int slot = 0;
@@ -181,7 +181,7 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                         const long long W2 = (g2 - 2 - aD + 1) / 2 + 8;
                         // (with the banded score as a lower bound the engine also drops every cell no path of that score can pass through:
                         // never more work than the matrix, so no area test)
-                        if (W2 > W && W2 < 30000) { const int lb = s1; v = pkg ? th_ksw_global_band_pk_wave(qp, len, cs, cl, (int)W2, mybnd, s_in, &s1, lb) : th_ksw_global_band_wave(qp, len, cs, cl, (int)W2, mybnd, s_in, &s1, lb); }
+                        if (W2 > W && W2 < 30000) { const int lb = s1; v = pkg ? th_ksw_global_band_pk_wave<false>(qp, len, cs, cl, (int)W2, mybnd, s_in, &s1, lb) : th_ksw_global_band_wave(qp, len, cs, cl, (int)W2, mybnd, s_in, &s1, lb); }
                     }
                     if (v < 0) v = th_ksw_global_wave<false>(qp, len, cs, cl, 0, mybnd, nullptr);
                     if (mode == 2) {

@@ -18,6 +18,7 @@ th_k_partition(const ThChainRec *__restrict__ rec, const int *__restrict__ n_rec
                int *__restrict__ par, int par_cap, int *__restrict__ par_top, int *__restrict__ par_off, int *__restrict__ par_n,
                int *__restrict__ bnd, long long bnd_stride, int *__restrict__ err, int cap_mul, int *__restrict__ queue)
 {
+    __shared__ int s_in[2][TH_WAVE][8];              // the packed strip engine's inbox (th_ksw_global_r_wave)
     const int lane = TH_LANE();
     const int wave = blockIdx.x;
     int *mybnd = bnd + (long long)wave * bnd_stride;
@@ -65,7 +66,9 @@ th_k_partition(const ThChainRec *__restrict__ rec, const int *__restrict__ n_rec
                 const int ql = s2 - s1 + k, tl = e2 - e1 + k;
                 if ((long long)((tl + 63) & ~63) * 6 > bnd_stride) { bad = 1; break; }
                 int bt = 0;
-                const int iden = th_ksw_global_wave<true>(b + s1 - k + 1, ql, b + e1 - k + 1, tl, s2 - e, mybnd, &bt);
+                // (round 4: a certified band first -- two inter-anchor spans of a repeat differ by the read's error rate -- instead of the full matrix
+                // in 32 bits on one wave, which at 5000-base periods was 50 ms during which the rest of the device had nothing to do)
+                const int iden = th_ksw_global_r_wave(b + s1 - k + 1, ql, b + e1 - k + 1, tl, s2 - e, mybnd, s_in, &bt, !P.part_full);
                 if ((double)iden >= (double)min(ql, tl) * P.one_minus_div) {
                     s = e; e = e2 - bt;
                     if (e == s) break;                       // no progress: ch_i = ch.len, :254-256

@@ -28,6 +28,11 @@
 #pragma once
 #include "th_dev.h"
 
+// The full-matrix engines are the last resort of every caller (a fraction of a per cent of the alignments): as functions of their own they
+// stay out of the callers' register allocation and instruction stream (they touch global memory only, so nothing is lost by not inlining them)
+#ifndef TH_KSW_FULL_ATTR
+#define TH_KSW_FULL_ATTR TH_NOINLINE
+#endif
 #define TH_KQ 2   // gap open
 #define TH_KE 1   // gap extend
 
@@ -37,7 +42,7 @@ __device__ __forceinline__ int th_ksw_sc(int a, int b) { return (a == 4 || b == 
 // ((tlen+63)&~63) * (WITH_R ? 6 : 4) ints (16-byte aligned).  Returns iden_n; *tback = back-projection
 // of q_left_ext.  Every lane of the wave must call; results are wave-uniform.
 template <bool WITH_R>
-__device__ int th_ksw_global_wave(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen,
+__device__ TH_KSW_FULL_ATTR int th_ksw_global_wave(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen,
                                   int q_left_ext, int *__restrict__ bnd, int *tback)
 {
     const int lane = TH_LANE();
@@ -564,7 +569,7 @@ __device__ __forceinline__ int th_ext_rank(int r, int t, int qlen, int tlen)
     return 1 + 4 * 0x1000000 + (t - en1);
 }
 
-__device__ void th_ksw_ext_wave(const uint8_t *__restrict__ q, int qs, int qlen, const uint8_t *__restrict__ t, int ts, int tlen,
+__device__ TH_KSW_FULL_ATTR void th_ksw_ext_wave(const uint8_t *__restrict__ q, int qs, int qlen, const uint8_t *__restrict__ t, int ts, int tlen,
                                 int *__restrict__ bnd, int *max_q, int *max_t)
 {
     const int lane = TH_LANE();
@@ -856,14 +861,22 @@ __device__ void th_ksw_ext_band_pk_wave(const uint8_t *__restrict__ q, int qs, i
 // path), same certificate -- interchangeable with th_ksw_global_band_wave bit for bit.  Five quantities flow to the right (H, F', CH, T2 and the
 // target base), two instructions each; comparisons are sign bits of saturating differences, selections are v_bfi.  The caller guarantees
 // qlen + tlen <= TH_KSW_PK_MAXLEN ('=' counts are at most min(qlen, tlen)).  bnd: ((tlen + 63) & ~63) * 4 ints; s_in: two 64-row inbox blocks.
-__device__ int th_ksw_global_band_pk_wave(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, int W, int *__restrict__ bnd, int (*s_in)[TH_WAVE][8], int *band_score, int slb = TH_NEG)
+// WITH_R: also the back-projection of ksw2_backtrack_left_end for q_left_ext (R0 / R1 / R2 of th_ksw_global_wave: the target bases the path consumes
+// from the point where the query's last q_left_ext bases begin), *tback; bnd then holds 6 ints per row.  Certified like iden_n: every optimal path
+// and every candidate that ties with one lies inside the band, so the functional is the full matrix's.
+template <bool WITH_R>
+__device__ int th_ksw_global_band_pk_wave(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, int W, int *__restrict__ bnd, int (*s_in)[TH_WAVE][8], int *band_score, int slb = TH_NEG,
+                                          int q_left_ext = 0, int *tback = nullptr)
 {
     const int lane = TH_LANE();
     const int D = tlen - qlen;
     const int lo = min(0, D) - W, hi = max(0, D) + W;
     int4 *bnd4 = (int4 *)bnd;
+    const int tpad = (tlen + 63) & ~63;
+    int2 *bndr = (int2 *)(bnd + 4 * tpad);    // {R0, R2} of the parked column (WITH_R)
+    const int jstar = qlen - q_left_ext;      // first column of the query suffix (WITH_R)
     const uint32_t ONE2 = TH_AD_ONE, QQ = TH_PK_DUP(TH_KQ), EE = TH_PK_DUP(TH_KE);
-    uint32_t res_c = 0, res_h = TH_PK_NEG;
+    uint32_t res_c = 0, res_h = TH_PK_NEG, res_r = 0;
     int prs = 0, ppre = -1;
     for (int j0 = 0; j0 < qlen; j0 += 2 * TH_WAVE) {
         const int c0 = j0 + 2 * lane, c1 = c0 + 1;
@@ -899,8 +912,11 @@ __device__ int th_ksw_global_band_pk_wave(const uint8_t *__restrict__ q, int qle
         const int rstar = tlen - 1 + 2 * own_l + own_h;
         uint32_t rowv = TH_PK(rs - 2 * lane, rs - 2 * lane - 1);
         uint32_t Hout = TH_PK_NEG, Fout = TH_PK_NEG, Cout = 0, T2out = 0, Tcur = 0x00040004u, Ecol = TH_PK_NEG, T1 = 0, Hdiag = TH_PK_NEG, Cdiag = 0;
-        int4 nb = { TH_NEG, TH_NEG, 0, 0 }; int nt = 4;
-        { const int row = rs + lane; if (row < tlen) { nt = t[row]; if (!first && row >= prs && row <= ppre) nb = bnd4[row]; } }
+        uint32_t R0out = 0, R2out = 0, R1 = 0, R0diag = 0;
+        const uint32_t JSM = (c0 == jstar ? 0xffffu : 0u) | (c1 == jstar ? 0xffff0000u : 0u);       // this lane's column(s) where the query suffix begins
+        const uint32_t TL2 = TH_PK_DUP(tlen);
+        int4 nb = { TH_NEG, TH_NEG, 0, 0 }; int2 nr = { 0, 0 }; int nt = 4;
+        { const int row = rs + lane; if (row < tlen) { nt = t[row]; if (!first && row >= prs && row <= ppre) { nb = bnd4[row]; if (WITH_R) nr = bndr[row]; } } }
         for (int s0 = 0; s0 < nsteps; s0 += TH_WAVE) {
             int (*inbox)[8] = s_in[(s0 >> 6) & 1];
             {
@@ -912,17 +928,23 @@ __device__ int th_ksw_global_band_pk_wave(const uint8_t *__restrict__ q, int qle
                     ib.x = (int)((uint32_t)hb << 16); ib.y = (int)((uint32_t)fb << 16); ib.z = 0; ib.w = 0;
                 } else { ib.x = (int)((uint32_t)max(nb.x, -32768) << 16); ib.y = (int)((uint32_t)max(nb.y, -32768) << 16); ib.z = (int)((uint32_t)nb.z << 16); ib.w = (int)((uint32_t)nb.w << 16); }
                 *(int4 *)&inbox[lane][0] = ib; inbox[lane][4] = ibT;
+                if (WITH_R) { inbox[lane][5] = first ? 0 : (int)((uint32_t)nr.x << 16); inbox[lane][6] = first ? 0 : (int)((uint32_t)nr.y << 16); }
             }
             TH_WAVE_FENCE();
             {
                 const int row = rs + s0 + TH_WAVE + lane;
-                nt = 4; nb.x = TH_NEG; nb.y = TH_NEG; nb.z = 0; nb.w = 0;
-                if (row < tlen) { nt = t[row]; if (!first && row >= prs && row <= ppre) nb = bnd4[row]; }
+                nt = 4; nb.x = TH_NEG; nb.y = TH_NEG; nb.z = 0; nb.w = 0; nr.x = 0; nr.y = 0;
+                if (row < tlen) { nt = t[row]; if (!first && row >= prs && row <= ppre) { nb = bnd4[row]; if (WITH_R) nr = bndr[row]; } }
             }
             const int kend = min(TH_WAVE, nsteps - s0);
             const bool top_ok = rs == 0 && s0 < 3 * TH_WAVE;
             int4 in = *(const int4 *)&inbox[0][0]; int inT = inbox[0][4];
             auto step = [&](int k, int4 &cin, int &cinT, int4 &nin, int &ninT) {
+                uint32_t R0l = 0, R2l = 0;
+                if (WITH_R) {       // (the border words of R0 / R2 are read where they are used: two more broadcast reads of the step's inbox entry)
+                    R0l = th_alignbit16(R0out, (uint32_t)th_shr1_inject((int)R0out, inbox[k][5]));
+                    R2l = th_alignbit16(R2out, (uint32_t)th_shr1_inject((int)R2out, inbox[k][6]));
+                }
                 const uint32_t L = th_alignbit16(Hout, (uint32_t)th_shr1_inject((int)Hout, cin.x));
                 const uint32_t Fl = th_alignbit16(Fout, (uint32_t)th_shr1_inject((int)Fout, cin.y));
                 const uint32_t Cl = th_alignbit16(Cout, (uint32_t)th_shr1_inject((int)Cout, cin.z));
@@ -932,6 +954,7 @@ __device__ int th_ksw_global_band_pk_wave(const uint8_t *__restrict__ q, int qle
                 if (top_ok) {
                     const uint32_t TOPM = th_pk_negmask_op(th_pk_sub(rowv, ONE2));      // rows <= 0
                     Ecol = th_sel(TOPM, ETOP, Ecol); T1 &= ~TOPM; Hdiag = th_sel(TOPM, HDTOP, Hdiag); Cdiag &= ~TOPM;
+                    if (WITH_R) { R1 = th_sel(TOPM, TL2, R1); R0diag = th_sel(TOPM, TL2, R0diag); }      // a path that leaves through the top border still owes an insertion: all of t is consumed
                 }
                 const uint32_t EM = th_pk_negmask_op(th_pk_sub(Tcur ^ Qp, ONE2));
                 uint32_t sc = th_sel(EM, ONE2, 0xfffefffeu);
@@ -946,14 +969,26 @@ __device__ int th_ksw_global_band_pk_wave(const uint8_t *__restrict__ q, int qle
                 const uint32_t xe = th_pk_negmask_op(th_pk_sub(hq, Ecol)), xf = th_pk_negmask_op(th_pk_sub(hq, Fl));
                 const uint32_t ch = th_sel(g_f, T2l, th_sel(g_e, T1, th_pk_sub(Cdiag, EM)));
                 const uint32_t t1 = th_sel(xe, T1, ch), t2 = th_sel(xf, T2l, ch);
+                uint32_t r0 = 0;
+                if (WITH_R) {
+                    // in the suffix's first column the counts start: tlen - i on the diagonal, tlen - 1 - i out of a horizontal gap (th_ksw_global_wave)
+                    const uint32_t TLr = th_pk_sub(TL2, rowv);
+                    const uint32_t A_ = th_sel(JSM, TLr, R0diag), B_ = th_sel(JSM, th_pk_sub(TLr, ONE2), R2l);
+                    r0 = th_sel(g_f, B_, th_sel(g_e, R1, A_));
+                    const uint32_t r1 = th_sel(xe, R1, r0), r2 = th_sel(xf, B_, r0);
+                    R0diag = R0l; R1 = r1; R0out = r0; R2out = r2;
+                }
                 Hdiag = L; Cdiag = Cl; T1 = t1;
                 const uint32_t nE = th_pk_sub(th_pk_max(Ecol, hq), EE), nF = th_pk_sub(th_pk_max(Fl, hq), EE);
                 const uint32_t OUT = th_pk_negmask_op(th_pk_sub(rowv, LOB) | th_pk_sub(HIB, rowv));
                 Hout = th_sel(OUT, TH_PK_NEG, h); Ecol = th_sel(OUT, TH_PK_NEG, nE); Fout = th_sel(OUT, TH_PK_NEG, nF); Cout = ch; T2out = t2;
-                if (last && rs + s0 + k == rstar) { res_c = ch; res_h = h; }          // (wave-uniform test; the owner's lane and half are picked below)
+                if (last && rs + s0 + k == rstar) { res_c = ch; res_h = h; res_r = r0; }          // (wave-uniform test; the owner's lane and half are picked below)
                 if (!last && lane == 63) {
                     const int row = rs + s0 + k - 2 * 63 - 1;
-                    if (row >= rs && row <= re) { int4 o; o.x = TH_PK_HI(Hout); o.y = TH_PK_HI(Fout); o.z = TH_PK_HI(Cout); o.w = TH_PK_HI(T2out); bnd4[row] = o; }
+                    if (row >= rs && row <= re) {
+                        int4 o; o.x = TH_PK_HI(Hout); o.y = TH_PK_HI(Fout); o.z = TH_PK_HI(Cout); o.w = TH_PK_HI(T2out); bnd4[row] = o;
+                        if (WITH_R) { int2 o2; o2.x = TH_PK_HI(R0out); o2.y = TH_PK_HI(R2out); bndr[row] = o2; }
+                    }
                 }
                 rowv = th_pk_add(rowv, ONE2);
             };
@@ -965,6 +1000,7 @@ __device__ int th_ksw_global_band_pk_wave(const uint8_t *__restrict__ q, int qle
         if (last) {
             const uint32_t rc = (uint32_t)TH_READLANE((int)res_c, own_l), rh = (uint32_t)TH_READLANE((int)res_h, own_l);
             res_c = (uint32_t)(own_h ? TH_PK_HI(rc) : TH_PK_LO(rc)); res_h = (uint32_t)(own_h ? TH_PK_HI(rh) : TH_PK_LO(rh));
+            if (WITH_R) { const uint32_t rr = (uint32_t)TH_READLANE((int)res_r, own_l); res_r = (uint32_t)(own_h ? TH_PK_HI(rr) : TH_PK_LO(rr)); }
         }
         prs = rs; ppre = re;
         TH_WAVE_FENCE();
@@ -972,6 +1008,29 @@ __device__ int th_ksw_global_band_pk_wave(const uint8_t *__restrict__ q, int qle
     const int iden = (int)res_c, hsc = (int)res_h <= -32768 ? TH_NEG : (int)res_h;
     const int gmin = 2 * W + 2 + (D < 0 ? -D : D);
     *band_score = hsc;
+    if (WITH_R && tback) *tback = (int)res_r;
     if (2LL * hsc > (long long)(qlen + tlen - gmin) - 4 * TH_KQ - 2LL * gmin * TH_KE) return iden;
     return -1;
+}
+
+// Global alignment with iden_n and the back-projection, cheapest exact engine first (the partition's bridging alignments, th_k_partition.hip):
+// a certified band of half-width tlen / 10 + 24 on the packed strip engine, then the band its banded score names (pruned with that score), then
+// the full matrix.  s_in: the strip engines' inbox (two 64-row blocks); bnd: ((tlen + 63) & ~63) * 6 ints.  Same results as th_ksw_global_wave<true>.
+__device__ __forceinline__ int th_ksw_global_r_wave(const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, int q_left_ext, int *__restrict__ bnd, int (*s_in)[TH_WAVE][8], int *tback, bool banded)
+{
+    if (banded && qlen + tlen <= TH_KSW_PK_MAXLEN && qlen >= 2 * TH_WAVE) {
+        const int D = tlen - qlen, aD = D < 0 ? -D : D;
+        const int W = tlen / 10 + 24;
+        if (64 + 2 * W + aD < (tlen * 3) / 4) {                       // (a band that is most of the matrix saves nothing)
+            int s1 = TH_NEG, tb = 0;
+            int v = th_ksw_global_band_pk_wave<true>(q, qlen, t, tlen, W, bnd, s_in, &s1, TH_NEG, q_left_ext, &tb);
+            if (v < 0 && s1 > TH_NEG) {
+                const long long g2 = ((long long)qlen + tlen - 2LL * s1 - 4 * TH_KQ) / (1 + 2 * TH_KE) + 2;
+                const long long W2 = (g2 - 2 - aD + 1) / 2 + 8;
+                if (W2 > W && W2 < 30000) { const int lb = s1; v = th_ksw_global_band_pk_wave<true>(q, qlen, t, tlen, (int)W2, bnd, s_in, &s1, lb, q_left_ext, &tb); }
+            }
+            if (v >= 0) { *tback = tb; return v; }
+        }
+    }
+    return th_ksw_global_wave<true>(q, qlen, t, tlen, q_left_ext, bnd, tback);
 }

@@ -118,7 +118,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
 {
     th_gpu *g = new th_gpu();
     g->para = *p;
-    g->dp.k = p->k; g->dp.w = p->w; g->dp.w_seq = env_int("TH_MINIMIZER_SEQ", 0) ? 1 : 0; g->dp.sort_bitonic = env_int("TH_SORT_BITONIC", 0) ? 1 : 0; g->dp.hpc = p->hpc; g->dp.min_p = p->min_p; g->dp.max_p = p->max_p; g->dp.one_minus_div = p->one_minus_div; g->dp.min_copy = p->min_copy;
+    g->dp.k = p->k; g->dp.w = p->w; g->dp.w_seq = env_int("TH_MINIMIZER_SEQ", 0) ? 1 : 0; g->dp.sort_bitonic = env_int("TH_SORT_BITONIC", 0) ? 1 : 0; g->dp.part_full = env_int("TH_PART_FULL", 0) ? 1 : 0; g->dp.hpc = p->hpc; g->dp.min_p = p->min_p; g->dp.max_p = p->max_p; g->dp.one_minus_div = p->one_minus_div; g->dp.min_copy = p->min_copy;
     g->dp.match = p->match; g->dp.mismatch = p->mismatch; g->dp.go1 = p->go1; g->dp.ge1 = p->ge1; g->dp.go2 = p->go2; g->dp.ge2 = p->ge2;
     g->device = device;
     // adapter search tables (th_k_adapter.hip): per consensus letter the query positions it matches, forward and reversed query
