@@ -162,7 +162,9 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
     g->waves_xw = env_int("TH_WAVES_XW", TH_PERSISTENT_WAVES(g->waves_xw));
     g->waves_xw_small = env_int("TH_WAVES_XW_SMALL", TH_PERSISTENT_WAVES(g->waves_xw_small));
     g->aln_wdiv = std::max(1, env_int("TH_ALN_WDIV", g->aln_wdiv)); g->aln_wadd = std::max(0, env_int("TH_ALN_WADD", g->aln_wadd));
-    g->aln_wtol = std::max(0, env_int("TH_ALN_WTOL", g->aln_wtol)); g->aln_mode = env_int("TH_ALN_MODE", g->aln_mode); g->aln_xpct = std::min(255, std::max(0, env_int("TH_ALN_XPCT", g->aln_xpct))) | std::min(4, std::max(1, env_int("TH_ALN_XPROBE", 1))) << 8 | (env_int("TH_ALN_PKSTRIP", 1) ? 0 : 1) << 11;      // (TH_ALN_XPROBE: registers of the flank extensions' probe: one since round 4 -- four measured 17-20 ms slower on configs 4 and 5) g->aln_probe_small = std::min(3, std::max(0, env_int("TH_ALN_PROBE_SMALL", 1))); g->aln_probe_auto = getenv("TH_ALN_PROBE_SMALL") ? 0 : 1;
+    // (TH_ALN_XPROBE: registers of the flank extensions' probe: one since round 4 -- four measured 17-20 ms slower on configs 4 and 5)
+    g->aln_wtol = std::max(0, env_int("TH_ALN_WTOL", g->aln_wtol)); g->aln_mode = env_int("TH_ALN_MODE", g->aln_mode); g->aln_xpct = std::min(255, std::max(0, env_int("TH_ALN_XPCT", g->aln_xpct))) | std::min(4, std::max(1, env_int("TH_ALN_XPROBE", 1))) << 8 | (env_int("TH_ALN_PKSTRIP", 1) ? 0 : 1) << 11;
+    g->aln_probe_small = std::min(3, std::max(0, env_int("TH_ALN_PROBE_SMALL", 1))); g->aln_probe_auto = getenv("TH_ALN_PROBE_SMALL") ? 0 : 1;
     return g;
 }
 
