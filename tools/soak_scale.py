@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""GPU box: byte identity of the command line against the oracle's on MORE reads than the tests take, drawn with other seeds
+(test_gpu_scale.py: 4096 / 4096 / 512 reads of seeds 1 / 2 / 3).   usage: python3 tools/soak_scale.py [scale]"""
+import hashlib, os, subprocess, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import tidehunter_amd as TH
+import th_util as U
+import oracle_lib as O
+O.load()
+EXE = os.path.join(R, "tidehunter_amd", "TideHunter-amd"); ORACLE = os.path.join(O.ODIR, "tho_oracle")
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+lib = TH.load_library()
+for name, n, period, copies, err, seed, opts in [("C3", 20000, 1000, 10, 0.10, 11, []), ("C2", 20000, 200, 20, 0.10, 12, ["-f", "2"]),
+                                                 ("C4", 2000, 5000, 4, 0.15, 13, []), ("p2000", 4000, 2000, 5, 0.12, 14, ["-f", "2"])]:
+    n = max(64, int(n * scale))
+    fn = "/dev/shm/soak_%s.fa" % name
+    U.write_fasta(fn, [TH.synth_read(lib, seed, i, period, copies, err) for i in range(n)], prefix="soak_%s_" % name)
+    t0 = time.time(); gpu = subprocess.run([EXE, *opts, fn], capture_output=True, check=True).stdout; t1 = time.time()
+    cpu = subprocess.run([ORACLE, "-t", str(U.effective_cpus()), *opts, fn], capture_output=True, check=True).stdout; t2 = time.time()
+    print("%-6s %6d reads (seed %d) %s: %s  records %d  md5 %s  gpu %.1f s  oracle %.1f s" % (
+        name, n, seed, " ".join(opts) or "-", "IDENTICAL" if gpu == cpu else "DIFFERENT", gpu.count(b">"), hashlib.md5(gpu).hexdigest(), t1 - t0, t2 - t1), flush=True)
+    os.unlink(fn)
