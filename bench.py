@@ -528,7 +528,7 @@ def main():
         per_launch_bytes = alg_bytes / float(launches)
         ach = per_launch_bytes / launch_s / 1e9 if launch_s > 0 else 0.0
         # traffic: HBM bytes of one launch of the dominant kernel from the PMC passes of this same command
-        # (tools/round3_end.sh -> profiles/rNN_hbm_traffic.json); counters cannot be read from inside the process, so
+        # (tools/round4_end.sh -> profiles/rNN_hbm_traffic.json); counters cannot be read from inside the process, so
         # the committed profile is quoted when it was taken at the same workload and batch size, else null
         traffic, traffic_src = None, None
         for pf in ("r04_hbm_traffic.json", "r03_hbm_traffic.json"):
@@ -547,7 +547,7 @@ def main():
                            "kernel_ms_per_step": {k: v / a.steps for k, v in kms.items()},
                            "algorithmic_bytes_per_launch": per_launch_bytes, "launches_per_step": launches / float(a.steps),
                            "note": "this path is instruction-issue bound, not bandwidth bound (DESIGN.md section 4): the HBM fraction is reported because "
-                                   "north_star names that roofline; profiles/r03_pmc_instr.json holds the VALU issue fractions"}
+                                   "north_star names that roofline; profiles/r04_pmc_instr.json holds the VALU issue fractions"}
         # the same steps with the upload INSIDE: th_process_batches() pipelines H2D of batch i+1 and the record arithmetic of batch i-1
         # under the kernels of batch i (what th_run_file does with batches from the reader)
         if world == 1 and a.steal == 0 and a.streamed != 0:
