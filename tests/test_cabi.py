@@ -66,3 +66,8 @@ def test_isa_untracked_lds_read_is_not_touched_before_its_wait(tmp_path):
                     "--cuda-device-only", "-S", os.path.join(src, "th_pipeline.hip"), "-o", str(out)], check=True, timeout=900)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_check_async_lds.py"), str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+    # the other thing the compiler cannot see inside inline asm: the stores with a scalar base (TH_STORE_U32_SADDR) must not read a base
+    # register that a vector instruction (the v_readlane of a spilled pointer) wrote fewer than five wait states before -- round 4 traced
+    # the GPU memory faults of two abandoned POA variants to exactly that (tools/isa_check_saddr_hazard.py)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_check_saddr_hazard.py"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

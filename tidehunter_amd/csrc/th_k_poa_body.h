@@ -496,7 +496,10 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
 
 // QCAP > 0: the query is staged in LDS (s_qs); RT = short: int16 ring with packed rows, RT = int: 32-bit ring (exact for any
 // score range, one column per lane).  The int16 variant returns -5 when the alignment's scores may not fit.
-template <int QCAP, typename RT>
+// DEFSC: the scoring is abPOA's default as TideHunter sets it (match 2, mismatch 4, gaps 4 / 2 and 24 / 1: src/abpoa_cons.c:12-28) and is compiled in --
+// the six values, their packed copies and the score table stop occupying scalar and vector registers of a loop that has none to spare (the packed
+// constants become inline operands of the v_pk_* instructions); any other scoring (-M / -X / -O / -E) runs the generic instantiation
+template <int QCAP, typename RT, bool DEFSC>
 __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t *s_qs, RT (*s_ring)[3][TH_POA_RS], int (*s_rmeta)[8], int qlen, const ThDevPara &P, const bool noband)
 {
     constexpr bool LQ = QCAP > 0, WIDE = sizeof(RT) == 4;
@@ -505,12 +508,16 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     // they are rebuilt at every call instead of being hoisted out of the job's alignment loop, where they would stay live -- and
     // get spilled to scratch, to be reloaded INSIDE the row loop -- across the other phases
     TH_OPAQUE_V(lane);
-    const int M = P.match, X = P.mismatch, O1 = P.go1, E1 = P.ge1, O2 = P.go2, E2 = P.ge2;
+    const int M = DEFSC ? 2 : P.match, X = DEFSC ? 4 : P.mismatch, O1 = DEFSC ? 4 : P.go1, E1 = DEFSC ? 2 : P.ge1, O2 = DEFSC ? 24 : P.go2, E2 = DEFSC ? 1 : P.ge2;
     qlen = TH_UNI(qlen);
     // noband (the rerun of a job whose adaptive band failed): a half-width beyond any column makes every row span 0..qlen through
     // the ordinary band arithmetic (a row's start is max(0, . - w) and never below a predecessor's, its end min(qlen, . + w))
     const int n = TH_UNI(g.n_node), w = noband ? qlen + 8 : TH_POA_WB + qlen / 100;
     uint32_t ncell = 0, nfull = 0;          // direction words / full cells handed out so far (32-bit: the region is clamped to 2^31 words)
+    // what is left for direction words, in 2-byte units: the region minus the full cells handed out (8 units each).  ONE scalar for the capacity test of
+    // every row -- the pair (nfull, g.cell_u2) was two spilled scalars read back with v_readlane per row (438.8 -> 433.0 ms); it goes negative when full
+    // cells alone overrun the region
+    int lim = (int)g.cell_u2;
     // Every real score lies within +-real_b: a path to (i, j) has at most i + j unit steps, the dearest of which is a
     // mismatch (X for two units) or a one-base gap (open + extend for one unit); E'/F carry one more open + extend.
     // Rows are cached as int16 (and packed rows are used) only if that, the upward drift of unreachable cells (M per
@@ -533,7 +540,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     uint32_t O1P = TH_PK_DUP(O1), O2P = TH_PK_DUP(O2), E1P = TH_PK_DUP(E1), E2P = TH_PK_DUP(E2);
     // the scalar register file of this kernel is full (the graph descriptor alone is ~35 pointer pairs), and a spilled scalar costs a
     // v_readlane -- a vector instruction -- at every use: the four constants every packed row uses several times live in VGPRs instead
-    TH_OPAQUE_V(O1P); TH_OPAQUE_V(O2P); TH_OPAQUE_V(E1P); TH_OPAQUE_V(E2P);
+    if (!DEFSC) { TH_OPAQUE_V(O1P); TH_OPAQUE_V(O2P); TH_OPAQUE_V(E1P); TH_OPAQUE_V(E2P); }
     const uint32_t TXB = (uint32_t)(32 - X) * 0x01010101u;           // score table of a packed row: one byte per query code A, C, G, T, biased by 32 ...
     // ... and with the match score in place for each node base: lane nb (0..4; 4 = N scores 0 against everything) of one register,
     // a row fetches its table with one v_readlane
@@ -596,7 +603,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 if (b > e) return -2;
                 if (e - b < TH_POA_RW) {
                     const int B0 = b & ~1, span = (e | 1) - B0 + 1, units = th_d_units(span, true);
-                    if (ncell + (uint32_t)units + nfull * 8u > g.cell_u2) return -3;
+                    if ((int)(ncell + (uint32_t)units) > lim) return -3;
                     const int my_off = (int)ncell + (TH_POA_D8 ? 0 : b - B0);      // (8-bit words: the offset of the even base column)
                     ncell += units;
                     int rmax = TH_NEG - 0x10000000, left = b, right = b;
@@ -637,7 +644,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                     if (b > e) return -2;
                     if (e - b < TH_POA_RW) {
                         const int B0 = b & ~1, span = (e | 1) - B0 + 1, units = th_d_units(span, inn_ == 1);
-                        if (ncell + (uint32_t)units + nfull * 8u > g.cell_u2) return -3;
+                        if ((int)(ncell + (uint32_t)units) > lim) return -3;
                         const int my_off = (int)ncell + ((TH_POA_D8 && inn_ == 1) ? 0 : b - B0);
                         uint16_t *dbase = g.dcell + ncell;
                         ncell += units;
@@ -687,8 +694,8 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                     if (e - b < TH_POA_RW) {
                         const int B0 = b & ~1, span = (e | 1) - B0 + 1, units = th_d_units(span, inn_ == 1);
                         const int full = (meta >> 24) & 1;
-                        if (full) nfull += span;
-                        if (ncell + (uint32_t)units + nfull * 8u > g.cell_u2) return -3;
+                        if (full) { nfull += span; lim -= 8 * span; }
+                        if ((int)(ncell + (uint32_t)units) > lim) return -3;
                         const int my_off = (int)ncell + ((TH_POA_D8 && inn_ == 1) ? 0 : b - B0), my_foff = full ? -(int)nfull + (b - B0) : 0;
                         uint16_t *dbase = g.dcell + ncell;
                         ncell += units;
@@ -744,8 +751,8 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         // A wave's scratch shrinks from ~18 to ~3-6 bytes per band cell, whatever the share of rows stored in full.
         const bool d8 = TH_POA_D8 && inn == 1;                   // one predecessor: 8-bit direction words (every reader goes by the in-degree)
         const int units = th_d_units(span, d8);
-        if (store_full) nfull += span;
-        if (ncell + (uint32_t)units + nfull * 8u > g.cell_u2) return -3;
+        if (store_full) { nfull += span; lim -= 8 * span; }
+        if ((int)(ncell + (uint32_t)units) > lim) return -3;
         const int my_off = (int)ncell + (d8 ? 0 : b - B0);       // 16-bit rows: offset of column b; 8-bit rows: of the even base column
         const int my_foff = store_full ? -(int)nfull + (b - B0) : 0;
         int4 *row = g.cell + my_foff; uint16_t *dbase = g.dcell + ncell; uint16_t *drow = dbase + (b - B0); uint8_t *drow8 = (uint8_t *)dbase + (b - B0);
@@ -1118,7 +1125,7 @@ __device__ int th_poa_consensus(ThPoaG &g, int n_seqs, uint8_t *__restrict__ con
 // status: 0 ok, 1 scratch too small for the graph, 2 band cells overflow, 3 empty band, 4 band lost the path,
 //         5 in-degree > 255, 6 consensus longer than cons_cap, 7 scores may not fit the int16 ring (rerun on the 32-bit variant)
 // QCAP: query bases staged in LDS (0: read from HBM); RT: element type of the LDS ring of recent rows (see th_poa_dp)
-template <int QCAP, typename RT>
+template <int QCAP, typename RT, bool DEFSC = false>
 // 6 waves per SIMD: 80 VGPRs (21 dwords of scratch) and 6.5 KB of LDS per wave (query codes packed two per byte); measured per
 // 65536 reads: 4 waves 588 ms, 5 waves 557 ms
 __global__ void __launch_bounds__(TH_POA_BLOCK) TH_WAVES_PER_SIMD(TH_POA_OCC_NS)
@@ -1180,7 +1187,7 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
             const int deg = th_poa_rows(my, (int)cap, (int)ocap, (int)opn, g.n_node, g.order != order0);
             TH_PROF(0);
             if (deg > 255) { st = 5; break; }
-            int bi = th_poa_dp<QCAP, RT>(g, q, s_qs, s_ring, s_rmeta, qlen, P, noband);
+            int bi = th_poa_dp<QCAP, RT, DEFSC>(g, q, s_qs, s_ring, s_rmeta, qlen, P, noband);
             bi = TH_UNI(bi);         // (the same in every lane, but loaded: a divergent `break` below would put the other phases under exec masks)
             if (test_fail && !noband && t % test_fail == 0 && bi >= 0) bi = -4;
             TH_PROF(1);

@@ -364,10 +364,13 @@ static int th_poa_launch(th_gpu *g, KTimer &kt, const ThIn &in, const int *list,
 {
     if (n_list <= 0) return 0;
     KT_BEGIN(TK_POA);
-#define POA_LAUNCH(NS, QC, RT) TH_LAUNCH((NS::th_k_poa<QC, RT>), wv, TH_POA_BLOCK, g->stream, (const ThTask *)g->d_tasks.p, list, n_list, (const ThUnit *)g->d_units.p, (const uint32_t *)in.d_roff.p, \
+    // (the default scoring -- src/abpoa_cons.c:12-28 -- has its own instantiation of the two int16 variants with the six values compiled in; TH_POA_DEFSC=0: the generic one)
+    const ThDevPara &dp = g->dp;
+    const bool defsc = dp.match == 2 && dp.mismatch == 4 && dp.go1 == 4 && dp.ge1 == 2 && dp.go2 == 24 && dp.ge2 == 1 && env_int("TH_POA_DEFSC", 1) != 0;
+#define POA_LAUNCH(NS, QC, RT, ...) TH_LAUNCH((NS::th_k_poa<QC, RT, ##__VA_ARGS__>), wv, TH_POA_BLOCK, g->stream, (const ThTask *)g->d_tasks.p, list, n_list, (const ThUnit *)g->d_units.p, (const uint32_t *)in.d_roff.p, \
                           (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, g->d_cons_len.p, g->d_status.p, queue, poa_flags)
-    if (cls == 1) POA_LAUNCH(thpoa_n, TH_POA_QCAP, short);
-    else if (cls == 2) POA_LAUNCH(thpoa_l, TH_POA_QCAP_LONG, short);
+    if (cls == 1) { if (defsc) POA_LAUNCH(thpoa_n, TH_POA_QCAP, short, true); else POA_LAUNCH(thpoa_n, TH_POA_QCAP, short); }
+    else if (cls == 2) { if (defsc) POA_LAUNCH(thpoa_l, TH_POA_QCAP_LONG, short, true); else POA_LAUNCH(thpoa_l, TH_POA_QCAP_LONG, short); }
     else if (max_unit <= TH_POA_QCAP_WIDE) POA_LAUNCH(thpoa_n, TH_POA_QCAP_WIDE, int);
     else POA_LAUNCH(thpoa_n, 0, int);
 #undef POA_LAUNCH

@@ -12,7 +12,7 @@ S=$(ls $W/*gfx950*.s | head -1)
 python3 - "$S" <<'PY'
 import re, sys
 txt = open(sys.argv[1]).read()
-m = re.search(r'^(_ZN7thpoa_n8th_k_poaILi3072Es[^:\n]*):\s.*?^\s*\.amdhsa_kernel \1(.*?)\.end_amdhsa_kernel', txt, re.S | re.M)
+m = re.search(r'^(_ZN7thpoa_n8th_k_poaILi3072EsLb1E[^:\n]*):\s.*?^\s*\.amdhsa_kernel \1(.*?)\.end_amdhsa_kernel', txt, re.S | re.M)
 body = m.group(0)
 ins = [l.split()[0] for l in body.splitlines() if l.startswith('\t') and not l.strip().startswith((';', '.'))]
 v = sum(i.startswith('v_') for i in ins); s = sum(i.startswith('s_') for i in ins)
@@ -22,3 +22,4 @@ g = lambda k: re.search(r'\.amdhsa_%s (\d+)' % k, body)
 print("th_k_poa<3072,short>: static VALU %d SALU %d lane-ops %d (spill-like %d) next_free_vgpr %s sgpr %s scratch %s" % (
     v, s, lane, spill, g('next_free_vgpr').group(1), g('next_free_sgpr').group(1), g('private_segment_fixed_size').group(1)))
 PY
+python3 $R/tools/isa_check_saddr_hazard.py "$S" | tail -2
