@@ -232,7 +232,12 @@ __device__ __forceinline__ int th_poa_rows_body(const ThPoaG &g)
             int needfull = on > TH_POA_INL;
 #pragma unroll
             for (int k = 0; k < TH_POA_INL; ++k) if (s[k] >= 0 && (s[k] - idx >= TH_POA_RING || s[k] == n - 1)) needfull = 1;
-            st_idx = ok ? idx : -1; st_rem = cur; st_meta = a.nb | min(in, 255) << 8 | min(on, 255) << 16 | needfull << 24;
+            // bit 26: every predecessor (one to four) is the row before or one of the three rows before inside this 64-row chunk, and no far row reads this
+            // one -- what the graph decides of the DP's bubble-row path (the band widths and cache states it also needs are known only there)
+            bool ring_ok = in >= 1 && in <= TH_POA_INL && !needfull && idx > 0;
+#pragma unroll
+            for (int k = 0; k < TH_POA_INL; ++k) if (k < in && !(p[k] == idx - 1 || (p[k] >= (idx & ~63) && p[k] < idx && idx - p[k] < TH_POA_RING))) ring_ok = false;
+            st_idx = ok ? idx : -1; st_rem = cur; st_meta = (int)ring_ok << 26 | a.nb | min(in, 255) << 8 | min(on, 255) << 16 | needfull << 24 | (int)(in == 1 && p[0] == idx - 1 && !needfull) << 25;     // bit 25: the DP's common row, as far as the graph decides it
 #pragma unroll
             for (int k = 0; k < TH_POA_INL; ++k) st_p[k] = p[k];
         }
@@ -596,7 +601,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         if (!WIDE && LQ) {
             // ---- the common row (58 % at the headline shape): one predecessor, the previous row, clean in its ring slot; no far row
             // will read this one; its band fits the ring.  Straight-line scalar set-up, then the packed row with one predecessor.
-            const int not_common = (((meta >> 8) & 0xff) ^ 1) | (p0 ^ (i - 1)) | (L_c ^ 3) | ((meta >> 24) & 1);
+            const int not_common = (((meta >> 25) & 1) ^ 1) | (L_c ^ 3);       // (bit 25 of the row's meta word, th_poa_rows: one predecessor, the row before, no far reader)
             if (not_common == 0) {
                 const int xd = qlen - rm;
                 const int b = max(max(0, min(L_l + 1, xd) - w), L_b), e = min(qlen, max(L_r + 1, xd) + w);
@@ -616,7 +621,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             // ---- the branch / merge rows of bubbles (35 %): up to four predecessors, each one of the three rows before this one, in
             // this 64-row chunk (or the previous row) and clean in its ring slot; no far row will read this one.  Same thing, unrolled.
             const int inn_ = (meta >> 8) & 0xff;
-            if (i > 0 && inn_ >= 1 && inn_ <= 4 && !((meta >> 24) & 1)) {
+            if ((meta >> 26) & 1) {
                 const int cb = i & ~63;
                 int mpl = 0x7fffffff, mpr = 0, mb = 0x7fffffff, bad = 0;
                 int qs0 = 0, qs1 = 0, qs2 = 0, qs3 = 0, qb0 = 0, qb1 = 0, qb2 = 0, qb3 = 0;
@@ -626,7 +631,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                     else { \
                         const int x_ = pi_ & 63; \
                         pb_ = TH_READLANE(m_beg, x_); pl_ = TH_READLANE(m_left, x_); pr_ = TH_READLANE(m_right, x_); \
-                        bad |= (pi_ < cb) | (pi_ >= i) | (i - pi_ >= TH_POA_RING) | (TH_READLANE(m_end, x_) - pb_ >= TH_POA_RW); \
+                        bad |= TH_READLANE(m_end, x_) - pb_ >= TH_POA_RW;      /* (where the predecessor sits: bit 26 of the meta word) */ \
                     } \
                     mpl = min(mpl, pl_ + 1); mpr = max(mpr, pr_ + 1); mb = min(mb, pb_); QS = pi_ & 3; QB = pb_ & ~1; \
                 } while (0)
