@@ -18,6 +18,8 @@
 #define th_writelane6(a, b, c, d, e, f, va, vb, vc, vd, ve, vf, l) do { if (TH_LANE() == (l)) { a = (va); b = (vb); c = (vc); d = (vd); e = (ve); f = (vf); } } while (0)
 __device__ __forceinline__ int th_shr1(int v, int fill) { int o = __shfl_up(v, 1); return TH_LANE() == 0 ? fill : o; }
 __device__ __forceinline__ int th_shl1(int v, int fill) { int o = __shfl_down(v, 1); return TH_LANE() == 63 ? fill : o; }
+__device__ __forceinline__ int th_shr1_z(int v) { return th_shr1(v, 0); }
+__device__ __forceinline__ int th_shl1_z(int v) { return th_shl1(v, 0); }
 // lane l <- lane l-1, lane 0 <- lane 0 of `inj` (a per-lane register: only its lane 0 matters)
 __device__ __forceinline__ int th_shr1_inject(int v, int inj) { int o = __shfl_up(v, 1); return TH_LANE() == 0 ? inj : o; }
 // rotate towards lane 0: lane l <- lane l+1, lane 63 <- lane 0

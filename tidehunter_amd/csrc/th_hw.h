@@ -35,6 +35,9 @@ __device__ __forceinline__ void th_writelane6(int &a, int &b, int &c, int &d, in
 #define TH_DPP(old, src, ctrl, rmask, bmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), (bmask), false)
 __device__ __forceinline__ int th_shr1(int v, int fill) { return TH_DPP(fill, v, 0x138, 0xf, 0xf); }   // wave_shr:1
 __device__ __forceinline__ int th_shl1(int v, int fill) { return TH_DPP(fill, v, 0x130, 0xf, 0xf); }   // wave_shl:1
+// the same with ZERO shifted in: bound_ctrl supplies it, no register has to be filled first (one instruction instead of two)
+__device__ __forceinline__ int th_shr1_z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int th_shl1_z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
 __device__ __forceinline__ int th_shr1_inject(int v, int inj) { return TH_DPP(inj, v, 0x138, 0xf, 0xf); }  // lane 0 keeps inj[0]
 __device__ __forceinline__ int th_rol1(int v) { return TH_DPP(v, v, 0x134, 0xf, 0xf); }                   // wave_rol:1
 // Inclusive scans: four dependent steps inside each row of 16 lanes (row_shr 1, 2, 4, 8: a lane without a source keeps its

@@ -172,7 +172,7 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             const int dq2h = (int)((uint32_t)(PK ? __mul24(dq, dq) : dq * dq) >> 1);
             const int clzh = TH_CLZ_NZ(dis1 + dis2) >> 1;
             const int s = TH_LANE_OF_MASK(conm, lane) ? (psc + matched + clzh) - dq2h : -0x40000000;        // score + 15
-            const int rb = max(th_shr1(th_wave_incl_max(s), TH_INT_MIN), best);      // best as seen just before this lane (lane 0: the running best)
+            const int rb = max(th_shr1_z(th_wave_incl_max(s)), best);             // (zero shifted into lane 0 -- one instruction less than minus infinity -- and best >= 16)      // best as seen just before this lane (lane 0: the running best)
             const unsigned long long impm = TH_BALLOT(s > rb);     // (a lane without a connection holds -2^30, below every best)
             // stop rules in scan order: :331 (dstop); :342 improving SAME/OVL and :344-346 non-improving OVL (SAME with fewer than 2k
             // matched bases), so OVL always stops; :349 max_h consecutive non-improving predecessors (only evaluated when reachable)

@@ -297,14 +297,14 @@ __device__ __forceinline__ void th_ad_step(ThAdState<NP> &S, uint32_t (&Hd)[NP],
     }
     uint32_t up[NP], upT[NP], lf[NP], lfT[NP];
     if (C == 0) {
-        const uint32_t pe = (uint32_t)th_shr1((int)S.E1[NP - 1], (int)TH_PK_NEG), pt = (uint32_t)th_shr1((int)S.TE[NP - 1], 0);
+        const uint32_t pe = (uint32_t)th_shr1((int)S.E1[NP - 1], (int)TH_PK_NEG), pt = (uint32_t)th_shr1_z((int)S.TE[NP - 1]);
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             up[k] = th_alignbit16(S.E1[k], k ? S.E1[k - 1] : pe); upT[k] = th_alignbit16(S.TE[k], k ? S.TE[k - 1] : pt);
             lf[k] = S.F1[k]; lfT[k] = S.TF[k];
         }
     } else {
-        const uint32_t nf = (uint32_t)th_shl1((int)S.F1[0], (int)TH_PK_NEG), nt = (uint32_t)th_shl1((int)S.TF[0], 0);
+        const uint32_t nf = (uint32_t)th_shl1((int)S.F1[0], (int)TH_PK_NEG), nt = (uint32_t)th_shl1_z((int)S.TF[0]);
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             lf[k] = th_alignbit16(k + 1 < NP ? S.F1[k + 1] : nf, S.F1[k]); lfT[k] = th_alignbit16(k + 1 < NP ? S.TF[k + 1] : nt, S.TF[k]);
