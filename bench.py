@@ -54,6 +54,17 @@ CONFIGS = {
 }
 
 
+def csrc_hash():
+    """identifies the kernel sources a traffic profile was taken with: md5 over the contents of tidehunter_amd/csrc/*.{hip,h} (name-sorted).  tools/hbm_traffic.sh
+    stores it in the profile; the bench line marks `roofline.traffic_stale` when the running build's differs."""
+    h = hashlib.md5()
+    d = os.path.join(ROOT, "tidehunter_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode()); h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def effective_cpus():
     """CPUs this process can actually use: the affinity mask capped by the cgroup CPU quota (the GPU boxes show 256 logical CPUs
     to nproc but schedule the container on a 16-CPU quota; threads beyond the quota only add throttling)"""
@@ -191,6 +202,7 @@ def cli_e2e(set_reads, copies, cfg, batch_opt, n_runs=2, pause_s=6.0):
                             "by_role_s": {"reader": float(mc.group(4)), "inflate": float(mc.group(5)), "upload_threads": float(mc.group(6)), "run_threads": float(mc.group(7)),
                                           "record_arithmetic_and_formatting": float(mc.group(8)), "writer": float(mc.group(9)), "runtime_and_rest": float(mc.group(10))},
                             "process_cpu_s_incl_startup": float(mp.group(2)) if mp else None, "cores_busy_mean": float(mc.group(1)) / inner}
+            n_fail = sum(int(x) for x in re.findall(r"warning: (\d+) consensus job\(s\) could not be aligned", err))
             md5 = hashlib.md5()
             with open(outp, "rb") as f:
                 for chunk in iter(lambda: f.read(1 << 24), b""):
@@ -198,7 +210,7 @@ def cli_e2e(set_reads, copies, cfg, batch_opt, n_runs=2, pause_s=6.0):
             runs.append({"reads_per_s": n_reads / inner, "seconds_first_byte_to_last_byte": inner, "wall_with_startup_s": wall,
                          "steady_reads_per_s": float(m.group(8)), "steady_window_s": float(m.group(9)), "startup_s": inner - float(m.group(9)),
                          "mbases_per_s": nbytes / inner / 1e6, "reader_busy_s": float(m.group(3)), "upload_busy_s": float(m.group(4)), "device_busy_s": float(m.group(5)),
-                         "collect_busy_s": float(m.group(6)), "writer_busy_s": float(m.group(7)), "output_md5": md5.hexdigest(), "host_cpu": host_cpu,
+                         "collect_busy_s": float(m.group(6)), "writer_busy_s": float(m.group(7)), "output_md5": md5.hexdigest(), "host_cpu": host_cpu, "n_jobs_without_consensus": n_fail,
                          "paused_before_s": pause})
         nopause = runs.pop()
         vals = [r["reads_per_s"] for r in runs]
@@ -208,7 +220,7 @@ def cli_e2e(set_reads, copies, cfg, batch_opt, n_runs=2, pause_s=6.0):
                 "host_cpu_note": "CPU seconds of the whole process between the first byte parsed and the last byte written (getrusage), per million reads, mean of the runs; "
                                  "by role in runs[].host_cpu (thread CPU clocks; the remainder is the HIP runtime's own threads).  The seam this replaces keeps n_thread workers "
                                  "and one writer busy (src/main.c:273-291,214-271); round 3 spent 29.9 here, 16 of them in spinning stream synchronisations",
-                "run_without_pause": nopause,
+                "run_without_pause": nopause, "n_jobs_without_consensus": sum(r["n_jobs_without_consensus"] for r in runs) + nopause["n_jobs_without_consensus"],
                 "reads": n_reads, "runs_reads_per_s": vals, "cold_reads_per_s": vals[0], "steady_reads_per_s": [r["steady_reads_per_s"] for r in runs],
                 "runs": runs, "batch_reads": batch_opt, "machine_warmup_run": machine_warmup, "pause_before_each_run_s": pause_s,
                 "what": "TideHunter-amd (reader -> H2D -> kernels -> record arithmetic -> writer) on a FASTA of %d x the read set in %s" % (copies, d)}
@@ -227,7 +239,7 @@ def other_shapes(names, steps=3):
                                 "--others", "", "--streamed", "0"], capture_output=True, text=True, timeout=900)
             j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
             out[c] = {"reads_per_s": j["value"], "mbases_per_s": j["mbases_per_s"], "ms_per_step": j["ms_per_step"], "reads_per_step": j["config"]["reads_per_step_per_gpu"],
-                      "kernel_ms_per_step": j["roofline"]["kernel_ms_per_step"], "workload": j["config"]["workload"]}
+                      "kernel_ms_per_step": j["roofline"]["kernel_ms_per_step"], "workload": j["config"]["workload"], "n_jobs_without_consensus": j.get("n_jobs_without_consensus")}
         except Exception as e:                                          # a shape that fails is reported, not hidden
             out[c] = {"error": repr(e)[:300]}
     return out
@@ -470,10 +482,11 @@ def main():
                        "order": "contiguous blocks in rank order = input order", "output_md5": hashlib.md5(gathered).hexdigest() if rank == 0 else None,
                        "what": "the FASTA text of the last step's records of every rank (th_format_output), gathered to rank 0 with torch.distributed.gather; outside the timed region"}
     sync_all()
+    st = th.stats()          # cumulative over warm-up, timed steps (and nothing else yet): jobs the POA kernels could not serve must be 0
     # the byte accounting ran on the last step (all steps process the same reads): scale it to the timed steps
     if (a.steal == 0 or not a.digest) and a.steps > 1:
         n_cons *= a.steps; alg_bytes *= a.steps
-    tot = torch.tensor([float(n_reads_mine), float(bases_mine), float(n_cons), float(alg_bytes), cpu_timed], dtype=torch.float64)
+    tot = torch.tensor([float(n_reads_mine), float(bases_mine), float(n_cons), float(alg_bytes), cpu_timed, float(st["jobs_without_consensus"]), float(st["poa_jobs_rerun"]), float(st["stage_reruns"]), float(st["jobs"])], dtype=torch.float64)
     cpu_by_rank = [cpu_timed]
     if dist is not None:
         dev = "cuda" if backend == "nccl" else "cpu"
@@ -507,6 +520,9 @@ def main():
                    "value_note": "`value` is the device path with the step's reads already in HBM, as the bench contract defines it; the same steps fed from HOST memory are "
                                  "`value_upload_inclusive` (PCIe inside, N=1), and `value_e2e` is the command line from the first byte parsed to the last byte written"},
         "consensus_per_read": n_cons_all / float(reads),
+        # recovery paths over warm-up + timed steps, all ranks: consensus jobs the POA kernels could not serve (reported WITHOUT a consensus: output that differs
+        # from the reference's -- must be 0), POA jobs given back and rerun on a slower path, reruns of stages 2-3 because an arena or table was too small
+        "n_jobs_without_consensus": int(tot[5].item()), "recovery_paths": {"poa_jobs_rerun": int(tot[6].item()), "stage_reruns": int(tot[7].item()), "consensus_jobs": int(tot[8].item())},
         "host_syncs_per_step": n_syncs, "read_set_generation_s": t_gen,
         # CPU seconds of each rank's process inside the timed region (getrusage; the record arithmetic threads and the runtime's own included), and
         # the same per million reads of the whole job: the host budget at N ranks is effective_cpus() / N cores each
@@ -530,24 +546,33 @@ def main():
         # traffic: HBM bytes of one launch of the dominant kernel from the PMC passes of this same command
         # (tools/round4_end.sh -> profiles/rNN_hbm_traffic.json); counters cannot be read from inside the process, so
         # the committed profile is quoted when it was taken at the same workload and batch size, else null
-        traffic, traffic_src = None, None
-        for pf in ("r04_hbm_traffic.json", "r03_hbm_traffic.json"):
+        traffic, traffic_lo, traffic_src, traffic_stale = None, None, None, None
+        my_hash = csrc_hash()
+        for pf in ("r05_hbm_traffic.json", "r04_hbm_traffic.json"):
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", pf)))
                 if prof.get("reads_per_launch") == B * a.steps // launches and prof.get("config", "c3") == a.config and a.steal == 0:
                     for kname, v in prof["kernels"].items():
                         if traffic is None and kname.replace("void ", "").split("<")[0].split("::")[-1] == dom:
-                            traffic, traffic_src = v["hbm_bytes_per_launch_corrected"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % pf
+                            traffic, traffic_lo = v["hbm_bytes_per_launch_corrected"], v.get("hbm_bytes_per_launch_uncorrected")
+                            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % pf
+                            # the profile names the kernel sources it was taken with: a kernel changed since then quotes stale bytes, and the line says so
+                            traffic_stale = prof.get("csrc_hash") != my_hash
             except (OSError, ValueError, KeyError):
                 pass
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "frac_of_measured_copy_peak": ach / HBM_COPY_GBS, "measured_copy_peak": HBM_COPY_GBS,
-                           "traffic": traffic, "traffic_source": traffic_src, "launch_ms": launch_s * 1000.0,
+                           "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale, "csrc_hash": my_hash, "launch_ms": launch_s * 1000.0,
+                           # what the HBM system really moves for this kernel: measured traffic / launch time, both bounds of the gfx950 FETCH correction
+                           "achieved_measured": [traffic_lo / launch_s / 1e9, traffic / launch_s / 1e9] if (traffic and traffic_lo and launch_s > 0) else None,
+                           "frac_measured": [traffic_lo / launch_s / 1e9 / HBM_PEAK_GBS, traffic / launch_s / 1e9 / HBM_PEAK_GBS] if (traffic and traffic_lo and launch_s > 0) else None,
+                           "traffic_over_algorithmic": traffic / per_launch_bytes if (traffic and per_launch_bytes) else None,
                            "kernel_ms_per_launch": {k: v / launches for k, v in kms.items()},
                            "kernel_ms_per_step": {k: v / a.steps for k, v in kms.items()},
                            "algorithmic_bytes_per_launch": per_launch_bytes, "launches_per_step": launches / float(a.steps),
-                           "note": "this path is instruction-issue bound, not bandwidth bound (DESIGN.md section 4): the HBM fraction is reported because "
-                                   "north_star names that roofline; profiles/r04_pmc_instr.json holds the VALU issue fractions"}
+                           "note": "`achieved` / `frac` price the ALGORITHMIC bytes (the contract's definition); `achieved_measured` / `frac_measured` are the HBM bytes the counters saw "
+                                   "(uncorrected, corrected) over the same launch time.  The path is instruction-issue bound (DESIGN.md section 5; profiles/r05_pmc_instr.json, "
+                                   "profiles/r05_poa_phases.json)"}
         # the same steps with the upload INSIDE: th_process_batches() pipelines H2D of batch i+1 and the record arithmetic of batch i-1
         # under the kernels of batch i (what th_run_file does with batches from the reader)
         if world == 1 and a.steal == 0 and a.streamed != 0:
@@ -579,6 +604,28 @@ def main():
         others = a.others if a.others is not None else ("c2,c4,c5" if (a.config == "c3" and world == 1 and "TH_BENCH_LIB" not in os.environ) else "")
         if others:
             out["other_shapes"] = other_shapes([c for c in others.split(",") if c])
+        # the figures a reader wants first, flat and LAST in the line (the driver keeps the tail of stdout)
+        def g(d, *ks):
+            for k in ks:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+        kstep = g(out, "roofline", "kernel_ms_per_step") or {}
+        nfail = [out.get("n_jobs_without_consensus"), g(out, "value_e2e", "n_jobs_without_consensus")] + [g(out, "other_shapes", c, "n_jobs_without_consensus") for c in ("c2", "c4", "c5")]
+        summ = {"value": out["value"], "value_upload_inclusive": g(out, "value_upload_inclusive", "value"), "value_e2e": g(out, "value_e2e", "value"),
+                "e2e_cold": g(out, "value_e2e", "cold_reads_per_s"), "e2e_no_pause": g(out, "value_e2e", "run_without_pause", "reads_per_s"),
+                "e2e_startup_s": g(out, "value_e2e", "runs", ) and [round(r["startup_s"], 2) for r in out["value_e2e"]["runs"]],
+                "host_cpu_s_per_1M_reads": g(out, "value_e2e", "host_cpu_s_per_1M_reads"),
+                "c2_reads_per_s": g(out, "other_shapes", "c2", "reads_per_s"), "c4_reads_per_s": g(out, "other_shapes", "c4", "reads_per_s"), "c5_reads_per_s": g(out, "other_shapes", "c5", "reads_per_s"),
+                "c2_reads_per_step": g(out, "other_shapes", "c2", "reads_per_step"),
+                "n_jobs_without_consensus": sum(x for x in nfail if x), "n_jobs_without_consensus_covers": "timed steps + warm-up, the end-to-end runs, the other shapes",
+                "poa_ms": kstep.get("th_k_poa"), "chain_dp_ms": kstep.get("th_k_chain_dp"), "align_ms": kstep.get("th_k_align"), "hits_ms": kstep.get("th_k_encode+th_k_hits"),
+                "chain_extract_ms": kstep.get("th_k_chain_extract"), "partition_ms": kstep.get("th_k_partition"), "ms_per_step": out["ms_per_step"],
+                "c4_align_ms": g(out, "other_shapes", "c4", "kernel_ms_per_step", "th_k_align"), "c4_poa_ms": g(out, "other_shapes", "c4", "kernel_ms_per_step", "th_k_poa"),
+                "c5_poa_ms": g(out, "other_shapes", "c5", "kernel_ms_per_step", "th_k_poa"), "c5_align_ms": g(out, "other_shapes", "c5", "kernel_ms_per_step", "th_k_align"),
+                "roofline_frac": g(out, "roofline", "frac"), "roofline_frac_measured": g(out, "roofline", "frac_measured"), "traffic_stale": g(out, "roofline", "traffic_stale"),
+                "cpu_baseline_reads_per_s": g(out, "cpu_baseline", "value"), "cpu_baseline_cores": g(out, "cpu_baseline", "cores")}
+        summ = {k: (round(v, 4 if abs(v) < 10 else 1) if isinstance(v, float) else v) for k, v in summ.items()}
+        out["summary"] = summ              # (dicts keep insertion order: this is the end of the line)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if a.config == "c5":

@@ -101,6 +101,11 @@ int th_batch_timing(th_handle_t *h, double *ms_kernel, int n);
 int th_batch_launches(th_handle_t *h);
 /* host synchronisations (stream drains) of the last th_batch_run(): three per batch -- after the job tables, after the POA, at the end */
 int th_batch_syncs(th_handle_t *h);
+/* cumulative counters of the handle since th_init(): out[0] consensus jobs left WITHOUT a consensus (a POA job the kernels could not serve even on their
+ * slow paths -- abPOA has no such failure mode, src/abpoa_cons.c:86-87, so anything but 0 is output that differs from the reference's; a warning goes to stderr),
+ * out[1] POA jobs given back and rerun (scratch estimate, int16 range, adaptive band), out[2] reruns of stages 2-3 / the job tables because an arena or a table
+ * was too small (the reference allocates the worst case, src/tandem_chain.c:361-368), out[3] batches, out[4] consensus jobs; returns 5 */
+int th_batch_stats(th_handle_t *h, long long *out, int n);
 
 /* The batch seam over a SEQUENCE of batches, pipelined: while the kernels of batch i run, batch i+1 is uploaded (own copy stream,
  * second input set in HBM) and the record arithmetic of batch i-1 fills out[i-1][..] (second result set).  Same results as

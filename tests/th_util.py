@@ -67,10 +67,12 @@ def oracle_records(seqs, para):
         return list(ex.map(lambda s: O.core(s, para), seqs))
 
 
-def assert_records_equal(seqs, got, para, label=""):
-    """got: TideHunter.process() output; compared field by field with the oracle's tho_core()."""
+def assert_records_equal(seqs, got, para, label="", want=None):
+    """got: TideHunter.process() output; compared field by field with the oracle's tho_core() (want: its records when the caller already has them)."""
     n = 0
-    want = oracle_records(seqs, para)
+    if want is None:
+        want = oracle_records(seqs, para)
+    assert len(want) == len(got) == len(seqs), (label, len(want), len(got), len(seqs))
     for idx, (s, recs) in enumerate(zip(seqs, got)):
         exp = want[idx]
         assert len(exp) == len(recs), "%s read %d: %d records, oracle %d" % (label, idx, len(recs), len(exp))

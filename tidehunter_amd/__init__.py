@@ -70,6 +70,7 @@ def load_library(path=None):
     lib.th_batch_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     lib.th_batch_launches.argtypes = [C.c_void_p]
     lib.th_batch_syncs.argtypes = [C.c_void_p]
+    lib.th_batch_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]
     lib.th_batch_run_steps.argtypes = [C.c_void_p, C.c_int, C.POINTER(TandemSeq), C.POINTER(C.c_double)]
     lib.th_process_batches.argtypes = [C.c_void_p, C.c_int, C.POINTER(pp), C.POINTER(ip), ip, C.POINTER(C.POINTER(TandemSeq))]
     lib.th_run_file.argtypes = [C.c_char_p, C.POINTER(Para), C.c_void_p, C.c_int, C.c_int]
@@ -181,6 +182,13 @@ class TideHunter:
         a = (C.c_double * 8)()
         self._check(self.lib.th_batch_run_steps(self.h, steps, self._ts, a))
         return {self.KERNELS[i]: a[i] for i in range(6)}
+
+    def stats(self):
+        """cumulative counters of the handle's recovery paths (th_batch_stats): consensus jobs left without a consensus, POA jobs rerun,
+        reruns of stages 2-3 / the job tables, batches, consensus jobs"""
+        v = (C.c_longlong * 8)()
+        self.lib.th_batch_stats(self.h, v, 8)
+        return dict(zip(("jobs_without_consensus", "poa_jobs_rerun", "stage_reruns", "batches", "jobs"), [int(x) for x in v[:5]]))
 
     def syncs(self):
         """host synchronisations (stream drains) of the last run()"""

@@ -111,10 +111,10 @@ static double quota_of(const char *dir)
     }
     return q;
 }
-int th_effective_cpus(void)
+static int g_eff_cpus = 1;
+static pthread_once_t g_eff_cpus_once = PTHREAD_ONCE_INIT;
+static void effective_cpus_init(void)        /* (once: the reader thread and the collector threads may ask first at the same time) */
 {
-    static int cached = 0;
-    if (cached) return cached;
     int n = 0;
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
@@ -131,7 +131,8 @@ int th_effective_cpus(void)
             if (!c2) continue;
             *c2 = 0;
             if (c1[1] == 0) { snprintf(rel2, sizeof(rel2), "%s", c2 + 1); continue; }
-            for (char *tok = strtok(c1 + 1, ","); tok; tok = strtok(NULL, ",")) if (!strcmp(tok, "cpu")) snprintf(rel1, sizeof(rel1), "%s", c2 + 1);
+            char *save = NULL;
+            for (char *tok = strtok_r(c1 + 1, ",", &save); tok; tok = strtok_r(NULL, ",", &save)) if (!strcmp(tok, "cpu")) snprintf(rel1, sizeof(rel1), "%s", c2 + 1);
         }
         fclose(f);
     }
@@ -150,9 +151,9 @@ int th_effective_cpus(void)
     }
     if (best > 0) { const int q = (int)(best + 0.999); if (q < n) n = q; }
     { const char *e = getenv("TH_EFFECTIVE_CPUS"); if (e && atoi(e) > 0) n = atoi(e); }      /* (tests) */
-    cached = n < 1 ? 1 : n;
-    return cached;
+    g_eff_cpus = n < 1 ? 1 : n;
 }
+int th_effective_cpus(void) { pthread_once(&g_eff_cpus_once, effective_cpus_init); return g_eff_cpus; }
 static int g_live_handles = 0;      /* handles of this process: they share the CPUs */
 
 /* ---------------------------------------------------------------- FASTA/FASTQ(.gz) reader (kseq grammar, src/kseq.h:176-215) */
@@ -308,14 +309,17 @@ static void lx_scan(th_lidx_t *x, size_t c)
     const size_t a = c * LX_CHUNK, b = a + LX_CHUNK < x->len ? a + LX_CHUNK : x->len;
     const size_t cap_max = (b - a) / 16 + 16;
     size_t cap = 1024, n = 0;
-    uint32_t *off = (uint32_t *)malloc(cap * sizeof(uint32_t));
+    uint32_t *off = (uint32_t *)malloc(cap * sizeof(uint32_t));      /* (no memory: the chunk is marked dense below and the parser's own memchr takes it) */
     const unsigned char *p = x->map + a, *e = x->map + b;
-    while (p < e) {
+    while (off && p < e) {
         const unsigned char *q = (const unsigned char *)memchr(p, '\n', (size_t)(e - p));
         if (!q) break;
         if (n == cap) {
             if (cap >= cap_max) { free(off); off = NULL; break; }
-            cap = cap * 2 < cap_max ? cap * 2 : cap_max; off = (uint32_t *)realloc(off, cap * sizeof(uint32_t));
+            cap = cap * 2 < cap_max ? cap * 2 : cap_max;
+            uint32_t *grown = (uint32_t *)realloc(off, cap * sizeof(uint32_t));
+            if (!grown) { free(off); off = NULL; break; }
+            off = grown;
         }
         off[n++] = (uint32_t)(q - (x->map + a));
         p = q + 1;
@@ -346,8 +350,10 @@ static th_lidx_t *lx_open(const unsigned char *map, size_t len)
 {
     if (len < 4 * LX_CHUNK || getenv("TH_READER_NOINDEX")) return NULL;          /* small inputs: the parser's own memchr is cheaper than threads */
     th_lidx_t *x = (th_lidx_t *)calloc(1, sizeof(*x));
+    if (!x) return NULL;                  /* (no index: the parser scans for newlines itself) */
     x->map = map; x->len = len; x->n_chunk = (len + LX_CHUNK - 1) / LX_CHUNK;
     x->ch = (lx_chunk_t *)calloc(x->n_chunk, sizeof(lx_chunk_t));
+    if (!x->ch) { free(x); return NULL; }
     pthread_mutex_init(&x->mu, NULL); pthread_cond_init(&x->cv, NULL);
     int want = th_effective_cpus() >= 8 ? 3 : th_effective_cpus() >= 4 ? 2 : 1;
     { const char *e = getenv("TH_READER_THREADS"); if (e && atoi(e) >= 1 && atoi(e) <= 8) want = atoi(e); }
@@ -850,6 +856,12 @@ int th_batch_timing(th_handle_t *h, double *ms_kernel, int n)
 }
 int th_batch_launches(th_handle_t *h) { return h->res[0].n_sub; }
 int th_batch_syncs(th_handle_t *h) { return th_gpu_syncs(h->gpu[0]); }
+int th_batch_stats(th_handle_t *h, long long *out, int n)
+{
+    for (int i = 0; i < n && i < 8; ++i) out[i] = 0;
+    for (int s = 0; s < TH_MAX_SUB; ++s) if (h->gpu[s]) { long long v[8] = { 0 }; th_gpu_stats(h->gpu[s], v, 8); for (int i = 0; i < n && i < 8; ++i) out[i] += v[i]; }
+    return 5;
+}
 long long th_debug_stage(th_handle_t *h, int what, void *dst, long long cap) { return h->res[0].n_sub == 1 ? th_gpu_debug(h->gpu[0], what, dst, cap) : -1; }
 
 typedef struct { int ed, start, end; } ed_res_t;

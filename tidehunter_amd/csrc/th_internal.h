@@ -61,6 +61,10 @@ int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot);
 int th_gpu_get(th_gpu_t *g, int out_slot, th_gpu_out_t *out);
 /* host synchronisations (hipStreamSynchronize / event waits) of the last run, and seconds this handle spent in device malloc so far */
 int th_gpu_syncs(th_gpu_t *g);
+/* cumulative counters of the handle's recovery paths: [0] consensus jobs left WITHOUT a consensus (a POA job the kernels could not serve: output that differs
+ * from the reference's, which has no such failure mode), [1] POA jobs given back and rerun, [2] reruns of stages 2-3 / the job tables because an arena or a
+ * table was too small, [3] batches, [4] consensus jobs; returns 5 */
+int th_gpu_stats(th_gpu_t *g, long long *out, int n);
 const char *th_gpu_error(void);
 
 /* test hook: copies an intermediate stage of the resident batch to the host.

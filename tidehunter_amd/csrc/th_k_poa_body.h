@@ -193,6 +193,21 @@ __device__ __forceinline__ int th_poa_rows_body(const ThPoaG &g)
             // the usual chunk: three lane shifts, three adds, two max3 per round (an edge that does not exist adds minus "infinity";
             // values near -TH_BIG are "no path yet" and lose every maximum against a real one), two rounds per convergence test
             const int inc1 = has1 ? 1 : -TH_BIG, inc2 = has2 ? 1 : -TH_BIG, inc3 = has3 ? 1 : -TH_BIG;
+            // Round 5.  The rounds below move a value ONE edge per round, and a chunk is mostly a chain (row i's successor is row i + 1): 64 rounds for 64
+            // rows -- 860 of the phase's ~1500 vector instructions per chunk (profiles/r05_poa_phases.json: the phase was 12 % of the kernel's vector issue).
+            // Along a run of rows whose next row is a successor, remain[i] >= remain[i + 1] + 1, i.e. remain + row is a SUFFIX MAXIMUM over the run: one
+            // segmented scan (segment number in the high bits of the key, lanes reversed so that the prefix scan of th_hw.h serves) hands every lane the
+            // best of its run, and the rounds only have to carry values across the run ends (branches of bubbles): two or three trips instead of 33.
+            // Exact: the start value P obeys base <= P <= T(P) <= the fixed point of the rounds' operator T, which is monotone; the loop ends at the same
+            // (unique: the graph is acyclic) fixed point it reached from `base`.
+            if (n < (1 << 21) - 128) {
+                const unsigned long long brk = ~__ballot(has1 != 0);                  // lanes that cannot take from the lane above
+                const int seg = (int)__popcll(brk >> lane);                            // run ends at or above this lane: the same number all along a run, smaller above it
+                int key = seg << 22 | (cur > -TH_BIG ? cur + lane + 2 : 0);          // (0: no path yet)
+                key = __shfl(key, 63 - lane); key = th_wave_incl_max(key); key = __shfl(key, 63 - lane);
+                const int best = key & 0x3fffff;
+                if (best) cur = best - lane - 2;
+            }
             for (int it = 0; it < TH_WAVE / 2 + 1; ++it) {
                 int c1 = th_shl1(cur, -TH_BIG), c2 = th_shl1(c1, -TH_BIG), c3 = th_shl1(c2, -TH_BIG);
                 const int v1 = max(max(base, c1 + inc1), max(c2 + inc2, c3 + inc3));
@@ -274,14 +289,30 @@ __device__ TH_POA_ROWS_ATTR int th_poa_rows(int *my, int cap, int ocap, int opn,
 }
 
 #if defined(TH_POA_PROF)
-__device__ unsigned long long th_poa_prof[24];    // 0..3 phase cycles; 4..7 traceback events (tiles loaded, run trips, run steps, single steps); 8..15 rows per category, 16..23 their cycles
+__device__ unsigned long long th_poa_prof[32];    // 24: consensus cycles, 25: staging + seed cycles, 26: jobs; 0..3 phase cycles; 4..7 traceback events (tiles loaded, run trips, run steps, single steps); 8..15 rows per category, 16..23 their cycles
+// per-wave accumulators of the row loop in LDS, one 64-bit add per row: rows in bits 40.., cycles below (per-lane register arrays of round 4 cost the loop 32 VGPRs)
+__shared__ unsigned long long s_poa_prof[10];     // 8: further trips of packed rows; 9: packed rows with a far predecessor / a far reader
+#define TH_PROF_ROW(cat, dt) do { if (TH_LANE() == 0) atomicAdd(&s_poa_prof[cat], (1ull << 40) + (unsigned long long)(dt)); } while (0)
 #define TH_PROF_CNT(k, v) do { if (TH_LANE() == 0) atomicAdd(&th_poa_prof[k], (unsigned long long)(v)); } while (0)
-#define TH_PROF_T0() unsigned long long pt_ = __builtin_amdgcn_s_memtime()
-#define TH_PROF(k) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (TH_LANE() == 0) atomicAdd(&th_poa_prof[k], n_ - pt_); pt_ = n_; } while (0)
+// -DTH_POA_PROF=1: events only (rows per path of the row loop, further trips, traceback events); =2: s_memtime cycles per phase and per row path as well
+#if TH_POA_PROF >= 2
+#define TH_PROF_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define TH_PROF_NOW() 0ull
+#endif
+#define TH_PROF_T0() unsigned long long pt_ = TH_PROF_NOW()
+#define TH_PROF(k) do { unsigned long long n_ = TH_PROF_NOW(); if (TH_POA_PROF >= 2 && TH_LANE() == 0) atomicAdd(&th_poa_prof[k], n_ - pt_); pt_ = n_; } while (0)
 #else
 #define TH_PROF_CNT(k, v) ((void)0)
 #define TH_PROF_T0() ((void)0)
 #define TH_PROF(k) ((void)0)
+#endif
+
+#if defined(TH_POA_DUP_PHASE)
+__device__ __forceinline__ int th_dup_n(int k) { int n = k == TH_POA_DUP_PHASE ? 2 : 1; asm volatile("" : "+s"(n)); return n; }
+#define TH_DUP_N(k) th_dup_n(k)
+#else
+#define TH_DUP_N(k) 1
 #endif
 
 // ---- banded DP; returns the row of the sink's best predecessor (>= 0) or a negative status ----
@@ -351,6 +382,9 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
             break;
         }
         if (t0) tail_dirty |= 1 << myslot;
+#if defined(TH_POA_PROF)
+        if (t0) TH_PROF_ROW(8, 0);
+#endif
 #else
         if (t0 && B0 + t0 > e) {                             // the trips so far were enough: clear the rest of the slot, unless it is clean already
             const int tdone = t0 >> 7, told = TH_TD_GET(tail_dirty, myslot);      // trips 0 .. tdone - 1 written now; trips 1 .. told held values before
@@ -484,7 +518,7 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
 // end of a packed row taken by one of the two straight-line paths of the row loop: the row becomes "the previous row", its band /
 // maximum columns / direction-word offset go into lane (row & 63) of the chunk registers, a complete chunk goes to the row tables
 #if defined(TH_POA_PROF)
-#define TH_POA_PK_PROF(cat) { pf_n[cat] += 1; pf_t[cat] += __builtin_amdgcn_s_memtime() - row_t0; }
+#define TH_POA_PK_PROF(cat) TH_PROF_ROW(cat, TH_PROF_NOW() - row_t0);
 #else
 #define TH_POA_PK_PROF(cat)
 #endif
@@ -566,9 +600,6 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
 #endif
     for (int x = lane; x < TH_POA_RING * 3 * TH_POA_PAD; x += TH_WAVE) s_ring[x / (3 * TH_POA_PAD)][(x / TH_POA_PAD) % 3][x % TH_POA_PAD] = (RT)(WIDE ? TH_NEG : -32768);
     TH_WAVE_FENCE();
-#if defined(TH_POA_PROF)
-    unsigned long long pf_n[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, pf_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-#endif
     for (int i = 0; i + 1 < n; ++i) {
         if ((i & 63) == 0) {
             const int r = i + lane;
@@ -579,7 +610,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             TH_VM_WAIT0();      // here, once per 64 rows -- not at the first use below, where it would drain every row's stores
         }
 #if defined(TH_POA_PROF)
-        const unsigned long long row_t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long row_t0 = TH_PROF_NOW();
 #endif
 #if TH_POA_REL
         if (L_rmax > TH_POA_REL_HI || L_rmax < -TH_POA_REL_HI) {
@@ -707,7 +738,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                         int rmax = TH_NEG - 0x10000000, left = b, right = b;
                         th_poa_pk_row<QCAP, RT, false, true, 2>(s_qs, s_ring, dbase, lane, b, e, B0, i & 3, (uint32_t)TH_READLANE((int)v_T, meta & 0xff), inn_, qs0, qs1, qs2, qs3, qb0, qb1, qb2, qb3,
                                                 E1, E2, O1P, O2P, E1P, E2P, tail_dirty, rmax, left, right, far_o, far_pb, far_pe, g.cell + far_po, full ? g.cell + my_foff : nullptr, neg_thr, base);
-                        TH_POA_PK_ROW_DONE(2, my_foff);
+                        TH_POA_PK_ROW_DONE(9, my_foff);
                         continue;
                     }
                 }
@@ -861,9 +892,9 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = cstate;
         TH_POA_SET_RMAX(pk ? rmax : rmax - base);      // (the 32-bit path works with absolute scores)
 #if defined(TH_POA_PROF)
-        { const unsigned long long dt = __builtin_amdgcn_s_memtime() - row_t0;
+        { const unsigned long long dt = TH_PROF_NOW() - row_t0;
           const int cat = pk ? 1 : inn != 1 ? 2 : p0 != i - 1 ? 3 : needfull ? 4 : 5;     // (0: common packed row) / other packed / several predecessors / one far predecessor / stores full cells / other
-          pf_n[cat] += 1; pf_t[cat] += dt; }
+          TH_PROF_ROW(cat, dt); }
 #endif
         th_writelane6(m_beg, m_end, m_left, m_right, m_off, m_foff, b, e, L_l, L_r, my_off, my_foff, sl);
         if (sl == 63 || i + 2 >= n) {          // chunk complete (or last row): its rows' metadata to the tables, coalesced
@@ -872,9 +903,6 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         }
         TH_WAVE_FENCE();
     }
-#if defined(TH_POA_PROF)
-    if (lane == 0) for (int c = 0; c < 8; ++c) { atomicAdd(&th_poa_prof[8 + c], pf_n[c]); atomicAdd(&th_poa_prof[16 + c], pf_t[c]); }
-#endif
     // global end: best predecessor row of the sink (row n-1) at column qlen, first in edge order
     int bi = -1, bs = 0;
     {
@@ -1148,6 +1176,10 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
     const int lane = TH_LANE();
     const int wave = blockIdx.x;
     int *my = scratch + (long long)wave * scratch_ints;
+#if defined(TH_POA_PROF)
+    if (lane < 10) s_poa_prof[lane] = 0;
+    TH_WAVE_FENCE();
+#endif
     for (;;) {
         // jobs differ a lot in length (units, copies): waves pull the next job from a shared counter
         const int qi = th_queue_pop(queue);
@@ -1175,6 +1207,7 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
             g.cell_u2 = (uint32_t)min(avail * 2, 0x7ff00000LL); g.dcell = (uint16_t *)p; g.cell = (int4 *)(p + avail);
         }
         int st = 0;
+        TH_PROF_CNT(26, 1);
         if (p - my > scratch_ints || g.cell_u2 < 2048 || U[0].len + 2 > cap) st = 1;
         if (!st) th_poa_seed(g, rb + U[0].start, U[0].len);
         for (int s = 1; s < T.n_units && !st; ++s) {
@@ -1186,33 +1219,39 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
             }
             TH_WAVE_FENCE();
             TH_PROF_T0();
-#ifdef TH_POA_DUP_ROWS      // measurement only: the phase twice (it is idempotent), to read its marginal cost off the kernel time
-            th_poa_rows(my, (int)cap, (int)ocap, (int)opn, g.n_node, g.order != order0);
-#endif
-            const int deg = th_poa_rows(my, (int)cap, (int)ocap, (int)opn, g.n_node, g.order != order0);
+            // TH_POA_DUP_PHASE (measurement only, tools/poa_phases.sh): phase k (0 row tables, 1 DP, 2 traceback, 3 consensus -- all idempotent) runs
+            // TWICE, in a loop whose trip count the compiler cannot see (one copy of the code), so that the phase's instructions and time are the
+            // difference of two counter passes
+            int deg = 0, bi = 0, no = 0;
+            for (int r_ = 0; r_ < TH_DUP_N(0); ++r_) deg = th_poa_rows(my, (int)cap, (int)ocap, (int)opn, g.n_node, g.order != order0);
             TH_PROF(0);
             if (deg > 255) { st = 5; break; }
-            int bi = th_poa_dp<QCAP, RT, DEFSC>(g, q, s_qs, s_ring, s_rmeta, qlen, P, noband);
+            for (int r_ = 0; r_ < TH_DUP_N(1); ++r_) bi = th_poa_dp<QCAP, RT, DEFSC>(g, q, s_qs, s_ring, s_rmeta, qlen, P, noband);
             bi = TH_UNI(bi);         // (the same in every lane, but loaded: a divergent `break` below would put the other phases under exec masks)
             if (test_fail && !noband && t % test_fail == 0 && bi >= 0) bi = -4;
             TH_PROF(1);
             if (bi < 0) { st = bi == -3 ? 2 : bi == -5 ? 7 : bi == -2 ? 3 : 4; break; }
-#ifdef TH_POA_DUP_TB
-            th_poa_traceback(g, bi, qlen);
-#endif
-            const int no = th_poa_traceback(g, bi, qlen);
+            for (int r_ = 0; r_ < TH_DUP_N(2); ++r_) no = th_poa_traceback(g, bi, qlen);
             TH_PROF(2);
             if (th_poa_merge(g, q, no)) { st = 1; break; }          // the graph outgrew its node capacity: rerun with twice the factor
             TH_PROF(3);
         }
         int cl = 0;
         if (!st) {
-            cl = th_poa_consensus(g, T.n_units, cons + T.cons_off, cov + T.cons_off, T.cons_cap);
+            TH_PROF_T0();
+            for (int r_ = 0; r_ < TH_DUP_N(3); ++r_) cl = th_poa_consensus(g, T.n_units, cons + T.cons_off, cov + T.cons_off, T.cons_cap);
+            TH_PROF(24);
             if (cl < 0) { st = 6; cl = 0; }
         }
         if (lane == 0) { cons_len[t] = st ? 0 : cl; status[t] = st; }
         TH_WAVE_FENCE();
     }
+#if defined(TH_POA_PROF)
+    TH_WAVE_FENCE();
+    if (lane < 8) { const unsigned long long v = s_poa_prof[lane]; atomicAdd(&th_poa_prof[8 + lane], v >> 40); atomicAdd(&th_poa_prof[16 + lane], v & ((1ull << 40) - 1)); }
+    if (lane == 8) atomicAdd(&th_poa_prof[27], s_poa_prof[8] >> 40);
+    if (lane == 9) { atomicAdd(&th_poa_prof[28], s_poa_prof[9] >> 40); atomicAdd(&th_poa_prof[29], s_poa_prof[9] & ((1ull << 40) - 1)); }
+#endif
 }
 }  // namespace TH_POA_NS
 #undef TH_RING_LD

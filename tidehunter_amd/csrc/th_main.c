@@ -38,8 +38,9 @@ static int usage(void)
     fprintf(stderr, "Version: %s\n\nUsage:   TideHunter-amd [options] in.fa/fq > cons.fa\n\n", th_version());
     fprintf(stderr, "Options: as TideHunter 1.5.5 (-k -w -H -c -e -p -P -M -X -O -E -5 -3 -a -o -m -r -u -l -F -s -f -t -h -v)\n");
     fprintf(stderr, "         -g --gpu LIST   HIP device ordinal(s), e.g. 0 or 0,1,2,3: the listed devices share the batches [0];  -b --batch INT   reads per device batch [32768]\n");
-    fprintf(stderr, "Note:    consensus calling implements the published abPOA algorithm (libabpoa itself is not linked): stages 1-3, alignment statistics and\n"
-                    "         all coordinates are bit-identical to TideHunter 1.5.5; consensus bases of noisy units may differ from upstream in rare tie cases.\n");
+    fprintf(stderr, "Note:    every stage is bit-identical to this repository's CPU restatement of TideHunter 1.5.5 (oracle/), which reproduces every known answer in the\n"
+                    "         reference tree; the ksw2 / edlib results are additionally identical to the reference's compiled code.  Consensus calling implements the\n"
+                    "         published abPOA algorithm (libabpoa itself is not linked and could not be compared): consensus bases of noisy units may differ from upstream.\n");
     return 1;
 }
 
@@ -47,6 +48,7 @@ static double now(void) { struct timeval t; gettimeofday(&t, NULL); return t.tv_
 
 int main(int argc, char **argv)
 {
+    setenv("TH_BLOCKING_DEVICE", "1", 0);      /* this process is ours: blocking waits in the runtime's slow paths too (the library never sets the device flag by itself) */
     th_para_t *p = th_init_para();
     FILE *out = stdout; char *s; double x, t0 = now();
     int c, batch = 0, rc = 0;

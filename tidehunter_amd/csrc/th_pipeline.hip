@@ -104,6 +104,7 @@ struct th_gpu {
     bool sc_on = false; ThAdRead *h_adr = nullptr; DBuf<ThAdRead> d_adr; DBuf<int> d_single; bool adr_up = false;     // -s: whole-read adapter searches
     th_pvec<ThTask> h_tasks; th_pvec<int> h_cons_len, h_status, h_sublist;     // slow paths only
     int n_sync = 0;
+    long long stat[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };      // cumulative, th_gpu_stats(): 0 jobs left without a consensus, 1 POA jobs given back for a rerun, 2 reruns of stages 2-3 / the job tables (arena or table too small), 3 batches, 4 consensus jobs
     int aln_wdiv = 10, aln_wadd = 24;     // first certified band of the unit alignments: half-width cons_len / wdiv + wadd
     int aln_xpct = 36;                    // flank extensions: band half-width requested from the anti-diagonal engine, percent of min(consensus, flank) (+ 8)
     int aln_probe_small = 1;              // long units whose sequences fit the two-register variant's staging area are probed and finished there (th_aln_class)
@@ -358,6 +359,7 @@ static int th_fetch_cnt(th_gpu *g, ThCnt **out)
     return 0;
 }
 extern "C" int th_gpu_syncs(th_gpu_t *g) { return g->n_sync; }
+extern "C" int th_gpu_stats(th_gpu_t *g, long long *out, int n) { for (int i = 0; i < n && i < 8; ++i) out[i] = g->stat[i]; return 5; }
 
 // one launch of the POA kernel over a task list (both variants write consensus / length / status at the task's own index)
 static int th_poa_launch(th_gpu *g, KTimer &kt, const ThIn &in, const int *list, int n_list, int cls /* 1 int16, 2 relative int16 (long units), 0 32-bit */, int max_unit, long long need, int wv, int *queue, int poa_flags)
@@ -605,7 +607,9 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
         } else break;
         // reset what the rerun accumulates again (the error flags that are being answered, arena tops, queue heads, the build's maxima)
         TH_LAUNCH(th_k_cnt_rerun, 1, 64, g->stream, dc, redo_extract ? 1 : 0, redo_part ? 1 : 0);
+        g->stat[2] += 1;
     }
+    g->stat[3] += 1;
     if (cnt->min_fb && g->dp.w > 1 && !g->dp.hpc && !g->dp.w_seq) {
         if (getenv("TH_MINIMIZER_STRICT")) return th_fail("the parallel minimizer rules marked a slot twice on " + std::to_string(cnt->min_fb) + " read(s) (sequential replay used)");
         if (trace) fprintf(stderr, "[th] minimizer selection: %d read(s) took the sequential replay\n", cnt->min_fb);
@@ -650,7 +654,9 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
                       g->aln_wdiv, g->aln_wadd, g->aln_wtol | g->aln_probe_small << 16, (const int *)g->d_rows.p, (const ThCnt *)dc, g->d_items.p, g->d_cc_off.p, g->d_jobs.p);
             KT_END(TK_ALIGN);
             TRY(th_fetch_cnt(g, &cnt));                                                 // ---- host synchronisation 2 of 3 ----
+            if (pass == 0) g->stat[4] += nt;
             if (pass == 0 && cnt->n_retry) {
+                g->stat[1] += cnt->n_retry;
                 TRY(th_poa_retries(g, kt, in, nt, poa_test_fail));
                 TH_LAUNCH(th_k_cnt_set, 1, 64, g->stream, &dc->n_retry, 0, &dc->n_failed, 0, &dc->max_cl, 0, &dc->max_need_big, 0);
                 TH_LAUNCH(th_k_cnt_set, 1, 64, g->stream, &dc->n_item_long, 0, (int *)nullptr, 0, (int *)nullptr, 0, (int *)nullptr, 0);
@@ -658,14 +664,17 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
             }
             break;
         }
+        g->stat[0] += cnt->n_failed;
         if (cnt->n_failed) fprintf(stderr, "[tidehunter_amd] warning: %d consensus job(s) could not be aligned (POA status 3-6, or no scratch for them) and are reported without a consensus\n", cnt->n_failed);
 #if defined(TH_POA_PROF)
-        { unsigned long long pr[24]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(thpoa_n::th_poa_prof), sizeof(pr));
-          fprintf(stderr, "[poa_prof] rows %llu dp %llu traceback %llu merge %llu (cycles summed over waves)\n", pr[0], pr[1], pr[2], pr[3]);
-          fprintf(stderr, "[poa_prof]   traceback: %llu tiles loaded, %llu run trips emitting %llu steps, %llu single steps\n", pr[4], pr[5], pr[6], pr[7]);
-          const char *cat[8] = { "common packed", "packed, one predecessor", "several predecessors", "one far predecessor", "stores full cells", "other", "packed, two predecessors", "packed, three or four" };
-          for (int c = 0; c < 8; ++c) fprintf(stderr, "[poa_prof]   %-26s rows %12llu cycles %16llu (%.0f per row)\n", cat[c], pr[8 + c], pr[16 + c], pr[8 + c] ? (double)pr[16 + c] / pr[8 + c] : 0.0);
-          unsigned long long z[24] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(thpoa_n::th_poa_prof), z, sizeof(z)); }
+        { unsigned long long pr[32]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(thpoa_n::th_poa_prof), sizeof(pr));
+          const char *cat[8] = { "common_packed", "packed_one_pred", "general_several_preds", "general_one_far_pred", "general_stores_full", "general_other", "packed_two_preds", "packed_three_four_preds" };
+          fprintf(stderr, "[poa_prof] {\"jobs\": %llu, \"cycles\": {\"rows\": %llu, \"dp\": %llu, \"traceback\": %llu, \"merge\": %llu, \"consensus\": %llu}, "
+                          "\"traceback\": {\"tiles\": %llu, \"run_trips\": %llu, \"run_steps\": %llu, \"single_steps\": %llu}, \"packed_further_trips\": %llu, \"dp_rows\": {",
+                  pr[26], pr[0], pr[1], pr[2], pr[3], pr[24], pr[4], pr[5], pr[6], pr[7], pr[27]);
+          for (int c = 0; c < 8; ++c) fprintf(stderr, "%s\"%s\": {\"rows\": %llu, \"cycles\": %llu}", c ? ", " : "", cat[c], pr[8 + c], pr[16 + c]);
+          fprintf(stderr, ", \"packed_far\": {\"rows\": %llu, \"cycles\": %llu}}}\n", pr[28], pr[29]);
+          unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(thpoa_n::th_poa_prof), z, sizeof(z)); }
 #endif
         // ---- unit-vs-consensus alignments and flank extensions: three item lists in one array, one kernel variant each ----
         const int ns = cnt->n_item_s, nm = ns + cnt->n_item_m, ni = nm + cnt->n_item_b, max_cl = cnt->max_cl;

@@ -31,9 +31,11 @@ static inline int th_rt_event_wait(th_event_t e) { TH_CHECK(hipEventSynchronize(
 static inline int th_rt_event_destroy(th_event_t e) { TH_CHECK(hipEventDestroy(e)); return 0; }
 // drains stream s without spinning: a blocking event behind everything enqueued so far
 static inline int th_rt_sync_event(th_stream_t s, th_event_t e) { if (th_rt_spin()) { TH_CHECK(hipStreamSynchronize(s)); return 0; } TH_CHECK(hipEventRecord(e, s)); TH_CHECK(hipEventSynchronize(e)); return 0; }
-// asks the runtime for blocking waits everywhere else too (hipStreamSynchronize in slow paths, hipFree, ...).  Only honoured before the
-// device's context exists; afterwards it fails harmlessly (torch or another handle got there first) -- the events above do not depend on it.
-static inline void th_rt_prefer_blocking() { if (!th_rt_spin()) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); } }
+// TH_BLOCKING_DEVICE=1 (opt-in; the TideHunter-amd executable sets it for its own process): asks the runtime for blocking waits everywhere else too
+// (hipStreamSynchronize in slow paths, hipFree, ...).  It is a per-device, PROCESS-WIDE scheduling flag -- it would also change how an embedding application
+// (torch, another library) waits -- so the library never sets it by itself; the hot path does not need it: its three waits per batch
+// are the blocking events above.  Only honoured before the device's context exists.
+static inline void th_rt_prefer_blocking() { const char *e = getenv("TH_BLOCKING_DEVICE"); if (e && atoi(e) && !th_rt_spin()) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); } }
 // a launch the runtime rejects (resource limits, wrong device, ...) must not pass silently: the enclosing function returns
 // th_launch_failed(...) (an int, defined by the pipeline before its first launch)
 #define TH_LAUNCH(kernel, grid, block, stream, ...) do { hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__); \
