@@ -65,6 +65,9 @@ static inline uint32_t th_pk_sub(uint32_t a, uint32_t b) { return TH_PK(th_sat16
 static inline uint32_t th_pk_max(uint32_t a, uint32_t b) { return TH_PK(TH_PK_LO(a) > TH_PK_LO(b) ? TH_PK_LO(a) : TH_PK_LO(b), TH_PK_HI(a) > TH_PK_HI(b) ? TH_PK_HI(a) : TH_PK_HI(b)); }
 static inline uint32_t th_pk_negmask(uint32_t a) { return (TH_PK_LO(a) < 0 ? 0xffffu : 0u) | (TH_PK_HI(a) < 0 ? 0xffff0000u : 0u); }
 static inline uint32_t th_alignbit16(uint32_t hi, uint32_t lo) { return (lo >> 16) | (hi << 16); }   // (lo.hi, hi.lo)
+#define TH_PK_SUB_IMM(x, K) th_pk_sub((x), TH_PK_DUP(K))
+static inline uint32_t th_pk_neg_outside(uint32_t m) { return ~m & 0x80008000u; }
+static inline uint32_t th_pk_score_sel(uint32_t qx) { return (((qx << 12) | qx) & 0x000f000fu) | 0x0c000c00u; }
 static inline uint32_t th_pk_negmask_op(uint32_t a) { return th_pk_negmask(a); }
 static inline uint32_t th_pk_sign(uint32_t a) { return (TH_PK_LO(a) < 0 ? 1u : 0u) | (TH_PK_HI(a) < 0 ? 0x10000u : 0u); }
 static inline uint32_t th_ubfe(uint32_t v, uint32_t off, uint32_t w) { return (v >> (off & 31)) & ((1u << w) - 1); }

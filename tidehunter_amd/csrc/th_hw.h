@@ -129,7 +129,34 @@ __device__ __forceinline__ uint32_t th_pk_add(uint32_t a, uint32_t b) { return _
 __device__ __forceinline__ uint32_t th_pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(th_s2_t, a), __builtin_bit_cast(th_s2_t, b))); }
 __device__ __forceinline__ uint32_t th_pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(th_s2_t, a), __builtin_bit_cast(th_s2_t, b))); }
 __device__ __forceinline__ uint32_t th_pk_negmask(uint32_t a) { const th_s2_t v = __builtin_bit_cast(th_s2_t, a); const th_s2_t r = v >> (th_s2_t)(15); return __builtin_bit_cast(uint32_t, r); }
-__device__ __forceinline__ uint32_t th_alignbit16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
+// (as ONE instruction with the shift as an inline operand: the compiler turns the builtin into a v_perm_b32 whose selector is a 32-bit literal, and VOP3 takes no
+// literal on gfx9 -- an s_mov_b32 per use.  The packed POA row ran nine such literal moves per trip, a fifth of its scalar instructions: round 5)
+__device__ __forceinline__ uint32_t th_alignbit16(uint32_t hi, uint32_t lo) { uint32_t r; asm("v_alignbit_b32 %0, %1, %2, 16" : "=v"(r) : "v"(hi), "v"(lo)); return r; }
+// both halves minus a constant in the range of the inline operands (0 .. 64), saturating: hipcc canonicalises sub_sat(x, K) to add_sat(x, -K), and -24 / -32
+// are literals where 24 / 32 are inline
+#define TH_PK_SUB_IMM(x, K) ({ uint32_t r_; asm("v_pk_sub_i16 %0, %1, %2 op_sel_hi:[1,0] clamp" : "=v"(r_) : "v"(x), "n"(K)); r_; })
+// 0x8000 ("minus infinity") in every 16-bit half the mask m (0xffff / 0 per half) leaves out: ~m & 0x80008000 as two VOP2 instructions of the fast class, the
+// constant a literal of the second -- the select (x & m) | that is then ONE v_and_or_b32 on three vector registers, where v_bfi_b32 against the constant
+// needed it in a scalar register (moved there per use)
+#ifndef TH_R5_NEGM_ASM
+#define TH_R5_NEGM_ASM 1
+#endif
+__device__ __forceinline__ uint32_t th_pk_neg_outside(uint32_t m)
+{
+#if TH_R5_NEGM_ASM
+    uint32_t r; asm("v_not_b32 %0, %1\n\tv_and_b32 %0, 0x80008000, %0" : "=&v"(r) : "v"(m)); return r;
+#else
+    return ~m & 0x80008000u;
+#endif
+}
+// the byte-permute selector of the packed row's score look-up from a byte holding two 4-bit query codes: ((x << 12 | x) & 0x000f000f) | 0x0c000c00 with the two
+// constants as VOP2 literals (fused into v_bitop3 / v_and_or they need scalar registers)
+__device__ __forceinline__ uint32_t th_pk_score_sel(uint32_t qx)
+{
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, 12, %1\n\tv_and_b32 %0, 0x000f000f, %0\n\tv_or_b32 %0, 0x0c000c00, %0" : "=&v"(r) : "v"(qx));
+    return r;
+}
 // the same as th_pk_negmask, but opaque to the optimiser: hipcc turns ashr(sub_sat(a, b), 15) feeding a bit-select into
 // two 16-bit compares, two v_cndmask and a v_perm; written as one instruction it stays v_pk_sub / v_pk_ashrrev / v_bfi
 __device__ __forceinline__ uint32_t th_pk_negmask_op(uint32_t a) { uint32_t r; asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }

@@ -189,25 +189,25 @@ __device__ __forceinline__ int th_poa_rows_body(const ThPoaG &g)
         }
         const bool fastrel = !hard && !__any(!nearok);
         int cur = base;
+        // Round 5.  The rounds below (either kind) move a value ONE edge per round, and a chunk is mostly a chain (row i's successor is row i + 1): 64 rounds for 64
+        // rows -- 860 of the phase's ~1500 vector instructions per chunk (profiles/r05_poa_phases.json: the phase was 12 % of the kernel's vector issue).
+        // Along a run of rows whose next row is a successor, remain[i] >= remain[i + 1] + 1, i.e. remain + row is a SUFFIX MAXIMUM over the run: one
+        // segmented scan (segment number in the high bits of the key, lanes reversed so that the prefix scan of th_hw.h serves) hands every lane the
+        // best of its run, and the rounds only have to carry values across the run ends (branches of bubbles): two or three trips instead of 33.
+        // Exact: the start value P obeys base <= P <= T(P) <= the fixed point of the rounds' operator T, which is monotone; the loop ends at the same
+        // (unique: the graph is acyclic) fixed point it reached from `base`.
+        if (n < (1 << 21) - 128) {
+            const unsigned long long brk = ~__ballot(has1 != 0);                  // lanes that cannot take from the lane above
+            const int seg = (int)__popcll(brk >> lane);                            // run ends at or above this lane: the same number all along a run, smaller above it
+            int key = seg << 22 | (cur > -TH_BIG ? cur + lane + 2 : 0);          // (0: no path yet)
+            key = __shfl(key, 63 - lane); key = th_wave_incl_max(key); key = __shfl(key, 63 - lane);
+            const int best = key & 0x3fffff;
+            if (best) cur = best - lane - 2;
+        }
         if (fastrel) {
             // the usual chunk: three lane shifts, three adds, two max3 per round (an edge that does not exist adds minus "infinity";
             // values near -TH_BIG are "no path yet" and lose every maximum against a real one), two rounds per convergence test
             const int inc1 = has1 ? 1 : -TH_BIG, inc2 = has2 ? 1 : -TH_BIG, inc3 = has3 ? 1 : -TH_BIG;
-            // Round 5.  The rounds below move a value ONE edge per round, and a chunk is mostly a chain (row i's successor is row i + 1): 64 rounds for 64
-            // rows -- 860 of the phase's ~1500 vector instructions per chunk (profiles/r05_poa_phases.json: the phase was 12 % of the kernel's vector issue).
-            // Along a run of rows whose next row is a successor, remain[i] >= remain[i + 1] + 1, i.e. remain + row is a SUFFIX MAXIMUM over the run: one
-            // segmented scan (segment number in the high bits of the key, lanes reversed so that the prefix scan of th_hw.h serves) hands every lane the
-            // best of its run, and the rounds only have to carry values across the run ends (branches of bubbles): two or three trips instead of 33.
-            // Exact: the start value P obeys base <= P <= T(P) <= the fixed point of the rounds' operator T, which is monotone; the loop ends at the same
-            // (unique: the graph is acyclic) fixed point it reached from `base`.
-            if (n < (1 << 21) - 128) {
-                const unsigned long long brk = ~__ballot(has1 != 0);                  // lanes that cannot take from the lane above
-                const int seg = (int)__popcll(brk >> lane);                            // run ends at or above this lane: the same number all along a run, smaller above it
-                int key = seg << 22 | (cur > -TH_BIG ? cur + lane + 2 : 0);          // (0: no path yet)
-                key = __shfl(key, 63 - lane); key = th_wave_incl_max(key); key = __shfl(key, 63 - lane);
-                const int best = key & 0x3fffff;
-                if (best) cur = best - lane - 2;
-            }
             for (int it = 0; it < TH_WAVE / 2 + 1; ++it) {
                 int c1 = th_shl1(cur, -TH_BIG), c2 = th_shl1(c1, -TH_BIG), c3 = th_shl1(c2, -TH_BIG);
                 const int v1 = max(max(base, c1 + inc1), max(c2 + inc2, c3 + inc3));
@@ -247,11 +247,11 @@ __device__ __forceinline__ int th_poa_rows_body(const ThPoaG &g)
             int needfull = on > TH_POA_INL;
 #pragma unroll
             for (int k = 0; k < TH_POA_INL; ++k) if (s[k] >= 0 && (s[k] - idx >= TH_POA_RING || s[k] == n - 1)) needfull = 1;
-            // bit 26: every predecessor (one to four) is the row before or one of the three rows before inside this 64-row chunk, and no far row reads this
+            // bit 26: every predecessor (one to four) is one of the three rows before this one, and no far row reads this
             // one -- what the graph decides of the DP's bubble-row path (the band widths and cache states it also needs are known only there)
             bool ring_ok = in >= 1 && in <= TH_POA_INL && !needfull && idx > 0;
 #pragma unroll
-            for (int k = 0; k < TH_POA_INL; ++k) if (k < in && !(p[k] == idx - 1 || (p[k] >= (idx & ~63) && p[k] < idx && idx - p[k] < TH_POA_RING))) ring_ok = false;
+            for (int k = 0; k < TH_POA_INL; ++k) if (k < in && !(p[k] < idx && idx - p[k] < TH_POA_RING)) ring_ok = false;      // (round 5: across a 64-row boundary too -- lane (row & 63) of the DP's chunk registers keeps a row's band until row + 64 overwrites it)
             st_idx = ok ? idx : -1; st_rem = cur; st_meta = (int)ring_ok << 26 | a.nb | min(in, 255) << 8 | min(on, 255) << 16 | needfull << 24 | (int)(in == 1 && p[0] == idx - 1 && !needfull) << 25;     // bit 25: the DP's common row, as far as the graph decides it
 #pragma unroll
             for (int k = 0; k < TH_POA_INL; ++k) st_p[k] = p[k];
@@ -370,6 +370,7 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
     // ================= packed row: lane l owns columns B0 + 128 t + 2 l and the next one =================
     uint32_t *wH = (uint32_t *)s_ring[myslot][0], *wE1 = (uint32_t *)s_ring[myslot][1], *wE2 = (uint32_t *)s_ring[myslot][2];
     int carry1 = -32768, carry2 = -32768;                   // F1 / F2 running maxima in the column-offset domain
+    int i1p = 0, i2p = 0;                                   // the previous trip's F1 / F2 scans: their last lane is read only if a further trip runs (four rows in five have one trip)
     for (int t0 = 0; t0 < TH_POA_TRIPS * 128; t0 += 128) {
         const int jr = t0 + 2 * lane, j0 = B0 + jr;
         const int wi = (jr + TH_POA_PAD) >> 1;              // this lane's pair in the row being written
@@ -397,13 +398,15 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
         }
         if (t0 && (t0 >> 7) > TH_TD_GET(tail_dirty, myslot)) TH_TD_SET(tail_dirty, myslot, t0 >> 7);
 #endif
+        if (t0) { const int c1_ = TH_READLANE(i1p, 63), c2_ = TH_READLANE(i2p, 63); carry1 = t0 > 128 ? max(carry1, c1_) : c1_; carry2 = t0 > 128 ? max(carry2, c2_) : c2_; }
         const bool lo_ok = j0 >= b && j0 <= e, hi_ok = j0 + 1 <= e;
         const uint32_t IM = (lo_ok ? 0xffffu : 0u) | (hi_ok ? 0xffff0000u : 0u);
+        const uint32_t NM = th_pk_neg_outside(IM);           // minus infinity in the halves outside the band: x inside | NM = th_sel(IM, x, TH_PK_NEG) as one and-or of three vector registers
         // substitution scores of the two columns from the row's table
         const uint32_t qx = s_qs[TH_LDS_SLACK_INDEX(j0, QCAP) >> 1];      // the pair's two 4-bit query codes; columns beyond e may read past the staged codes (still inside the workgroup's LDS): they are masked out below
         // T: the four biased scores of this row's node base against A, C, G, T, one per byte; code 4 (N, and the column 0 / beyond-the-
         // query filler) selects byte 0 of the other source, the bias itself.  One byte permute looks both columns up.
-        const uint32_t SC = th_pk_sub(th_perm(32u, T, (((qx << 12) | qx) & 0x000f000fu) | 0x0c000c00u), 0x00200020u);
+        const uint32_t SC = TH_PK_SUB_IMM(th_perm(32u, T, th_pk_score_sel(qx)), 32);
         // predecessor rows (all in the ring): diagonal pair (j0-1, j0) and vertical pairs (j0, j0+1) of each; anything outside
         // a row's band reads -inf (its slot is clean, indices beyond either end are sent to the padding).  The first
         // predecessor in edge order wins ties, as in the one-column-per-lane path; PMV / PE1V / PE2V hold the winners' edge
@@ -442,13 +445,15 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
         const uint32_t hnf = th_pk_max(hnf1, e2v), dg2 = th_pk_sub(hnf1, e2v);
         // row maximum: the maximum of H is a maximum of hnf (an F value is always below the hnf it came from), and H == max only
         // where hnf == max.  Scanned here, next to the two F scans: three independent dependency chains fill each other's wait states
-        const uint32_t hm2 = th_sel(IM, hnf, TH_PK_NEG);
+        const uint32_t hm2 = th_and_or(hnf, IM, NM);
         const int hmv = th_wave_incl_max(max(TH_PK_LO(hm2), TH_PK_HI(hm2)));
         // F1 / F2: max-plus prefix over the row in the domain value + column * extension
         const uint32_t JR = TH_PK(jr, jr + 1);
         const uint32_t JE1 = TH_PK(TH_PK_LO(JR) * E1, TH_PK_HI(JR) * E1), JE2 = TH_PK(TH_PK_LO(JR) * E2, TH_PK_HI(JR) * E2);
-        const uint32_t a1 = th_sel(IM, th_pk_add(th_pk_sub(hnf, O1P), JE1), TH_PK_NEG);
-        const uint32_t a2 = th_sel(IM, th_pk_add(th_pk_sub(hnf, O2P), JE2), TH_PK_NEG);
+        const uint32_t a1 = th_and_or(th_pk_add(th_pk_sub(hnf, O1P), JE1), IM, NM);
+        // (the default second gap open, 24, as an inline operand of the subtraction: as -24 of an addition it is a literal in a scalar register, moved there per trip)
+#define TH_SUB_O2(x) ((__builtin_constant_p(O2P) && O2P == TH_PK_DUP(24)) ? TH_PK_SUB_IMM((x), 24) : th_pk_sub((x), O2P))
+        const uint32_t a2 = th_and_or(th_pk_add(TH_SUB_O2(hnf), JE2), IM, NM);
         // lane totals are scanned as two 32-bit values: v_max_i32 takes the DPP operand directly (one instruction per
         // step), a packed max would need a move and an identity fill per step
         const int a1l = TH_PK_LO(a1), a2l = TH_PK_LO(a2);
@@ -456,14 +461,15 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
         // best before this lane's pair.  (In the first trip the carries are minus infinity, the smallest value of the domain: nothing to take the
         // maximum with; the compiler peels that trip, so the test costs nothing.)
         const int b1 = t0 ? max(th_shr1(i1, carry1), carry1) : th_shr1(i1, -32768), b2 = t0 ? max(th_shr1(i2, carry2), carry2) : th_shr1(i2, -32768);
-        carry1 = t0 ? max(carry1, TH_READLANE(i1, 63)) : TH_READLANE(i1, 63); carry2 = t0 ? max(carry2, TH_READLANE(i2, 63)) : TH_READLANE(i2, 63);
+        i1p = i1; i2p = i2;
         const uint32_t x1 = TH_PK(b1, max(b1, a1l)), x2 = TH_PK(b2, max(b2, a2l));                 // (before lo, before hi)
         const uint32_t f1 = th_pk_sub(x1, JE1), f2 = th_pk_sub(x2, JE2);
         const uint32_t h3 = th_pk_max(hnf, f1), dg3 = th_pk_sub(hnf, f1);
         const uint32_t h = th_pk_max(h3, f2), dg4 = th_pk_sub(h3, f2);
         // direction word of the two columns: the sign bits of eight saturating differences, two differences per byte permute (its sign
         // selectors deliver 0xff / 0x00 per half), one bit position per pair (layout: th_k_poa.hip)
-        const uint32_t hO1 = th_pk_sub(h, O1P), hO2 = th_pk_sub(h, O2P);
+        const uint32_t hO1 = th_pk_sub(h, O1P), hO2 = TH_SUB_O2(h);
+#undef TH_SUB_O2
         const uint32_t xf1 = th_pk_sub(hO1, f1), xf2 = th_pk_sub(hO2, f2);
         const uint32_t n1 = th_pk_sub(th_pk_max(hO1, e1v), E1P), n2 = th_pk_sub(th_pk_max(hO2, e2v), E2P);
         // column b-1 / e+1 of an odd edge land in the row's own padding.  drow is the word of column B0 (the row's even base): a
@@ -492,7 +498,7 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
             wE1[wi] = th_sel(IM & ~th_pk_negmask_op(th_pk_sub(n1, THRP)), n1, TH_PK_NEG);
             wE2[wi] = th_sel(IM & ~th_pk_negmask_op(th_pk_sub(n2, THRP)), n2, TH_PK_NEG);
 #else
-            wH[wi] = th_sel(IM, h, TH_PK_NEG); wE1[wi] = th_sel(IM, n1, TH_PK_NEG); wE2[wi] = th_sel(IM, n2, TH_PK_NEG);
+            wH[wi] = th_and_or(h, IM, NM); wE1[wi] = th_and_or(n1, IM, NM); wE2[wi] = th_and_or(n2, IM, NM);
 #endif
         }
         if (FAR && full_row) {
@@ -628,7 +634,6 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
 #endif
         const int sl = i & 63;
         const int meta = TH_READLANE(c_meta, sl), rm = TH_READLANE(c_rem, sl);
-        const int p0 = TH_READLANE(c_p0, sl);
         if (!WIDE && LQ) {
             // ---- the common row (58 % at the headline shape): one predecessor, the previous row, clean in its ring slot; no far row
             // will read this one; its band fits the ring.  Straight-line scalar set-up, then the packed row with one predecessor.
@@ -649,11 +654,13 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                     continue;
                 }
             }
+        }
+        const int p0 = TH_READLANE(c_p0, sl);          // (after the common row, which does not need it)
+        if (!WIDE && LQ) {
             // ---- the branch / merge rows of bubbles (35 %): up to four predecessors, each one of the three rows before this one, in
             // this 64-row chunk (or the previous row) and clean in its ring slot; no far row will read this one.  Same thing, unrolled.
             const int inn_ = (meta >> 8) & 0xff;
             if ((meta >> 26) & 1) {
-                const int cb = i & ~63;
                 int mpl = 0x7fffffff, mpr = 0, mb = 0x7fffffff, bad = 0;
                 int qs0 = 0, qs1 = 0, qs2 = 0, qs3 = 0, qb0 = 0, qb1 = 0, qb2 = 0, qb3 = 0;
 #define TH_POA_RING_PRED(PI, QS, QB) do { \
@@ -700,14 +707,13 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             // this one, which then also stores its cells in full.  Everything still inside this 64-row chunk; the rest goes on to the
             // general path below (one column per lane in 32 bits).
             if (i > 0 && inn_ >= 1 && inn_ <= 4) {
-                const int cb = i & ~63;
                 int mpl = 0x7fffffff, mpr = 0, mb = 0x7fffffff, bad = 0;
                 int qs0 = 0, qs1 = 0, qs2 = 0, qs3 = 0, qb0 = 0, qb1 = 0, qb2 = 0, qb3 = 0;
                 int far_o = -1, far_pb = 0, far_pe = -1, far_po = 0;
 #define TH_POA_FAR_PRED(O, PI, QS, QB) do { \
                     const int pi_ = (PI); int pb_ = 0, pl_ = 0, pr_ = 0; \
                     if (pi_ == i - 1 && L_c == 3) { pb_ = L_b; pl_ = L_l; pr_ = L_r; } \
-                    else if (pi_ >= cb && pi_ < i) { \
+                    else if (pi_ < i && i - pi_ < TH_WAVE) {      /* (its band is still in lane pi_ & 63 of the chunk registers: row pi_ + 64 has not been written yet) */ \
                         const int x_ = pi_ & 63; \
                         pb_ = TH_READLANE(m_beg, x_); pl_ = TH_READLANE(m_left, x_); pr_ = TH_READLANE(m_right, x_); \
                         const int pe_ = TH_READLANE(m_end, x_); \
