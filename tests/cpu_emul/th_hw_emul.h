@@ -66,6 +66,9 @@ static inline uint32_t th_pk_max(uint32_t a, uint32_t b) { return TH_PK(TH_PK_LO
 static inline uint32_t th_pk_negmask(uint32_t a) { return (TH_PK_LO(a) < 0 ? 0xffffu : 0u) | (TH_PK_HI(a) < 0 ? 0xffff0000u : 0u); }
 static inline uint32_t th_alignbit16(uint32_t hi, uint32_t lo) { return (lo >> 16) | (hi << 16); }   // (lo.hi, hi.lo)
 #define TH_PK_SUB_IMM(x, K) th_pk_sub((x), TH_PK_DUP(K))
+static inline int th_smax(int a, int b) { return a > b ? a : b; }
+static inline int th_smin(int a, int b) { return a < b ? a : b; }
+static inline int th_smax0(int a) { return a > 0 ? a : 0; }
 static inline uint32_t th_pk_neg_outside(uint32_t m) { return ~m & 0x80008000u; }
 static inline uint32_t th_pk_score_sel(uint32_t qx) { return (((qx << 12) | qx) & 0x000f000fu) | 0x0c000c00u; }
 static inline uint32_t th_pk_negmask_op(uint32_t a) { return th_pk_negmask(a); }

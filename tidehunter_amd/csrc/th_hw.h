@@ -83,6 +83,11 @@ __device__ __forceinline__ int th_wave_incl_sum(int v)
 // vector code under execution masks.
 #define TH_UNI(x) __builtin_amdgcn_readfirstlane(x)
 
+// max / min of wave-uniform values ON THE SCALAR UNIT: for max(max(0, x), y) of three scalars hipcc picks v_mov + v_max3_i32 + v_readfirstlane (and a vector
+// compare for the test that follows): four vector instructions per POA row where two scalar ones do
+__device__ __forceinline__ int th_smax(int a, int b) { int r; asm("s_max_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
+__device__ __forceinline__ int th_smin(int a, int b) { int r; asm("s_min_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
+__device__ __forceinline__ int th_smax0(int a) { int r; asm("s_max_i32 %0, %1, 0" : "=s"(r) : "s"(a) : "scc"); return r; }
 #define TH_UNI_PTR(T, p) ((T *)(((unsigned long long)(uint32_t)TH_UNI((int)((unsigned long long)(p) >> 32)) << 32) | (uint32_t)TH_UNI((int)(unsigned long long)(p))))
 // compiler fences on single values: TH_OPAQUE_V(x) makes x (in a VGPR) opaque to the optimiser from here on, TH_KEEP_V(x) is a use of x
 // at this point (loads that feed it are issued before it); neither emits an instruction

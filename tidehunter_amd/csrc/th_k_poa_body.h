@@ -350,6 +350,7 @@ __device__ __forceinline__ int th_dup_n(int k) { int n = k == TH_POA_DUP_PHASE ?
 #define TH_TD_GET(td, s) (((td) >> (2 * (s))) & 3)
 #define TH_TD_SET(td, s, v) ((td) = ((td) & ~(3 << (2 * (s)))) | ((v) << (2 * (s))))
 #define TH_RIDX(j, beg) ((j) - ((beg) & ~1) + TH_POA_PAD)
+#define TH_LC_ON (1 << 25)      // L_c (the previous row is cached, clean, in its ring slot) as the bit of the row tables' meta word it is tested against
 
 // One packed row: lane l owns columns B0 + 128 t + 2 l and the next one; every predecessor (npk of them, ring slot q_slot*, even
 // band base q_pb*) sits clean in the LDS ring.  Writes the row's ring slot and its 16-bit direction words (drow: column B0), returns
@@ -529,7 +530,7 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
 #define TH_POA_PK_PROF(cat)
 #endif
 #define TH_POA_PK_ROW_DONE(cat, FOFF) do { \
-        L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = 3; TH_POA_SET_RMAX(rmax); \
+        L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = TH_LC_ON; TH_POA_SET_RMAX(rmax); \
         TH_POA_PK_PROF(cat) \
         th_writelane6(m_beg, m_end, m_left, m_right, m_off, m_foff, b, e, L_l, L_r, my_off, (FOFF), sl); \
         if (sl == 63 || i + 2 >= n) { \
@@ -637,10 +638,12 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         if (!WIDE && LQ) {
             // ---- the common row (58 % at the headline shape): one predecessor, the previous row, clean in its ring slot; no far row
             // will read this one; its band fits the ring.  Straight-line scalar set-up, then the packed row with one predecessor.
-            const int not_common = (((meta >> 25) & 1) ^ 1) | (L_c ^ 3);       // (bit 25 of the row's meta word, th_poa_rows: one predecessor, the row before, no far reader)
-            if (not_common == 0) {
+            // (bit 25 of the row's meta word, th_poa_rows: one predecessor, the row before, no far reader; L_c is that very bit when the previous row sits clean in
+            // its ring slot, else 0: the test is one s_and_b32 and a branch on its condition code -- as two booleans it was seven scalar instructions, round 5)
+            if (meta & L_c) {
                 const int xd = qlen - rm;
-                const int b = max(max(0, min(L_l + 1, xd) - w), L_b), e = min(qlen, max(L_r + 1, xd) + w);
+                // (scalar max / min: hipcc makes a vector max3 + a vector compare of these -- th_hw.h)
+                const int b = th_smax(th_smax0(th_smin(L_l + 1, xd) - w), L_b), e = th_smin(qlen, th_smax(L_r + 1, xd) + w);
                 if (b > e) return -2;
                 if (e - b < TH_POA_RW) {
                     const int B0 = b & ~1, span = (e | 1) - B0 + 1, units = th_d_units(span, true);
@@ -665,7 +668,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 int qs0 = 0, qs1 = 0, qs2 = 0, qs3 = 0, qb0 = 0, qb1 = 0, qb2 = 0, qb3 = 0;
 #define TH_POA_RING_PRED(PI, QS, QB) do { \
                     const int pi_ = (PI); int pb_, pl_, pr_; \
-                    if (pi_ == i - 1) { pb_ = L_b; pl_ = L_l; pr_ = L_r; bad |= L_c ^ 3; } \
+                    if (pi_ == i - 1) { pb_ = L_b; pl_ = L_l; pr_ = L_r; bad |= L_c ^ TH_LC_ON; } \
                     else { \
                         const int x_ = pi_ & 63; \
                         pb_ = TH_READLANE(m_beg, x_); pl_ = TH_READLANE(m_left, x_); pr_ = TH_READLANE(m_right, x_); \
@@ -683,7 +686,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 }
                 if (!bad) {
                     const int xd = qlen - rm;
-                    const int b = max(max(0, min(mpl, xd) - w), mb), e = min(qlen, max(mpr, xd) + w);
+                    const int b = th_smax(th_smax0(th_smin(mpl, xd) - w), mb), e = th_smin(qlen, th_smax(mpr, xd) + w);
                     if (b > e) return -2;
                     if (e - b < TH_POA_RW) {
                         const int B0 = b & ~1, span = (e | 1) - B0 + 1, units = th_d_units(span, inn_ == 1);
@@ -712,7 +715,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 int far_o = -1, far_pb = 0, far_pe = -1, far_po = 0;
 #define TH_POA_FAR_PRED(O, PI, QS, QB) do { \
                     const int pi_ = (PI); int pb_ = 0, pl_ = 0, pr_ = 0; \
-                    if (pi_ == i - 1 && L_c == 3) { pb_ = L_b; pl_ = L_l; pr_ = L_r; } \
+                    if (pi_ == i - 1 && L_c != 0) { pb_ = L_b; pl_ = L_l; pr_ = L_r; } \
                     else if (pi_ < i && i - pi_ < TH_WAVE) {      /* (its band is still in lane pi_ & 63 of the chunk registers: row pi_ + 64 has not been written yet) */ \
                         const int x_ = pi_ & 63; \
                         pb_ = TH_READLANE(m_beg, x_); pl_ = TH_READLANE(m_left, x_); pr_ = TH_READLANE(m_right, x_); \
@@ -757,7 +760,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         // predecessors as the packed row reads them: ring slot and even band base of each; ring_all: every predecessor is one of
         // the three rows before this one and sits (clean) in its ring slot
         int q_slot0 = (i - 1) & 3, q_slot1 = 0, q_slot2 = 0, q_slot3 = 0, q_pb0 = L_b & ~1, q_pb1 = 0, q_pb2 = 0, q_pb3 = 0;
-        bool ring_all = fast && L_c == 3;
+        bool ring_all = fast && L_c != 0;
         // ---- band: pull the predecessors' band start and row-maximum columns ----
         int b = 0, e;
         if (fast) {
@@ -771,7 +774,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 const int pi = o == 0 ? p0 : o == 1 ? p1 : o == 2 ? p2 : o == 3 ? p3 : g.pos[th_poa_in(g, vid, o)];
                 const int s = pi & 3;
                 int pb, pl, pr, pe;
-                if (pi == i - 1) { pb = L_b; pl = L_l; pr = L_r; pe = L_c == 3 ? L_b : L_b + TH_POA_RW; }
+                if (pi == i - 1) { pb = L_b; pl = L_l; pr = L_r; pe = L_c != 0 ? L_b : L_b + TH_POA_RW; }
                 else if (pi >= (i & ~63)) { pb = TH_READLANE(m_beg, pi & 63); pl = TH_READLANE(m_left, pi & 63); pr = TH_READLANE(m_right, pi & 63); pe = TH_READLANE(m_end, pi & 63); }
                 else { pb = TH_UNI(g.r_beg[pi]); pl = TH_UNI(g.r_mpl[pi]); pr = TH_UNI(g.r_mpr[pi]); pe = pb + TH_POA_RW; }     // a row of the previous chunk: not worth a fourth load
                 mpl = min(mpl, pl + 1); mpr = max(mpr, pr + 1); mb = min(mb, pb);
@@ -894,8 +897,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             else if (hm == rmax) right = c0 + th_msb64(mm);
         }
         }
-        const int cstate = cache_me ? 3 : 0;
-        L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = cstate;
+        L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = cache_me ? TH_LC_ON : 0;
         TH_POA_SET_RMAX(pk ? rmax : rmax - base);      // (the 32-bit path works with absolute scores)
 #if defined(TH_POA_PROF)
         { const unsigned long long dt = TH_PROF_NOW() - row_t0;
