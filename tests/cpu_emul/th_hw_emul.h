@@ -47,6 +47,7 @@ __device__ __forceinline__ int th_wave_incl_sum(int v)
 #define TH_UNI_PTR(T, p) (p)
 #define TH_OPAQUE_V(x) ((void)0)
 #define TH_KEEP_V(x) ((void)0)
+#define TH_OPAQUE_S(x) ((void)0)
 #define TH_NOINLINE
 #define TH_LDS_SLACK_INDEX(i, cap) (min((int)(i), (int)(cap)))       // (a static array here: stay inside it)
 

@@ -93,6 +93,7 @@ __device__ __forceinline__ int th_smax0(int a) { int r; asm("s_max_i32 %0, %1, 0
 // at this point (loads that feed it are issued before it); neither emits an instruction
 #define TH_OPAQUE_V(x) asm volatile("" : "+v"(x))
 #define TH_KEEP_V(x) asm volatile("" : : "v"(x))
+#define TH_OPAQUE_S(x) asm volatile("" : "+s"(x))      // the same for a wave-uniform value in scalar registers; being volatile it also pins its basic block (no if-conversion)
 #define TH_NOINLINE __attribute__((noinline))
 // index into an LDS array that may run past its logical end by a few entries (the reads stay inside the workgroup's LDS and their
 // values are discarded): nothing to do on the hardware

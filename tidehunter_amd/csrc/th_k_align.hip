@@ -154,8 +154,12 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                     }
                     const int np_first = np;
                     const bool ad_first = np != 0;
+                    // half-width of the widest band actually run on this pair so far (the follow-up compared W2 with the first band ASKED for, W, although a
+                    // one-register probe may have run in its place -- a 5000-base unit 5 % from its consensus has W2 ~ 300 < W = 524 and went to the 32-bit full matrix
+                    // instead of a pruned band of W2); -1: nothing ran here (mode 3: the launch before did, and did not certify, so its band was narrower than W2)
+                    int w_tried = -1;
                     while (np) {
-                        v = th_ad_align<NPMAX>(np, qp, len, cs, cl, s_seq, &s1); have_s1 = true;
+                        v = th_ad_align<NPMAX>(np, qp, len, cs, cl, s_seq, &s1); have_s1 = true; w_tried = max(w_tried, (256 * np - 2 - aD) / 2);
                         if (wide_first && np == np_first && np >= 3 && lane == 0) { atomicAdd(&wide_stat[0], 1); if (v < 0) atomicAdd(&wide_stat[1], 1); }
                         if (aln_stat && lane == 0) { const int o_ = np == np_first ? 0 : 2; atomicAdd(&aln_stat[o_], 1); if (v < 0) atomicAdd(&aln_stat[o_ + 1], 1); }
                         if (v >= 0) break;
@@ -168,7 +172,7 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                     }
                     // (the strip engines: two columns per lane on packed int16 where the scores fit -- round 4 -- else one column per lane in 32 bits)
                     const bool pkg = pkstrip && len + cl <= TH_KSW_PK_MAXLEN;
-                    if (!ad_first && mode != 3 && 64 + 2 * W + aD < (cl * 3) / 4) { v = pkg ? th_ksw_global_band_pk_wave<false>(qp, len, cs, cl, W, mybnd, s_in, &s1) : th_ksw_global_band_wave(qp, len, cs, cl, W, mybnd, s_in, &s1); have_s1 = true; }
+                    if (!ad_first && mode != 3 && 64 + 2 * W + aD < (cl * 3) / 4) { v = pkg ? th_ksw_global_band_pk_wave<false>(qp, len, cs, cl, W, mybnd, s_in, &s1) : th_ksw_global_band_wave(qp, len, cs, cl, W, mybnd, s_in, &s1); have_s1 = true; w_tried = max(w_tried, W); }
                     if (mode == 3) { s1 = item_s1[it]; have_s1 = s1 != TH_ALN_NO_S1; }       // deferred by the launch before, with its banded score
                     if (v < 0 && defer && mode == 1) {          // what is left is strip-engine work (a wider certified band, the full matrix): on that engine's own launch
                         int slot = 0;
@@ -181,7 +185,7 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                         const long long W2 = (g2 - 2 - aD + 1) / 2 + 8;
                         // (with the banded score as a lower bound the engine also drops every cell no path of that score can pass through:
                         // never more work than the matrix, so no area test)
-                        if (W2 > W && W2 < 30000) { const int lb = s1; v = pkg ? th_ksw_global_band_pk_wave<false>(qp, len, cs, cl, (int)W2, mybnd, s_in, &s1, lb) : th_ksw_global_band_wave(qp, len, cs, cl, (int)W2, mybnd, s_in, &s1, lb); }
+                        if (W2 > w_tried && W2 < 30000) { const int lb = s1; v = pkg ? th_ksw_global_band_pk_wave<false>(qp, len, cs, cl, (int)W2, mybnd, s_in, &s1, lb) : th_ksw_global_band_wave(qp, len, cs, cl, (int)W2, mybnd, s_in, &s1, lb); }
                     }
                     if (v < 0) v = th_ksw_global_wave<false>(qp, len, cs, cl, 0, mybnd, nullptr);
                     if (mode == 2) {

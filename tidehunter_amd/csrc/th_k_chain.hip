@@ -156,7 +156,9 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             // The rules are evaluated as 64-bit lane masks of single comparisons, combined on the scalar unit (a boolean expression per
             // lane would be materialised as 0/1 registers and compared again for every ballot).
             unsigned long long dstopm = TH_BALLOT(pe < cs);                              // :331  predecessor ends before cur starts
-            if (base < TH_WAVE - 1) dstopm |= ~0ull << (base + 1);                      // ... or does not exist (idx = base - lane < 0): last trip only
+            // ... or does not exist (idx = base - lane < 0): the last trip only, under a real branch (the volatile asm keeps hipcc from turning it into a shift and two
+            // selects on every trip)
+            if (base < TH_WAVE - 1) { unsigned long long none = ~0ull << (base + 1); TH_OPAQUE_S(none); dstopm |= none; }
             // :154 compares cp >= pp * 1.8 in double.  fl(1.8) exceeds 1.8 by a relative 2.5e-17, less than half an ulp,
             // so pp * fl(1.8) rounds to exactly 1.8 pp whenever that is an integer and stays > 0.19 away from every
             // integer otherwise: the comparison equals 5 cp >= 9 pp for all periods below 2^28 (th_gpu_upload checks).
@@ -183,14 +185,14 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
                 const int iter_after = below ? lane - th_msb64(below) : iter + lane + 1;
                 stopm |= ~impm & TH_BALLOT(iter_after >= max_h);
             }
-            // the improvements taken are those up to the first stopping lane; the last of them is the new best
-            if (stopm) {
-                const unsigned long long taken = impm & (stopm ^ (stopm - 1));          // lanes up to and including the lowest set bit
-                if (taken) { const int last = th_msb64nz(taken); best = TH_READLANE(s, last); bi = base - last; }
-                break;
-            }
-            if (impm) { const int last = th_msb64nz(impm); best = TH_READLANE(s, last); bi = base - last; iter = 63 - last; }
+            // the improvements taken are those up to the first stopping lane; the last of them is the new best.  ONE update for both outcomes of the trip
+            // (round 5): stopm ^ (stopm - 1) is every lane up to and including the lowest stopping one and ALL lanes when none stops, so the scan that goes on
+            // and the scan that ends take their improvements through the same code, and the loop has one exit test (the two copies of the update and the
+            // structurizer's flags between them were ~10 scalar instructions of a trip's 54); `iter` of a scan that ends is never read
+            const unsigned long long taken = impm & (stopm ^ (stopm - 1));
+            if (taken) { const int last = th_msb64nz(taken); best = TH_READLANE(s, last); bi = base - last; iter = 63 - last; }
             else iter += TH_WAVE;
+            if (stopm) break;
             TH_LDS_ASYNC_WAIT(rec_next);       // (here, before the value is copied or used: the compiler does not track the asynchronous read)
         }
         TH_LDS_ASYNC_WAIT(rec_next);           // a scan that stopped leaves its last request in flight: its registers stay reserved until it lands

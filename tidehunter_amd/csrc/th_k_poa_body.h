@@ -112,24 +112,30 @@ __device__ __forceinline__ int *th_poa_carve(ThPoaG &g, int *my, long long cap, 
 // remain of a successor in the chunk just finished comes from that chunk's registers (a lane shuffle), not from memory.
 struct ThPoaRows2 { int u, on, in, nb, o4[TH_POA_INL], i4[TH_POA_INL]; };
 struct ThPoaRows3 { int u, on, in, nb, s[TH_POA_INL], p[TH_POA_INL]; };
+// (Round 5: the three stages are BRANCH-FREE.  A lane outside the chunk -- the top chunk's tail, or any lane while the pipeline drains below row 0 -- reads a row
+// that exists (its index clamped) and an edge slot that does not exist reads node 0; what was read is then discarded by a select.  As predicated loads every
+// `ok ? g.x[u] : 0` was a basic block of its own -- execution-mask save, branch, restore around one load: ~45 blocks per 64 rows, a quarter of the phase's
+// instructions; the edge slots are read four at a time.)
 __device__ __forceinline__ int th_poa_rows_l1(const ThPoaG &g, int c0, int n)
 {
-    const int idx = c0 + TH_LANE();
-    return (c0 >= 0 && idx < n) ? g.order[idx] : 0;
+    return g.order[min(max(c0 + TH_LANE(), 0), n - 1)];
 }
 __device__ __forceinline__ void th_poa_rows_l2(const ThPoaG &g, int c0, int n, int u, ThPoaRows2 &a)
 {
     const int idx = c0 + TH_LANE(); const bool ok = c0 >= 0 && idx < n;
-    a.u = u; a.on = ok ? g.outn[u] : 0; a.in = ok ? g.inn[u] : 0; a.nb = ok ? g.nbase[u] : 0;
-#pragma unroll
-    for (int k = 0; k < TH_POA_INL; ++k) { a.o4[k] = ok ? g.out4[u * TH_POA_INL + k] : 0; a.i4[k] = ok ? g.in4[u * TH_POA_INL + k] : 0; }
+    const int on = g.outn[u], in = g.inn[u], nb = g.nbase[u];
+    const int4 o = ((const int4 *)g.out4)[u], i = ((const int4 *)g.in4)[u];          // (TH_POA_INL == 4 slots per node; slots beyond the degree hold anything)
+    a.u = u; a.on = ok ? on : 0; a.in = ok ? in : 0; a.nb = ok ? nb : 0;
+    a.o4[0] = o.x; a.o4[1] = o.y; a.o4[2] = o.z; a.o4[3] = o.w; a.i4[0] = i.x; a.i4[1] = i.y; a.i4[2] = i.z; a.i4[3] = i.w;
 }
 __device__ __forceinline__ void th_poa_rows_l3(const ThPoaG &g, int c0, int n, const ThPoaRows2 &a, ThPoaRows3 &r)
 {
-    const int idx = c0 + TH_LANE(); const bool ok = c0 >= 0 && idx < n;
-    r.u = a.u; r.on = a.on; r.in = a.in; r.nb = a.nb;
+    r.u = a.u; r.on = a.on; r.in = a.in; r.nb = a.nb;          // (degrees are 0 in lanes outside the chunk: th_poa_rows_l2)
 #pragma unroll
-    for (int k = 0; k < TH_POA_INL; ++k) { r.s[k] = (ok && k < a.on) ? g.pos[a.o4[k]] : -1; r.p[k] = (ok && k < a.in) ? g.pos[a.i4[k]] : -1; }
+    for (int k = 0; k < TH_POA_INL; ++k) {
+        const int ps = g.pos[k < a.on ? a.o4[k] : 0], pp = g.pos[k < a.in ? a.i4[k] : 0];
+        r.s[k] = k < a.on ? ps : -1; r.p[k] = k < a.in ? pp : -1;
+    }
 }
 __device__ __forceinline__ int th_poa_rows_body(const ThPoaG &g)
 {
@@ -167,7 +173,8 @@ __device__ __forceinline__ int th_poa_rows_body(const ThPoaG &g)
 #pragma unroll
         for (int k = 0; k < TH_POA_INL; ++k) {
             const int o = __shfl(prev_rem, (s[k] - c0) & 63);
-            if (s[k] >= c0 + TH_WAVE) { if (s[k] < c0 + 2 * TH_WAVE) base = max(base, o + 1); else far = true; }
+            base = max(base, (unsigned)(s[k] - c0 - TH_WAVE) < (unsigned)TH_WAVE ? o + 1 : -TH_BIG);      // (selects, not branches: a divergent `if` is an execution-mask block per edge slot)
+            far = far || s[k] >= c0 + 2 * TH_WAVE;
         }
         const bool big = ok && on > TH_POA_INL;
         if (__any(far || big)) {
@@ -183,9 +190,10 @@ __device__ __forceinline__ int th_poa_rows_body(const ThPoaG &g)
         // in-chunk successors are almost always 1..3 rows ahead: then a relaxation round is three lane shifts
         bool nearok = true; int has1 = 0, has2 = 0, has3 = 0;
 #pragma unroll
-        for (int k = 0; k < TH_POA_INL; ++k) if (s[k] >= c0 && s[k] < c0 + TH_WAVE) {
-            const int dl = s[k] - idx;
-            if (dl == 1) has1 = 1; else if (dl == 2) has2 = 1; else if (dl == 3) has3 = 1; else nearok = false;
+        for (int k = 0; k < TH_POA_INL; ++k) {          // (selects, not branches; an absent slot holds -1: not in the chunk)
+            const int dl = s[k] - idx; const bool inch = (unsigned)(s[k] - c0) < (unsigned)TH_WAVE;
+            has1 |= (int)(inch && dl == 1); has2 |= (int)(inch && dl == 2); has3 |= (int)(inch && dl == 3);
+            nearok = nearok && (!inch || (unsigned)(dl - 1) < 3u);
         }
         const bool fastrel = !hard && !__any(!nearok);
         int cur = base;
@@ -196,14 +204,16 @@ __device__ __forceinline__ int th_poa_rows_body(const ThPoaG &g)
         // best of its run, and the rounds only have to carry values across the run ends (branches of bubbles): two or three trips instead of 33.
         // Exact: the start value P obeys base <= P <= T(P) <= the fixed point of the rounds' operator T, which is monotone; the loop ends at the same
         // (unique: the graph is acyclic) fixed point it reached from `base`.
-        if (n < (1 << 21) - 128) {
-            const unsigned long long brk = ~__ballot(has1 != 0);                  // lanes that cannot take from the lane above
-            const int seg = (int)__popcll(brk >> lane);                            // run ends at or above this lane: the same number all along a run, smaller above it
-            int key = seg << 22 | (cur > -TH_BIG ? cur + lane + 2 : 0);          // (0: no path yet)
-            key = __shfl(key, 63 - lane); key = th_wave_incl_max(key); key = __shfl(key, 63 - lane);
-            const int best = key & 0x3fffff;
-            if (best) cur = best - lane - 2;
-        }
+        // (the scan is repeated after every round of either loop below: a round carries values across the run ends, the scan down the whole run beneath -- one
+        // more RUN final per trip, ~10 per chunk, where a round alone finishes one more ROW)
+        const bool scan_ok = n < (1 << 21) - 128;
+        const int seg = (int)__popcll(~__ballot(has1 != 0) >> lane) << 22;            // run ends at or above this lane (the same number all along a run, smaller above it), in the key's high bits
+#define TH_POA_RUN_SCAN(cur) do { if (scan_ok) { \
+            int key_ = seg | ((cur) > -TH_BIG ? (cur) + lane + 2 : 0);          /* (0: no path yet) */ \
+            key_ = __shfl(key_, 63 - lane); key_ = th_wave_incl_max(key_); key_ = __shfl(key_, 63 - lane); \
+            const int best_ = key_ & 0x3fffff; \
+            if (best_) (cur) = best_ - lane - 2; } } while (0)
+        TH_POA_RUN_SCAN(cur);
         if (fastrel) {
             // the usual chunk: three lane shifts, three adds, two max3 per round (an edge that does not exist adds minus "infinity";
             // values near -TH_BIG are "no path yet" and lose every maximum against a real one), two rounds per convergence test
@@ -212,7 +222,8 @@ __device__ __forceinline__ int th_poa_rows_body(const ThPoaG &g)
                 int c1 = th_shl1(cur, -TH_BIG), c2 = th_shl1(c1, -TH_BIG), c3 = th_shl1(c2, -TH_BIG);
                 const int v1 = max(max(base, c1 + inc1), max(c2 + inc2, c3 + inc3));
                 c1 = th_shl1(v1, -TH_BIG); c2 = th_shl1(c1, -TH_BIG); c3 = th_shl1(c2, -TH_BIG);
-                const int v2 = max(max(base, c1 + inc1), max(c2 + inc2, c3 + inc3));
+                int v2 = max(max(base, c1 + inc1), max(c2 + inc2, c3 + inc3));
+                TH_POA_RUN_SCAN(v2);
                 const bool ch = v2 != cur;
                 cur = v2;
                 if (!__any(ch)) break;
@@ -239,6 +250,7 @@ __device__ __forceinline__ int th_poa_rows_body(const ThPoaG &g)
                 }
                 TH_WAVE_FENCE();
             }
+            TH_POA_RUN_SCAN(v);
             const bool ch = ok && v != cur;
             cur = v;
             if (!__any(ch)) break;
@@ -308,12 +320,15 @@ __shared__ unsigned long long s_poa_prof[10];     // 8: further trips of packed 
 #define TH_PROF(k) ((void)0)
 #endif
 
-#if defined(TH_POA_DUP_PHASE)
-__device__ __forceinline__ int th_dup_n(int k) { int n = k == TH_POA_DUP_PHASE ? 2 : 1; asm volatile("" : "+s"(n)); return n; }
-#define TH_DUP_N(k) th_dup_n(k)
-#else
-#define TH_DUP_N(k) 1
+// Every phase of an alignment runs inside a loop whose trip count -- ONE -- the compiler cannot see.  Measured, not designed (round 5, profiles/r05_poa_phases.json:
+// the phase-attribution build with no phase repeated ran 390.4 ms against the plain product's 394.9, 195.6 against 202.2 x 10^9 vector instructions per launch):
+// the opaque loops keep hipcc from moving code and live ranges across the phase boundaries of the job loop, which the row loop pays for in scalar spills.
+// -DTH_POA_DUP_PHASE=k (tools/poa_phases.sh) makes phase k's count two.
+#ifndef TH_POA_DUP_PHASE
+#define TH_POA_DUP_PHASE (-1)
 #endif
+__device__ __forceinline__ int th_dup_n(int k) { int n = k == TH_POA_DUP_PHASE ? 2 : 1; TH_OPAQUE_S(n); return n; }
+#define TH_DUP_N(k) th_dup_n(k)
 
 // ---- banded DP; returns the row of the sink's best predecessor (>= 0) or a negative status ----
 // The three most recent rows stay in an LDS ring (H, E1', E2' per column, int16) together with their band and
