@@ -36,7 +36,9 @@ struct ThTask {
     int narrow;      // 1: the job starts on the int16 POA variant (th_poa_job_is_narrow), 0: on the 32-bit one
     int noband;      // host, slow path: the job is being rerun without the adaptive band
 };
-struct ThUnit { int start, len; };   // start = index of the unit's first base inside the read
+#define TH_SLB_MIN_UNIT 2300           // th_k_poa computes the bounds for jobs whose longest unit has at least this many bases
+#define TH_SLB_NONE (-0x40000000)      // no score bound for this unit alignment (th_k_poa: th_poa_unit_bounds; th_k_align)
+struct ThUnit { int start, len, which, pad_; };   // start = index of the unit's first base inside the read; which = its index among the run's units (the alignment items' `which`: round 5)
 
 // The pipeline's device counters: one block, zeroed by th_k_encode at the start of a batch.  Kernels get pointers to single fields.
 struct ThCnt {
@@ -73,6 +75,7 @@ static_assert(sizeof(ThCnt) == 256, "counter block");
 #define TH_E_MINIMIZER 8          // minimizer selection repeated a word or overflowed its buffer
 #define TH_E_ALN_VERIFY 64        // TH_ALN_MODE=2: a banded alignment differs from the full matrix
 #define TH_E_MSA_UNITS 128        // a job with fewer than two units ("Not enough sequences to perform msa.", src/abpoa_cons.c:61)
+#define TH_E_ALN_BOUND 512        // th_k_align: a band sized by a lower bound found less than the bound (the bound was none: a bug in whoever supplied it)
 #define TH_E_JOB_CAP 256          // job / unit / par_pos tables too small (rerun the build with larger ones)
 
 

@@ -96,7 +96,8 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
            const uint8_t *__restrict__ cons, const int *__restrict__ cons_len,
            int *__restrict__ bnd, long long bnd_stride, int *__restrict__ iden, int *__restrict__ ext, int *__restrict__ err, int *__restrict__ queue,
            int wdiv, int wadd, int wtol, int mode, int xpct, const int *__restrict__ n_items_ptr, ThAlnItem *__restrict__ defer, int *__restrict__ defer_n, int *__restrict__ wide_stat,
-           const int *__restrict__ item_s1, int *__restrict__ defer_s1, int *__restrict__ aln_stat = nullptr)
+           const int *__restrict__ item_s1, int *__restrict__ defer_s1, int *__restrict__ aln_stat = nullptr,
+           const int *__restrict__ unit_slb = nullptr /* round 5: per unit alignment (T.aln_off + which) a lower bound of its ksw2 score from the POA's own alignment of the unit, or TH_SLB_NONE */)
 {
     // one LDS area, used either as the left-border inbox of the strip sweep (two 64-row blocks, 4 KB) or as the staged bases
     // of the anti-diagonal engine (never both at once)
@@ -141,13 +142,26 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                     int np = (mode == 1 || mode == 2) ? th_ad_pick(len, cl, max(W - wtol, 0), LDSB, NPMAX) : 0;
                     // no band of this variant's registers reaches the first band asked for (a long unit on the two-register variant: th_aln_class):
                     // ONE register as a probe -- its banded score sizes the band that can be certified and prunes the strip sweep that follows
-                    if (np == 0 && (mode == 1 || mode == 2) && NPMAX <= 2 && th_ad_pick(len, cl, 0, LDSB, NPMAX) == 1) np = 1;
+                    // Round 5 (configs 4 / 5): a LONG unit -- one whose first band would be a one-register probe or three registers and more -- starts from the bound the POA
+                    // left for it (th_poa_unit_bounds: the score of the unit's own path through the graph against the consensus columns, a valid global alignment):
+                    // the band that is certified for any optimum >= that bound is run at once -- on the registers if they reach it, else on the pruned strips with
+                    // the bound as their lower bound -- instead of a probe whose only product was a (worse) bound.  Exactness does not rest on the bound: the register
+                    // band carries its own certificate, and a strip sweep whose banded score comes out BELOW the bound (impossible for a valid one) is redone in full.
+                    const int slb0 = (unit_slb != nullptr && (mode == 1 || mode == 2)) ? TH_UNI(unit_slb[T.aln_off + I.which]) : TH_SLB_NONE;
+                    const bool from_slb = slb0 != TH_SLB_NONE && (np == 0 || np >= 3);
+                    if (from_slb) {
+                        const long long g2 = ((long long)len + cl - 2LL * slb0 - 4 * TH_KQ) / (1 + 2 * TH_KE) + 2;
+                        const long long W2 = (g2 - 2 - aD + 1) / 2 + 8;
+                        np = W2 < 4096 ? th_ad_pick(len, cl, (int)W2, LDSB, NPMAX) : 0;
+                        s1 = slb0; have_s1 = true;
+                    }
+                    if (!from_slb && np == 0 && (mode == 1 || mode == 2) && NPMAX <= 2 && th_ad_pick(len, cl, 0, LDSB, NPMAX) == 1) np = 1;
                     // A first band of three registers per lane or more (units of several thousand bases) that keeps failing its certificate in
                     // this launch -- pairs as divergent as config 4's, 15 % error: no band short of the matrix can be certified -- is probed
                     // with ONE register first: the probe's banded score sizes the band that could be certified, and the pair goes on to the
                     // full matrix for a sixth of the wide pass it would have wasted.  The launch counts its wide first bands and their
                     // failures (wide_stat[0], [1]); which engine computes an alignment never changes its result.
-                    const bool wide_first = np >= 3 && wide_stat != nullptr;
+                    const bool wide_first = !from_slb && np >= 3 && wide_stat != nullptr;
                     if (wide_first) {
                         const int tries = TH_LOAD_L2(&wide_stat[0]), fails = TH_LOAD_L2(&wide_stat[1]);
                         if (TH_UNI(tries) >= 8 && 2 * TH_UNI(fails) > TH_UNI(tries) && th_ad_pick(len, cl, 0, LDSB, NPMAX) == 1) np = 1;
@@ -160,6 +174,7 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                     int w_tried = -1;
                     while (np) {
                         v = th_ad_align<NPMAX>(np, qp, len, cs, cl, s_seq, &s1); have_s1 = true; w_tried = max(w_tried, (256 * np - 2 - aD) / 2);
+                        if (from_slb && s1 < slb0 && lane == 0) atomicOr(err, TH_E_ALN_BOUND);      // (the band was sized to hold a path of score slb0: a banded score below it says the POA's bound was none -- never seen; the tests would)
                         if (wide_first && np == np_first && np >= 3 && lane == 0) { atomicAdd(&wide_stat[0], 1); if (v < 0) atomicAdd(&wide_stat[1], 1); }
                         if (aln_stat && lane == 0) { const int o_ = np == np_first ? 0 : 2; atomicAdd(&aln_stat[o_], 1); if (v < 0) atomicAdd(&aln_stat[o_ + 1], 1); }
                         if (v >= 0) break;
@@ -172,7 +187,7 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                     }
                     // (the strip engines: two columns per lane on packed int16 where the scores fit -- round 4 -- else one column per lane in 32 bits)
                     const bool pkg = pkstrip && len + cl <= TH_KSW_PK_MAXLEN;
-                    if (!ad_first && mode != 3 && 64 + 2 * W + aD < (cl * 3) / 4) { v = pkg ? th_ksw_global_band_pk_wave<false>(qp, len, cs, cl, W, mybnd, s_in, &s1) : th_ksw_global_band_wave(qp, len, cs, cl, W, mybnd, s_in, &s1); have_s1 = true; w_tried = max(w_tried, W); }
+                    if (!ad_first && !from_slb && mode != 3 && 64 + 2 * W + aD < (cl * 3) / 4) { v = pkg ? th_ksw_global_band_pk_wave<false>(qp, len, cs, cl, W, mybnd, s_in, &s1) : th_ksw_global_band_wave(qp, len, cs, cl, W, mybnd, s_in, &s1); have_s1 = true; w_tried = max(w_tried, W); }
                     if (mode == 3) { s1 = item_s1[it]; have_s1 = s1 != TH_ALN_NO_S1; }       // deferred by the launch before, with its banded score
                     if (v < 0 && defer && mode == 1) {          // what is left is strip-engine work (a wider certified band, the full matrix): on that engine's own launch
                         int slot = 0;
@@ -185,7 +200,12 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                         const long long W2 = (g2 - 2 - aD + 1) / 2 + 8;
                         // (with the banded score as a lower bound the engine also drops every cell no path of that score can pass through:
                         // never more work than the matrix, so no area test)
-                        if (W2 > w_tried && W2 < 30000) { const int lb = s1; v = pkg ? th_ksw_global_band_pk_wave<false>(qp, len, cs, cl, (int)W2, mybnd, s_in, &s1, lb) : th_ksw_global_band_wave(qp, len, cs, cl, (int)W2, mybnd, s_in, &s1, lb); }
+                        if (W2 > w_tried && W2 < 30000) {
+                            const int lb = s1; v = pkg ? th_ksw_global_band_pk_wave<false>(qp, len, cs, cl, (int)W2, mybnd, s_in, &s1, lb) : th_ksw_global_band_wave(qp, len, cs, cl, (int)W2, mybnd, s_in, &s1, lb);
+                            // (a path of score lb fits the band its score sizes, so the sweep finds at least lb -- unless lb was no lower bound at all: checked
+                            // here for every bound, the POA's included, loudly, and the pair redone in full)
+                            if (s1 < lb) { v = -1; if (lane == 0) atomicOr(err, TH_E_ALN_BOUND); }
+                        }
                     }
                     if (v < 0) v = th_ksw_global_wave<false>(qp, len, cs, cl, 0, mybnd, nullptr);
                     if (mode == 2) {

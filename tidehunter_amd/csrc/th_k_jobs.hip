@@ -31,7 +31,7 @@ __host__ __device__ static inline long long th_poa_need_ints(int n_units, int su
     int fexp = 0; for (double f = 1.5; f * 1.99 < cell_factor; f *= 2) ++fexp;        // the attempt's factor as the kernel is told it: 1.5 * 2^fexp
     const ThPoaCaps K = th_poa_caps(n_units, sum_len, max_len, fexp, noband);
     const long long cap = K.cap, ocap = K.ocap, opn = K.opn;
-    const long long graph = 39 * cap + 2 * ocap + 5 * opn + 512;
+    const long long graph = 40 * cap + 2 * ocap + 5 * opn + ((long long)sum_len + 16) + 512;      // (round 5: + the units' node paths and the nodes' consensus columns, th_poa_carve)
     if (noband) return (graph + (long long)(cap * ((long long)max_len + 4) * (cell_factor > 1.5 ? 1.25 : 1.0) * 4.5) + 63) & ~63LL;   // full rows, all stored in full
     const long long w = TH_POA_WB + max_len / 100;
     const long long span = 2 * w + 1 + 48 + max_len / 30;
@@ -98,7 +98,7 @@ __device__ __forceinline__ void th_jobs_walk(const ThJobTables &J, const ThDevPa
                     const int start = pp[u], end = pp[u + 1];
                     if (start < 0 || end < 0 || start >= L - 1 || end + 1 > L) continue;
                     const int len = end - start;
-                    if (EMIT) { ThUnit x = { start + 1, len }; J.units[c[2] + n_units] = x; }
+                    if (EMIT) { ThUnit x = { start + 1, len, u - i, 0 }; J.units[c[2] + n_units] = x; }
                     if (n_units == 0) first_len = len;
                     ++n_units; sum_len += len; max_len = max(max_len, len);
                 }

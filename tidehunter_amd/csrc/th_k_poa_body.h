@@ -13,6 +13,7 @@ struct ThPoaG {
     int *r_off, *r_foff;       // offset (2-byte units) of a row's direction words -- of its band start (16-bit rows) or of its even base column (8-bit rows: in-degree 1) -- / of its band start among the full cells (rows that store them)
     int *cntB, *headB, *aft;
     int *ops, *pv, *glo, *pth;
+    int *upath, *ccol;         // round 5: the node of every base of every unit, unit after unit (the alignments' paths) / by node id: its column's place in the consensus, or -1
     int4 *cell; uint16_t *dcell; uint32_t cell_u2;     // cell_u2: size of the region in 2-byte units (clamped to 2^31: row offsets are ints); full cells (rows some far row will read, rows of in-degree > 4) / 16-bit direction words (all other rows)
 };
 
@@ -66,7 +67,7 @@ __device__ __forceinline__ void th_poa_init_node(ThPoaG &g, int v, int b, int nr
 }
 
 // ---- first unit: chain source(0) -> bases(2..L+1) -> sink(1); order = source, bases, sink ----
-__device__ void th_poa_seed(ThPoaG &g, const uint8_t *__restrict__ q, int L)
+__device__ void th_poa_seed(ThPoaG &g, const uint8_t *__restrict__ q, int L, int *__restrict__ upath)
 {
     const int lane = TH_LANE();
     for (int j = lane; j < L; j += TH_WAVE) {
@@ -75,6 +76,7 @@ __device__ void th_poa_seed(ThPoaG &g, const uint8_t *__restrict__ q, int L)
         g.inn[v] = 1; g.in4[v * TH_POA_INL] = j == 0 ? 0 : v - 1;
         g.outn[v] = 1; g.out4[v * TH_POA_INL] = j == L - 1 ? 1 : v + 1;
         g.order[1 + j] = v; g.pos[v] = 1 + j;
+        if (upath) upath[j] = v;
     }
     if (lane == 0) {
         th_poa_init_node(g, 0, 4, 0); th_poa_init_node(g, 1, 4, 0);
@@ -88,7 +90,7 @@ __device__ void th_poa_seed(ThPoaG &g, const uint8_t *__restrict__ q, int L)
 
 __device__ __forceinline__ int *th_carve(int *&p, long long cnt) { int *r = p; p += (cnt + 3) & ~3LL; return r; }
 // the arrays of one job's graph inside the wave's scratch; returns the first unused int (the cell region starts there)
-__device__ __forceinline__ int *th_poa_carve(ThPoaG &g, int *my, long long cap, long long ocap, long long opn)
+__device__ __forceinline__ int *th_poa_carve(ThPoaG &g, int *my, long long cap, long long ocap, long long opn, long long upn = 0)
 {
     int *p = my;
     g.nbase = th_carve(p, cap); g.nread = th_carve(p, cap); g.ring = th_carve(p, cap); g.inn = th_carve(p, cap); g.outn = th_carve(p, cap);
@@ -101,6 +103,7 @@ __device__ __forceinline__ int *th_poa_carve(ThPoaG &g, int *my, long long cap, 
     g.r_off = th_carve(p, cap); g.r_foff = th_carve(p, cap);
     g.cntB = th_carve(p, cap); g.headB = th_carve(p, cap); g.aft = th_carve(p, cap);
     g.ops = th_carve(p, 2 * opn); g.pv = th_carve(p, opn); g.glo = th_carve(p, opn); g.pth = th_carve(p, opn + 2);
+    g.upath = th_carve(p, upn); g.ccol = th_carve(p, upn ? cap : 0);      // (last: a caller that does not use them -- th_poa_rows -- carves the same offsets without)
     return p;
 }
 
@@ -1052,7 +1055,7 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
 
 // ---- merge the alignment (ops were written backwards; rows refer to the CURRENT order) ----
 // returns 1 (graph abandoned) when the new nodes would not fit the job's node capacity
-__device__ int th_poa_merge(ThPoaG &g, const uint8_t *__restrict__ q, int n_ops)
+__device__ int th_poa_merge(ThPoaG &g, const uint8_t *__restrict__ q, int n_ops, int *__restrict__ upath /* this unit's slice of g.upath, or null */)
 {
     const int lane = TH_LANE(), n_old = g.n_node;
     for (int p = lane; p < n_old; p += TH_WAVE) { g.cntB[p] = 0; g.headB[p] = 0x7fffffff; g.aft[p] = -1; }
@@ -1088,7 +1091,7 @@ __device__ int th_poa_merge(ThPoaG &g, const uint8_t *__restrict__ q, int n_ops)
         const bool isnode = ok && op != 2;
         if (isnode) g.nread[v] += 1;
         const unsigned long long pmk = __ballot(isnode);
-        if (isnode) g.pth[1 + path_cnt + th_mbcnt(pmk)] = v;
+        if (isnode) { const int k_ = path_cnt + th_mbcnt(pmk); g.pth[1 + k_] = v; if (upath) upath[k_] = v; }
         path_cnt += __popcll(pmk);
         if (ok) { g.pv[f] = kind == 2 ? v : -1; g.glo[f] = op == 0 ? lo : -1; }
     }
@@ -1139,13 +1142,13 @@ __device__ int th_poa_merge(ThPoaG &g, const uint8_t *__restrict__ q, int n_ops)
 }
 
 // ---- row-column consensus: one column = one aligned ring (its members are adjacent in the order) ----
-__device__ int th_poa_consensus(ThPoaG &g, int n_seqs, uint8_t *__restrict__ cons, int *__restrict__ cov, int cons_cap)
+__device__ int th_poa_consensus(ThPoaG &g, int n_seqs, uint8_t *__restrict__ cons, int *__restrict__ cov, int cons_cap, bool want_cols)
 {
     const int lane = TH_LANE(), n = g.n_node;
     int cl = 0, over = 0;
     for (int c0 = 0; c0 < n; c0 += TH_WAVE) {
         const int idx = c0 + lane;
-        int bb = -1, best = 0;
+        int bb = -1, best = 0, lead_u = -1;          // lead_u: this lane leads the column of node lead_u
         if (idx >= 1 && idx < n) {
             const int u = g.order[idx];
             if (u != 1) {
@@ -1164,19 +1167,67 @@ __device__ int th_poa_consensus(ThPoaG &g, int n_seqs, uint8_t *__restrict__ con
                     if (c_t > best) { best = c_t; bb = 3; }
                     if (c_n > best) { best = c_n; bb = 4; }
                     if (TH_POA_GAP_WINS_TIE ? n_seqs - tot >= best : n_seqs - tot > best) bb = -1;
+                    lead_u = u;
                 }
             }
         }
         const unsigned long long em = __ballot(bb >= 0);
+        int oc = -1;
         if (bb >= 0) {
             const int o = cl + th_mbcnt(em);
-            if (o < cons_cap) { cons[o] = (uint8_t)bb; cov[o] = best; } else over = 1;
+            if (o < cons_cap) { cons[o] = (uint8_t)bb; cov[o] = best; oc = o; } else over = 1;
         }
+        // round 5: every node of the column learns the column's place in the consensus (-1: the column was dropped) -- what th_poa_unit_bounds scores the units' paths with
+        if (want_cols && lead_u >= 0) { int m = lead_u; do { g.ccol[m] = oc; m = g.ring[m]; } while (m != lead_u); }
         cl += __popcll(em);
     }
     return __any(over) ? -1 : cl;
 }
 
+
+// ---- round 5: a lower bound of every unit's ksw2 score against the consensus, for free ----
+// The POA has aligned every unit to the graph the consensus was read from: the unit's path (g.upath) against the kept columns (g.ccol) IS a global
+// alignment of the unit and the consensus -- a unit base in a kept column is a match / mismatch column, one in a dropped column an inserted base, a kept
+// column the path skips a deleted one.  Its score under ksw2's scheme as TideHunter sets it (src/ksw2_align.c:12-17,68: 1 / -2, -1 against N,
+// a gap of l bases 2 + l) bounds the optimum of ksw2_global (src/gen_cons.c:213) from below, and th_k_align sizes a band that is certified for any optimum
+// >= that bound -- no probing pass for the long units of configs 4 / 5.  One pass per unit, 64 bases per trip: the previous kept column is an exclusive
+// prefix maximum (columns grow along a path), gap openings are "this element dropped, the one before kept".  Its own function, like th_poa_rows.
+__device__ TH_NOINLINE void th_poa_unit_bounds(int *my, int cap, int ocap, int opn, int upn, const ThUnit *__restrict__ U, int n_units, const uint8_t *__restrict__ rb,
+                                               const uint8_t *__restrict__ cons, int cl, int *__restrict__ slb)
+{
+    my = TH_UNI_PTR(int, my);
+    ThPoaG g;
+    th_poa_carve(g, my, TH_UNI(cap), TH_UNI(ocap), TH_UNI(opn), TH_UNI(upn));
+    const int lane = TH_LANE();
+    cl = TH_UNI(cl); n_units = TH_UNI(n_units);
+    int off = 0;
+    for (int s = 0; s < n_units; ++s) {
+        const int len = TH_UNI(U[s].len), which = TH_UNI(U[s].which);
+        const uint8_t *q = rb + TH_UNI(U[s].start);
+        const int *path = g.upath + off;
+        int last = -1, prev_kept = 1, sum = 0;          // last kept column so far; was the element before this trip kept (the start counts: a leading insertion opens a gap)
+        for (int j0 = 0; j0 < len; j0 += TH_WAVE) {
+            const int j = j0 + lane; const bool ok = j < len;
+            const int c = ok ? g.ccol[path[ok ? j : 0]] : -1;
+            const bool kept = ok && c >= 0;
+            const int ub = ok ? (int)q[j] : 0, cb = kept ? (int)cons[c] : 0;
+            int sc = kept ? ((ub == 4 || cb == 4) ? -1 : (ub == cb ? 1 : -2)) : 0;
+            const int inc = th_wave_incl_max(kept ? c : -1);
+            const int prevc = max(th_shr1(inc, -1), last);                       // the kept column before this element
+            const int dgap = kept ? c - prevc - 1 : 0;
+            if (dgap > 0) sc -= 2 + dgap;
+            const int pk = th_shr1((int)kept, prev_kept);
+            if (ok && !kept) sc -= 1 + (pk ? 2 : 0);
+            sum += th_wave_incl_sum(sc);                                         // (lane 63 holds the trip's total)
+            last = max(last, TH_READLANE(inc, 63));
+            prev_kept = TH_READLANE((int)kept, min(len - j0, TH_WAVE) - 1);
+        }
+        int total = TH_READLANE(sum, 63);
+        if (cl - 1 - last > 0) total -= 2 + (cl - 1 - last);                    // the consensus columns after the unit's last kept one
+        if (lane == 0) slb[which] = total;
+        off += len;
+    }
+}
 
 // status: 0 ok, 1 scratch too small for the graph, 2 band cells overflow, 3 empty band, 4 band lost the path,
 //         5 in-degree > 255, 6 consensus longer than cons_cap, 7 scores may not fit the int16 ring (rerun on the 32-bit variant)
@@ -1187,7 +1238,8 @@ template <int QCAP, typename RT, bool DEFSC = false>
 __global__ void __launch_bounds__(TH_POA_BLOCK) TH_WAVES_PER_SIMD(TH_POA_OCC_NS)
 th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_list, const ThUnit *__restrict__ units, const uint32_t *__restrict__ roff,
          const uint8_t *__restrict__ bseq, ThDevPara P, int *__restrict__ scratch, long long scratch_ints,
-         uint8_t *__restrict__ cons, int *__restrict__ cov, int *__restrict__ cons_len, int *__restrict__ status, int *__restrict__ queue, int flags)
+         uint8_t *__restrict__ cons, int *__restrict__ cov, int *__restrict__ cons_len, int *__restrict__ status, int *__restrict__ queue, int flags,
+         int *__restrict__ slb /* per alignment item (T.aln_off + which): the units' score bounds, th_poa_unit_bounds -- or null */)
 {
     // flags: bit 0 = no adaptive band (the rerun of a job whose band failed); bits 8.. = test knob TH_POA_TEST_FAIL: jobs whose
     // index is a multiple of it report status 4 on the banded pass, so the tests can drive the rerun path
@@ -1211,6 +1263,7 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
         const ThTask T = tasks[t];
         const uint8_t *rb = bseq + roff[T.read];
         const ThUnit *U = units + T.unit_off;
+        if (slb) for (int x = lane; x < T.pos_n - 1; x += TH_WAVE) slb[T.aln_off + x] = TH_SLB_NONE;      // (no bound unless the job gets that far)
         if (T.n_units <= 2) {            // src/abpoa_cons.c:60-83: consensus := unit 0
             const int len = U[0].len;
             const int st = len > T.cons_cap ? 6 : 0;
@@ -1223,7 +1276,11 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
         // (flags bit 5, test knob TH_POA_TEST_SMALLCAP: the first attempt carves node arrays just above the longest unit, so that the tests drive the status-1 rerun)
         const long long cap = (flags & 32) ? min(K.cap, (long long)T.max_len + 8) : K.cap, ocap = K.ocap, opn = cap + T.max_len + 2;
         g.cap = (int)cap; g.n_node = 0;
-        int *p = th_poa_carve(g, my, cap, ocap, opn);
+        // (bounds only where th_k_align uses them: units long enough for a first band of three registers per lane or a probe -- consensus beyond ~2200 bases; the
+        // headline shape's jobs skip the pass and its path stores)
+        const bool want_b = slb != nullptr && T.max_len >= TH_SLB_MIN_UNIT;
+        const long long upn = want_b ? (long long)T.sum_len + 8 : 0;
+        int *p = th_poa_carve(g, my, cap, ocap, opn, upn);
         const int *order0 = g.order;       // (th_poa_merge swaps order / order2)
         {
             const long long avail = (scratch_ints - (p - my)) & ~3LL;
@@ -1232,7 +1289,8 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
         int st = 0;
         TH_PROF_CNT(26, 1);
         if (p - my > scratch_ints || g.cell_u2 < 2048 || U[0].len + 2 > cap) st = 1;
-        if (!st) th_poa_seed(g, rb + U[0].start, U[0].len);
+        if (!st) th_poa_seed(g, rb + U[0].start, U[0].len, want_b ? g.upath : nullptr);
+        int up_off = U[0].len;
         for (int s = 1; s < T.n_units && !st; ++s) {
             const uint8_t *q = rb + U[s].start; const int qlen = U[s].len;
             if (LQ) for (int x = lane; 2 * x < qlen + 3; x += TH_WAVE) {
@@ -1256,15 +1314,17 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
             if (bi < 0) { st = bi == -3 ? 2 : bi == -5 ? 7 : bi == -2 ? 3 : 4; break; }
             for (int r_ = 0; r_ < TH_DUP_N(2); ++r_) no = th_poa_traceback(g, bi, qlen);
             TH_PROF(2);
-            if (th_poa_merge(g, q, no)) { st = 1; break; }          // the graph outgrew its node capacity: rerun with twice the factor
+            if (th_poa_merge(g, q, no, want_b ? g.upath + up_off : nullptr)) { st = 1; break; }          // the graph outgrew its node capacity: rerun with twice the factor
+            up_off += qlen;
             TH_PROF(3);
         }
         int cl = 0;
         if (!st) {
             TH_PROF_T0();
-            for (int r_ = 0; r_ < TH_DUP_N(3); ++r_) cl = th_poa_consensus(g, T.n_units, cons + T.cons_off, cov + T.cons_off, T.cons_cap);
+            for (int r_ = 0; r_ < TH_DUP_N(3); ++r_) cl = th_poa_consensus(g, T.n_units, cons + T.cons_off, cov + T.cons_off, T.cons_cap, want_b);
             TH_PROF(24);
             if (cl < 0) { st = 6; cl = 0; }
+            else if (want_b) { TH_WAVE_FENCE(); th_poa_unit_bounds(my, (int)cap, (int)ocap, (int)opn, (int)upn, U, T.n_units, rb, cons + T.cons_off, cl, slb + T.aln_off); }
         }
         if (lane == 0) { cons_len[t] = st ? 0 : cl; status[t] = st; }
         TH_WAVE_FENCE();

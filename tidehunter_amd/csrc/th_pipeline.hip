@@ -95,7 +95,7 @@ struct th_gpu {
     DBuf<unsigned long long> d_gsort, d_eps;
     DBuf<ThCnt> d_cnt; th_pvec<ThCnt> h_cnt;
     DBuf<ThChainRec> d_rec;
-    DBuf<int> d_par, d_par_off, d_par_n, d_par_dst, d_parc, d_bnd, d_scratch, d_cov, d_cons_len, d_status, d_iden, d_ext;
+    DBuf<int> d_par, d_par_off, d_par_n, d_par_dst, d_parc, d_bnd, d_scratch, d_cov, d_cons_len, d_status, d_iden, d_ext, d_slb;
     DBuf<int> d_rows, d_list_n, d_list_w, d_list_l, d_sublist;      // per-read / per-job counters of the table builds, POA task lists
     DBuf<ThTask> d_tasks; DBuf<ThUnit> d_units; DBuf<ThAlnItem> d_items, d_defer; DBuf<int> d_defer_s1; DBuf<th_job_t> d_jobs;
     int reserve_n = 0; Arena arena;
@@ -108,6 +108,7 @@ struct th_gpu {
     int aln_wdiv = 10, aln_wadd = 24;     // first certified band of the unit alignments: half-width cons_len / wdiv + wadd
     int aln_xpct = 36;                    // flank extensions: band half-width requested from the anti-diagonal engine, percent of min(consensus, flank) (+ 8)
     int aln_probe_small = 1;              // long units whose sequences fit the two-register variant's staging area are probed and finished there (th_aln_class)
+    int aln_slb = 1;                      // the POA leaves a score bound per unit alignment (th_poa_unit_bounds) and th_k_align starts long units from it (TH_ALN_SLB=0: off)
     int aln_probe_auto = 1;               // ... unless the batch BEFORE was mostly such units (config 4: there the dedicated launches of round 3 are faster, config 5 gains 6 %)
     int aln_wtol = 16, aln_mode = 1;      // anti-diagonal engine: accepted shortfall of its band against that half-width; 0 = strip engine only, 2 = verify against the full matrix
     int waves_part = 8192, waves_poa = 6144, waves_aln = 8192, waves_xw = 2048, waves_xw_small = 3584;   // persistent grids: 256 CUs x 4 SIMDs x resident waves (extraction: 256 CUs x 8 / x 14 waves by their LDS)
@@ -165,6 +166,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
     g->aln_wdiv = std::max(1, env_int("TH_ALN_WDIV", g->aln_wdiv)); g->aln_wadd = std::max(0, env_int("TH_ALN_WADD", g->aln_wadd));
     // (TH_ALN_XPROBE: registers of the flank extensions' probe: one since round 4 -- four measured 17-20 ms slower on configs 4 and 5)
     g->aln_wtol = std::max(0, env_int("TH_ALN_WTOL", g->aln_wtol)); g->aln_mode = env_int("TH_ALN_MODE", g->aln_mode); g->aln_xpct = std::min(255, std::max(0, env_int("TH_ALN_XPCT", g->aln_xpct))) | std::min(4, std::max(1, env_int("TH_ALN_XPROBE", 1))) << 8 | (env_int("TH_ALN_PKSTRIP", 1) ? 0 : 1) << 11;
+    g->aln_slb = env_int("TH_ALN_SLB", 1);
     g->aln_probe_small = std::min(3, std::max(0, env_int("TH_ALN_PROBE_SMALL", 1))); g->aln_probe_auto = getenv("TH_ALN_PROBE_SMALL") ? 0 : 1;
     return g;
 }
@@ -181,7 +183,7 @@ extern "C" void th_gpu_destroy(th_gpu_t *g)
     g->d_cov_c.release(); g->d_cc_off.release(); g->d_hit_end.release(); g->d_hit_per.release(); g->d_hit_n.release(); g->d_score.release(); g->d_from.release(); g->d_cells.release();
     g->d_read_ch_base.release(); g->d_read_ch_n.release(); g->d_gsort.release(); g->d_eps.release(); g->d_cnt.release(); g->d_rec.release();
     g->d_par.release(); g->d_par_off.release(); g->d_par_n.release(); g->d_par_dst.release(); g->d_parc.release(); g->d_bnd.release(); g->d_scratch.release();
-    g->d_cov.release(); g->d_cons_len.release(); g->d_status.release(); g->d_iden.release(); g->d_ext.release();
+    g->d_cov.release(); g->d_cons_len.release(); g->d_status.release(); g->d_iden.release(); g->d_ext.release(); g->d_slb.release();
     g->d_rows.release(); g->d_list_n.release(); g->d_list_w.release(); g->d_list_l.release(); g->d_sublist.release();
     g->d_tasks.release(); g->d_units.release(); g->d_items.release(); g->d_defer.release(); g->d_defer_s1.release(); g->d_jobs.release(); g->d_adp.release(); g->d_ad.release(); g->d_adr.release(); g->d_single.release(); delete g->h_adr;
     if (g->stage_ok) for (int b = 0; b < 2; ++b) { th_rt_host_free(g->h_stage[b]); th_rt_event_destroy(g->stage_ev[b]); }
@@ -370,7 +372,7 @@ static int th_poa_launch(th_gpu *g, KTimer &kt, const ThIn &in, const int *list,
     const ThDevPara &dp = g->dp;
     const bool defsc = dp.match == 2 && dp.mismatch == 4 && dp.go1 == 4 && dp.ge1 == 2 && dp.go2 == 24 && dp.ge2 == 1 && env_int("TH_POA_DEFSC", 1) != 0;
 #define POA_LAUNCH(NS, QC, RT, ...) TH_LAUNCH((NS::th_k_poa<QC, RT, ##__VA_ARGS__>), wv, TH_POA_BLOCK, g->stream, (const ThTask *)g->d_tasks.p, list, n_list, (const ThUnit *)g->d_units.p, (const uint32_t *)in.d_roff.p, \
-                          (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, g->d_cons_len.p, g->d_status.p, queue, poa_flags)
+                          (const uint8_t *)g->d_bseq.p, g->dp, g->d_scratch.p, need, g->d_cons.p, g->d_cov.p, g->d_cons_len.p, g->d_status.p, queue, poa_flags, g->aln_slb ? g->d_slb.p : (int *)nullptr)
     if (cls == 1) { if (defsc) POA_LAUNCH(thpoa_n, TH_POA_QCAP, short, true); else POA_LAUNCH(thpoa_n, TH_POA_QCAP, short); }
     else if (cls == 2) { if (defsc) POA_LAUNCH(thpoa_l, TH_POA_QCAP_LONG, short, true); else POA_LAUNCH(thpoa_l, TH_POA_QCAP_LONG, short); }
     else if (max_unit <= TH_POA_QCAP_WIDE) POA_LAUNCH(thpoa_n, TH_POA_QCAP_WIDE, int);
@@ -625,7 +627,7 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
     TRY(th_rt_d2h(out.parc.data(), g->d_parc.p, (size_t)par_total * 4, g->stream));
     if (nt && !g->para.only_unit) {
         TRY(g->d_cons.ensure((size_t)cons_total)); TRY(g->d_cov.ensure((size_t)cons_total));
-        TRY(g->d_cons_len.ensure(nt)); TRY(g->d_status.ensure(nt)); TRY(g->d_iden.ensure((size_t)aln_total + 1)); TRY(g->d_ext.ensure((size_t)nt * 4));
+        TRY(g->d_cons_len.ensure(nt)); TRY(g->d_status.ensure(nt)); TRY(g->d_iden.ensure((size_t)aln_total + 1)); TRY(g->d_ext.ensure((size_t)nt * 4)); if (g->aln_slb) TRY(g->d_slb.ensure((size_t)aln_total + 1));
         TRY(g->d_cc_off.ensure(nt)); TRY(g->d_rows.ensure((size_t)std::max<long long>((long long)n * TH_JOB_COLS, (long long)nt * TH_ITEM_COLS)));
         TRY(g->d_items.ensure((size_t)aln_total + 2 * (size_t)nt + 1));
         // ---- POA: persistent waves with private scratch, two kernel variants over two device-built task lists.  The common one keeps
@@ -692,22 +694,23 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
                   g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, &dc->err, (q), g->aln_wdiv, g->aln_wadd, g->aln_wtol
             const int big_first = nm, big_n = ni - big_first;           // (the second list is empty since round 3: th_aln_class)
             const int *no_n = nullptr, *no_s1 = nullptr; ThAlnItem *no_defer = nullptr; int *no_dn = nullptr, *no_ws = nullptr, *no_ds1 = nullptr;
+            const int *slb_ = g->aln_slb ? (const int *)g->d_slb.p : (const int *)nullptr;      // (TH_ALN_SLB=0: no bounds from the POA -- round 4's probes)
             int *aln_stat = trace ? dc->aln_first : (int *)nullptr;          // (TH_TRACE: first / second bands tried and not certified)
             // TH_ALN_PROBE_SMALL=3: the first launch, too, hands what its anti-diagonal engine cannot certify (long units after their one-register probe)
             // on to the strip-engine launch at the end instead of finishing it in place
             const bool defer_small = g->aln_probe_small == 3 && g->aln_mode == 1;
             if (defer_small || (big_n && big_first < ni)) { TRY(g->d_defer.ensure((size_t)ni)); TRY(g->d_defer_s1.ensure((size_t)ni)); }
             ThAlnItem *sd = defer_small ? g->d_defer.p : no_defer; int *sdn = defer_small ? &dc->n_defer : no_dn, *sds1 = defer_small ? g->d_defer_s1.p : no_ds1;
-            if (ns) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(0, ns, &dc->q_aln_s), g->aln_mode, g->aln_xpct, no_n, sd, sdn, no_ws, no_s1, sds1, aln_stat);
-            if (nm > ns) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(nm - ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(ns, nm - ns, &dc->q_aln_m), g->aln_mode, g->aln_xpct, no_n, sd, sdn, no_ws, no_s1, sds1, aln_stat);
+            if (ns) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(0, ns, &dc->q_aln_s), g->aln_mode, g->aln_xpct, no_n, sd, sdn, no_ws, no_s1, sds1, aln_stat, slb_);
+            if (nm > ns) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(nm - ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(ns, nm - ns, &dc->q_aln_m), g->aln_mode, g->aln_xpct, no_n, sd, sdn, no_ws, no_s1, sds1, aln_stat, slb_);
             if (big_n && big_first < ni) {
                 // the big-area variant hands the alignments its anti-diagonal engine could not certify on to a second launch of the small-area one
                 // (mode 3): same results, but their strip-engine work then runs at three waves per SIMD instead of one or two
                 // (16 KB of staging area when every item fits it -- units of up to ~6000 bases: eight waves per CU instead of six)
                 if (cnt->max_need_big <= TH_ALN_BIG16)
-                    TH_LAUNCH((th_k_align<TH_ALN_BIG16, 6>), std::min(big_n, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(big_first, big_n, &dc->q_aln_b), g->aln_mode, g->aln_xpct, no_n, g->d_defer.p, &dc->n_defer, dc->aln_wide, no_s1, g->d_defer_s1.p);
+                    TH_LAUNCH((th_k_align<TH_ALN_BIG16, 6>), std::min(big_n, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(big_first, big_n, &dc->q_aln_b), g->aln_mode, g->aln_xpct, no_n, g->d_defer.p, &dc->n_defer, dc->aln_wide, no_s1, g->d_defer_s1.p, (int *)nullptr, slb_);
                 else
-                    TH_LAUNCH((th_k_align<TH_ALN_BIG, 6>), std::min(big_n, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(big_first, big_n, &dc->q_aln_b), g->aln_mode, g->aln_xpct, no_n, g->d_defer.p, &dc->n_defer, dc->aln_wide, no_s1, g->d_defer_s1.p);
+                    TH_LAUNCH((th_k_align<TH_ALN_BIG, 6>), std::min(big_n, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(big_first, big_n, &dc->q_aln_b), g->aln_mode, g->aln_xpct, no_n, g->d_defer.p, &dc->n_defer, dc->aln_wide, no_s1, g->d_defer_s1.p, (int *)nullptr, slb_);
             }
             if (g->aln_mode == 1 && (defer_small || (big_n && big_first < ni)))
                 TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(ni, wa), TH_ALN_BLOCK, g->stream, (const ThAlnItem *)g->d_defer.p, 0, (const ThTask *)g->d_tasks.p, (const int *)g->d_parc.p,
@@ -744,6 +747,7 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
     TRY(th_rt_d2h(out.jobs.data(), g->d_jobs.p, (size_t)nt * sizeof(th_job_t), g->stream));
     TRY(th_fetch_cnt(g, &cnt));                                                         // ---- host synchronisation 3 of 3 ----
     if (cnt->err & TH_E_ALN_VERIFY) return th_fail("TH_ALN_MODE=2: a banded alignment differs from the full matrix");
+    if (cnt->err & TH_E_ALN_BOUND) return th_fail("th_k_align: a band sized by a lower bound scored below the bound (the POA's unit bound was not one)");
     if (cnt->err) return th_fail("alignment boundary buffer overflow");
     out.n_jobs = nt;
     if (trace) fprintf(stderr, "[th] unit alignments of the small-area launch: %d first bands, %d not certified; %d second bands, %d not certified\n", cnt->aln_first[0], cnt->aln_first[1], cnt->aln_first[2], cnt->aln_first[3]);
