@@ -230,7 +230,7 @@ def test_gpu_large_batch_is_deterministic(th):
 
 
 @pytest.mark.parametrize("env", [dict(TH_ALN_MODE="2"), dict(TH_ALN_MODE="2", TH_ALN_WADD="200"), dict(TH_ALN_MODE="2", TH_ALN_WADD="600"),
-                                 dict(TH_ALN_MODE="2", TH_ALN_WTOL="0"), dict(TH_ALN_MODE="0")])
+                                 dict(TH_ALN_MODE="2", TH_ALN_WTOL="0"), dict(TH_ALN_MODE="0"), dict(TH_ALN_MODE="2", TH_ALN_SLB="0"), dict(TH_ALN_SLB="0")])
 def test_gpu_alignment_engines(monkeypatch, env):
     """unit-vs-consensus alignments: the anti-diagonal band engine with 1..6 registers per lane (TH_ALN_WADD widens the
     requested band), verified on the device against the full matrix (TH_ALN_MODE=2 fails the run on any difference), and the
@@ -248,6 +248,22 @@ def test_gpu_alignment_engines(monkeypatch, env):
     seqs.append(bytes(s))
     got = t.process(seqs)
     assert U.assert_records_equal(seqs, got, para, "alignment engines %r" % (env,)) >= 20
+    t.close()
+
+
+@pytest.mark.parametrize("env", [dict(), dict(TH_ALN_MODE="2"), dict(TH_ALN_SLB="0")])
+def test_gpu_long_units_start_from_the_poa_bound(monkeypatch, env):
+    """round 5: th_k_poa leaves, per unit, the ksw2 score of the unit's own path through the graph against the consensus columns (a valid global alignment, so a
+    lower bound of ksw2_global's optimum, src/gen_cons.c:213) and th_k_align runs long units on the band that bound certifies instead of probing for a bound.
+    Units of 2500 ... 5000 bases at 10 ... 16 % on the relative-int16 and the 32-bit POA variants; TH_ALN_MODE=2 recomputes every result on the full matrix on
+    the device, TH_ALN_SLB=0 is round 4's probing flow; a bound that is none fails the run (TH_E_ALN_BOUND).  Records equal the oracle's."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    t = TH.TideHunter(device=0)
+    seqs = _synth(t.lib, 10, 5000, 4, 0.15, 3) + _synth(t.lib, 6, 3000, 5, 0.12, 7) + _synth(t.lib, 4, 2500, 6, 0.16, 8) + _synth(t.lib, 4, 4000, 5, 0.10, 9) + _synth(t.lib, 2, 7000, 4, 0.12, 10)
+    got = t.process(seqs)
+    assert U.assert_records_equal(seqs, got, O.default_para(), "POA bounds %r" % (env,)) >= 20
+    assert t.stats()["jobs_without_consensus"] == 0
     t.close()
 
 

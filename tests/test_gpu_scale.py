@@ -36,7 +36,11 @@ def _run(cmd):
 
 def _both(tmp_path, opts, infile):
     O.load()
-    gpu = _run([EXE, *opts, str(infile)])
+    r = subprocess.run([EXE, *opts, str(infile)], check=True, capture_output=True)
+    # a consensus job the POA kernels could not serve ends WITHOUT a consensus behind a warning on stderr (the reference has no such failure mode,
+    # src/abpoa_cons.c:86-87): none may occur at scale
+    assert b"could not be aligned" not in r.stderr, r.stderr[-400:]
+    gpu = r.stdout
     cpu = _run([ORACLE, "-t", str(CORES), *opts, str(infile)])
     return gpu, cpu
 

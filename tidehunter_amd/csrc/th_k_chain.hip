@@ -143,7 +143,10 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
         const int base0 = cur - 1;
         unsigned long long rec_next = (PK && base0 >= 0) ? fetch(base0, bslot) : 0ull;
         TH_LDS_ASYNC_WAIT(rec_next);
-        for (int base = base0; base >= 0; base -= TH_WAVE, bslot = RP2 ? 0 : (bslot >= TH_WAVE ? bslot - TH_WAVE : bslot - TH_WAVE + RING)) {
+        // (round 5: ONE exit, at the bottom -- the kernel is bound by scalar issue, and a `break` in the middle of a `for` with an increment of its own cost a dozen scalar
+        // instructions of flags and re-tests per trip; base0 >= 0 here, so the first trip always runs)
+        int base = base0;
+        for (;;) {
             const int idx = base - lane;
             const bool valid = idx >= 0;
             int pe, pp, psc;
@@ -174,8 +177,15 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             const int dq2h = (int)((uint32_t)(PK ? __mul24(dq, dq) : dq * dq) >> 1);
             const int clzh = TH_CLZ_NZ(dis1 + dis2) >> 1;
             const int s = TH_LANE_OF_MASK(conm, lane) ? (psc + matched + clzh) - dq2h : -0x40000000;        // score + 15
-            const int rb = max(th_shr1_z(th_wave_incl_max(s)), best);             // (zero shifted into lane 0 -- one instruction less than minus infinity -- and best >= 16)      // best as seen just before this lane (lane 0: the running best)
-            const unsigned long long impm = TH_BALLOT(s > rb);     // (a lane without a connection holds -2^30, below every best)
+            // Which lanes improve the best IN SCAN ORDER.  Round 5: a lane can only improve if it beats the running best the trip started with, and when at most ONE lane
+            // does, that lane is the improvement (everything in front of it is <= best) -- no prefix maximum needed: one compare and a population count instead of the
+            // nine vector instructions of the scan (six dependent DPP steps, their copy, the shift, the maximum) on all but the trips with several candidates
+            // (a scan's first trip or two: afterwards the best is high and candidates are rare).  15 x 10^9 of the kernel's 67 x 10^9 vector instructions.
+            unsigned long long impm = TH_BALLOT(s > best);     // (a lane without a connection holds -2^30, below every best)
+            if (__popcll(impm) > 1) {
+                const int rb = max(th_shr1_z(th_wave_incl_max(s)), best);             // best as seen just before this lane (lane 0: the running best; zero shifted into lane 0 -- one instruction less than minus infinity -- and best >= 16)
+                impm = TH_BALLOT(s > rb);
+            }
             // stop rules in scan order: :331 (dstop); :342 improving SAME/OVL and :344-346 non-improving OVL (SAME with fewer than 2k
             // matched bases), so OVL always stops; :349 max_h consecutive non-improving predecessors (only evaluated when reachable)
             unsigned long long stopm = dstopm | (conm & TH_BALLOT(cp == pp) & (impm | TH_BALLOT(matched < 2 * k)));
@@ -192,7 +202,13 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             const unsigned long long taken = impm & (stopm ^ (stopm - 1));
             if (taken) { const int last = th_msb64nz(taken); best = TH_READLANE(s, last); bi = base - last; iter = 63 - last; }
             else iter += TH_WAVE;
-            if (stopm) break;
+            // the scan ended, or this was the trip that reached hit 0 (base - 64 negative): as ONE 64-bit word and one test -- two booleans become two lane masks, an OR, an AND
+            // with exec and a vector-condition branch
+            unsigned long long ends = stopm | (unsigned long long)((uint32_t)(base - TH_WAVE) >> 31);
+            TH_OPAQUE_S(ends);
+            if (ends) break;
+            base -= TH_WAVE;
+            if (!RP2) bslot = bslot >= TH_WAVE ? bslot - TH_WAVE : bslot - TH_WAVE + RING;
             TH_LDS_ASYNC_WAIT(rec_next);       // (here, before the value is copied or used: the compiler does not track the asynchronous read)
         }
         TH_LDS_ASYNC_WAIT(rec_next);           // a scan that stopped leaves its last request in flight: its registers stay reserved until it lands

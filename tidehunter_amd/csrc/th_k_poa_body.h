@@ -682,17 +682,17 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             // this 64-row chunk (or the previous row) and clean in its ring slot; no far row will read this one.  Same thing, unrolled.
             const int inn_ = (meta >> 8) & 0xff;
             if ((meta >> 26) & 1) {
-                int mpl = 0x7fffffff, mpr = 0, mb = 0x7fffffff, bad = 0;
+                int mpl = 0x7fffffff, mpr = 0, mb = 0x7fffffff, wmax = 0;
                 int qs0 = 0, qs1 = 0, qs2 = 0, qs3 = 0, qb0 = 0, qb1 = 0, qb2 = 0, qb3 = 0;
+                // (round 5: ONE code path per predecessor, all on the scalar unit.  The previous row's band sits in its lane of the chunk registers like any other
+                // row's -- its end-of-row write-lane put it there -- so the `pi == i - 1` branch onto the L_* scalars is gone; "cached" is "its band fits the ring"
+                // for every row that reaches this path, so the widest predecessor band, one running s_max, replaces the per-predecessor flag that hipcc kept in a
+                // vector register: ~10 scalar + 2 vector instructions per predecessor, 600 M predecessors per launch)
 #define TH_POA_RING_PRED(PI, QS, QB) do { \
-                    const int pi_ = (PI); int pb_, pl_, pr_; \
-                    if (pi_ == i - 1) { pb_ = L_b; pl_ = L_l; pr_ = L_r; bad |= L_c ^ TH_LC_ON; } \
-                    else { \
-                        const int x_ = pi_ & 63; \
-                        pb_ = TH_READLANE(m_beg, x_); pl_ = TH_READLANE(m_left, x_); pr_ = TH_READLANE(m_right, x_); \
-                        bad |= TH_READLANE(m_end, x_) - pb_ >= TH_POA_RW;      /* (where the predecessor sits: bit 26 of the meta word) */ \
-                    } \
-                    mpl = min(mpl, pl_ + 1); mpr = max(mpr, pr_ + 1); mb = min(mb, pb_); QS = pi_ & 3; QB = pb_ & ~1; \
+                    const int pi_ = (PI), x_ = pi_ & 63; \
+                    const int pb_ = TH_READLANE(m_beg, x_), pl_ = TH_READLANE(m_left, x_), pr_ = TH_READLANE(m_right, x_); \
+                    wmax = th_smax(wmax, TH_READLANE(m_end, x_) - pb_);      /* (where the predecessor sits: bit 26 of the meta word) */ \
+                    mpl = th_smin(mpl, pl_ + 1); mpr = th_smax(mpr, pr_ + 1); mb = th_smin(mb, pb_); QS = pi_ & 3; QB = pb_ & ~1; \
                 } while (0)
                 TH_POA_RING_PRED(p0, qs0, qb0);
                 if (inn_ > 1) {
@@ -702,7 +702,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                         if (inn_ > 3) TH_POA_RING_PRED(TH_READLANE(c_p3, sl), qs3, qb3);
                     }
                 }
-                if (!bad) {
+                if (wmax < TH_POA_RW) {
                     const int xd = qlen - rm;
                     const int b = th_smax(th_smax0(th_smin(mpl, xd) - w), mb), e = th_smin(qlen, th_smax(mpr, xd) + w);
                     if (b > e) return -2;
@@ -733,8 +733,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 int far_o = -1, far_pb = 0, far_pe = -1, far_po = 0;
 #define TH_POA_FAR_PRED(O, PI, QS, QB) do { \
                     const int pi_ = (PI); int pb_ = 0, pl_ = 0, pr_ = 0; \
-                    if (pi_ == i - 1 && L_c != 0) { pb_ = L_b; pl_ = L_l; pr_ = L_r; } \
-                    else if (pi_ < i && i - pi_ < TH_WAVE) {      /* (its band is still in lane pi_ & 63 of the chunk registers: row pi_ + 64 has not been written yet) */ \
+                    if (pi_ < i && i - pi_ < TH_WAVE) {      /* (its band is still in lane pi_ & 63 of the chunk registers: row pi_ + 64 has not been written yet) */ \
                         const int x_ = pi_ & 63; \
                         pb_ = TH_READLANE(m_beg, x_); pl_ = TH_READLANE(m_left, x_); pr_ = TH_READLANE(m_right, x_); \
                         const int pe_ = TH_READLANE(m_end, x_); \
@@ -1263,7 +1262,7 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
         const ThTask T = tasks[t];
         const uint8_t *rb = bseq + roff[T.read];
         const ThUnit *U = units + T.unit_off;
-        if (slb) for (int x = lane; x < T.pos_n - 1; x += TH_WAVE) slb[T.aln_off + x] = TH_SLB_NONE;      // (no bound unless the job gets that far)
+        if (slb) for (int x = lane; x < T.pos_n - 1; x += TH_WAVE) slb[T.aln_off + x] = TH_SLB_NONE;      // (no bound unless the job gets that far -- every variant writes this: th_k_align reads the slot)
         if (T.n_units <= 2) {            // src/abpoa_cons.c:60-83: consensus := unit 0
             const int len = U[0].len;
             const int st = len > T.cons_cap ? 6 : 0;
@@ -1278,7 +1277,10 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
         g.cap = (int)cap; g.n_node = 0;
         // (bounds only where th_k_align uses them: units long enough for a first band of three registers per lane or a probe -- consensus beyond ~2200 bases; the
         // headline shape's jobs skip the pass and its path stores)
-        const bool want_b = slb != nullptr && T.max_len >= TH_SLB_MIN_UNIT;
+        // (compiled out of the absolute-int16 variant: its units end where the bounds begin -- 6 (qlen + rows) < 32000, th_poa_dp -- and the dead code cost the
+        // headline kernel 3 ms through register allocation)
+        constexpr bool HAS_BOUNDS = TH_POA_REL || sizeof(RT) == 4;
+        const bool want_b = HAS_BOUNDS && slb != nullptr && T.max_len >= TH_SLB_MIN_UNIT;
         const long long upn = want_b ? (long long)T.sum_len + 8 : 0;
         int *p = th_poa_carve(g, my, cap, ocap, opn, upn);
         const int *order0 = g.order;       // (th_poa_merge swaps order / order2)
