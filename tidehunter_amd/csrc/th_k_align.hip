@@ -44,6 +44,9 @@ __device__ __forceinline__ int th_ad_run(bool has_n, const uint8_t *st, const ui
 template <int NPMAX>
 __device__ __forceinline__ int th_ad_align(int np, const uint8_t *__restrict__ q, int qlen, const uint8_t *__restrict__ t, int tlen, uint8_t *s_seq, int *score)
 {
+    // (the lengths come out of per-lane loads: said to be wave-uniform here, the engine's loop counters and phase limits live in scalar registers and its loops are
+    // scalar loops -- two vector instructions of a pair of anti-diagonals' 77 were the loop's own counter and compare: round 5)
+    np = TH_UNI(np); qlen = TH_UNI(qlen); tlen = TH_UNI(tlen);
     const int D = tlen - qlen, aD = D < 0 ? -D : D;
     const int W = (256 * np - 2 - aD) / 2;
     int lo = min(0, D) - W; lo -= lo & 1;                   // even; the band is as wide as the registers allow
@@ -70,6 +73,7 @@ __device__ __forceinline__ bool th_adx_run(bool has_n, const uint8_t *st, const 
 template <int NPXMAX>
 __device__ __forceinline__ bool th_adx_align(int np, const uint8_t *__restrict__ q, int qs, int qlen, const uint8_t *__restrict__ t, int ts, int tlen, uint8_t *s_seq, int *mq, int *mt, int *bh)
 {
+    np = TH_UNI(np); qlen = TH_UNI(qlen); tlen = TH_UNI(tlen);
     const uint8_t *st, *sq;
     const bool has_n = th_ad_stage(q, qlen, t, tlen, 128 * np, s_seq, &st, &sq, qs, ts);
     bool ok = false;

@@ -9,7 +9,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o run -- python3 $R/bench.py --steps 1 --warmup 0 --quick --config $CFG > $O/pmc_$c.log 2>&1
 done
 python3 - <<PY
-import csv, glob, json, os, collections
+import csv, glob, json, os, collections, sys
+sys.path.insert(0, "$R")
 O = "$O"
 res = collections.defaultdict(dict)
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -29,7 +30,7 @@ for k, v in res.items():
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of bench.py --steps 1 --warmup 0 --quick (one stream: one launch of every kernel "
                    "per step); corrected = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md (calibrated for 16-byte-per-lane streaming reads), uncorrected = "
                    "(FETCH_SIZE + WRITE_SIZE) * 1024: narrow scattered reads lie between the two",
-           "reads_per_launch": {"c3": 100000, "c2": 65536, "c4": 20000, "c5": 100000}["$CFG"], "config": "$CFG", "kernels": res}, open(os.path.join(O, "hbm_traffic.json"), "w"), indent=1)
+           "reads_per_launch": {"c3": 100000, "c2": 65536, "c4": 20000, "c5": 100000}["$CFG"], "config": "$CFG", "csrc_hash": __import__("bench").csrc_hash(), "kernels": res}, open(os.path.join(O, "hbm_traffic.json"), "w"), indent=1)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch_corrected"])[:8]:
     print("%-60s fetch %8.1f GB  write %8.1f GB  corrected %8.1f GB" % (k[:60], v.get("FETCH_SIZE_KB_per_launch", 0) / 1e6 * 1.024, v.get("WRITE_SIZE_KB_per_launch", 0) / 1e6 * 1.024, v["hbm_bytes_per_launch_corrected"] / 1e9))
 PY
