@@ -113,6 +113,15 @@ __device__ __forceinline__ int *th_poa_carve(ThPoaG &g, int *my, long long cap, 
 // relaxation, so it is software-pipelined: each trip issues level 1 for the chunk three trips ahead, level 2 for the one two ahead,
 // level 3 for the next one, and stores the PREVIOUS chunk's results; everything a trip consumes was issued a trip earlier.  The
 // remain of a successor in the chunk just finished comes from that chunk's registers (a lane shuffle), not from memory.
+#if defined(TH_POA_PROF)
+__device__ unsigned long long th_poa_prof_rows[8];      // row-table phase: 0 fast chunks, 1 general chunks, 2 rounds of the fast loop (two per trip), 3 rounds of the general loop, 4 calls
+#define TH_PROF_ROWS(k, v) do { if (TH_LANE() == 0) atomicAdd(&th_poa_prof_rows[k], (unsigned long long)(v)); } while (0)
+#else
+#define TH_PROF_ROWS(k, v) ((void)0)
+#endif
+#ifndef TH_POA_ROWS_ONE_ROUND
+#define TH_POA_ROWS_ONE_ROUND 1      // one round per run scan (round 5: a trip finishes one more run whether it holds one round or two)
+#endif
 struct ThPoaRows2 { int u, on, in, nb, o4[TH_POA_INL], i4[TH_POA_INL]; };
 struct ThPoaRows3 { int u, on, in, nb, s[TH_POA_INL], p[TH_POA_INL]; };
 // (Round 5: the three stages are BRANCH-FREE.  A lane outside the chunk -- the top chunk's tail, or any lane while the pipeline drains below row 0 -- reads a row
@@ -212,7 +221,7 @@ __device__ __forceinline__ int th_poa_rows_body(const ThPoaG &g)
         const bool scan_ok = n < (1 << 21) - 128;
         const int seg = (int)__popcll(~__ballot(has1 != 0) >> lane) << 22;            // run ends at or above this lane (the same number all along a run, smaller above it), in the key's high bits
 #define TH_POA_RUN_SCAN(cur) do { if (scan_ok) { \
-            int key_ = seg | ((cur) > -TH_BIG ? (cur) + lane + 2 : 0);          /* (0: no path yet) */ \
+            int key_ = seg | ((cur) > -(TH_BIG / 2) ? (cur) + lane + 2 : 0);    /* (0: no path yet -- a lane the rounds have not reached holds -TH_BIG plus a few rounds' drift, never a real value) */ \
             key_ = __shfl(key_, 63 - lane); key_ = th_wave_incl_max(key_); key_ = __shfl(key_, 63 - lane); \
             const int best_ = key_ & 0x3fffff; \
             if (best_) (cur) = best_ - lane - 2; } } while (0)
@@ -221,11 +230,15 @@ __device__ __forceinline__ int th_poa_rows_body(const ThPoaG &g)
             // the usual chunk: three lane shifts, three adds, two max3 per round (an edge that does not exist adds minus "infinity";
             // values near -TH_BIG are "no path yet" and lose every maximum against a real one), two rounds per convergence test
             const int inc1 = has1 ? 1 : -TH_BIG, inc2 = has2 ? 1 : -TH_BIG, inc3 = has3 ? 1 : -TH_BIG;
-            for (int it = 0; it < TH_WAVE / 2 + 1; ++it) {
+            TH_PROF_ROWS(0, 1);
+            for (int it = 0; it < TH_WAVE + 1; ++it) {
+                TH_PROF_ROWS(2, TH_POA_ROWS_ONE_ROUND ? 1 : 2);
                 int c1 = th_shl1(cur, -TH_BIG), c2 = th_shl1(c1, -TH_BIG), c3 = th_shl1(c2, -TH_BIG);
-                const int v1 = max(max(base, c1 + inc1), max(c2 + inc2, c3 + inc3));
-                c1 = th_shl1(v1, -TH_BIG); c2 = th_shl1(c1, -TH_BIG); c3 = th_shl1(c2, -TH_BIG);
                 int v2 = max(max(base, c1 + inc1), max(c2 + inc2, c3 + inc3));
+                if (!TH_POA_ROWS_ONE_ROUND) {
+                    c1 = th_shl1(v2, -TH_BIG); c2 = th_shl1(c1, -TH_BIG); c3 = th_shl1(c2, -TH_BIG);
+                    v2 = max(max(base, c1 + inc1), max(c2 + inc2, c3 + inc3));
+                }
                 TH_POA_RUN_SCAN(v2);
                 const bool ch = v2 != cur;
                 cur = v2;
@@ -233,6 +246,8 @@ __device__ __forceinline__ int th_poa_rows_body(const ThPoaG &g)
             }
         } else
         for (int it = 0; it < TH_WAVE + 1; ++it) {
+            if (it == 0) TH_PROF_ROWS(1, 1);
+            TH_PROF_ROWS(3, 1);
             int v = base;
             {
 #pragma unroll

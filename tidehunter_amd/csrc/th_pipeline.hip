@@ -676,7 +676,10 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
                   pr[26], pr[0], pr[1], pr[2], pr[3], pr[24], pr[4], pr[5], pr[6], pr[7], pr[27]);
           for (int c = 0; c < 8; ++c) fprintf(stderr, "%s\"%s\": {\"rows\": %llu, \"cycles\": %llu}", c ? ", " : "", cat[c], pr[8 + c], pr[16 + c]);
           fprintf(stderr, ", \"packed_far\": {\"rows\": %llu, \"cycles\": %llu}}}\n", pr[28], pr[29]);
-          unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(thpoa_n::th_poa_prof), z, sizeof(z)); }
+          unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(thpoa_n::th_poa_prof), z, sizeof(z));
+          unsigned long long rw[8]; hipMemcpyFromSymbol(rw, HIP_SYMBOL(thpoa_n::th_poa_prof_rows), sizeof(rw));
+          fprintf(stderr, "[poa_prof_rows] {\"fast_chunks\": %llu, \"general_chunks\": %llu, \"fast_rounds\": %llu, \"general_rounds\": %llu}\n", rw[0], rw[1], rw[2], rw[3]);
+          hipMemcpyToSymbol(HIP_SYMBOL(thpoa_n::th_poa_prof_rows), z, sizeof(rw)); }
 #endif
         // ---- unit-vs-consensus alignments and flank extensions: three item lists in one array, one kernel variant each ----
         const int ns = cnt->n_item_s, nm = ns + cnt->n_item_m, ni = nm + cnt->n_item_b, max_cl = cnt->max_cl;

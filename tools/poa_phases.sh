@@ -1,12 +1,14 @@
 #!/bin/bash
 # GPU box: where th_k_poa's instructions and time go, per phase and per row category  ->  gpurun_out/poa_phases/poa_phases.json
 #   (copied to profiles/r05_poa_phases.json).  Build container first:
-#     tools/build_variant.sh base; tools/build_variant.sh prof -DTH_POA_PROF; for k in 0 1 2 3; do tools/build_variant.sh dup$k -DTH_POA_DUP_PHASE=$k; done
+#     tools/build_variant.sh base; tools/build_variant.sh prof1 -DTH_POA_PROF=1; for k in 0 1 2 3 9; do tools/build_variant.sh dup$k -DTH_POA_DUP_PHASE=$k; done
+#   then tools/poa_phases_report.py > profiles/r05_poa_phases.json (build container: it reads the ISA)
 # Method.  (1) PHASES: variant dup<k> runs phase k (0 row tables, 1 DP, 2 traceback, 3 consensus; all idempotent) twice inside the job loop, in a loop
 #     whose trip count the compiler cannot see, so one copy of the code; per variant one rocprofv3 pass with --kernel-trace --pmc SQ_INSTS_VALU
 #     SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES of `bench.py --quick --steps 1 --warmup 0` and one un-profiled bench line for the kernel time.
 #     phase k = dup<k> - dup9 (the same code with no phase repeated); merge + job set-up + seed = base - the four.
-# (2) ROW CATEGORIES of the DP: the prof variant counts rows per path of the row loop and sums s_memtime cycles per path (one LDS add per row) and per phase.
+# (2) ROW CATEGORIES of the DP: the prof1 variant (-DTH_POA_PROF=1: events only) counts rows per path of the row loop (one LDS add per row), further trips, traceback
+#     events and the row-table phase's chunks and relaxation rounds.  (-DTH_POA_PROF=2 adds s_memtime cycles per path; that build faults on the GPU -- not used.)
 # (3) STATIC: tools/isa_blocks.py counts of the straight-line row bodies are added by tools/poa_phases_report.py in the build container (it has the ISA).
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/poa_phases; mkdir -p $O; export TMPDIR=/tmp
 E=$R/tests/cpu_emul
@@ -47,12 +49,14 @@ times = collections.defaultdict(list)
 for l in open(os.path.join(O, "times.txt")):
     v, j = l.split(" ", 1); times[v].append(json.loads(j).get("th_k_poa"))
 prof = {}
-for v in ("prof1", "prof"):
+for v in ("prof1",):
     try:
-        ls = [json.loads(l.split("[poa_prof] ", 1)[1]) for l in open(os.path.join(O, v + ".txt")) if "{" in l]
+        ls = [json.loads(l.split("[poa_prof] ", 1)[1]) for l in open(os.path.join(O, v + ".txt")) if "[poa_prof] {" in l]
         prof[v] = ls[-1] if ls else None
+        lr = [json.loads(l.split("[poa_prof_rows] ", 1)[1]) for l in open(os.path.join(O, v + ".txt")) if "[poa_prof_rows] {" in l]
+        prof[v + "_rows"] = lr[-1] if lr else None
     except OSError:
         prof[v] = None
-json.dump({"pmc": res, "poa_ms": times, "prof_events_build": prof["prof1"], "prof_cycles_build": prof["prof"]}, open(os.path.join(O, "poa_phases_raw.json"), "w"), indent=1)
+json.dump({"pmc": res, "poa_ms": times, "prof_events_build": prof.get("prof1"), "prof_rows": prof.get("prof1_rows"), "prof_cycles_build": prof.get("prof")}, open(os.path.join(O, "poa_phases_raw.json"), "w"), indent=1)
 print(json.dumps({"pmc": res, "poa_ms": times}, indent=1)); print(prof)
 PY

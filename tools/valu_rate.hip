@@ -23,7 +23,7 @@
                          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),       \
                            "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])  \
                          : "v"(b), "s"(m)                                                                   \
-                         : "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "m0");           \
+                         : "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47");           \
         }                                                                                                   \
         unsigned s = 0;                                                                                     \
         for (int i = 0; i < 16; ++i) s ^= a[i];                                                             \
