@@ -976,14 +976,16 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
     int t_d = 0, t_p0 = -1, t_p1 = -1, t_p2 = -1, t_p3 = -1, t_ok = 0;
     unsigned long long t_run = 0;           // tile cells that are plain diagonal steps: match state, predecessor = the row above
     unsigned long long t_any = 0; int t_pr = 0;     // ... diagonal steps in match state to ANY predecessor row (t_pr: that row): one short trip each
+    unsigned long long t_okm = 0;          // tile cells that lie inside their row's band (t_ok as a lane mask)
     while (ci > 0) {
         // the walk is wave-uniform; saying so at every trip keeps its state in scalar registers and its branches scalar (the compiler
         // otherwise treats the loop-carried state as divergent and compiles every step under exec masks)
         ci = TH_UNI(ci); cj = TH_UNI(cj); st = TH_UNI(st); no = TH_UNI(no); ti = TH_UNI(ti); tj = TH_UNI(tj);
         int k = ti - ci, o = cj - (tj - k) + 1;
-        bool hit0 = k >= 0 && k <= 15 && o >= 0 && o <= 3;
-        const int ok0 = TH_READLANE(t_ok, hit0 ? (k * 4 + o) : 0);
-        if (!hit0 || !ok0) {
+        // (round 5: 0 <= k <= 15 and 0 <= o <= 3 as ONE test -- arithmetic shifts leave 0 only inside the ranges -- and the cell's "inside its row's band" flag from a lane
+        // mask taken once per tile instead of a lane read per step: ~8 scalar and one vector instruction off each of the ~500 M steps per launch)
+        const int out0 = (k >> 4) | (o >> 2);
+        if (out0 != 0 || !((t_okm >> ((k * 4 + o) & 63)) & 1)) {
             ti = ci; tj = cj;
             TH_PROF_CNT(4, 1);
             const int row = ti - (lane >> 2), col = tj - (lane >> 2) + (lane & 3) - 1;
@@ -1004,6 +1006,7 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
             {
                 const int want = (int)TH_D_PM((uint32_t)t_d);
                 const int pr = want == 0 ? t_p0 : want == 1 ? t_p1 : want == 2 ? t_p2 : t_p3;
+                t_okm = __ballot(t_ok != 0);
                 t_any = __ballot(t_ok && TH_D_SRC((uint32_t)t_d) == 0 && want < TH_POA_INL);
                 t_run = t_any & __ballot(pr == row - 1);
                 t_pr = pr;
@@ -1048,8 +1051,8 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
         // a gap state continues only if the cell we arrived at says so (its word may sit in the tile)
         {
             const int k2 = ti - ci, o2 = cj - (tj - k2) + 1;
-            const bool hit = k2 >= 0 && k2 <= 15 && o2 >= 0 && o2 <= 3;
-            const int okv = TH_READLANE(t_ok, hit ? (k2 * 4 + o2) : 0), dv = TH_READLANE(t_d, hit ? (k2 * 4 + o2) : 0);
+            const bool hit = ((k2 >> 4) | (o2 >> 2)) == 0;
+            const int okv = (int)((t_okm >> ((k2 * 4 + o2) & 63)) & 1), dv = TH_READLANE(t_d, hit ? (k2 * 4 + o2) : 0);
             if (moved_gap) {
                 if (ci == 0) st = 0;
                 else {
