@@ -546,7 +546,7 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
         // (each half compared with the scalar maximum as a sign-extended operand: no packed copy of the maximum to build on the scalar unit)
         const unsigned long long mlo = __ballot(TH_PK_LO(hm2) == hm), mhi = __ballot(TH_PK_HI(hm2) == hm);
         const unsigned long long many = mlo | mhi;
-        if (t0 == 0 || (hm >= rmax && many)) {
+        if (t0 == 0 || hm >= rmax) {               // (`many` is never empty: a trip runs only if it holds an in-band column, and that lane reaches the trip's maximum)
             const int fa = th_ctz64nz(many), la = th_msb64nz(many);
             const int fl = B0 + t0 + 2 * fa + (int)(~(mlo >> fa) & 1ull);
             const int lr = B0 + t0 + 2 * la + (int)((mhi >> la) & 1ull);
@@ -566,7 +566,7 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
         L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = TH_LC_ON; TH_POA_SET_RMAX(rmax); \
         TH_POA_PK_PROF(cat) \
         th_writelane6(m_beg, m_end, m_left, m_right, m_off, m_foff, b, e, L_l, L_r, my_off, (FOFF), sl); \
-        if (sl == 63 || i + 2 >= n) { \
+        if (i == flush_row) { \
             const int r_ = (i & ~63) + lane; \
             if (r_ <= i) { g.r_beg[r_] = m_beg; g.r_end[r_] = m_end; g.r_off[r_] = m_off; g.r_foff[r_] = m_foff; g.r_mpl[r_] = m_left; g.r_mpr[r_] = m_right; } \
         } \
@@ -633,6 +633,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     // (one v_writelane each per row); they go to the row tables in HBM 64 rows at a time, so the common row issues no
     // metadata store at all.  A predecessor inside the chunk is read back with v_readlane, an older one from the tables.
     int m_beg = 0, m_end = 0, m_left = 0, m_right = 0, m_off = 0, m_foff = 0;
+    int flush_row = 0;
 #if TH_POA_TRIPS == 2
     int tail_dirty = (1 << TH_POA_RING) - 1;      // ring slots whose columns beyond the first 128 are not known to hold minus infinity (see th_poa_pk_row)
 #else
@@ -642,6 +643,8 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     TH_WAVE_FENCE();
     for (int i = 0; i + 1 < n; ++i) {
         if ((i & 63) == 0) {
+            flush_row = th_smin(i | 63, n - 2);          // the row after which the chunk registers go to the tables: the chunk's last, or the last row of all (ONE compare per row
+                                                         // instead of the two tests and their boolean algebra: round 5)
             const int r = i + lane;
             if (r < n) {
                 c_meta = g.r_meta[r]; c_rem = g.r_rem[r]; c_id = g.order[r];
@@ -742,7 +745,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             // rows, or a predecessor too wide to be cached) -- it is read from its full cells in HBM -- and / or some far row will read
             // this one, which then also stores its cells in full.  Everything still inside this 64-row chunk; the rest goes on to the
             // general path below (one column per lane in 32 bits).
-            if (i > 0 && inn_ >= 1 && inn_ <= 4) {
+            if ((unsigned)(inn_ - 1) < 4u) {          // one to four predecessors (row 0, the source, has none): one compare
                 int mpl = 0x7fffffff, mpr = 0, mb = 0x7fffffff, bad = 0;
                 int qs0 = 0, qs1 = 0, qs2 = 0, qs3 = 0, qb0 = 0, qb1 = 0, qb2 = 0, qb3 = 0;
                 int far_o = -1, far_pb = 0, far_pe = -1, far_po = 0;
@@ -937,7 +940,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
           TH_PROF_ROW(cat, dt); }
 #endif
         th_writelane6(m_beg, m_end, m_left, m_right, m_off, m_foff, b, e, L_l, L_r, my_off, my_foff, sl);
-        if (sl == 63 || i + 2 >= n) {          // chunk complete (or last row): its rows' metadata to the tables, coalesced
+        if (i == flush_row) {          // chunk complete (or last row): its rows' metadata to the tables, coalesced
             const int r = (i & ~63) + lane;
             if (r <= i) { g.r_beg[r] = m_beg; g.r_end[r] = m_end; g.r_off[r] = m_off; g.r_foff[r] = m_foff; g.r_mpl[r] = m_left; g.r_mpr[r] = m_right; }
         }
