@@ -1274,6 +1274,7 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
 #if defined(TH_POA_PROF)
     if (lane < 10) s_poa_prof[lane] = 0;
     TH_WAVE_FENCE();
+    const unsigned long long prof_t_start = __builtin_amdgcn_s_memtime(); int prof_jobs = 0;
 #endif
     for (;;) {
         // jobs differ a lot in length (units, copies): waves pull the next job from a shared counter
@@ -1311,6 +1312,9 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
         }
         int st = 0;
         TH_PROF_CNT(26, 1);
+#if defined(TH_POA_PROF)
+        ++prof_jobs;
+#endif
         if (p - my > scratch_ints || g.cell_u2 < 2048 || U[0].len + 2 > cap) st = 1;
         if (!st) th_poa_seed(g, rb + U[0].start, U[0].len, want_b ? g.upath : nullptr);
         int up_off = U[0].len;
@@ -1354,6 +1358,8 @@ th_k_poa(const ThTask *__restrict__ tasks, const int *__restrict__ list, int n_l
     }
 #if defined(TH_POA_PROF)
     TH_WAVE_FENCE();
+    // when the waves of the persistent grid run out of jobs: per wave, the time from its start to its last job's end: shortest / longest / mean (the tail of the dynamic queue; all waves of the grid are resident from the start)
+    if (lane == 0 && prof_jobs > 0) { const unsigned long long te = __builtin_amdgcn_s_memtime() - prof_t_start;      /* (per wave that took a job: the counters of different XCDs share no base) */ atomicMin(&th_poa_prof_rows[5], te); atomicMax(&th_poa_prof_rows[6], te); atomicAdd(&th_poa_prof_rows[7], te >> 10); atomicAdd(&th_poa_prof_rows[4], 1ull); }
     if (lane < 8) { const unsigned long long v = s_poa_prof[lane]; atomicAdd(&th_poa_prof[8 + lane], v >> 40); atomicAdd(&th_poa_prof[16 + lane], v & ((1ull << 40) - 1)); }
     if (lane == 8) atomicAdd(&th_poa_prof[27], s_poa_prof[8] >> 40);
     if (lane == 9) { atomicAdd(&th_poa_prof[28], s_poa_prof[9] >> 40); atomicAdd(&th_poa_prof[29], s_poa_prof[9] & ((1ull << 40) - 1)); }

@@ -679,7 +679,8 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
           unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(thpoa_n::th_poa_prof), z, sizeof(z));
           unsigned long long rw[8]; hipMemcpyFromSymbol(rw, HIP_SYMBOL(thpoa_n::th_poa_prof_rows), sizeof(rw));
           fprintf(stderr, "[poa_prof_rows] {\"fast_chunks\": %llu, \"general_chunks\": %llu, \"fast_rounds\": %llu, \"general_rounds\": %llu}\n", rw[0], rw[1], rw[2], rw[3]);
-          hipMemcpyToSymbol(HIP_SYMBOL(thpoa_n::th_poa_prof_rows), z, sizeof(rw)); }
+          fprintf(stderr, "[poa_prof_tail] {\"waves\": %d, \"waves_that_took_jobs\": %llu, \"busy_ticks_shortest\": %llu, \"busy_ticks_longest\": %llu, \"busy_ticks_mean\": %llu}\n", wv_n, rw[4], rw[5], rw[6], rw[4] ? (rw[7] << 10) / rw[4] : 0ull);
+          unsigned long long z2[8] = { 0, 0, 0, 0, 0, ~0ull, 0, 0 }; hipMemcpyToSymbol(HIP_SYMBOL(thpoa_n::th_poa_prof_rows), z2, sizeof(z2)); }
 #endif
         // ---- unit-vs-consensus alignments and flank extensions: three item lists in one array, one kernel variant each ----
         const int ns = cnt->n_item_s, nm = ns + cnt->n_item_m, ni = nm + cnt->n_item_b, max_cl = cnt->max_cl;
