@@ -56,6 +56,7 @@ __device__ __forceinline__ int th_wave_incl_sum(int v)
 #define TH_STORE_U16_SADDR(base, off, v) (*(uint16_t *)((char *)(base) + (uint32_t)(off)) = (uint16_t)(v))
 #define TH_LDS_READ64_ASYNC(p) (*(p))
 #define TH_LDS_ASYNC_WAIT(v) ((void)0)
+#define TH_LDS_ASYNC_TAKE(dst, v) ((dst) = (v))
 #define TH_LANE_OF_MASK(m, lane) (((m) >> (lane)) & 1ull)
 #define TH_CLZ_NZ(x) ((unsigned)(x) ? __builtin_clz((unsigned)(x)) : 32)
 static inline int __mul24(int a, int b) { return (int)((unsigned)a * (unsigned)b); }

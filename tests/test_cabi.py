@@ -62,7 +62,9 @@ def test_isa_untracked_lds_read_is_not_touched_before_its_wait(tmp_path):
         pytest.skip("hipcc not available")
     src = os.path.join(ROOT, "tidehunter_amd", "csrc")
     out = tmp_path / "th_pipeline.s"
-    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-value", "-Wno-pass-failed", "-w", "-I" + src, "-I" + os.path.join(ROOT, "include"),
+    flags = subprocess.run(["make", "-s", "--no-print-directory", "-C", src, "print-hipflags"], capture_output=True, text=True, check=True).stdout.split()      # the product's own
+    assert "--offload-arch=gfx950" in flags
+    subprocess.run([hipcc] + flags + ["-w", "-I" + src, "-I" + os.path.join(ROOT, "include"),
                     "--cuda-device-only", "-S", os.path.join(src, "th_pipeline.hip"), "-o", str(out)], check=True, timeout=900)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_check_async_lds.py"), str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -296,7 +296,7 @@ def test_gpu_chain_dp_ring_variants_agree(monkeypatch):
     lib = TH.load_library()
     seqs = [TH.synth_read(lib, 9, i, (1000, 300, 2000)[i % 3], (10, 30, 5)[i % 3], 0.10) for i in range(96)]
     para = O.default_para(only_unit=1)
-    for ring in ("512", "0", "768", "1024"):
+    for ring in (os.environ["TH_ONLY_RING"],) if os.environ.get("TH_ONLY_RING") else ("512", "0", "768", "1024"):      # (TH_ONLY_RING: tools/ring_bisect.sh)
         monkeypatch.setenv("TH_CHAIN_RING", ring)
         t = TH.TideHunter(device=0, only_unit=1)
         t.process(seqs)

@@ -127,6 +127,10 @@ __device__ __forceinline__ unsigned long long th_lds_read64_async(const void *p)
 }
 #define TH_LDS_READ64_ASYNC(p) th_lds_read64_async(p)
 #define TH_LDS_ASYNC_WAIT(v) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory")
+// ... and the form a loop needs that requests the NEXT value while it works on this one: wait, then copy INSIDE the asm block into registers of their own.  (As a wait
+// with a tied operand followed by a C++ copy, the allocator may place the copy in front of the wait -- it is free to, the asm being "some operation on a register" -- and
+// did once the wait stood at the top of the trip loop: stale records, found by the 768-entry ring's GPU test; tools/isa_check_async_lds.py follows the control flow now.)
+#define TH_LDS_ASYNC_TAKE(dst, v) asm volatile("s_waitcnt lgkmcnt(0)\n\tv_mov_b64 %0, %1" : "=&v"(dst) : "v"(v) : "memory")
 #define TH_LANE_OF_MASK(m, lane) __builtin_amdgcn_inverse_ballot_w64(m)      // this lane's bit of a wave-uniform mask: the mask IS the condition register
 #define TH_CLZ_NZ(x) __builtin_clz((unsigned)(x))          // x != 0 where the result is used (garbage lanes are discarded by the caller)
 

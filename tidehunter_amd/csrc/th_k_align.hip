@@ -93,6 +93,11 @@ __device__ __forceinline__ bool th_adx_align(int np, const uint8_t *__restrict__
 // band or the full matrix -- runs on the strip engine, which needs 4 KB of LDS, and at this variant's 24 KB and 250 registers it would
 // run at one or two waves per SIMD (config 4: 5000 x 5000 pairs at 15 % error were 470 of the 849 ms of a step that way).
 #define TH_ALN_NO_S1 (-0x40000000)
+#if defined(TH_ALN_PROF)
+// -DTH_ALN_PROF=1 (tools/build_variant.sh; never the product): how evenly a launch's dynamic queue keeps its waves busy -- per wave that took an item, the ticks from its
+// start to its exit: [0] waves, [1] shortest, [2] longest, [3] sum >> 10, [4] items; printed and reset by th_pipeline.hip after every launch
+__device__ unsigned long long th_aln_prof[8] = { 0, ~0ull, 0, 0, 0, 0, 0, 0 };
+#endif
 template <int LDSB, int NPMAX>
 __global__ void __launch_bounds__(TH_ALN_BLOCK) TH_ALN_OCC
 th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__restrict__ tasks, const int *__restrict__ pos,
@@ -118,9 +123,15 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
     const bool pkstrip = !((xpct >> 11) & 1);      // bit 11 of xpct (TH_ALN_PKSTRIP=0): the one-column strip engines only (A/B runs, the tests' cross-check)
     xpct &= 0xff;
     if (n_items_ptr) n_items = TH_UNI(*n_items_ptr);
+#if defined(TH_ALN_PROF)
+    const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime(); int prof_items = 0;
+#endif
     for (;;) {
         const int it = th_queue_pop(queue);   // dynamic work queue: items range from a short extension to a full matrix
         if (it >= n_items) break;
+#if defined(TH_ALN_PROF)
+        ++prof_items;
+#endif
         const ThAlnItem I = items[it];
         const ThTask T = tasks[I.task];
         const int cl = cons_len[I.task];
@@ -283,4 +294,8 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
             if (lane == 0) { const int o = 4 * I.task + (I.which == -1 ? 0 : 2); ext[o] = mq; ext[o + 1] = mt; }
         }
     }
+#if defined(TH_ALN_PROF)
+    if (lane == 0 && prof_items > 0) { const unsigned long long te = __builtin_amdgcn_s_memtime() - prof_t0;
+        atomicAdd(&th_aln_prof[0], 1ull); atomicMin(&th_aln_prof[1], te); atomicMax(&th_aln_prof[2], te); atomicAdd(&th_aln_prof[3], te >> 10); atomicAdd(&th_aln_prof[4], (unsigned long long)prof_items); }
+#endif
 }

@@ -132,36 +132,46 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
         // wave's outstanding global stores -- the previous hit's results -- before every trip).  Lanes before the first hit read some
         // record and are discarded by the `valid` mask.  Slot of idx = base - lane: (cur_slot - (cur - base) - lane) mod RING, the
         // wave-uniform part reduced on the scalar unit.
-        auto fetch = [&](int base_, int bslot_) -> unsigned long long {
+        auto fetch_ring = [&](int base_, int bslot_) -> unsigned long long {
             const int idx_ = base_ - lane;
-            if (RING && base_ - (TH_WAVE - 1) >= ring_lo)
-                return TH_LDS_READ64_ASYNC(&s_ring[RING ? (threadIdx.x >> 6) : 0][RP2 ? (idx_ & (RING - 1)) : (int)min((uint32_t)(bslot_ - lane), (uint32_t)(bslot_ - lane + RING))]);
-            return R[max(idx_, 0)];
+            return TH_LDS_READ64_ASYNC(&s_ring[RING ? (threadIdx.x >> 6) : 0][RP2 ? (idx_ & (RING - 1)) : (int)min((uint32_t)(bslot_ - lane), (uint32_t)(bslot_ - lane + RING))]);
         };
+        auto fetch_hbm = [&](int base_) -> unsigned long long { return R[max(base_ - lane, 0)]; };
         // The next trip's records are requested before this trip is resolved (seven scans in eight go on): the trip is a chain of
         // dependent steps -- load, score, prefix maximum, masks, branch -- and the wave has nothing else to overlap the load with.
         const int base0 = cur - 1;
-        unsigned long long rec_next = (PK && base0 >= 0) ? fetch(base0, bslot) : 0ull;
-        TH_LDS_ASYNC_WAIT(rec_next);
+        // a trip at `base` asks for the records base - 64 .. base - 127: from the ring if base >= ring_from, from HBM if base >= 64, not at all below that
+        const int ring_from = RING ? th_smax(ring_lo + 2 * TH_WAVE - 1, TH_WAVE) : 0x7fffffff;
+        unsigned long long rec_next = 0ull;
+        if (PK) { if (RING && base0 - (TH_WAVE - 1) >= ring_lo) rec_next = fetch_ring(base0, bslot); else rec_next = fetch_hbm(base0); }
         // (round 5: ONE exit, at the bottom -- the kernel is bound by scalar issue, and a `break` in the middle of a `for` with an increment of its own cost a dozen scalar
-        // instructions of flags and re-tests per trip; base0 >= 0 here, so the first trip always runs)
+        // instructions of flags and re-tests per trip; base0 >= 0 here, so the first trip always runs.  The wait for the requested records is the FIRST thing of a trip:
+        // at the bottom and behind the loop, hipcc merged the two waits' blocks and re-tested the exit flag after them)
         int base = base0;
+        unsigned long long endw = 0ull;                 // set by the trip that reaches hit 0: the loop's exit test is ONE 64-bit word, stopm | endw
+        // byte offset, in the wave's ring, of this lane's record of the trip last requested (power-of-two rings): the next trip's is 64 slots below it, modulo the ring --
+        // a subtraction and a mask where slot = (base - 64 - lane) & (RING - 1), times 8, plus the ring's address were four instructions a trip
+        int rbo = (RING && RP2) ? ((base0 - lane) & (RING - 1)) << 3 : 0;
         for (;;) {
+            unsigned long long rec;
+            TH_LDS_ASYNC_TAKE(rec, rec_next);  // (wait and copy in one asm block, before anything else reads the value: the compiler does not track the asynchronous read)
             const int idx = base - lane;
             const bool valid = idx >= 0;
             int pe, pp, psc;
             if (PK) {
-                const unsigned long long rec = rec_next;
-                if (base >= TH_WAVE) rec_next = fetch(base - TH_WAVE, RP2 ? 0 : (bslot >= TH_WAVE ? bslot - TH_WAVE : bslot - TH_WAVE + RING));
+                if (base >= ring_from) {
+                    if (RP2) { rbo = (rbo - 8 * TH_WAVE) & (8 * RING - 1); rec_next = TH_LDS_READ64_ASYNC((const unsigned long long *)((const char *)ring + rbo)); }
+                    else rec_next = fetch_ring(base - TH_WAVE, bslot >= TH_WAVE ? bslot - TH_WAVE : bslot - TH_WAVE + RING);
+                } else if (base >= TH_WAVE) rec_next = fetch_hbm(base - TH_WAVE);
                 pe = (int)((uint32_t)rec >> 16); pp = (int)((uint32_t)rec & 0xffffu); psc = (int)(rec >> 32);
             } else { pe = valid ? E[idx] : 0; pp = valid ? Pd[idx] : 1; psc = valid ? S[idx] : 0; }
             const int ps = pe - pp;
             // The rules are evaluated as 64-bit lane masks of single comparisons, combined on the scalar unit (a boolean expression per
             // lane would be materialised as 0/1 registers and compared again for every ballot).
             unsigned long long dstopm = TH_BALLOT(pe < cs);                              // :331  predecessor ends before cur starts
-            // ... or does not exist (idx = base - lane < 0): the last trip only, under a real branch (the volatile asm keeps hipcc from turning it into a shift and two
-            // selects on every trip)
-            if (base < TH_WAVE - 1) { unsigned long long none = ~0ull << (base + 1); TH_OPAQUE_S(none); dstopm |= none; }
+            // ... or does not exist (idx = base - lane < 0): the last trip only, under a real branch (the volatile asm keeps hipcc from turning it into shifts and
+            // selects on every trip); base == 63 has all its lanes and only ends the loop
+            if (base < TH_WAVE) { unsigned long long none = (~0ull << base) << 1; TH_OPAQUE_S(none); dstopm |= none; endw = 1ull; }
             // :154 compares cp >= pp * 1.8 in double.  fl(1.8) exceeds 1.8 by a relative 2.5e-17, less than half an ulp,
             // so pp * fl(1.8) rounds to exactly 1.8 pp whenever that is an integer and stays > 0.19 away from every
             // integer otherwise: the comparison equals 5 cp >= 9 pp for all periods below 2^28 (th_gpu_upload checks).
@@ -182,34 +192,41 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             // nine vector instructions of the scan (six dependent DPP steps, their copy, the shift, the maximum) on all but the trips with several candidates
             // (a scan's first trip or two: afterwards the best is high and candidates are rare).  15 x 10^9 of the kernel's 67 x 10^9 vector instructions.
             unsigned long long impm = TH_BALLOT(s > best);     // (a lane without a connection holds -2^30, below every best)
-            if (__popcll(impm) > 1) {
-                const int rb = max(th_shr1_z(th_wave_incl_max(s)), best);             // best as seen just before this lane (lane 0: the running best; zero shifted into lane 0 -- one instruction less than minus infinity -- and best >= 16)
-                impm = TH_BALLOT(s > rb);
-            }
             // stop rules in scan order: :331 (dstop); :342 improving SAME/OVL and :344-346 non-improving OVL (SAME with fewer than 2k
-            // matched bases), so OVL always stops; :349 max_h consecutive non-improving predecessors (only evaluated when reachable)
-            unsigned long long stopm = dstopm | (conm & TH_BALLOT(cp == pp) & (impm | TH_BALLOT(matched < 2 * k)));
-            if (iter + TH_WAVE >= max_h) {
-                const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1);
-                const unsigned long long below = impm & upto;
-                const int iter_after = below ? lane - th_msb64(below) : iter + lane + 1;
-                stopm |= ~impm & TH_BALLOT(iter_after >= max_h);
+            // matched bases), so OVL always stops; :349 max_h consecutive non-improving predecessors (only evaluated when reachable).
+            // Most trips have NO candidate (the best is high after a scan's first trips): they pay one 64-bit test for everything a candidate entails -- the prefix
+            // maximum, the improving-SAME stops, the improvements taken -- and the max_h rule in its candidate-free form
+            const unsigned long long samem = conm & TH_BALLOT(cp == pp);
+            unsigned long long stopm = dstopm | (samem & TH_BALLOT(matched < 2 * k));
+            if (impm) {
+                if (impm & (impm - 1)) {
+                    const int rb = max(th_shr1_z(th_wave_incl_max(s)), best);             // best as seen just before this lane (lane 0: the running best; zero shifted into lane 0 -- one instruction less than minus infinity -- and best >= 16)
+                    impm = TH_BALLOT(s > rb);
+                }
+                stopm |= samem & impm;
+                if (iter + TH_WAVE >= max_h) {
+                    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1);
+                    const unsigned long long below = impm & upto;
+                    const int iter_after = below ? lane - th_msb64(below) : iter + lane + 1;
+                    stopm |= ~impm & TH_BALLOT(iter_after >= max_h);
+                }
+                // the improvements taken are those up to the first stopping lane; the last of them is the new best.  ONE update for both outcomes of the trip
+                // (round 5): stopm ^ (stopm - 1) is every lane up to and including the lowest stopping one and ALL lanes when none stops, so the scan that goes on
+                // and the scan that ends take their improvements through the same code; `iter` of a scan that ends is never read
+                const unsigned long long taken = impm & (stopm ^ (stopm - 1));
+                iter += TH_WAVE;
+                if (taken) { const int last = th_msb64nz(taken); best = TH_READLANE(s, last); bi = base - last; iter = 63 - last; }
+            } else {
+                if (iter + TH_WAVE >= max_h) stopm |= TH_BALLOT(iter + lane + 1 >= max_h);
+                iter += TH_WAVE;
             }
-            // the improvements taken are those up to the first stopping lane; the last of them is the new best.  ONE update for both outcomes of the trip
-            // (round 5): stopm ^ (stopm - 1) is every lane up to and including the lowest stopping one and ALL lanes when none stops, so the scan that goes on
-            // and the scan that ends take their improvements through the same code, and the loop has one exit test (the two copies of the update and the
-            // structurizer's flags between them were ~10 scalar instructions of a trip's 54); `iter` of a scan that ends is never read
-            const unsigned long long taken = impm & (stopm ^ (stopm - 1));
-            if (taken) { const int last = th_msb64nz(taken); best = TH_READLANE(s, last); bi = base - last; iter = 63 - last; }
-            else iter += TH_WAVE;
-            // the scan ended, or this was the trip that reached hit 0 (base - 64 negative): as ONE 64-bit word and one test -- two booleans become two lane masks, an OR, an AND
-            // with exec and a vector-condition branch
-            unsigned long long ends = stopm | (unsigned long long)((uint32_t)(base - TH_WAVE) >> 31);
+            // the scan ended, or this was the trip that reached hit 0: as ONE 64-bit word and one test -- two booleans become two lane masks, an AND with exec and
+            // a vector-condition branch
+            unsigned long long ends = stopm | endw;
             TH_OPAQUE_S(ends);
             if (ends) break;
             base -= TH_WAVE;
             if (!RP2) bslot = bslot >= TH_WAVE ? bslot - TH_WAVE : bslot - TH_WAVE + RING;
-            TH_LDS_ASYNC_WAIT(rec_next);       // (here, before the value is copied or used: the compiler does not track the asynchronous read)
         }
         TH_LDS_ASYNC_WAIT(rec_next);           // a scan that stopped leaves its last request in flight: its registers stay reserved until it lands
         best -= 15;

@@ -641,6 +641,11 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
 #endif
     for (int x = lane; x < TH_POA_RING * 3 * TH_POA_PAD; x += TH_WAVE) s_ring[x / (3 * TH_POA_PAD)][(x / TH_POA_PAD) % 3][x % TH_POA_PAD] = (RT)(WIDE ? TH_NEG : -32768);
     TH_WAVE_FENCE();
+    // ONE exit for the row loop (round 5).  A `return` inside it -- empty band, out of cells: eight sites -- makes a loop with nine exits, which LLVM unifies into one by way of a
+    // dispatch word that every row then sets, copies, tests and branches on (~20 scalar instructions per row of the common path's ~110, in the gfx950 assembly).  A failing row
+    // instead records its code and moves the row counter to the end -- through a value the compiler cannot see through, or it would thread the jump back into an exit.
+    int dp_fail = 0;
+#define TH_POA_DP_FAIL(code) { dp_fail = (code); int stop_ = n; TH_OPAQUE_S(stop_); i = stop_; continue; }
     for (int i = 0; i + 1 < n; ++i) {
         if ((i & 63) == 0) {
             flush_row = th_smin(i | 63, n - 2);          // the row after which the chunk registers go to the tables: the chunk's last, or the last row of all (ONE compare per row
@@ -680,10 +685,10 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 const int xd = qlen - rm;
                 // (scalar max / min: hipcc makes a vector max3 + a vector compare of these -- th_hw.h)
                 const int b = th_smax(th_smax0(th_smin(L_l + 1, xd) - w), L_b), e = th_smin(qlen, th_smax(L_r + 1, xd) + w);
-                if (b > e) return -2;
+                if (b > e) TH_POA_DP_FAIL(-2);
                 if (e - b < TH_POA_RW) {
                     const int B0 = b & ~1, span = (e | 1) - B0 + 1, units = th_d_units(span, true);
-                    if ((int)(ncell + (uint32_t)units) > lim) return -3;
+                    if ((int)(ncell + (uint32_t)units) > lim) TH_POA_DP_FAIL(-3);
                     const int my_off = (int)ncell + (TH_POA_D8 ? 0 : b - B0);      // (8-bit words: the offset of the even base column)
                     ncell += units;
                     int rmax = TH_NEG - 0x10000000, left = b, right = b;
@@ -723,10 +728,10 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 if (wmax < TH_POA_RW) {
                     const int xd = qlen - rm;
                     const int b = th_smax(th_smax0(th_smin(mpl, xd) - w), mb), e = th_smin(qlen, th_smax(mpr, xd) + w);
-                    if (b > e) return -2;
+                    if (b > e) TH_POA_DP_FAIL(-2);
                     if (e - b < TH_POA_RW) {
                         const int B0 = b & ~1, span = (e | 1) - B0 + 1, units = th_d_units(span, inn_ == 1);
-                        if ((int)(ncell + (uint32_t)units) > lim) return -3;
+                        if ((int)(ncell + (uint32_t)units) > lim) TH_POA_DP_FAIL(-3);
                         const int my_off = (int)ncell + ((TH_POA_D8 && inn_ == 1) ? 0 : b - B0);
                         uint16_t *dbase = g.dcell + ncell;
                         ncell += units;
@@ -770,12 +775,12 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
                 if (!bad) {
                     const int xd = qlen - rm;
                     const int b = max(max(0, min(mpl, xd) - w), mb), e = min(qlen, max(mpr, xd) + w);
-                    if (b > e) return -2;
+                    if (b > e) TH_POA_DP_FAIL(-2);
                     if (e - b < TH_POA_RW) {
                         const int B0 = b & ~1, span = (e | 1) - B0 + 1, units = th_d_units(span, inn_ == 1);
                         const int full = (meta >> 24) & 1;
                         if (full) { nfull += span; lim -= 8 * span; }
-                        if ((int)(ncell + (uint32_t)units) > lim) return -3;
+                        if ((int)(ncell + (uint32_t)units) > lim) TH_POA_DP_FAIL(-3);
                         const int my_off = (int)ncell + ((TH_POA_D8 && inn_ == 1) ? 0 : b - B0), my_foff = full ? -(int)nfull + (b - B0) : 0;
                         uint16_t *dbase = g.dcell + ncell;
                         ncell += units;
@@ -820,7 +825,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             e = min(qlen, max(mpr, qlen - rm) + w);
         }
         b = TH_UNI(b); e = TH_UNI(e);
-        if (b > e) return -2;
+        if (b > e) TH_POA_DP_FAIL(-2);
         // a row owns the cells of columns (b & ~1) .. (e | 1): packed rows store column pairs
         const int B0 = b & ~1, span = (e | 1) - B0 + 1;
         const int myslot = i & 3, lslot = (i - 1) & 3;
@@ -832,7 +837,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         const bool d8 = TH_POA_D8 && inn == 1;                   // one predecessor: 8-bit direction words (every reader goes by the in-degree)
         const int units = th_d_units(span, d8);
         if (store_full) { nfull += span; lim -= 8 * span; }
-        if ((int)(ncell + (uint32_t)units) > lim) return -3;
+        if ((int)(ncell + (uint32_t)units) > lim) TH_POA_DP_FAIL(-3);
         const int my_off = (int)ncell + (d8 ? 0 : b - B0);       // 16-bit rows: offset of column b; 8-bit rows: of the even base column
         const int my_foff = store_full ? -(int)nfull + (b - B0) : 0;
         int4 *row = g.cell + my_foff; uint16_t *dbase = g.dcell + ncell; uint16_t *drow = dbase + (b - B0); uint8_t *drow8 = (uint8_t *)dbase + (b - B0);
@@ -946,6 +951,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         }
         TH_WAVE_FENCE();
     }
+    if (dp_fail) return dp_fail;
     // global end: best predecessor row of the sink (row n-1) at column qlen, first in edge order
     int bi = -1, bs = 0;
     {

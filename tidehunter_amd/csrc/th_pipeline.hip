@@ -680,7 +680,10 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
           unsigned long long rw[8]; hipMemcpyFromSymbol(rw, HIP_SYMBOL(thpoa_n::th_poa_prof_rows), sizeof(rw));
           fprintf(stderr, "[poa_prof_rows] {\"fast_chunks\": %llu, \"general_chunks\": %llu, \"fast_rounds\": %llu, \"general_rounds\": %llu}\n", rw[0], rw[1], rw[2], rw[3]);
           fprintf(stderr, "[poa_prof_tail] {\"waves\": %d, \"waves_that_took_jobs\": %llu, \"busy_ticks_shortest\": %llu, \"busy_ticks_longest\": %llu, \"busy_ticks_mean\": %llu}\n", wv_n, rw[4], rw[5], rw[6], rw[4] ? (rw[7] << 10) / rw[4] : 0ull);
-          unsigned long long z2[8] = { 0, 0, 0, 0, 0, ~0ull, 0, 0 }; hipMemcpyToSymbol(HIP_SYMBOL(thpoa_n::th_poa_prof_rows), z2, sizeof(z2)); }
+          unsigned long long z2[8] = { 0, 0, 0, 0, 0, ~0ull, 0, 0 }; hipMemcpyToSymbol(HIP_SYMBOL(thpoa_n::th_poa_prof_rows), z2, sizeof(z2));
+          hipMemcpyFromSymbol(rw, HIP_SYMBOL(thpoa_l::th_poa_prof_rows), sizeof(rw));        // the long-unit variant's launches of this batch (configs 4 / 5)
+          if (rw[4]) fprintf(stderr, "[poa_prof_tail_long] {\"waves_that_took_jobs\": %llu, \"busy_ticks_shortest\": %llu, \"busy_ticks_longest\": %llu, \"busy_ticks_mean\": %llu}\n", rw[4], rw[5], rw[6], (rw[7] << 10) / rw[4]);
+          hipMemcpyToSymbol(HIP_SYMBOL(thpoa_l::th_poa_prof_rows), z2, sizeof(z2)); }
 #endif
         // ---- unit-vs-consensus alignments and flank extensions: three item lists in one array, one kernel variant each ----
         const int ns = cnt->n_item_s, nm = ns + cnt->n_item_m, ni = nm + cnt->n_item_b, max_cl = cnt->max_cl;
@@ -705,7 +708,20 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
             const bool defer_small = g->aln_probe_small == 3 && g->aln_mode == 1;
             if (defer_small || (big_n && big_first < ni)) { TRY(g->d_defer.ensure((size_t)ni)); TRY(g->d_defer_s1.ensure((size_t)ni)); }
             ThAlnItem *sd = defer_small ? g->d_defer.p : no_defer; int *sdn = defer_small ? &dc->n_defer : no_dn, *sds1 = defer_small ? g->d_defer_s1.p : no_ds1;
+#if defined(TH_ALN_PROF)
+            auto aln_prof = [&](const char *what, int grid) {
+                th_rt_sync_event(g->stream, g->sync_ev);
+                unsigned long long pr[8]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(th_aln_prof), sizeof(pr));
+                if (pr[0]) fprintf(stderr, "[aln_prof] {\"launch\": \"%s\", \"waves\": %d, \"waves_that_took_items\": %llu, \"items\": %llu, \"busy_ticks_shortest\": %llu, \"busy_ticks_longest\": %llu, \"busy_ticks_mean\": %llu}\n",
+                                   what, grid, pr[0], pr[4], pr[1], pr[2], (pr[3] << 10) / pr[0]);
+                unsigned long long z[8] = { 0, ~0ull, 0, 0, 0, 0, 0, 0 }; hipMemcpyToSymbol(HIP_SYMBOL(th_aln_prof), z, sizeof(z));
+            };
+#define TH_ALN_PROF_AFTER(what, grid) aln_prof(what, grid)
+#else
+#define TH_ALN_PROF_AFTER(what, grid) ((void)0)
+#endif
             if (ns) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(0, ns, &dc->q_aln_s), g->aln_mode, g->aln_xpct, no_n, sd, sdn, no_ws, no_s1, sds1, aln_stat, slb_);
+            if (ns) TH_ALN_PROF_AFTER("first: 2 registers", std::min(ns, wa));
             if (nm > ns) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(nm - ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(ns, nm - ns, &dc->q_aln_m), g->aln_mode, g->aln_xpct, no_n, sd, sdn, no_ws, no_s1, sds1, aln_stat, slb_);
             if (big_n && big_first < ni) {
                 // the big-area variant hands the alignments its anti-diagonal engine could not certify on to a second launch of the small-area one
@@ -715,11 +731,13 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
                     TH_LAUNCH((th_k_align<TH_ALN_BIG16, 6>), std::min(big_n, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(big_first, big_n, &dc->q_aln_b), g->aln_mode, g->aln_xpct, no_n, g->d_defer.p, &dc->n_defer, dc->aln_wide, no_s1, g->d_defer_s1.p, (int *)nullptr, slb_);
                 else
                     TH_LAUNCH((th_k_align<TH_ALN_BIG, 6>), std::min(big_n, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(big_first, big_n, &dc->q_aln_b), g->aln_mode, g->aln_xpct, no_n, g->d_defer.p, &dc->n_defer, dc->aln_wide, no_s1, g->d_defer_s1.p, (int *)nullptr, slb_);
+                TH_ALN_PROF_AFTER("long units: 6 registers", std::min(big_n, wa));
             }
             if (g->aln_mode == 1 && (defer_small || (big_n && big_first < ni)))
                 TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(ni, wa), TH_ALN_BLOCK, g->stream, (const ThAlnItem *)g->d_defer.p, 0, (const ThTask *)g->d_tasks.p, (const int *)g->d_parc.p,
                           (const uint32_t *)in.d_roff.p, (const uint8_t *)g->d_bseq.p, (const uint8_t *)g->d_cons.p, (const int *)g->d_cons_len.p,
                           g->d_bnd.p, bnd_aln, g->d_iden.p, g->d_ext.p, &dc->err, &dc->q_aln_d, g->aln_wdiv, g->aln_wadd, g->aln_wtol, 3, g->aln_xpct, (const int *)&dc->n_defer, no_defer, no_dn, no_ws, (const int *)g->d_defer_s1.p, no_ds1);
+            if (g->aln_mode == 1 && (defer_small || (big_n && big_first < ni))) TH_ALN_PROF_AFTER("deferred: strips", std::min(ni, wa));
 #undef TH_ALN_ARGS
         }
         KT_END(TK_ALIGN);
