@@ -228,6 +228,52 @@ def test_gpu_flank_extensions_match_reference_vectors(gpu_lib, kv, label, cfg):
         assert len(bad) == 0, "%s (%s): %d pairs differ from the reference, first %s: got %s want %s" % (label, key, len(bad), bad[:5], got[bad[:3]], kv[key][bad[:3]])
 
 
+def _noisy(rng, codes, err):
+    """substitutions, insertions and deletions in equal parts, as th_synth_read draws them"""
+    out = []
+    for b in codes:
+        if rng.random() < err:
+            k = int(rng.integers(0, 3))
+            if k == 0:
+                out.append((int(b) + 1 + int(rng.integers(0, 3))) & 3)
+            elif k == 1:
+                out.append(int(b)); out.append(int(rng.integers(0, 4)))
+        else:
+            out.append(int(b))
+    return np.array(out, dtype=np.uint8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(mode=1), dict(mode=2), dict(mode=1, variant=1), dict(mode=1, xpct=36 | 2 << 8)], ids=["pipeline", "verified_on_device", "16k_variant", "two_register_probe"])
+def test_gpu_flank_longer_than_the_staging_area_is_probed_on_its_prefix(gpu_lib, cfg):
+    """round 5: a flank that does not fit th_k_align's staging area next to the consensus (config 4: a 5000-base consensus and 7000 ... 10 000 flank bases when the first unit
+    boundary was found a period late) went to the full matrix unprobed; it is probed on the prefix that fits -- a lower bound of the whole maximum -- and finished on the pruned
+    strips.  Results against the oracle's ksw2_left_ext / ksw2_right_ext (src/ksw2_align.c:175-215) and against the device's own full matrix (mode 0): flanks that continue the
+    repeat past a whole period, one that stops matching half way, one of random bases"""
+    rng = np.random.default_rng(11)
+    pairs = {1: [], 2: []}
+    for cl, extra, err in ((5000, 2600, 0.15), (4800, 4300, 0.12), (5200, 1900, 0.15), (3000, 7200, 0.10)):
+        cons = rng.integers(0, 4, cl).astype(np.uint8)
+        rep = np.concatenate([cons] * 4)
+        pairs[2].append((cons, _noisy(rng, rep[:cl + extra], err)))                      # right: the flank starts where the consensus starts
+        pairs[1].append((cons, _noisy(rng, rep[len(rep) - cl - extra:], err)))           # left: the flank ends where the consensus ends
+    cons = rng.integers(0, 4, 5000).astype(np.uint8)
+    half = np.concatenate([_noisy(rng, cons[:2500], 0.1), rng.integers(0, 4, 5500).astype(np.uint8)])
+    pairs[2].append((cons, half)); pairs[1].append((cons, half[::-1].copy()))
+    pairs[2].append((cons, rng.integers(0, 4, 7600).astype(np.uint8))); pairs[1].append((cons, rng.integers(0, 4, 7600).astype(np.uint8)))
+    for kind in (1, 2):
+        v = {"q_cat": np.concatenate([q for q, _ in pairs[kind]]), "t_cat": np.concatenate([t for _, t in pairs[kind]]),
+             "q_off": np.concatenate([[0], np.cumsum([len(q) for q, _ in pairs[kind]])]).astype(np.int32), "t_off": np.concatenate([[0], np.cumsum([len(t) for _, t in pairs[kind]])]).astype(np.int32)}
+        idx = np.arange(len(pairs[kind]))
+        got, st = align_pairs(gpu_lib, v, idx, kind, cfg)
+        assert st[0] == 0, "device error flags %d" % st[0]
+        full, st0 = align_pairs(gpu_lib, v, idx, kind, dict(mode=0))
+        assert st0[0] == 0 and (got == full).all(), (kind, got, full)
+        for i in (0, 3, 4):
+            q, t = pairs[kind][i]
+            assert tuple(int(x) for x in got[i]) == O.ksw2_ext(q, t, left=(kind == 1)), (kind, i)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("banded", [0, 1], ids=["full_matrix", "certified_band_then_pruned_band"])
 def test_gpu_global_with_cigar_backprojection_matches_reference_vectors(gpu_lib, kv, banded):

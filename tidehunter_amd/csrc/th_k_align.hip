@@ -85,6 +85,31 @@ __device__ __forceinline__ bool th_adx_align(int np, const uint8_t *__restrict__
     return ok;
 }
 
+// A flank that does not fit the staging area next to the consensus even with ONE register's band (config 4: a first unit boundary found a period late leaves 7000-10 000
+// flank bases for a 5000-base consensus) used to go to the FULL matrix unprobed: 80 of config 4's 40 010 extensions, 100-390 M clocks each where the others take 20 M --
+// the last 80 of the first launch's 213 ms belonged to them (-DTH_ALN_PROF=1, round 5).  It is probed on the PREFIX that fits: cell (i, j) of an extension depends on the
+// prefixes i and j alone, so every cell of the prefix's matrix has the same value in the whole one, and a banded maximum over the prefix is a lower bound of the whole
+// maximum -- all the pruned strips need (such a band certifies the prefix, not the flank: only its maximum is used).  Two registers: four found the same bound (the
+// alignment leaves either band after ~2000 bases at 15 %), and the four-register engine inlined here spilled -- 128 bytes more of stack per lane for the whole KERNEL,
+// which cost config 5, where no such flank exists, 14 of its 405 ms.  A probe that finds nothing positive -- a flank that does not continue the repeat -- still prunes: 1 bounds the
+// maximum from below whenever a positive cell exists, and when none does the pruned sweep finds none either (ksw2 reports (-1, -1): its maximum starts at 0 and only a larger
+// H moves it, ksw2_extz2_sse.c), so max(bh, 1) is exact for every pair; H of such a flank falls by ~0.6 per base, and a cell whose H plus the diagonal steps left is
+// below 1 is dead.  Out of line: the common path keeps its registers.
+template <int LDSB>
+__device__ TH_NOINLINE void th_aln_long_flank(const uint8_t *__restrict__ qp, int st, int cl, const uint8_t *__restrict__ tp, int tlen, uint8_t *s_seq, int *__restrict__ mybnd, int (*s_in)[TH_WAVE][8],
+                                              bool pkstrip, int *mq, int *mt, int *bh_out)
+{
+    const int tl_p = min(tlen, LDSB - cl - 16 - 512 * 2);
+    int a_ = -1, b_ = -1, bh = 0;
+    (void)th_adx_align<2>(2, qp, st, cl, tp, st, tl_p, s_seq, &a_, &b_, &bh);
+    const int slb = max(bh, 1);
+    int W = 512;
+    while (W < cl + tlen && th_ext_bound_w(W, cl, tlen) >= slb) W += 64;
+    if (pkstrip && cl + tlen <= TH_KSW_PK_MAXLEN) th_ksw_ext_band_pk_wave(qp, st, cl, tp, st, tlen, W, slb, mybnd, s_in, mq, mt);
+    else th_ksw_ext_band_wave(qp, st, cl, tp, st, tlen, W, slb, mybnd, s_in, mq, mt);
+    *bh_out = bh;
+}
+
 // mode: 0 strip engine only (th_ksw_global_band_wave), 1 anti-diagonal engine first (default), 2 both and compare (err bit 64 on a
 // difference), 3 strip engine for the deferred items of the launch before (see `defer`; item_s1: their banded scores).
 // n_items_ptr: the item count when it only exists on the device (the deferred list).
@@ -96,9 +121,9 @@ __device__ __forceinline__ bool th_adx_align(int np, const uint8_t *__restrict__
 #if defined(TH_ALN_PROF)
 // -DTH_ALN_PROF=1 (tools/build_variant.sh; never the product): how evenly a launch's dynamic queue keeps its waves busy -- per wave that took an item, the ticks from its
 // start to its exit: [0] waves, [1] shortest, [2] longest, [3] sum >> 10, [4] items; printed and reset by th_pipeline.hip after every launch
-__device__ unsigned long long th_aln_prof[8] = { 0, ~0ull, 0, 0, 0, 0, 0, 0 };
+__device__ unsigned long long th_aln_prof[40] = { 0, ~0ull };      // [8 + b]: waves whose ticks >> 25 == b (histogram, last bucket open); [5] ticks of the costliest item, [6] its index
 #endif
-template <int LDSB, int NPMAX>
+template <int LDSB, int NPMAX, bool LPT = false>      // LPT: the list is walked longest flanks first (`pass_queue`; an instantiation of its own: the plain walk keeps its registers)
 __global__ void __launch_bounds__(TH_ALN_BLOCK) TH_ALN_OCC
 th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__restrict__ tasks, const int *__restrict__ pos,
            const uint32_t *__restrict__ roff, const uint8_t *__restrict__ bseq,
@@ -106,7 +131,8 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
            int *__restrict__ bnd, long long bnd_stride, int *__restrict__ iden, int *__restrict__ ext, int *__restrict__ err, int *__restrict__ queue,
            int wdiv, int wadd, int wtol, int mode, int xpct, const int *__restrict__ n_items_ptr, ThAlnItem *__restrict__ defer, int *__restrict__ defer_n, int *__restrict__ wide_stat,
            const int *__restrict__ item_s1, int *__restrict__ defer_s1, int *__restrict__ aln_stat = nullptr,
-           const int *__restrict__ unit_slb = nullptr /* round 5: per unit alignment (T.aln_off + which) a lower bound of its ksw2 score from the POA's own alignment of the unit, or TH_SLB_NONE */)
+           const int *__restrict__ unit_slb = nullptr /* round 5: per unit alignment (T.aln_off + which) a lower bound of its ksw2 score from the POA's own alignment of the unit, or TH_SLB_NONE */,
+           int *__restrict__ pass_queue = nullptr /* round 5: four more queue heads -- the list is walked five times, LONGEST FLANKS FIRST (see the loop) -- or null: one walk in list order */)
 {
     // one LDS area, used either as the left-border inbox of the strip sweep (two 64-row blocks, 4 KB) or as the staged bases
     // of the anti-diagonal engine (never both at once)
@@ -119,19 +145,29 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
     // registers per lane of the flank extensions' PROBE (upper bits of xpct; 1 by default): a long flank no register band is expected to certify is
     // probed for the lower bound that prunes its strip sweep -- the repeat's continuation hugs the main diagonal, so the narrowest band finds
     // (nearly) the true maximum at a quarter of the four-register probe of round 3
-    const int xprobe = min(4, max(1, ((xpct >> 8) & 7) ? ((xpct >> 8) & 7) : 1));
-    const bool pkstrip = !((xpct >> 11) & 1);      // bit 11 of xpct (TH_ALN_PKSTRIP=0): the one-column strip engines only (A/B runs, the tests' cross-check)
-    xpct &= 0xff;
+    // (taken out of the ONE word where they are used -- cold places all -- instead of four values held across the item loop: this kernel's scalar registers are full, and
+    // what does not fit is spilled to vector lanes; config 5's 392 ms moved by 15 with one more such value, round 5)
+    const int xword = xpct;
+#define xprobe (min(4, max(1, ((xword >> 8) & 7))))
+#define longflank (!((xword >> 12) & 1))       /* bit 12 (TH_ALN_LONGFLANK=0): flanks too long for the staging area go to the full matrix unprobed, as before round 5 (A/B runs) */
+#define pkstrip (!((xword >> 11) & 1))         /* bit 11 (TH_ALN_PKSTRIP=0): the one-column strip engines only (A/B runs, the tests' cross-check) */
+#define xpct (xword & 0xff)
     if (n_items_ptr) n_items = TH_UNI(*n_items_ptr);
 #if defined(TH_ALN_PROF)
     const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime(); int prof_items = 0;
 #endif
+    // Longest first (round 5).  A launch with few items per wave ends when its unluckiest wave does: config 4's first launch -- 40 010 flank extensions of 1 to 5000 bases,
+    // 13 per wave, in job order -- kept its waves busy 0.62 of the time of the longest one (the -DTH_ALN_PROF=1 build), 80 of its 213 ms.  With `pass_queue` the list is
+    // walked five times, each walk through a queue head of its own and taking only its class: flanks too long for the staging area (probed on a prefix, finished on the
+    // pruned strips: the costliest items by far), flanks of >= 3072 bases, >= 1536, >= 768, then everything else; a wave that
+    // pops an item of another class drops it (three loads).  The host asks for this when a launch has fewer than 64 items per wave; where items are plenty (the headline
+    // shape: 358 per wave) the order does not matter and the extra pops would only cost.
+    constexpr int n_pass = LPT ? 5 : 1;
+    for (int pass = 0; pass < n_pass; ++pass) {
+    int *const q_ = (!LPT || pass == n_pass - 1) ? queue : pass_queue + pass;
     for (;;) {
-        const int it = th_queue_pop(queue);   // dynamic work queue: items range from a short extension to a full matrix
+        const int it = th_queue_pop(q_);   // dynamic work queue: items range from a short extension to a full matrix
         if (it >= n_items) break;
-#if defined(TH_ALN_PROF)
-        ++prof_items;
-#endif
         const ThAlnItem I = items[it];
         const ThTask T = tasks[I.task];
         const int cl = cons_len[I.task];
@@ -139,6 +175,17 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
         const int L = (int)(roff[T.read + 1] - roff[T.read]);
         const uint8_t *cs = cons + T.cons_off;
         const int *ps = pos + T.pos_off;
+        if (LPT) {
+            int cls = 4;
+            if (I.which < 0) { const int tl = I.which == -1 ? ps[0] + 1 : L - ps[T.pos_n - 1] - 1; cls = cl + tl + 528 > LDSB ? 0 : tl >= 3072 ? 1 : tl >= 1536 ? 2 : tl >= 768 ? 3 : 4; }
+            if (TH_UNI(cls) != pass) continue;
+        }
+#if defined(TH_ALN_PROF)
+        ++prof_items;
+        const unsigned long long prof_i0 = __builtin_amdgcn_s_memtime();
+        unsigned long long prof_desc = 0;      // flank items: tlen | cl << 16 | max(bh, 0) << 32 | path << 60 (1 certified band, 2 pruned strips, 3 full matrix; +4: prefix probe)
+        struct ProfItem { unsigned long long t0; int it, lane; const unsigned long long *desc; __device__ ~ProfItem() { if (lane == 0) { const unsigned long long d = __builtin_amdgcn_s_memtime() - t0; if (atomicMax(&th_aln_prof[5], d) < d) { th_aln_prof[6] = (unsigned long long)it; th_aln_prof[7] = *desc; } } } } prof_item_{ prof_i0, it, lane, &prof_desc };
+#endif
         if (I.which >= 0) {
             int v = 0;
             if (cl > 0) {
@@ -269,7 +316,17 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                                 done = true;
                             }
                         }
-                        if (!done) th_ksw_ext_wave(qp, st, cl, tp, st, tlen, mybnd, &mq, &mt);
+#if defined(TH_ALN_PROF)
+                        prof_desc = (unsigned long long)tlen | (unsigned long long)cl << 16 | (unsigned long long)max(bh, 0) << 32 | (unsigned long long)(!done ? 3 : bh > 0 && mq >= -1 ? 2 : 1) << 60;
+#endif
+                        // (what no band could be staged for -- flank and consensus together longer than the staging area -- is probed on a prefix and pruned: th_aln_long_flank.
+                        // Only in the longest-first instantiation, the launches with few items per wave, where one such item IS the launch's tail: the call's mere presence
+                        // moved config 5's launch -- 605 items per wave, no such flank -- from 405 to 420 ms whatever its form (in line, out of line, at this site or in
+                        // front of the probes, stack frame or none: five builds), and with hundreds of items per wave an outlier of 100 ms is rarely the last one running)
+                        if (!done) {
+                            if (LPT && mode && longflank && cl + tlen < 30000 && cl + tlen + 512 + 16 > LDSB && LDSB - cl - 16 - 1024 >= 1024) th_aln_long_flank<LDSB>(qp, st, cl, tp, tlen, s_seq, mybnd, s_in, pkstrip, &mq, &mt, &bh);
+                            else th_ksw_ext_wave(qp, st, cl, tp, st, tlen, mybnd, &mq, &mt);
+                        }
                         if (mode == 2) {
                             // verification: the full matrix against whatever engine produced (mq, mt), and against BOTH pruned strip engines run with the
                             // best lower bound at hand (the probe's banded maximum, or 1: any slb <= the true maximum must give the full matrix's cells)
@@ -294,8 +351,13 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
             if (lane == 0) { const int o = 4 * I.task + (I.which == -1 ? 0 : 2); ext[o] = mq; ext[o + 1] = mt; }
         }
     }
+    }
 #if defined(TH_ALN_PROF)
     if (lane == 0 && prof_items > 0) { const unsigned long long te = __builtin_amdgcn_s_memtime() - prof_t0;
-        atomicAdd(&th_aln_prof[0], 1ull); atomicMin(&th_aln_prof[1], te); atomicMax(&th_aln_prof[2], te); atomicAdd(&th_aln_prof[3], te >> 10); atomicAdd(&th_aln_prof[4], (unsigned long long)prof_items); }
+        atomicAdd(&th_aln_prof[0], 1ull); atomicMin(&th_aln_prof[1], te); atomicMax(&th_aln_prof[2], te); atomicAdd(&th_aln_prof[3], te >> 10); atomicAdd(&th_aln_prof[4], (unsigned long long)prof_items); atomicAdd(&th_aln_prof[8 + min((int)(te >> 25), 31)], 1ull); }
 #endif
 }
+#undef xprobe
+#undef longflank
+#undef pkstrip
+#undef xpct

@@ -108,6 +108,7 @@ struct th_gpu {
     int aln_wdiv = 10, aln_wadd = 24;     // first certified band of the unit alignments: half-width cons_len / wdiv + wadd
     int aln_xpct = 36;                    // flank extensions: band half-width requested from the anti-diagonal engine, percent of min(consensus, flank) (+ 8)
     int aln_probe_small = 1;              // long units whose sequences fit the two-register variant's staging area are probed and finished there (th_aln_class)
+    int aln_lpt = -1;                     // first alignment launch walks its list longest flanks first: -1 when it has few items per wave (default), TH_ALN_LPT=0 never, 1 always
     int aln_slb = 1;                      // the POA leaves a score bound per unit alignment (th_poa_unit_bounds) and th_k_align starts long units from it (TH_ALN_SLB=0: off)
     int aln_probe_auto = 1;               // ... unless the batch BEFORE was mostly such units (config 4: there the dedicated launches of round 3 are faster, config 5 gains 6 %)
     int aln_wtol = 16, aln_mode = 1;      // anti-diagonal engine: accepted shortfall of its band against that half-width; 0 = strip engine only, 2 = verify against the full matrix
@@ -165,8 +166,9 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
     g->waves_xw_small = env_int("TH_WAVES_XW_SMALL", TH_PERSISTENT_WAVES(g->waves_xw_small));
     g->aln_wdiv = std::max(1, env_int("TH_ALN_WDIV", g->aln_wdiv)); g->aln_wadd = std::max(0, env_int("TH_ALN_WADD", g->aln_wadd));
     // (TH_ALN_XPROBE: registers of the flank extensions' probe: one since round 4 -- four measured 17-20 ms slower on configs 4 and 5)
-    g->aln_wtol = std::max(0, env_int("TH_ALN_WTOL", g->aln_wtol)); g->aln_mode = env_int("TH_ALN_MODE", g->aln_mode); g->aln_xpct = std::min(255, std::max(0, env_int("TH_ALN_XPCT", g->aln_xpct))) | std::min(4, std::max(1, env_int("TH_ALN_XPROBE", 1))) << 8 | (env_int("TH_ALN_PKSTRIP", 1) ? 0 : 1) << 11;
+    g->aln_wtol = std::max(0, env_int("TH_ALN_WTOL", g->aln_wtol)); g->aln_mode = env_int("TH_ALN_MODE", g->aln_mode); g->aln_xpct = std::min(255, std::max(0, env_int("TH_ALN_XPCT", g->aln_xpct))) | std::min(4, std::max(1, env_int("TH_ALN_XPROBE", 1))) << 8 | (env_int("TH_ALN_PKSTRIP", 1) ? 0 : 1) << 11 | (env_int("TH_ALN_LONGFLANK", 1) ? 0 : 1) << 12;
     g->aln_slb = env_int("TH_ALN_SLB", 1);
+    g->aln_lpt = env_int("TH_ALN_LPT", -1);
     g->aln_probe_small = std::min(3, std::max(0, env_int("TH_ALN_PROBE_SMALL", 1))); g->aln_probe_auto = getenv("TH_ALN_PROBE_SMALL") ? 0 : 1;
     return g;
 }
@@ -711,16 +713,22 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
 #if defined(TH_ALN_PROF)
             auto aln_prof = [&](const char *what, int grid) {
                 th_rt_sync_event(g->stream, g->sync_ev);
-                unsigned long long pr[8]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(th_aln_prof), sizeof(pr));
-                if (pr[0]) fprintf(stderr, "[aln_prof] {\"launch\": \"%s\", \"waves\": %d, \"waves_that_took_items\": %llu, \"items\": %llu, \"busy_ticks_shortest\": %llu, \"busy_ticks_longest\": %llu, \"busy_ticks_mean\": %llu}\n",
-                                   what, grid, pr[0], pr[4], pr[1], pr[2], (pr[3] << 10) / pr[0]);
-                unsigned long long z[8] = { 0, ~0ull, 0, 0, 0, 0, 0, 0 }; hipMemcpyToSymbol(HIP_SYMBOL(th_aln_prof), z, sizeof(z));
+                unsigned long long pr[40]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(th_aln_prof), sizeof(pr));
+                if (pr[0]) { fprintf(stderr, "[aln_prof] {\"launch\": \"%s\", \"waves\": %d, \"waves_that_took_items\": %llu, \"items\": %llu, \"busy_ticks_shortest\": %llu, \"busy_ticks_longest\": %llu, \"busy_ticks_mean\": %llu, "
+                                   "\"costliest_item_ticks\": %llu, \"costliest_item\": %llu, \"its_tlen\": %llu, \"its_cl\": %llu, \"its_bh\": %llu, \"its_path\": %llu, \"waves_by_ticks_shr_25\": [", what, grid, pr[0], pr[4], pr[1], pr[2], (pr[3] << 10) / pr[0], pr[5], pr[6],
+                                   pr[7] & 0xffff, (pr[7] >> 16) & 0xffff, (pr[7] >> 32) & 0xfffffff, pr[7] >> 60);
+                             for (int b = 0; b < 32; ++b) fprintf(stderr, "%s%llu", b ? ", " : "", pr[8 + b]);
+                             fprintf(stderr, "]}\n"); }
+                unsigned long long z[40] = { 0, ~0ull }; hipMemcpyToSymbol(HIP_SYMBOL(th_aln_prof), z, sizeof(z));
             };
 #define TH_ALN_PROF_AFTER(what, grid) aln_prof(what, grid)
 #else
 #define TH_ALN_PROF_AFTER(what, grid) ((void)0)
 #endif
-            if (ns) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(0, ns, &dc->q_aln_s), g->aln_mode, g->aln_xpct, no_n, sd, sdn, no_ws, no_s1, sds1, aln_stat, slb_);
+            // (few items per wave: longest flanks first -- th_k_align's `pass_queue`; TH_ALN_LPT=0 / 1 forces it off / on)
+            int *lpt = (g->aln_lpt == 1 || (g->aln_lpt < 0 && (long long)ns < 64LL * wa)) ? dc->q_aln_pass : (int *)nullptr;
+            if (ns && lpt) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2, true>), std::min(ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(0, ns, &dc->q_aln_s), g->aln_mode, g->aln_xpct, no_n, sd, sdn, no_ws, no_s1, sds1, aln_stat, slb_, lpt);
+            else if (ns) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(0, ns, &dc->q_aln_s), g->aln_mode, g->aln_xpct, no_n, sd, sdn, no_ws, no_s1, sds1, aln_stat, slb_);
             if (ns) TH_ALN_PROF_AFTER("first: 2 registers", std::min(ns, wa));
             if (nm > ns) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), std::min(nm - ns, wa), TH_ALN_BLOCK, g->stream, TH_ALN_ARGS(ns, nm - ns, &dc->q_aln_m), g->aln_mode, g->aln_xpct, no_n, sd, sdn, no_ws, no_s1, sds1, aln_stat, slb_);
             if (big_n && big_first < ni) {

@@ -5,7 +5,7 @@ set -e
 R=$(cd $(dirname $0)/.. && pwd); N=$1; shift
 W=/tmp/th_variant_$N; mkdir -p $W; cd $R/tidehunter_amd/csrc
 F="$(make -s --no-print-directory print-hipflags) -I. -I../../include $*"      # the product's flags (csrc/Makefile) + the variant's
-/opt/rocm/bin/hipcc $F -c th_pipeline.hip -o $W/pipe.o -save-temps=obj 2>/dev/null
+/opt/rocm/bin/hipcc $F -c th_pipeline.hip -o $W/pipe.o -save-temps=obj 2>$W/hipcc.err || { grep -m5 -A3 "error" $W/hipcc.err; exit 1; }
 gcc -O2 -g -std=gnu99 -fPIC -Wall -Wno-misleading-indentation -I. -I../../include -c th_host.c -o $W/host.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tests/cpu_emul/libth_$N.so $W/pipe.o $W/host.o -lz -lm -lpthread
 S=$(ls $W/*gfx950*.s | head -1)
