@@ -337,7 +337,7 @@ def main():
     e2e = None
     if rank == 0 and world == 1 and a.e2e != 0 and not (a.e2e < 0 and a.config != "c3") and "TH_BENCH_LIB" not in os.environ:      # (by default only for the headline workload)
         try:
-            e2e = cli_e2e(set_reads, a.e2e if a.e2e > 0 else 20, cfg, 32768)      # (32768 = the command line's default batch; 20 x the set = 2 000 000 reads: start-up is ~0.2 s of each run)
+            e2e = cli_e2e(set_reads, a.e2e if a.e2e > 0 else 20, cfg, 65536)      # (65536 = the command line's default batch; 20 x the set = 2 000 000 reads: start-up is ~0.2 s of each run)
         except Exception as ex:                       # reported, never fatal for the bench line
             e2e = {"error": repr(ex)[:400]}
     th = TH.TideHunter(device=local, lib_path=os.environ.get("TH_BENCH_LIB"), **kw)

@@ -73,3 +73,42 @@ def test_isa_untracked_lds_read_is_not_touched_before_its_wait(tmp_path):
     # the GPU memory faults of two abandoned POA variants to exactly that (tools/isa_check_saddr_hazard.py)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_check_saddr_hazard.py"), str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_isa_checker_follows_control_flow(tmp_path):
+    """the checker of the untracked LDS read on hand-written assembly: the case that got past its first version (round 5) -- the request sits at the bottom of the trip
+    loop's body, the wait at the loop's top, and the register allocator has put a copy of the value IN FRONT of the wait: reached only through the back edge -- a read
+    whose destination is used only after a wait on every path (clean), and a path that reaches a use through a conditional branch around the wait"""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "isa_check_async_lds.py")
+    kernel = "_Z13th_k_chain_dpILb1ELi512EEvPKji9ThDevParaPKiS4_S4_PiS5_Py"
+    wrap = lambda body: "%s:\n%s\n\ts_endpgm\n\t.amdhsa_kernel %s\n\t.end_amdhsa_kernel\n" % (kernel, body, kernel)
+    hoisted = wrap("""\tds_read_b64 v[22:23], v14
+.LBB0_1:
+\ts_waitcnt vmcnt(0)
+\tv_mov_b64_e32 v[24:25], v[22:23]
+\ts_waitcnt lgkmcnt(0)
+\tv_add_u32_e32 v1, v24, v25
+\tds_read_b64 v[22:23], v14
+\ts_cmp_eq_u64 s[4:5], 0
+\ts_cbranch_scc1 .LBB0_1""")
+    clean = wrap("""\tds_read_b64 v[22:23], v14
+.LBB0_1:
+\ts_waitcnt lgkmcnt(0)
+\tv_mov_b64_e32 v[24:25], v[22:23]
+\tds_read_b64 v[22:23], v14
+\ts_cmp_eq_u64 s[4:5], 0
+\ts_cbranch_scc1 .LBB0_1
+\ts_waitcnt vmcnt(0) lgkmcnt(0)
+\tv_mov_b32_e32 v22, 0""")
+    around = wrap("""\tds_read_b64 v[22:23], v14
+\ts_cbranch_scc1 .LBB0_2
+\ts_waitcnt lgkmcnt(0)
+.LBB0_2:
+\tv_add_u32_e32 v1, v22, v23""")
+    for name, text, want in (("hoisted", hoisted, 1), ("clean", clean, 0), ("around", around, 1)):
+        f = tmp_path / (name + ".s")
+        f.write_text(text)
+        r = subprocess.run([sys.executable, tool, str(f)], capture_output=True, text=True)
+        assert r.returncode == want, (name, r.stdout)

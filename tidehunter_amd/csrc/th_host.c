@@ -1491,11 +1491,16 @@ static void *pipe_device(void *arg)
 int th_run_file_multi(const char *read_fn, th_para_t *p, FILE *out, const int *devices_in, int n_dev_in, int batch_reads)
 {
     if (n_dev_in < 1 || n_dev_in > TH_MAX_DEV) return host_fail("between 1 and 16 devices");
-    if (batch_reads <= 0) batch_reads = 32768;      /* per-position arrays + POA scratch of one pipeline: ~35 GB of HBM at 10 kb reads; two pipelines per device */
+    /* 65536 reads (and at most 2^30 bases, pipe_reader) per batch since round 5: per-position arrays + POA scratch of one pipeline ~70 GB of HBM at 10 kb reads, so the second
+     * pipeline of a device retires (pipe_device: an arena must fit a third of the free memory) and ONE pipeline of 65536-read batches runs.  The matrix on 1 000 000 headline
+     * reads after the round's kernel work (gpurun_out e2e sweep, round 5): 2 x 32768 (the default until then) 146.6 k reads/s steady, 1 x 65536 154.4 k, 2 x 65536 153.5 k,
+     * 1 x 100000 153.7 k, 1 x 50000 151.0 k, 3 x 32768 148.3 k -- with the kernels 10 % faster the half-size batches' grid-fill granularity (5 POA jobs per wave instead of 10)
+     * costs more than the overlap of two pipelines hides. */
+    if (batch_reads <= 0) batch_reads = 65536;
     /* Two pipelines (handle + upload / run / collect threads each) per listed device: while one is inside its POA / alignment
      * launches the other's short, latency-bound kernels (hits, sort, extraction, partition) and its three synchronisations are
-     * hidden -- 116.2 k against 112.4 k reads/s on 1 000 000 reads of config 3 (two pipelines of 32768-read batches against one of
-     * 65536: the same memory; profiles/r03_e2e_pipelines.txt).  TH_WORKERS_PER_DEV=1..4 overrides; a second pipeline
+     * hidden -- 116.2 k against 112.4 k reads/s on 1 000 000 reads of config 3 in round 3 (two pipelines of 32768-read batches against one of
+     * 65536: the same memory; profiles/r03_e2e_pipelines.txt; with `-b 32768` that is still what runs).  TH_WORKERS_PER_DEV=1..4 overrides; a second pipeline
      * that does not fit the device's memory retires (pipe_device). */
     int wpd = 2;
     { const char *e = getenv("TH_WORKERS_PER_DEV"); if (e && atoi(e) >= 1 && atoi(e) <= 4) wpd = atoi(e); }

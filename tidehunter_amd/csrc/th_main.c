@@ -37,7 +37,7 @@ static int usage(void)
     fprintf(stderr, "\nTideHunter-amd: Tandem repeats detection and consensus calling from noisy long reads (MI355X/HIP hot path)\n\n");
     fprintf(stderr, "Version: %s\n\nUsage:   TideHunter-amd [options] in.fa/fq > cons.fa\n\n", th_version());
     fprintf(stderr, "Options: as TideHunter 1.5.5 (-k -w -H -c -e -p -P -M -X -O -E -5 -3 -a -o -m -r -u -l -F -s -f -t -h -v)\n");
-    fprintf(stderr, "         -g --gpu LIST   HIP device ordinal(s), e.g. 0 or 0,1,2,3: the listed devices share the batches [0];  -b --batch INT   reads per device batch [32768]\n");
+    fprintf(stderr, "         -g --gpu LIST   HIP device ordinal(s), e.g. 0 or 0,1,2,3: the listed devices share the batches [0];  -b --batch INT   reads per device batch [65536]\n");
     fprintf(stderr, "Note:    every stage is bit-identical to this repository's CPU restatement of TideHunter 1.5.5 (oracle/), which reproduces every known answer in the\n"
                     "         reference tree; the ksw2 / edlib results are additionally identical to the reference's compiled code.  Consensus calling implements the\n"
                     "         published abPOA algorithm (libabpoa itself is not linked and could not be compared): consensus bases of noisy units may differ from upstream.\n");

@@ -19,7 +19,7 @@ cd $R
 bash tools/pmc_cache.sh round5/cache c3 > $O/cache_summary.txt 2>&1; cp $O/cache/pmc_cache.json $O/r05_pmc_cache.json
 bash tools/pmc_instr.sh > $O/pmc_instr_summary.txt 2>&1; cp $R/gpurun_out/pmc_instr/pmc_instr.json $O/r05_pmc_instr.json
 TH_BENCH_BATCH=100000 bash tools/pmc_lds.sh > $O/pmc_lds_summary.txt 2>&1; cp $R/gpurun_out/pmc_lds/pmc_lds.json $O/r05_pmc_lds.json
-PAUSE=6 bash tools/e2e.sh round5 10 "2:32768 2:32768 1:65536" > /dev/null 2>&1
+PAUSE=6 bash tools/e2e.sh round5 10 "2:65536 2:65536 2:32768 1:65536" > /dev/null 2>&1
 grep -v "^\[th\] " $O/e2e.txt | grep -v "complete at" > $O/r05_cli_e2e.txt
 bash tools/shape_stats.sh "c3 c4 c5" > $O/r05_shape_launches.txt 2>&1
 cat $O/r05_pytest_gpu.txt; tail -c 1800 $O/r05_bench.json; tail -9 $O/traffic_summary.txt; tail -9 $O/pmc_instr_summary.txt; grep "host CPU\|run_file\] [0-9]" $O/r05_cli_e2e.txt
