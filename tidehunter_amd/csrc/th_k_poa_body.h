@@ -976,6 +976,147 @@ __device__ __forceinline__ uint32_t th_poa_dir(const ThPoaG &g, int row, int o)
     return th_d16_expand(g.dcell[g.r_off[row] + o]);
 }
 
+// ---- traceback: wave-uniform walk over tiles of 16 rows x 4 diagonals; the tile is DECODED by all lanes, WALKED on the scalar unit, its operations WRITTEN by all lanes ----
+// Round 6.  Round 5's walk (below, -DTH_POA_TB=5) took one scalar trip per event -- tile load, run of plain diagonal steps, single step -- and stored every step's
+// operation from lane 0 under an execution mask of its own: 45 scalar + 22 vector instructions per event, 500 M events per launch of 100 000 headline reads
+// (profiles/r05_poa_phases.json).  Here a tile is lane l = 4 k + c <-> cell (row ti - k, column tj - k + 2 - c): the walk enters at lane 2 and EVERY move goes to a
+// higher lane -- a diagonal step to the row d above to l + 3 d + 1, a vertical one (deletion) to l + 3 d, a horizontal one (insertion) to l + 1 -- so
+//   * what the walk needs of a cell is decoded ONCE per tile by the cell's own lane: lane masks of the plain diagonal steps, of the diagonal steps to any predecessor,
+//     of the four "the gap goes on" bits, and the successor LANE of a diagonal step in a register (one v_readlane per step to another predecessor);
+//   * the walk keeps a lane position and three visited masks (any / deletion / insertion) in scalar registers and stores nothing;
+//   * when it leaves the tile the visited lanes write their operations together: a lane's rank among the visited ones is its place in the path.
+// A gap state that leaves the tile is carried into the next one and tested against the entry cell's word there (round 5 fetched that one word from memory).
+#ifndef TH_POA_TB
+#define TH_POA_TB 6
+#endif
+#if TH_POA_TB >= 6
+__device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
+{
+    const int lane = TH_LANE();
+    const int lk = lane >> 2, lc = lane & 3;
+    int no = 0, ci = TH_UNI(bi), cj = TH_UNI(qlen), st = 0;
+    constexpr unsigned long long C4 = 0x1111111111111111ull;
+    while (ci > 0) {
+        // the walk is wave-uniform; saying so at every tile keeps its state in scalar registers and its branches scalar
+        ci = TH_UNI(ci); cj = TH_UNI(cj); st = TH_UNI(st); no = TH_UNI(no);
+        const int ti = ci, tj = cj;
+        TH_PROF_CNT(4, 1);
+        // ---- the tile: every lane fetches and decodes its cell
+        const int row = ti - lk, col = tj - lk + 2 - lc;
+        // t_w: the cell's direction word as the DP stored it -- the raw 16-bit word (th_k_poa.hip), or bit 31 | the 32-bit word of a row with more than four predecessors;
+        // 0 outside the row's band, as in round 5's walk.  The lanes decode the raw form (two instructions per mask); expanding it to the TH_D_* layout was 20 vector
+        // instructions per tile for fields only the gap steps read -- those expand their one word on the scalar unit (TH_TB_D)
+        int t_w = 0, t_p0 = -1, t_p1 = -1, t_p2 = -1, t_p3 = -1;
+        if (row >= 1) {
+            // everything indexed by the row is requested at once; the direction word is the only dependent load
+            const int rb = g.r_beg[row], re = g.r_end[row], meta = g.r_meta[row], roff = g.r_off[row], rfoff = g.r_foff[row];
+            const int4 pp = ((const int4 *)g.r_p)[row];
+            t_p0 = pp.x; t_p1 = pp.y; t_p2 = pp.z; t_p3 = pp.w;
+            TH_KEEP_V(rb); TH_KEEP_V(re); TH_KEEP_V(meta); TH_KEEP_V(roff); TH_KEEP_V(rfoff);
+            if (col >= rb && col <= re) {
+                const int deg_ = (meta >> 8) & 0xff;
+                if (deg_ > TH_D16_WIDE_DEG) t_w = g.cell[rfoff + (col - rb)].w | (int)0x80000000;
+                else if (TH_POA_D8 && deg_ == 1) { const uint32_t b_ = ((const uint8_t *)(g.dcell + roff))[col - (rb & ~1)]; t_w = (int)((b_ & 0x0fu) | (b_ & 0xf0u) << 4); }
+                else t_w = (int)g.dcell[roff + (col - rb)];
+            }
+        }
+        const uint32_t uw = (uint32_t)t_w;
+        int wantm = (int)((uw >> TH_D16_PM_SHIFT) & 3u);
+        bool mstep = row >= 1 && (uw & 0x0303u) == 0;                                             // no source flag set: the diagonal (a cell outside its band reads as word 0: a step to its first predecessor)
+        bool xe1 = (uw & 0x400u) != 0, xe2 = (uw & 0x004u) != 0, xf1 = (uw & 0x800u) != 0, xf2 = (uw & 0x008u) != 0;
+        if (__any(t_w < 0)) {                                                                     // rows with more than four predecessors in the tile (rare): the 32-bit layout
+            if (t_w < 0) {
+                const uint32_t d = uw & 0x7fffffffu;
+                wantm = (int)TH_D_PM(d) & 3; mstep = TH_D_SRC(d) == 0 && TH_D_PM(d) < TH_POA_INL;
+                xe1 = (d & TH_D_XE1) != 0; xe2 = (d & TH_D_XE2) != 0; xf1 = (d & TH_D_XF1) != 0; xf2 = (d & TH_D_XF2) != 0;
+            }
+        }
+        const int t_pr_lo = (wantm & 1) ? t_p1 : t_p0, t_pr_hi = (wantm & 1) ? t_p3 : t_p2;
+        const int t_pr = (wantm & 2) ? t_pr_hi : t_pr_lo;                                         // the row a diagonal step goes to (selects: as a chain of tests hipcc makes execution-mask blocks of it)
+        const int dd = row - t_pr;
+        // successor lane of the diagonal step, 64 if it leaves the tile (or reaches the source row: the walk ends there)
+        const int t_nl = (mstep && t_pr >= 1 && lk + dd <= 15 && lc - dd + 1 >= 0) ? lane + 3 * dd + 1 : 64;
+        const unsigned long long m_any = TH_BALLOT(mstep);
+        const unsigned long long m_run = TH_BALLOT(mstep && dd == 1 && row >= 2);               // plain steps: match state, the row above
+        const unsigned long long x_e1 = TH_BALLOT(xe1), x_e2 = TH_BALLOT(xe2), x_f1 = TH_BALLOT(xf1), x_f2 = TH_BALLOT(xf2);
+#define TH_TB_D(p_) ({ const int w_ = TH_READLANE(t_w, (p_)); w_ < 0 ? (uint32_t)w_ & 0x7fffffffu : th_d16_expand((uint32_t)w_); })
+#define TH_TB_XM(st_) ((st_) == 1 ? x_e1 : (st_) == 2 ? x_e2 : (st_) == 3 ? x_f1 : x_f2)
+#define TH_TB_ROW(p_) (ti - ((p_) >> 2))
+#define TH_TB_COL(p_) (tj - ((p_) >> 2) + 2 - ((p_) & 3))
+        // ---- the walk inside the tile: scalar unit only (plus one lane read per irregular step).  ONE exit at the bottom (a loop with several `break`s gets a
+        // dispatch word that every trip sets and tests -- DESIGN.md, "Control flow the scalar unit does not pay for"): a move that leaves the tile puts the lane position
+        // beyond it -- 64 .. 67 when the position itself still says where the walk is (a run of plain steps off the tile's last row), 128 when xr / xc do
+        int p = 2, xr = 0, xc = 0;
+        unsigned long long vis = 0, vis_d = 0, vis_i = 0;
+        if (st) { if (!((TH_TB_XM(st) >> 2) & 1)) st = 0; }       // a gap state carried in: does the entry cell extend it?
+        do {
+            const unsigned long long bit = 1ull << p;
+            vis |= bit;                                                             // (every trip leaves lane p by exactly one operation)
+            if (st == 0) {
+                // a run of plain diagonal steps down this tile column is taken in one go (most of the path at 10 % error)
+                const unsigned long long colb = (m_run >> p) & C4;                 // bit 4 x: step x of the run is plain (zeros beyond the tile's last row)
+                const int run = th_ctz64(~colb & C4) >> 2;
+                if (run > 0) {
+                    vis |= (C4 >> (64 - 4 * run)) << p;
+                    p += 4 * run;
+                    TH_PROF_CNT(5, 1); TH_PROF_CNT(6, run);
+                } else if (m_any & bit) {                                           // a diagonal step to another predecessor (the branch / merge rows of bubbles)
+                    TH_PROF_CNT(7, 1);
+                    const int nl = TH_READLANE(t_nl, p);
+                    if (nl >= 64) { xr = TH_READLANE(t_pr, p); xc = TH_TB_COL(p) - 1; p = 128; } else p = nl;
+                } else {
+                    TH_PROF_CNT(7, 1);
+                    const uint32_t d = TH_TB_D(p);
+                    st = (int)TH_D_SRC(d);
+                    if (st == 0) {                                                  // a diagonal step along an overflow edge (in-degree > 4)
+                        xr = TH_UNI(g.pos[th_poa_in(g, g.order[TH_TB_ROW(p)], (int)TH_D_PM(d))]); xc = TH_TB_COL(p) - 1; p = 128;
+                    } else vis &= ~bit;                                             // a gap starts here: nothing leaves the cell in this trip, the next one takes the gap step
+                }
+            } else if (st <= 2) {                                                   // deletion: to a predecessor row, same column
+                TH_PROF_CNT(7, 1);
+                vis_d |= bit;
+                const uint32_t d = TH_TB_D(p);
+                const int want = st == 1 ? (int)TH_D_PE1(d) : (int)TH_D_PE2(d);
+                const int r_ = TH_TB_ROW(p);
+                int pi;
+                if (want < TH_POA_INL) { const int a0 = TH_READLANE(t_p0, p), a1 = TH_READLANE(t_p1, p), a2 = TH_READLANE(t_p2, p), a3 = TH_READLANE(t_p3, p); pi = want == 0 ? a0 : want == 1 ? a1 : want == 2 ? a2 : a3; }
+                else pi = TH_UNI(g.pos[th_poa_in(g, g.order[r_], want)]);
+                const int d_ = r_ - pi;
+                if (pi >= 1 && (p >> 2) + d_ <= 15 && (p & 3) - d_ >= 0) { p += 3 * d_; if (!((TH_TB_XM(st) >> p) & 1)) st = 0; }
+                else { xr = pi; xc = TH_TB_COL(p); p = 128; }
+            } else {                                                                // insertion: same row, the column before
+                TH_PROF_CNT(7, 1);
+                vis_i |= bit;
+                if ((p & 3) == 3) { xr = TH_TB_ROW(p); xc = TH_TB_COL(p) - 1; p = 128; }
+                else { p += 1; if (!((TH_TB_XM(st) >> p) & 1)) st = 0; }
+            }
+        } while (p < 64);
+        if (p < 128) { ci = TH_TB_ROW(p); cj = TH_TB_COL(p); } else { ci = xr; cj = xc; }
+#undef TH_TB_XM
+#undef TH_TB_D
+#undef TH_TB_ROW
+#undef TH_TB_COL
+        // ---- the visited cells write their operations: rank among the visited lanes = place in the path
+        if (TH_LANE_OF_MASK(vis, lane)) {
+            const int k_ = no + th_mbcnt(vis);
+            const bool is_d = TH_LANE_OF_MASK(vis_d, lane), is_i = TH_LANE_OF_MASK(vis_i, lane);
+            int2 w;
+            w.x = is_i ? 1 : ((row << 2) | (is_d ? 2 : 0));
+            w.y = is_d ? -1 : col - 1;
+            ((int2 *)g.ops)[k_] = w;
+        }
+        no += (int)__popcll(vis);
+    }
+    no = TH_UNI(no); cj = TH_UNI(cj);
+    for (int c0 = cj; c0 > 0; c0 -= TH_WAVE) {      // the source row: what is left of the query is inserted
+        const int j = c0 - lane;
+        if (j > 0) { g.ops[2 * (no + lane)] = 1; g.ops[2 * (no + lane) + 1] = j - 1; }
+        no += min(c0, TH_WAVE);
+    }
+    TH_WAVE_FENCE();
+    return no;
+}
+#else
 // ---- traceback: wave-uniform walk; direction words come from tiles of 16 rows x 4 diagonals ----
 __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
 {
@@ -1078,6 +1219,8 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
     TH_WAVE_FENCE();
     return no;
 }
+
+#endif
 
 // ---- merge the alignment (ops were written backwards; rows refer to the CURRENT order) ----
 // returns 1 (graph abandoned) when the new nodes would not fit the job's node capacity
