@@ -49,6 +49,10 @@ CONFIGS = {
     "c5": dict(period=None, copies=None, err=0.10, seed=5, set_size=100000, batch=100000,
                label="C5: periods {200,500,1000,2000,5000} by read index, copies max(3, 10000 // period), 10 percent error, both strands, "
                      "5'/3' adapters (-5/-3: full-length path + adapter search)"),
+    # ONE long-read point, OUTSIDE the contract (not a BASELINE.json config): rolling-circle / satellite-like reads of 100 kb.  Reads of 65 536 bases and more
+    # leave the packed chain-DP records and the 32-bit LDS sort words (64-bit words, HBM bitonic sort beyond 16 384 k-mers): the one regime where a fallback path could dominate
+    "c_long": dict(period=2000, copies=50, err=0.10, seed=7, set_size=2000, batch=2000,
+                   label="c_long -- NOT a BASELINE.json config: 2000 synthetic reads of ~100 kb, period 2000 x 50 copies, 10 percent error (long-read fallback paths)"),
     # rehearsal shape for the CPU-emulation tests of the multi-rank path (never a bench line)
     "tiny": dict(period=60, copies=6, err=0.08, seed=3, set_size=64, batch=4, label="tiny rehearsal shape (tests only)"),
 }
@@ -62,7 +66,70 @@ def csrc_hash():
     for fn in sorted(os.listdir(d)):
         if fn.endswith((".hip", ".h")):
             h.update(fn.encode()); h.update(open(os.path.join(d, fn), "rb").read())
+    # ... and the compiler flags (one of them is an LLVM-internal switch that changes the code of every kernel; a profile taken under other flags is stale too)
+    try:
+        h.update(subprocess.run(["make", "-s", "--no-print-directory", "-C", d, "print-hipflags"], capture_output=True, timeout=30).stdout.strip())
+    except (OSError, subprocess.SubprocessError):
+        h.update(b"hipflags unknown")
     return h.hexdigest()[:16]
+
+
+# SURVEY.md 8(d), "secondary ceiling": these kernels are integer DP bound by VECTOR INSTRUCTION ISSUE, not by bytes.  A SIMD issues one vector wave-instruction of the class
+# the DP bodies are made of (max, compare, v_pk_*, DPP, VOP3, lane ops) every 4.2 cycles -- measured on this chip, tools/valu_rate.hip -> profiles/r05_valu_rate.txt --
+# so 1024 SIMDs x 2.39 GHz / 4.2 is the most such instructions per second the device retires.
+ISSUE_SIMDS, ISSUE_CLOCK_HZ, ISSUE_CYCLES = 1024, 2.39e9, 4.2
+SECONDARY_KERNELS = (("th_k_poa", "th_k_poa<"), ("th_k_align", "th_k_align<"), ("th_k_chain_dp", "th_k_chain_dp<"))
+
+
+def newest_profile(suffix):
+    """(dict, file name) of the newest profiles/rNN_<suffix> (round number descending), or (None, None)"""
+    pd = os.path.join(ROOT, "profiles")
+    try:
+        names = sorted((f for f in os.listdir(pd) if re.match(r"r\d\d_" + re.escape(suffix) + "$", f)), reverse=True)
+    except OSError:
+        names = []
+    for f in names:
+        try:
+            return json.load(open(os.path.join(pd, f))), f
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
+def secondary_roofline(kms, launches, reads_per_launch, config, my_hash, steal):
+    """`roofline.secondary`: per big kernel the vector / scalar wave-instructions of one launch (quoted from the newest profiles/rNN_pmc_instr.json, a rocprofv3 --pmc pass of this
+    same command; marked stale when the kernel sources or flags have changed since), the issue ceiling they are priced against, issue_frac = vector instructions / (ceiling x the
+    launch time measured LIVE in this run), the DP cells of one launch (profiles/rNN_dp_cells.json: device counters of the profiling build -- a property of the workload), cells / s
+    and vector instructions per cell."""
+    ceiling = ISSUE_SIMDS * ISSUE_CLOCK_HZ / ISSUE_CYCLES
+    pmc, pmc_fn = newest_profile("pmc_instr.json")
+    cells, cells_fn = newest_profile("dp_cells.json")
+    ok_pmc = bool(pmc) and pmc.get("reads_per_launch", 100000) == reads_per_launch and pmc.get("config", "c3") == config and steal == 0
+    ok_cells = bool(cells) and cells.get("reads_per_launch") == reads_per_launch and cells.get("config") == config and steal == 0
+    out = {"bound": "vector_issue", "unit": "wave-instructions/s", "peak": ceiling,
+           "peak_is": "%d SIMDs x %.2f GHz / %.1f cycles per vector wave-instruction of the DP class (profiles/r05_valu_rate.txt)" % (ISSUE_SIMDS, ISSUE_CLOCK_HZ / 1e9, ISSUE_CYCLES),
+           "instr_source": ("profiles/" + pmc_fn) if ok_pmc else None, "instr_stale": (pmc.get("csrc_hash") != my_hash) if ok_pmc else None,
+           "cells_source": ("profiles/" + cells_fn) if ok_cells else None, "kernels": {}}
+    tot_cells, tot_s = 0.0, 0.0
+    for grp, pat in SECONDARY_KERNELS:
+        launch_s = kms.get(grp, 0.0) / 1000.0 / launches
+        k = {"launch_ms": launch_s * 1000.0}
+        if ok_pmc:
+            rows = [v for n, v in pmc["kernels"].items() if pat in n]
+            if rows:
+                valu, salu = sum(r["valu_wave_instr"] / max(r["launches"], 1) for r in rows), sum(r["salu_wave_instr"] / max(r["launches"], 1) for r in rows)
+                k.update({"valu_wave_instr": valu, "salu_wave_instr": salu, "achieved": valu / launch_s if launch_s > 0 else None,
+                          "issue_frac": valu / launch_s / ceiling if launch_s > 0 else None,
+                          "scalar_issue_frac": salu * 4.25 / ISSUE_CYCLES / launch_s / ceiling if launch_s > 0 else None})
+        if ok_cells and grp in cells["kernels"]:
+            c = float(cells["kernels"][grp]["dp_cells_per_launch"])
+            k.update({"dp_cells": c, "gcells_per_s": c / launch_s / 1e9 if launch_s > 0 else None, "cell": cells["kernels"][grp].get("cell")})
+            if k.get("valu_wave_instr"):
+                k["valu_lane_instr_per_cell"] = k["valu_wave_instr"] * 64.0 / c          # a wave-instruction is 64 lane-instructions
+            tot_cells += c; tot_s += launch_s
+        out["kernels"][grp] = k
+    out["total_gcells_per_s"] = tot_cells / tot_s / 1e9 if tot_s > 0 else None
+    return out
 
 
 def effective_cpus():
@@ -264,7 +331,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1: auto, 0: skip)")
     ap.add_argument("--e2e", type=int, default=-1, help="copies of the read set in the end-to-end command-line run (-1: 20 for the headline workload, 0: skip)")
     ap.add_argument("--streamed", type=int, default=-1, help="also time the steps through th_process_batches(), H2D inside (-1: at N=1, 0: skip)")
-    ap.add_argument("--others", default=None, help="comma-separated configs for `other_shapes` (default: c2,c4,c5 with the headline workload at N=1; '' to skip)")
+    ap.add_argument("--others", default=None, help="comma-separated configs for `other_shapes` (default: c2,c4,c5,c_long with the headline workload at N=1; '' to skip)")
     ap.add_argument("--digest", action="store_true", help="add an md5 over all records of the timed steps in read order (tests)")
     ap.add_argument("--quick", action="store_true", help="the timed steps only: no CPU baseline, end-to-end run, streamed run or other shapes (profiler passes)")
     a = ap.parse_args()
@@ -548,7 +615,7 @@ def main():
         # the committed profile is quoted when it was taken at the same workload and batch size, else null
         traffic, traffic_lo, traffic_src, traffic_stale = None, None, None, None
         my_hash = csrc_hash()
-        for pf in ("r05_hbm_traffic.json", "r04_hbm_traffic.json"):
+        for pf in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.match(r"r\d\d_hbm_traffic.json$", f)), reverse=True)[:2]:
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", pf)))
                 if prof.get("reads_per_launch") == B * a.steps // launches and prof.get("config", "c3") == a.config and a.steal == 0:
@@ -571,8 +638,8 @@ def main():
                            "kernel_ms_per_step": {k: v / a.steps for k, v in kms.items()},
                            "algorithmic_bytes_per_launch": per_launch_bytes, "launches_per_step": launches / float(a.steps),
                            "note": "`achieved` / `frac` price the ALGORITHMIC bytes (the contract's definition); `achieved_measured` / `frac_measured` are the HBM bytes the counters saw "
-                                   "(uncorrected, corrected) over the same launch time.  The path is instruction-issue bound (DESIGN.md section 5; profiles/r05_pmc_instr.json, "
-                                   "profiles/r05_poa_phases.json)"}
+                                   "(uncorrected, corrected) over the same launch time.  The path is bound by vector instruction issue: `secondary` prices that (SURVEY.md 8(d))"}
+        out["roofline"]["secondary"] = secondary_roofline(kms, launches, B * a.steps // launches, a.config, my_hash, a.steal)
         # the same steps with the upload INSIDE: th_process_batches() pipelines H2D of batch i+1 and the record arithmetic of batch i-1
         # under the kernels of batch i (what th_run_file does with batches from the reader)
         if world == 1 and a.steal == 0 and a.streamed != 0:
@@ -601,7 +668,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(read_at, n_cpu, cfg)
             except Exception as ex:
                 out["cpu_baseline"] = {"error": repr(ex)[:400]}
-        others = a.others if a.others is not None else ("c2,c4,c5" if (a.config == "c3" and world == 1 and "TH_BENCH_LIB" not in os.environ) else "")
+        others = a.others if a.others is not None else ("c2,c4,c5,c_long" if (a.config == "c3" and world == 1 and "TH_BENCH_LIB" not in os.environ) else "")
         if others:
             out["other_shapes"] = other_shapes([c for c in others.split(",") if c])
         # the figures a reader wants first, flat and LAST in the line (the driver keeps the tail of stdout)
@@ -610,19 +677,25 @@ def main():
                 d = d.get(k) if isinstance(d, dict) else None
             return d
         kstep = g(out, "roofline", "kernel_ms_per_step") or {}
-        nfail = [out.get("n_jobs_without_consensus"), g(out, "value_e2e", "n_jobs_without_consensus")] + [g(out, "other_shapes", c, "n_jobs_without_consensus") for c in ("c2", "c4", "c5")]
+        nfail = [out.get("n_jobs_without_consensus"), g(out, "value_e2e", "n_jobs_without_consensus")] + [g(out, "other_shapes", c, "n_jobs_without_consensus") for c in ("c2", "c4", "c5", "c_long")]
         summ = {"value": out["value"], "value_upload_inclusive": g(out, "value_upload_inclusive", "value"), "value_e2e": g(out, "value_e2e", "value"),
                 "e2e_cold": g(out, "value_e2e", "cold_reads_per_s"), "e2e_no_pause": g(out, "value_e2e", "run_without_pause", "reads_per_s"),
                 "e2e_startup_s": g(out, "value_e2e", "runs", ) and [round(r["startup_s"], 2) for r in out["value_e2e"]["runs"]],
                 "host_cpu_s_per_1M_reads": g(out, "value_e2e", "host_cpu_s_per_1M_reads"),
                 "c2_reads_per_s": g(out, "other_shapes", "c2", "reads_per_s"), "c4_reads_per_s": g(out, "other_shapes", "c4", "reads_per_s"), "c5_reads_per_s": g(out, "other_shapes", "c5", "reads_per_s"),
                 "c2_reads_per_step": g(out, "other_shapes", "c2", "reads_per_step"),
+                "c_long_reads_per_s": g(out, "other_shapes", "c_long", "reads_per_s"), "c_long_mbases_per_s": g(out, "other_shapes", "c_long", "mbases_per_s"),
+                "c_long_hits_ms": g(out, "other_shapes", "c_long", "kernel_ms_per_step", "th_k_encode+th_k_hits"), "c_long_ms_per_step": g(out, "other_shapes", "c_long", "ms_per_step"),
                 "n_jobs_without_consensus": sum(x for x in nfail if x), "n_jobs_without_consensus_covers": "timed steps + warm-up, the end-to-end runs, the other shapes",
                 "poa_ms": kstep.get("th_k_poa"), "chain_dp_ms": kstep.get("th_k_chain_dp"), "align_ms": kstep.get("th_k_align"), "hits_ms": kstep.get("th_k_encode+th_k_hits"),
                 "chain_extract_ms": kstep.get("th_k_chain_extract"), "partition_ms": kstep.get("th_k_partition"), "ms_per_step": out["ms_per_step"],
                 "c4_align_ms": g(out, "other_shapes", "c4", "kernel_ms_per_step", "th_k_align"), "c4_poa_ms": g(out, "other_shapes", "c4", "kernel_ms_per_step", "th_k_poa"),
                 "c5_poa_ms": g(out, "other_shapes", "c5", "kernel_ms_per_step", "th_k_poa"), "c5_align_ms": g(out, "other_shapes", "c5", "kernel_ms_per_step", "th_k_align"),
                 "roofline_frac": g(out, "roofline", "frac"), "roofline_frac_measured": g(out, "roofline", "frac_measured"), "traffic_stale": g(out, "roofline", "traffic_stale"),
+                "issue_frac_poa": g(out, "roofline", "secondary", "kernels", "th_k_poa", "issue_frac"), "issue_frac_align": g(out, "roofline", "secondary", "kernels", "th_k_align", "issue_frac"),
+                "issue_frac_chain_dp": g(out, "roofline", "secondary", "kernels", "th_k_chain_dp", "issue_frac"), "issue_instr_stale": g(out, "roofline", "secondary", "instr_stale"),
+                "total_gcells_per_s": g(out, "roofline", "secondary", "total_gcells_per_s"), "poa_gcells_per_s": g(out, "roofline", "secondary", "kernels", "th_k_poa", "gcells_per_s"),
+                "poa_valu_lane_instr_per_cell": g(out, "roofline", "secondary", "kernels", "th_k_poa", "valu_lane_instr_per_cell"),
                 "cpu_baseline_reads_per_s": g(out, "cpu_baseline", "value"), "cpu_baseline_cores": g(out, "cpu_baseline", "cores")}
         summ = {k: (round(v, 4 if abs(v) < 10 else 1) if isinstance(v, float) else v) for k, v in summ.items()}
         out["summary"] = summ              # (dicts keep insertion order: this is the end of the line)

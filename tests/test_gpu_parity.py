@@ -230,7 +230,9 @@ def test_gpu_large_batch_is_deterministic(th):
 
 
 @pytest.mark.parametrize("env", [dict(TH_ALN_MODE="2"), dict(TH_ALN_MODE="2", TH_ALN_WADD="200"), dict(TH_ALN_MODE="2", TH_ALN_WADD="600"),
-                                 dict(TH_ALN_MODE="2", TH_ALN_WTOL="0"), dict(TH_ALN_MODE="0"), dict(TH_ALN_MODE="2", TH_ALN_SLB="0"), dict(TH_ALN_SLB="0")])
+                                 dict(TH_ALN_MODE="2", TH_ALN_WTOL="0"), dict(TH_ALN_MODE="0"), dict(TH_ALN_MODE="2", TH_ALN_SLB="0"), dict(TH_ALN_SLB="0"),
+                                 # (small batches take the longest-first instantiation of th_k_align, the headline's 358 items per wave the plain one -- both at this size)
+                                 dict(TH_ALN_LPT="0"), dict(TH_ALN_LPT="1", TH_ALN_MODE="2")])
 def test_gpu_alignment_engines(monkeypatch, env):
     """unit-vs-consensus alignments: the anti-diagonal band engine with 1..6 registers per lane (TH_ALN_WADD widens the
     requested band), verified on the device against the full matrix (TH_ALN_MODE=2 fails the run on any difference), and the
@@ -296,7 +298,7 @@ def test_gpu_chain_dp_ring_variants_agree(monkeypatch):
     lib = TH.load_library()
     seqs = [TH.synth_read(lib, 9, i, (1000, 300, 2000)[i % 3], (10, 30, 5)[i % 3], 0.10) for i in range(96)]
     para = O.default_para(only_unit=1)
-    for ring in (os.environ["TH_ONLY_RING"],) if os.environ.get("TH_ONLY_RING") else ("512", "0", "768", "1024"):      # (TH_ONLY_RING: tools/ring_bisect.sh)
+    for ring in (os.environ["TH_ONLY_RING"],) if os.environ.get("TH_ONLY_RING") else ("512", "0", "640", "768", "1024"):      # (TH_ONLY_RING: tools/ring_bisect.sh)
         monkeypatch.setenv("TH_CHAIN_RING", ring)
         t = TH.TideHunter(device=0, only_unit=1)
         t.process(seqs)

@@ -175,3 +175,69 @@ def test_gpu_poa_equals_independent_exact_poa(period, copies, err, seed, full, p
         assert ub == d, "the node order changed a consensus (unbanded restatement != exact POA)"
         band_only += 1
     assert band_only * 200 <= len(jobs), "%d of %d POA jobs are changed by the adaptive band" % (band_only, len(jobs))
+
+
+def test_gpu_structurizer_flag_changes_no_result(tmp_path):
+    """the product is compiled with `-mllvm -structurizecfg-skip-uniform-regions=true` (csrc/Makefile), an LLVM-internal switch that upstream keeps off --
+    every wave-uniform region of every kernel is left unstructured, and correctness rests on divergence analysis calling only truly uniform regions uniform.  The same sources
+    built WITHOUT the flag (`make -C tidehunter_amd/csrc nostruct` -> tests/cpu_emul/libth_nostruct.so; built here if the snapshot does not carry it) must give the same bytes:
+    ~2000 reads over four shapes -- the headline shape, short periods, long units on the relative-int16 POA and the six-register alignment variant, and config 5's mixed periods
+    with adapters on both strands -- through th_format_output (the text mini_tandem_output prints, src/main.c:214-271), md5 per shape."""
+    import hashlib
+    ns = os.path.join(U.ROOT, "tests", "cpu_emul", "libth_nostruct.so")
+    if not os.path.exists(ns) or os.path.getmtime(ns) < os.path.getmtime(os.path.join(U.ROOT, "tidehunter_amd", "libtidehunter_amd.so")) - 3600:
+        subprocess.run(["make", "-s", "-C", os.path.join(U.ROOT, "tidehunter_amd", "csrc"), "nostruct"], check=True, timeout=900)
+    lib = TH.load_library()
+    c5, ad = U.config5_spec(tmp_path, 500)
+    shapes = {"c3": ([TH.synth_read(lib, 61, i, 1000, 10, 0.10) for i in range(768)], None),
+              "c2": ([TH.synth_read(lib, 62, i, 200, 20, 0.10) for i in range(512)], None),
+              "c4": ([TH.synth_read(lib, 63, i, 5000, 4, 0.15) for i in range(96)] + [TH.synth_read(lib, 64, i, 2500, 5, 0.12) for i in range(96)], None),
+              "c5": (c5, ad)}
+    md5 = {}
+    for which, path in (("flag_on", None), ("flag_off", ns)):
+        for name, (reads, adapters) in shapes.items():
+            t = TH.TideHunter(device=0, lib_path=path, adapters=adapters)
+            t.process(reads)
+            text = t.format_output([b"r%d" % i for i in range(len(reads))])
+            st = t.stats()
+            t.close()
+            assert st["jobs_without_consensus"] == 0 and len(text) > 100 * len(reads) // 2
+            md5[(which, name)] = hashlib.md5(text).hexdigest()
+    print("structurizer flag on / off md5:", {n: (md5[("flag_on", n)], md5[("flag_off", n)]) for n in shapes})
+    for name in shapes:
+        assert md5[("flag_on", name)] == md5[("flag_off", name)], "%s: the two builds print different bytes" % name
+
+
+def _bench_ranks(nproc, port, *args):
+    """bench.py itself with the REAL library, `nproc` gloo ranks sharing device 0 (TH_BENCH_BACKEND=gloo TH_BENCH_DEVICE=0): one JSON line"""
+    import json
+    import sys
+    env = dict(os.environ, TH_BENCH_BACKEND="gloo", TH_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TH_BENCH_LIB"):
+        env.pop(k, None)
+    common = ["--config", "c3", "--steps", "1", "--warmup", "1", "--digest", "--cpu-sample", "0", "--e2e", "0", "--streamed", "0", "--others", "", *args]
+    bench = os.path.join(U.ROOT, "bench.py")
+    if nproc == 1:
+        cmd = [sys.executable, bench, "--gpus", "1", *common]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port), bench, "--gpus", str(nproc), *common]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    return json.loads(lines[0])
+
+
+def test_gpu_bench_two_ranks_on_one_device_match_one_rank():
+    """the multi-rank path of bench.py had only ever run on the CPU-emulation library.  Here the REAL library runs multi-process -- two ranks under
+    torch.distributed.run, each with its own handle on device 0, gloo for the barrier / sums / ordered gather (no second GPU on this box: RCCL is what the driver's SCALE run
+    adds) -- on 2 x 768 reads of the headline shape, static blocks by cumulative bases and blocks stolen through the shared ticket counter: the record digest and the md5 of
+    the gathered text equal the one-rank run's over the same global list (src/main.c:273-291,402-425: the reference's chunk loop, one process)."""
+    one = _bench_ranks(1, 29561, "--batch", "1536")
+    two = _bench_ranks(2, 29562, "--batch", "768")
+    steal = _bench_ranks(2, 29563, "--batch", "768", "--steal", "3")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and steal["n_gpus"] == 2
+    assert one["records_digest_reads"] == two["records_digest_reads"] == steal["records_digest_reads"] == 1536
+    assert one["records_digest"] == two["records_digest"] == steal["records_digest"]
+    assert two["result_gather"]["backend"] == "gloo" and len(two["result_gather"]["bytes_by_rank"]) == 2 and all(b > 0 for b in two["result_gather"]["bytes_by_rank"])
+    assert two["result_gather"]["output_md5"] == one["result_gather"]["output_md5"] and two["result_gather"]["bytes"] == one["result_gather"]["bytes"] > 1000000
+    assert one["n_jobs_without_consensus"] == two["n_jobs_without_consensus"] == steal["n_jobs_without_consensus"] == 0

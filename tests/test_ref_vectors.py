@@ -244,7 +244,8 @@ def _noisy(rng, codes, err):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [dict(mode=1), dict(mode=2), dict(mode=1, variant=1), dict(mode=1, xpct=36 | 2 << 8)], ids=["pipeline", "verified_on_device", "16k_variant", "two_register_probe"])
+@pytest.mark.parametrize("cfg", [dict(mode=1, variant=3), dict(mode=2, variant=3), dict(mode=1, variant=3, xpct=36 | 1 << 12), dict(mode=1), dict(mode=1, variant=1), dict(mode=1, variant=3, xpct=36 | 2 << 8)],
+                         ids=["longest_first_instantiation", "verified_on_device", "long_flank_path_switched_off", "plain_instantiation", "16k_variant", "two_register_probe"])
 def test_gpu_flank_longer_than_the_staging_area_is_probed_on_its_prefix(gpu_lib, cfg):
     """round 5: a flank that does not fit th_k_align's staging area next to the consensus (config 4: a 5000-base consensus and 7000 ... 10 000 flank bases when the first unit
     boundary was found a period late) went to the full matrix unprobed; it is probed on the prefix that fits -- a lower bound of the whole maximum -- and finished on the pruned
@@ -267,6 +268,13 @@ def test_gpu_flank_longer_than_the_staging_area_is_probed_on_its_prefix(gpu_lib,
         idx = np.arange(len(pairs[kind]))
         got, st = align_pairs(gpu_lib, v, idx, kind, cfg)
         assert st[0] == 0, "device error flags %d" % st[0]
+        # (the prefix probe lives in the longest-first instantiation only -- variant 3 of the hook, which hands the kernel its pass queues; st[4] counts the
+        # flanks that took th_aln_long_flank: all six must when the path is on, none when bit 12 of xpct switches it off or another instantiation runs)
+        took = int(st[4])
+        if cfg.get("variant") == 3 and not (cfg.get("xpct", 0) >> 12) & 1:
+            assert took == len(idx), "th_aln_long_flank ran for %d of %d flanks" % (took, len(idx))
+        else:
+            assert took == 0
         full, st0 = align_pairs(gpu_lib, v, idx, kind, dict(mode=0))
         assert st0[0] == 0 and (got == full).all(), (kind, got, full)
         for i in (0, 3, 4):

@@ -83,7 +83,10 @@ extern "C" int th_debug_align_pairs(int device, int kind, int n, const uint8_t *
     const int *no_n = nullptr, *no_s1 = nullptr; ThAlnItem *no_defer = nullptr; int *no_dn = nullptr, *no_ws = nullptr, *no_ds1 = nullptr;
 #define DBG_ARGS(itm, cnt, q) (const ThAlnItem *)(itm), (cnt), p_tasks, p_parc, p_roff, p_rd, p_cs, p_clen, p_bnd, bnd_aln, p_iden, p_ext, &dc->err, (q), wdiv, wadd, wtol
     ThAlnItem *df = use_defer ? p_defer : no_defer; int *dfn = use_defer ? &dc->n_defer : no_dn, *dfs = use_defer ? p_ds1 : no_ds1;
-    if (variant == 0) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), waves, TH_ALN_BLOCK, s, DBG_ARGS(p_items, n, &dc->q_aln_s), mode, xpct, no_n, no_defer, no_dn, no_ws, no_s1, no_ds1);
+    // variant 3: the LONGEST-FIRST instantiation of the two-register variant with its pass queues -- the only one that holds th_aln_long_flank (prefix probe + pruned strips);
+    // stats[4] counts the flanks that took it
+    if (variant == 3) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2, true>), waves, TH_ALN_BLOCK, s, DBG_ARGS(p_items, n, &dc->q_aln_s), mode, xpct, no_n, no_defer, no_dn, no_ws, no_s1, no_ds1, dc->aln_first, (const int *)nullptr, dc->q_aln_pass);
+    else if (variant == 0) TH_LAUNCH((th_k_align<TH_ALN_SMALL, 2>), waves, TH_ALN_BLOCK, s, DBG_ARGS(p_items, n, &dc->q_aln_s), mode, xpct, no_n, no_defer, no_dn, no_ws, no_s1, no_ds1);
     else if (variant == 1) TH_LAUNCH((th_k_align<TH_ALN_BIG16, 6>), waves, TH_ALN_BLOCK, s, DBG_ARGS(p_items, n, &dc->q_aln_b), mode, xpct, no_n, df, dfn, dc->aln_wide, no_s1, dfs);
     else TH_LAUNCH((th_k_align<TH_ALN_BIG, 6>), waves, TH_ALN_BLOCK, s, DBG_ARGS(p_items, n, &dc->q_aln_b), mode, xpct, no_n, df, dfn, dc->aln_wide, no_s1, dfs);
     if (variant != 0 && use_defer && mode == 1)
@@ -98,7 +101,7 @@ extern "C" int th_debug_align_pairs(int device, int kind, int n, const uint8_t *
         for (int i = 0; i < n; ++i) { out[2 * i] = ext[4 * i + (kind == 1 ? 0 : 2)]; out[2 * i + 1] = ext[4 * i + (kind == 1 ? 1 : 3)]; }
     }
     TRY(th_rt_sync(s));
-    if (stats) { stats[0] = hc.err; stats[1] = hc.n_defer; stats[2] = hc.aln_wide[0]; stats[3] = hc.aln_wide[1]; stats[4] = stats[5] = stats[6] = stats[7] = 0; }
+    if (stats) { stats[0] = hc.err; stats[1] = hc.n_defer; stats[2] = hc.aln_wide[0]; stats[3] = hc.aln_wide[1]; stats[4] = hc.aln_first[4]; stats[5] = stats[6] = stats[7] = 0; }
     return 0;
 }
 

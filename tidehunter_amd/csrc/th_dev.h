@@ -65,9 +65,9 @@ struct ThCnt {
     int aln_wide[2];         // wide first bands (three registers per lane and more) tried / failed in the big-area alignment launch
     int max_need_big;        // bytes of staging area the largest item of the third alignment list could ask for
     int n_item_long;         // unit alignments of jobs too long for a two-register first band (th_aln_class: probed on the small variant, or the big variant's)
-    int aln_first[4];        // unit alignments: first bands tried / not certified on the anti-diagonal engine, second bands tried / not certified (TH_TRACE prints them)
+    int aln_first[5];        // unit alignments: first bands tried / not certified on the anti-diagonal engine, second bands tried / not certified; [4] flanks probed on a prefix (th_aln_long_flank) -- TH_TRACE prints them, the debug hook returns [4]
     int q_aln_pass[4];       // queue heads of the first alignment launch's earlier passes (longest flanks first: th_k_align, `pass_queue`)
-    int pad3[10];
+    int pad3[9];
 };
 static_assert(sizeof(ThCnt) == 256, "counter block");
 #define TH_E_REC_OVERFLOW 1       // chain record arena too small (rerun the extraction with a larger one)

@@ -122,7 +122,16 @@ __device__ TH_NOINLINE void th_aln_long_flank(const uint8_t *__restrict__ qp, in
 // -DTH_ALN_PROF=1 (tools/build_variant.sh; never the product): how evenly a launch's dynamic queue keeps its waves busy -- per wave that took an item, the ticks from its
 // start to its exit: [0] waves, [1] shortest, [2] longest, [3] sum >> 10, [4] items; printed and reset by th_pipeline.hip after every launch
 __device__ unsigned long long th_aln_prof[40] = { 0, ~0ull };      // [8 + b]: waves whose ticks >> 25 == b (histogram, last bucket open); [5] ticks of the costliest item, [6] its index
+// round 6: where a launch's time goes BY CLASS of item -- [class][0] items, [1] ticks (a wave works on one item at a time: the classes' ticks sum to the waves' busy time),
+// [2] cells the register-band engine computed (anti-diagonals x 128 x registers, every band run on the item), [3] cells of the band the item's FINAL score certifies
+// (anti-diagonals / 2 x its diagonals: what any exact banded method must at least look at).  Classes: 0 / 1 unit alignment certified on its first band of one / two registers,
+// 2 on a second register band, 3 handed to the strip launch (time until then), 4 strip engines or full matrix here, 5 / 6 left extension certified on its first band / not,
+// 7 / 8 right extension likewise, 9 nothing to align
+__device__ unsigned long long th_aln_cls[12][4];
 #endif
+// a flank extension that cannot be staged next to its consensus even with ONE register's band: the class the longest-first walk takes first and th_aln_long_flank serves
+// (ONE predicate for both sites: ADVICE r5)
+template <int LDSB> __device__ __forceinline__ bool th_aln_unstaged_flank(int cl, int tlen) { return cl + tlen + 512 + 16 > LDSB; }
 template <int LDSB, int NPMAX, bool LPT = false>      // LPT: the list is walked longest flanks first (`pass_queue`; an instantiation of its own: the plain walk keeps its registers)
 __global__ void __launch_bounds__(TH_ALN_BLOCK) TH_ALN_OCC
 th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__restrict__ tasks, const int *__restrict__ pos,
@@ -177,14 +186,17 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
         const int *ps = pos + T.pos_off;
         if (LPT) {
             int cls = 4;
-            if (I.which < 0) { const int tl = I.which == -1 ? ps[0] + 1 : L - ps[T.pos_n - 1] - 1; cls = cl + tl + 528 > LDSB ? 0 : tl >= 3072 ? 1 : tl >= 1536 ? 2 : tl >= 768 ? 3 : 4; }
+            if (I.which < 0) { const int tl = I.which == -1 ? ps[0] + 1 : L - ps[T.pos_n - 1] - 1; cls = th_aln_unstaged_flank<LDSB>(cl, tl) ? 0 : tl >= 3072 ? 1 : tl >= 1536 ? 2 : tl >= 768 ? 3 : 4; }
             if (TH_UNI(cls) != pass) continue;
         }
 #if defined(TH_ALN_PROF)
         ++prof_items;
         const unsigned long long prof_i0 = __builtin_amdgcn_s_memtime();
         unsigned long long prof_desc = 0;      // flank items: tlen | cl << 16 | max(bh, 0) << 32 | path << 60 (1 certified band, 2 pruned strips, 3 full matrix; +4: prefix probe)
-        struct ProfItem { unsigned long long t0; int it, lane; const unsigned long long *desc; __device__ ~ProfItem() { if (lane == 0) { const unsigned long long d = __builtin_amdgcn_s_memtime() - t0; if (atomicMax(&th_aln_prof[5], d) < d) { th_aln_prof[6] = (unsigned long long)it; th_aln_prof[7] = *desc; } } } } prof_item_{ prof_i0, it, lane, &prof_desc };
+        int prof_cls = 9; unsigned long long prof_cells = 0, prof_need = 0;
+        struct ProfItem { unsigned long long t0; int it, lane; const unsigned long long *desc; const int *cls; const unsigned long long *cells, *need;
+                          __device__ ~ProfItem() { if (lane == 0) { const unsigned long long d = __builtin_amdgcn_s_memtime() - t0; if (atomicMax(&th_aln_prof[5], d) < d) { th_aln_prof[6] = (unsigned long long)it; th_aln_prof[7] = *desc; }
+                                                                   atomicAdd(&th_aln_cls[*cls][0], 1ull); atomicAdd(&th_aln_cls[*cls][1], d); atomicAdd(&th_aln_cls[*cls][2], *cells); atomicAdd(&th_aln_cls[*cls][3], *need); } } } prof_item_{ prof_i0, it, lane, &prof_desc, &prof_cls, &prof_cells, &prof_need };
 #endif
         if (I.which >= 0) {
             int v = 0;
@@ -236,6 +248,12 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                     int w_tried = -1;
                     while (np) {
                         v = th_ad_align<NPMAX>(np, qp, len, cs, cl, s_seq, &s1); have_s1 = true; w_tried = max(w_tried, (256 * np - 2 - aD) / 2);
+#if defined(TH_ALN_PROF)
+                        prof_cells += (unsigned long long)(len + cl) * 128ull * (unsigned long long)np;
+                        if (v >= 0) { prof_cls = np != np_first ? 2 : np == 1 ? 0 : 1;
+                                      const long long g_ = ((long long)len + cl - 2LL * s1 - 4 * TH_KQ) / (1 + 2 * TH_KE) + 2, w_ = (g_ - 2 - aD + 1) / 2;
+                                      prof_need = (unsigned long long)((len + cl) / 2) * (unsigned long long)(2 * max(w_, 0LL) + aD + 1); }
+#endif
                         if (from_slb && s1 < slb0 && lane == 0) atomicOr(err, TH_E_ALN_BOUND);      // (the band was sized to hold a path of score slb0: a banded score below it says the POA's bound was none -- never seen; the tests would)
                         if (wide_first && np == np_first && np >= 3 && lane == 0) { atomicAdd(&wide_stat[0], 1); if (v < 0) atomicAdd(&wide_stat[1], 1); }
                         if (aln_stat && lane == 0) { const int o_ = np == np_first ? 0 : 2; atomicAdd(&aln_stat[o_], 1); if (v < 0) atomicAdd(&aln_stat[o_ + 1], 1); }
@@ -254,8 +272,14 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                     if (v < 0 && defer && mode == 1) {          // what is left is strip-engine work (a wider certified band, the full matrix): on that engine's own launch
                         int slot = 0;
                         if (lane == 0) { slot = atomicAdd(defer_n, 1); defer[slot] = I; defer_s1[slot] = have_s1 ? s1 : TH_ALN_NO_S1; }
+#if defined(TH_ALN_PROF)
+                        prof_cls = 3;
+#endif
                         continue;
                     }
+#if defined(TH_ALN_PROF)
+                    if (v < 0 || prof_cls == 9) prof_cls = 4;
+#endif
                     if (v < 0 && have_s1) {
                         // strip engine for the second, wider certified band (more divergent than ~12 %)
                         const long long g2 = ((long long)len + cl - 2LL * s1 - 4 * TH_KQ) / (1 + 2 * TH_KE) + 2;
@@ -302,6 +326,11 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                             if (!np && mn >= 1024) np = xprobe;
                             while (np && cl + tlen + 512 * np + 16 <= LDSB) {
                                 done = th_adx_align<4>(np, qp, st, cl, tp, st, tlen, s_seq, &mq, &mt, &bh);
+#if defined(TH_ALN_PROF)
+                                prof_cls = (I.which == -1 ? 5 : 7) + ((done && prof_cells == 0) ? 0 : 1);
+                                prof_cells += (unsigned long long)(cl + tlen) * 128ull * (unsigned long long)np;
+                                if (done) { int nn_ = 1; while (nn_ < 4 && th_adx_bound(nn_, cl, tlen) >= max(bh, 1)) ++nn_; prof_need = (unsigned long long)(max(mq, 0) + max(mt, 0) + 2) * 128ull * (unsigned long long)nn_; }
+#endif
                                 if (done || bh <= 0) break;
                                 int np2 = 0;
                                 for (int c = np + 1; c <= 4; ++c) if (th_adx_bound(c, cl, tlen) < bh) { np2 = c; break; }
@@ -323,8 +352,14 @@ th_k_align(const ThAlnItem *__restrict__ items, int n_items, const ThTask *__res
                         // Only in the longest-first instantiation, the launches with few items per wave, where one such item IS the launch's tail: the call's mere presence
                         // moved config 5's launch -- 605 items per wave, no such flank -- from 405 to 420 ms whatever its form (in line, out of line, at this site or in
                         // front of the probes, stack frame or none: five builds), and with hundreds of items per wave an outlier of 100 ms is rarely the last one running)
+#if defined(TH_ALN_PROF)
+                        if (prof_cls == 9) prof_cls = I.which == -1 ? 6 : 8;
+#endif
                         if (!done) {
-                            if (LPT && mode && longflank && cl + tlen < 30000 && cl + tlen + 512 + 16 > LDSB && LDSB - cl - 16 - 1024 >= 1024) th_aln_long_flank<LDSB>(qp, st, cl, tp, tlen, s_seq, mybnd, s_in, pkstrip, &mq, &mt, &bh);
+                            if (LPT && mode && longflank && cl + tlen < 30000 && th_aln_unstaged_flank<LDSB>(cl, tlen) && LDSB - cl - 16 - 1024 >= 1024) {
+                                th_aln_long_flank<LDSB>(qp, st, cl, tp, tlen, s_seq, mybnd, s_in, pkstrip, &mq, &mt, &bh);
+                                if (aln_stat && lane == 0) atomicAdd(&aln_stat[4], 1);       // (TH_TRACE and the debug hook: flanks probed on their prefix)
+                            }
                             else th_ksw_ext_wave(qp, st, cl, tp, st, tlen, mybnd, &mq, &mt);
                         }
                         if (mode == 2) {

@@ -15,6 +15,11 @@
 #define TH_XFAST_SMALL 4608     // ... and those with at most this many its low-LDS instantiation
 
 enum { TH_NO_CON = 0, TH_REG_CON = 1, TH_SAME_CON = 2, TH_OVL_CON = 3 };
+#if defined(TH_CHAIN_PROF)
+// -DTH_CHAIN_PROF=1 (tools/build_variant.sh; never the product): [0] heads scanned, [1] trips of 64 predecessor evaluations, [2] hits, [3] followers -- the chain DP's
+// "cells" for the bench line's secondary roofline (pair evaluations = 64 x trips); printed and reset by th_pipeline.hip after every batch
+__device__ unsigned long long th_chain_prof[4];
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Chain DP, one read per wavefront.  `cur` advances sequentially (its predecessors' scores must be
@@ -95,6 +100,9 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
         const int d = c_e - q_e;
         const bool fol = okl && (cb + lane) >= 1 && c_p == q_p && d >= 1 && d < k && d <= c_p;
         const unsigned long long follm = TH_BALLOT(fol), okm = TH_BALLOT(okl);
+#if defined(TH_CHAIN_PROF)
+        if (lane == 0) { atomicAdd(&th_chain_prof[2], (unsigned long long)__popcll(okm)); atomicAdd(&th_chain_prof[3], (unsigned long long)__popcll(follm)); }
+#endif
         const int fcon = fol ? 2 * d - ((31 - TH_CLZ_NZ(2 * d)) >> 1) : 0;
         const int ps = th_wave_incl_sum(fcon);                  // followers: score = score of the run's head + ps - ps[head]
         int seg_sc = carry_sc, seg_ps = 0, seg_lo = 0;          // the segment before the chunk's first head continues the previous chunk's last run
@@ -147,12 +155,18 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
         // (round 5: ONE exit, at the bottom -- the kernel is bound by scalar issue, and a `break` in the middle of a `for` with an increment of its own cost a dozen scalar
         // instructions of flags and re-tests per trip; base0 >= 0 here, so the first trip always runs.  The wait for the requested records is the FIRST thing of a trip:
         // at the bottom and behind the loop, hipcc merged the two waits' blocks and re-tested the exit flag after them)
+#if defined(TH_CHAIN_PROF)
+        int prof_trips = 0;
+#endif
         int base = base0;
         unsigned long long endw = 0ull;                 // set by the trip that reaches hit 0: the loop's exit test is ONE 64-bit word, stopm | endw
         // byte offset, in the wave's ring, of this lane's record of the trip last requested (power-of-two rings): the next trip's is 64 slots below it, modulo the ring --
         // a subtraction and a mask where slot = (base - 64 - lane) & (RING - 1), times 8, plus the ring's address were four instructions a trip
         int rbo = (RING && RP2) ? ((base0 - lane) & (RING - 1)) << 3 : 0;
         for (;;) {
+#if defined(TH_CHAIN_PROF)
+            ++prof_trips;
+#endif
             unsigned long long rec;
             TH_LDS_ASYNC_TAKE(rec, rec_next);  // (wait and copy in one asm block, before anything else reads the value: the compiler does not track the asynchronous read)
             const int idx = base - lane;
@@ -228,6 +242,9 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             base -= TH_WAVE;
             if (!RP2) bslot = bslot >= TH_WAVE ? bslot - TH_WAVE : bslot - TH_WAVE + RING;
         }
+#if defined(TH_CHAIN_PROF)
+        if (lane == 0) { atomicAdd(&th_chain_prof[0], 1ull); atomicAdd(&th_chain_prof[1], (unsigned long long)prof_trips); }
+#endif
         TH_LDS_ASYNC_WAIT(rec_next);           // a scan that stopped leaves its last request in flight: its registers stay reserved until it lands
         best -= 15;
         if (lane == 0 && best > init) {                                                                 // :352-354

@@ -254,6 +254,9 @@ th_k_items_emit(const int *__restrict__ n_tasks, const ThTask *__restrict__ task
     jobs[t].cons_off = co; jobs[t].cons_len = cl; jobs[t].status = st;
 }
 
+// every entry of an int array to one value (the score bounds of the unit alignments start as "none": a job whose POA never runs -- no scratch for it -- would otherwise
+// hand th_k_align the PREVIOUS batch's bounds: ADVICE r5)
+__global__ void __launch_bounds__(256) th_k_fill_i32(int *__restrict__ p, int n, int v) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) p[i] = v; }
 __global__ void th_k_cnt_zero(ThCnt *C) { int *p = (int *)C; for (int i = threadIdx.x; i < (int)(sizeof(ThCnt) / 4); i += blockDim.x) p[i] = 0; }
 // before a rerun of stages 2-3 / the job build: the flags that are being answered, and what the rerun accumulates again
 __global__ void th_k_cnt_rerun(ThCnt *C, int redo_extract, int redo_part)

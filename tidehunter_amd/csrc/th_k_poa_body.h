@@ -558,7 +558,8 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
 // end of a packed row taken by one of the two straight-line paths of the row loop: the row becomes "the previous row", its band /
 // maximum columns / direction-word offset go into lane (row & 63) of the chunk registers, a complete chunk goes to the row tables
 #if defined(TH_POA_PROF)
-#define TH_POA_PK_PROF(cat) TH_PROF_ROW(cat, TH_PROF_NOW() - row_t0);
+// (-DTH_POA_PROF=1, events only: the "cycles" field of a row category carries its BAND CELLS instead -- e - b + 1 per row: the DP cells of the bench line's secondary roofline)
+#define TH_POA_PK_PROF(cat) TH_PROF_ROW(cat, TH_POA_PROF >= 2 ? TH_PROF_NOW() - row_t0 : (unsigned long long)(e - b + 1));
 #else
 #define TH_POA_PK_PROF(cat)
 #endif
@@ -940,7 +941,7 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
         L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = cache_me ? TH_LC_ON : 0;
         TH_POA_SET_RMAX(pk ? rmax : rmax - base);      // (the 32-bit path works with absolute scores)
 #if defined(TH_POA_PROF)
-        { const unsigned long long dt = TH_PROF_NOW() - row_t0;
+        { const unsigned long long dt = TH_POA_PROF >= 2 ? TH_PROF_NOW() - row_t0 : (unsigned long long)(e - b + 1);
           const int cat = pk ? 1 : inn != 1 ? 2 : p0 != i - 1 ? 3 : needfull ? 4 : 5;     // (0: common packed row) / other packed / several predecessors / one far predecessor / stores full cells / other
           TH_PROF_ROW(cat, dt); }
 #endif

@@ -521,10 +521,16 @@ __device__ __forceinline__ bool th_ksw_ext_ad_wave(const uint8_t *s_t, const uin
     }
     const int endA = max(hi, -lo);
     const int limB = min(min(2 * tlen - hi, 2 * qlen + lo), R);
+    // Round 6: the band follows the MAIN diagonal, so it leaves the matrix where the shorter sequence ends -- position u of anti-diagonal pair m = rp / 2 is the cell
+    // (i', j') = (m + lo2 + u, m - lo2 - u), 0 <= u < 128 NP, and none of them has j' <= qlen once m > qlen + 64 NP, none i' <= tlen once m > tlen + 64 NP.  Every later
+    // anti-diagonal holds minus infinity only (the third loop's mask) and cannot move a best that starts at 0: the sweep ends there instead of at qlen + tlen.  The
+    // headline shape's right flank is what the partition left of the read -- ~3000 bases against a 1000-base consensus: 2130 anti-diagonals instead of 3970
+    // (profiles/r06_align_phases.json: the extensions were 18 % of the launch)
+    const int Rend = min(R, 2 * min(qlen, tlen) + 128 * NP + 4);
     int rp = 0;
-    for (; rp <= endA && rp <= R; rp += 2) th_adx_pair_steps<NP, HASN, 0>(S, HA, HB, s_t, s_q, rp, lo2, qlen, tlen, uhb0, uhb1);
+    for (; rp <= endA && rp <= Rend; rp += 2) th_adx_pair_steps<NP, HASN, 0>(S, HA, HB, s_t, s_q, rp, lo2, qlen, tlen, uhb0, uhb1);
     for (; rp + 1 <= limB; rp += 2) th_adx_pair_steps<NP, HASN, 1>(S, HA, HB, s_t, s_q, rp, lo2, qlen, tlen, uhb0, uhb1);
-    for (; rp <= R; rp += 2) th_adx_pair_steps<NP, HASN, 2>(S, HA, HB, s_t, s_q, rp, lo2, qlen, tlen, uhb0, uhb1);
+    for (; rp <= Rend; rp += 2) th_adx_pair_steps<NP, HASN, 2>(S, HA, HB, s_t, s_q, rp, lo2, qlen, tlen, uhb0, uhb1);
     // this lane's best candidate, then the wave's: (H desc, anti-diagonal asc, SSE visiting rank asc)
     int bestH = 0, bestR = 0x7fffffff, bestT = -1, bestRank = 0x7fffffff;
 #pragma unroll

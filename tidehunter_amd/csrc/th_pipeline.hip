@@ -112,6 +112,10 @@ struct th_gpu {
     int aln_slb = 1;                      // the POA leaves a score bound per unit alignment (th_poa_unit_bounds) and th_k_align starts long units from it (TH_ALN_SLB=0: off)
     int aln_probe_auto = 1;               // ... unless the batch BEFORE was mostly such units (config 4: there the dedicated launches of round 3 are faster, config 5 gains 6 %)
     int aln_wtol = 16, aln_mode = 1;      // anti-diagonal engine: accepted shortfall of its band against that half-width; 0 = strip engine only, 2 = verify against the full matrix
+    // TH_REPLAY=1 -- MEASUREMENT ONLY (tools/host_ceiling.sh; the product never sets it): a pipeline's first batch of a size runs for real and its result records are kept; every
+    // later batch of the same size and base count gets them copied back INSTEAD of kernels.  With an input whose batches all hold the same reads (N copies of one set, batch = set) the
+    // output is still the right bytes, and reader -> upload -> record arithmetic + formatting -> writer run at whatever rate the HOST sustains: the eight-GPU host budget measured on one box
+    int replay = 0; bool replay_ok = false; int replay_n = 0; long long replay_T = 0; ThOut replay_out;
     int waves_part = 8192, waves_poa = 6144, waves_aln = 8192, waves_xw = 2048, waves_xw_small = 3584;   // persistent grids: 256 CUs x 4 SIMDs x resident waves (extraction: 256 CUs x 8 / x 14 waves by their LDS)
 };
 
@@ -169,6 +173,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
     g->aln_wtol = std::max(0, env_int("TH_ALN_WTOL", g->aln_wtol)); g->aln_mode = env_int("TH_ALN_MODE", g->aln_mode); g->aln_xpct = std::min(255, std::max(0, env_int("TH_ALN_XPCT", g->aln_xpct))) | std::min(4, std::max(1, env_int("TH_ALN_XPROBE", 1))) << 8 | (env_int("TH_ALN_PKSTRIP", 1) ? 0 : 1) << 11 | (env_int("TH_ALN_LONGFLANK", 1) ? 0 : 1) << 12;
     g->aln_slb = env_int("TH_ALN_SLB", 1);
     g->aln_lpt = env_int("TH_ALN_LPT", -1);
+    g->replay = env_int("TH_REPLAY", 0);      // measurement only (th_gpu::replay)
     g->aln_probe_small = std::min(3, std::max(0, env_int("TH_ALN_PROBE_SMALL", 1))); g->aln_probe_auto = getenv("TH_ALN_PROBE_SMALL") ? 0 : 1;
     return g;
 }
@@ -472,6 +477,7 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
     for (int k = 0; k < 8; ++k) out.ms_k[k] = 0;
     out.jobs.clear(); out.parc.clear();
     if (n == 0) return 0;
+    if (g->replay && g->replay_ok && n == g->replay_n && T == g->replay_T) { out = g->replay_out; g->stat[3] += 1; g->stat[4] += out.n_jobs; return 0; }      // (measurement only: see th_gpu::replay)
     KTimer kt; kt.s = g->stream;
     int rec_cap = std::max(n, g->reserve_n) * 8 + 4096;
     if (getenv("TH_REC_CAP")) rec_cap = std::max(1, atoi(getenv("TH_REC_CAP")));      // test knob: forces the arena-growth path
@@ -501,7 +507,7 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
 #define CHAIN_LAUNCH(RG) TH_LAUNCH((th_k_chain_dp<true, RG>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)in.d_roff.p, n, g->dp, \
                   (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p, g->d_eps.p)
         const int ring = env_int("TH_CHAIN_RING", 512);
-        if (ring >= 1024) CHAIN_LAUNCH(1024); else if (ring >= 768) CHAIN_LAUNCH(768); else if (ring >= 512) CHAIN_LAUNCH(512); else CHAIN_LAUNCH(0);
+        if (ring >= 1024) CHAIN_LAUNCH(1024); else if (ring >= 768) CHAIN_LAUNCH(768); else if (ring >= 640) CHAIN_LAUNCH(640); else if (ring >= 512) CHAIN_LAUNCH(512); else CHAIN_LAUNCH(0);
 #undef CHAIN_LAUNCH
     } else
         TH_LAUNCH((th_k_chain_dp<false, 0>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)in.d_roff.p, n, g->dp,
@@ -632,6 +638,7 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
         TRY(g->d_cons_len.ensure(nt)); TRY(g->d_status.ensure(nt)); TRY(g->d_iden.ensure((size_t)aln_total + 1)); TRY(g->d_ext.ensure((size_t)nt * 4)); if (g->aln_slb) TRY(g->d_slb.ensure((size_t)aln_total + 1));
         TRY(g->d_cc_off.ensure(nt)); TRY(g->d_rows.ensure((size_t)std::max<long long>((long long)n * TH_JOB_COLS, (long long)nt * TH_ITEM_COLS)));
         TRY(g->d_items.ensure((size_t)aln_total + 2 * (size_t)nt + 1));
+        if (g->aln_slb) TH_LAUNCH(th_k_fill_i32, (aln_total + 256) / 256, 256, g->stream, g->d_slb.p, aln_total + 1, TH_SLB_NONE);
         // ---- POA: persistent waves with private scratch, two kernel variants over two device-built task lists.  The common one keeps
         // recent rows as int16 in LDS (packed rows, 6 waves per SIMD); jobs whose scores may not fit int16 (long units, unusual scoring)
         // or whose units exceed its query staging buffer run on the 32-bit-ring variant.
@@ -670,6 +677,11 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
         }
         g->stat[0] += cnt->n_failed;
         if (cnt->n_failed) fprintf(stderr, "[tidehunter_amd] warning: %d consensus job(s) could not be aligned (POA status 3-6, or no scratch for them) and are reported without a consensus\n", cnt->n_failed);
+#if defined(TH_CHAIN_PROF)
+        { unsigned long long cp[4]; hipMemcpyFromSymbol(cp, HIP_SYMBOL(th_chain_prof), sizeof(cp));
+          fprintf(stderr, "[chain_prof] {\"heads_scanned\": %llu, \"trips\": %llu, \"pair_evaluations\": %llu, \"hits\": %llu, \"followers\": %llu}\n", cp[0], cp[1], cp[1] * 64ull, cp[2], cp[3]);
+          unsigned long long z4[4] = { 0, 0, 0, 0 }; hipMemcpyToSymbol(HIP_SYMBOL(th_chain_prof), z4, sizeof(z4)); }
+#endif
 #if defined(TH_POA_PROF)
         { unsigned long long pr[32]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(thpoa_n::th_poa_prof), sizeof(pr));
           const char *cat[8] = { "common_packed", "packed_one_pred", "general_several_preds", "general_one_far_pred", "general_stores_full", "general_other", "packed_two_preds", "packed_three_four_preds" };
@@ -720,6 +732,14 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
                              for (int b = 0; b < 32; ++b) fprintf(stderr, "%s%llu", b ? ", " : "", pr[8 + b]);
                              fprintf(stderr, "]}\n"); }
                 unsigned long long z[40] = { 0, ~0ull }; hipMemcpyToSymbol(HIP_SYMBOL(th_aln_prof), z, sizeof(z));
+                unsigned long long cl_[12][4]; hipMemcpyFromSymbol(cl_, HIP_SYMBOL(th_aln_cls), sizeof(cl_));
+                static const char *cls_name[10] = { "unit: first band, 1 register, certified", "unit: first band, 2 registers, certified", "unit: second register band", "unit: handed to the strip launch",
+                                                    "unit: strip engines / full matrix", "left extension: first band certified", "left extension: more than one pass", "right extension: first band certified",
+                                                    "right extension: more than one pass", "nothing to align" };
+                if (pr[0]) { fprintf(stderr, "[aln_prof_classes] {\"launch\": \"%s\", \"classes\": [", what);
+                             for (int c = 0; c < 10; ++c) fprintf(stderr, "%s{\"class\": \"%s\", \"items\": %llu, \"ticks\": %llu, \"cells_computed\": %llu, \"cells_certified_band\": %llu}", c ? ", " : "", cls_name[c], cl_[c][0], cl_[c][1], cl_[c][2], cl_[c][3]);
+                             fprintf(stderr, "]}\n"); }
+                memset(cl_, 0, sizeof(cl_)); hipMemcpyToSymbol(HIP_SYMBOL(th_aln_cls), cl_, sizeof(cl_));
             };
 #define TH_ALN_PROF_AFTER(what, grid) aln_prof(what, grid)
 #else
@@ -785,6 +805,7 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
     kt.collect(out.ms_k);
     out.ms_kernels = 0; out.ms_dominant = 0;
     for (int k = 0; k < TK_N; ++k) { out.ms_kernels += out.ms_k[k]; out.ms_dominant = std::max(out.ms_dominant, out.ms_k[k]); }
+    if (g->replay && !(g->replay_ok && n <= g->replay_n)) { g->replay_out = out; g->replay_n = n; g->replay_T = T; g->replay_ok = true; }      // (measurement only: the largest batch so far is the one replayed)
     return 0;
 }
 

@@ -25,7 +25,8 @@ for k in acc:
     valu, salu, s = acc[k].get("SQ_INSTS_VALU", 0.0), acc[k].get("SQ_INSTS_SALU", 0.0), dur.get(k, 0.0)
     out[k] = {"launches": len(n[k]), "valu_wave_instr": valu, "salu_wave_instr": salu, "seconds_under_counters": s,
               "valu_busy_upper": (valu * 4.2 / (1024 * 2.39e9 * s)) if s > 0 else None, "salu_busy_upper": (salu * 4.25 / (1024 * 2.39e9 * s)) if s > 0 else None}
-json.dump({"note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU, one pass of `bench.py --steps 1 --warmup 0` (%d reads of config 3 per launch); " % int(os.environ.get("TH_BENCH_BATCH", "100000")) +
+import sys; sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); import bench
+json.dump({"csrc_hash": bench.csrc_hash(), "config": "c3", "reads_per_launch": int(os.environ.get("TH_BENCH_BATCH", "100000")), "note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU, one pass of `bench.py --steps 1 --warmup 0` (%d reads of config 3 per launch); " % int(os.environ.get("TH_BENCH_BATCH", "100000")) +
                    "valu_busy_upper = VALU wave-instructions x 4.2 cycles / (1024 SIMDs x 2.39 GHz x kernel seconds in this pass), salu_busy_upper likewise at 4.25 cycles (prices: profiles/r05_valu_rate.txt)", "kernels": out},
           open(os.path.join(O, "pmc_instr.json"), "w"), indent=1)
 for k, v in out.items(): print("%-40s valu %.3e salu %.3e  %.3f s  valu busy <= %.2f  salu busy <= %.2f" % (k[:40], v["valu_wave_instr"], v["salu_wave_instr"], v["seconds_under_counters"], v["valu_busy_upper"] or 0, v["salu_busy_upper"] or 0))
