@@ -4,6 +4,7 @@
 # of kernels.  The input is K copies of ONE set of S reads with batch = S and no ramp step, so every batch holds the same reads and the replayed output is still the right bytes:
 # its md5 is compared with a real run of the same file.  Reader -> upload (real H2D) -> record arithmetic + formatting -> writer then run with P pipelines (all on device 0) at
 # whatever rate the host sustains under the container's CPU quota; TH_TRACE prints the steady rate (per pipeline, after its first batch) and the CPU seconds by role.
+# REPLAY_ENV="TH_WAVES_POA=768 TH_WAVES_ALN=1024" (replay runs only): smaller persistent grids, so that EIGHT pipelines' POA scratch fits the one device's memory.
 #   usage: tools/host_ceiling.sh [outfile=gpurun_out/host_ceiling.txt] [pipelines="8 4 2 1"] [S=16384] [K=122]
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=${1:-$R/gpurun_out/host_ceiling.txt}; PIPES=${2:-8 4 2 1}; S=${3:-16384}; K=${4:-122}
 D=/dev/shm; [ -d $D ] || D=/tmp
@@ -27,7 +28,7 @@ REAL=$(md5sum < $D/hc.real | cut -d' ' -f1); echo "records: $(grep -c '^>' $D/hc
 for P in $PIPES; do
   sleep 6
   echo "== TH_REPLAY=1, $P pipeline(s) on device 0, batch $S" >> $O
-  TH_REPLAY=1 TH_WORKERS_PER_DEV=1 TH_RAMP0=$S TH_TRACE=1 timeout 600 $R/tidehunter_amd/TideHunter-amd -g $(g $P) -b $S -o $D/hc.out $D/hc.fa 2>&1 | grep "run_file\]\|Real time\|rror" >> $O
+  env ${REPLAY_ENV:-TH_X=0} TH_REPLAY=1 TH_WORKERS_PER_DEV=1 TH_RAMP0=$S TH_TRACE=1 timeout 600 $R/tidehunter_amd/TideHunter-amd -g $(g $P) -b $S -o $D/hc.out $D/hc.fa 2>&1 | grep "run_file\]\|Real time\|rror" >> $O
   M=$(md5sum < $D/hc.out | cut -d' ' -f1); echo "records: $(grep -c '^>' $D/hc.out) md5: $M $([ "$M" = "$REAL" ] && echo '(= the real run)' || echo '(DIFFERS from the real run)')" >> $O
   rm -f $D/hc.out
 done
