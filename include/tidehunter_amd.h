@@ -81,7 +81,8 @@ void th_destroy(th_handle_t *h);
 
 /* The batch seam, src/main.c:402-425: fills out[0..n) so that th_output() prints what
  * mini_tandem_output() would.  Equivalent to calling tidehunter_core() (src/tidehunter.h:85) on every
- * read.  out[] must come from th_alloc_tandem_seq(); slots are reset first. */
+ * read.  out[]: slots laid out as the reference's alloc_tandem_seq() (src/main.c:293-311) or th_alloc_tandem_seq()
+ * allocate them (the same allocation: INTEGRATION.md passes the reference's own); slots are reset first. */
 int th_process_batch(th_handle_t *h, const char *const *seqs, const int *lens, int n, th_tandem_seq_t *out);
 
 /* The same in three steps, so that a caller (bench.py) can keep a batch resident in HBM and time

@@ -81,6 +81,9 @@ __device__ __forceinline__ int th_wave_incl_sum(int v)
 // A value that is the same in every lane but that the compiler cannot prove uniform (it came from a per-lane load or an LDS
 // read): v_readfirstlane moves it to an SGPR, so that what depends on it is scalar code and scalar branches instead of
 // vector code under execution masks.
+// INVARIANT: the value MUST be the same in every active lane.  The build leaves wave-uniform regions unstructured (-structurizecfg-skip-uniform-regions, csrc/Makefile),
+// so a branch on a TH_UNI() value is a SCALAR branch taken by the whole wave: were the value lane-dependent, the lanes that disagree with lane 0 would silently follow lane 0's
+// path (with the structurizer they would merely compute lane 0's value).  tests/test_gpu_scale.py::test_gpu_structurizer_flag_changes_no_result compares the two builds.
 #define TH_UNI(x) __builtin_amdgcn_readfirstlane(x)
 
 // max / min of wave-uniform values ON THE SCALAR UNIT: for max(max(0, x), y) of three scalars hipcc picks v_mov + v_max3_i32 + v_readfirstlane (and a vector
