@@ -383,8 +383,9 @@ def test_emul_chain_dp_lds_ring_wraps(emu, monkeypatch):
     """reads with more hits than the LDS ring of the chain DP holds (512): the ring wraps, scores are patched in place; with and
     without the ring the DP equals the oracle's (stages only: -u skips POA, which is what makes 10 kb reads slow in the emulation)"""
     seqs = [TH.synth_read(TH.load_library(), 9, 0, 300, 8, 0.08), TH.synth_read(TH.load_library(), 9, 1, 150, 14, 0.1), TH.synth_read(TH.load_library(), 9, 2, 60, 6, 0.1)]
-    for ring in ("512", "640", "768", "1024", "0"):
-        monkeypatch.setenv("TH_CHAIN_RING", ring)
+    for ring in ("512", "nolists", "640", "768", "1024", "0"):
+        monkeypatch.setenv("TH_CHAIN_RING", "512" if ring == "nolists" else ring)
+        monkeypatch.setenv("TH_CHAIN_CLS", "0" if ring == "nolists" else "1")
         th = TH.TideHunter(lib_path=emu, only_unit=1)
         th.process(seqs)
         assert int(th.debug_stage(1, 4 * len(seqs), np.int32)[0]) > 1000

@@ -293,13 +293,14 @@ def test_gpu_two_concurrent_halves_match_one_pipeline(monkeypatch):
 @pytest.mark.gpu
 def test_gpu_chain_dp_ring_variants_agree(monkeypatch):
     """th_k_chain_dp with its LDS ring of 512 records (the default: next trip's records requested by an LDS read the compiler does not
-    track), without a ring (every trip from HBM) and with the 768 / 1024-entry rings: identical hits, scores, predecessors, chains and
-    par_pos on reads whose windows are longer than the ring, all against the oracle's stage dumps"""
+    track) with and without the period-class lists of round 6, without a ring (every trip from HBM) and with the 640 / 768 / 1024-entry rings: identical hits, scores,
+    predecessors, chains and par_pos on reads whose windows are longer than the ring, all against the oracle's stage dumps"""
     lib = TH.load_library()
     seqs = [TH.synth_read(lib, 9, i, (1000, 300, 2000)[i % 3], (10, 30, 5)[i % 3], 0.10) for i in range(96)]
     para = O.default_para(only_unit=1)
-    for ring in (os.environ["TH_ONLY_RING"],) if os.environ.get("TH_ONLY_RING") else ("512", "0", "640", "768", "1024"):      # (TH_ONLY_RING: tools/ring_bisect.sh)
-        monkeypatch.setenv("TH_CHAIN_RING", ring)
+    for ring in (os.environ["TH_ONLY_RING"],) if os.environ.get("TH_ONLY_RING") else ("512", "nolists", "0", "640", "768", "1024"):      # (TH_ONLY_RING: tools/ring_bisect.sh)
+        monkeypatch.setenv("TH_CHAIN_RING", "512" if ring == "nolists" else ring)
+        monkeypatch.setenv("TH_CHAIN_CLS", "0" if ring == "nolists" else "1")      # (round 6: the default ring runs with the period-class lists; "nolists": every head scans the hit array)
         t = TH.TideHunter(device=0, only_unit=1)
         t.process(seqs)
         U.stage_compare(t, seqs, para)

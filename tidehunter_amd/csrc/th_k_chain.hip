@@ -18,7 +18,7 @@ enum { TH_NO_CON = 0, TH_REG_CON = 1, TH_SAME_CON = 2, TH_OVL_CON = 3 };
 #if defined(TH_CHAIN_PROF)
 // -DTH_CHAIN_PROF=1 (tools/build_variant.sh; never the product): [0] heads scanned, [1] trips of 64 predecessor evaluations, [2] hits, [3] followers -- the chain DP's
 // "cells" for the bench line's secondary roofline (pair evaluations = 64 x trips); printed and reset by th_pipeline.hip after every batch
-__device__ unsigned long long th_chain_prof[4];
+__device__ unsigned long long th_chain_prof[8];      // [4] heads that scanned a list, [5] their trips, [6] list entries written, [7] lists
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -37,12 +37,49 @@ __device__ unsigned long long th_chain_prof[4];
 // times through L2 (the in-flight working set of 8192 waves x 34 KB does not fit L2, so those re-reads were fabric traffic:
 // 888 GB per 100 000 reads, profiles/r01_hbm_traffic.json).  Trips that reach further back than the ring (rare: more than
 // ~450 hits within one period) read HBM as before.
-template <bool PK, int RING>      // RING: entries of the LDS ring (0 = none, 512, 768, 1024); slot of hit x = x mod RING
+// ---- PERIOD-CLASS LISTS (round 6; CLS).  A head evaluates 836 predecessors on average at the headline shape and 230 of them can connect at all: a connection needs
+// 5 cp < 9 pp and 5 pp < 9 cp (src/tandem_chain.c:154), and a third of a tandem repeat's hits carry two, three, ... unit lengths as period, so every 64-hit block of the
+// window holds hits of every class and nothing can be skipped block-wise (docs/HISTORY.md).  Instead each read keeps index-ordered LISTS of its finished hits by period class:
+// periods are binned at ratio 2^(1/3) (th_pbin); every bin that holds at least TH_CLS_MIN_HEADS run heads gets a list of ALL hits whose period bin a head of that bin could
+// connect to (a superset, bin-aligned; the scan's own period test stays).  A list entry is the hit's packed record {end << 16 | period, FINAL score} plus its 16-bit index;
+// the hits of a 64-hit chunk are appended when the chunk is done (scores final, from registers), so the lists are contiguous, in index order, and a trip over a list is one
+// coalesced load like a trip over the hit array.  A head of a listed bin scans (i) the hits of its own chunk before it -- one unfiltered trip from the LDS ring, as every scan
+// starts -- and (ii) its list from the chunk's start downwards: the same trip, order and rules as the scan of the hit array; the hits it never sees are NO_CON ones, which
+// count in the max_h rule only, and that rule is evaluated on hit INDICES.  (A first version kept 16-bit indices only and gathered the records by them: 40 % fewer
+// instructions and 134 ms against 93 -- the gathers tripled the kernel's line traffic, and it was fabric-bound already.)  The list area holds TH_CLS_DUP entries per base
+// slot of the read; lists that do not fit are dropped and their heads scan the hit array as before: same results either way (TH_CHAIN_CLS=0: no lists at all).
+#define TH_CLS_NB 120           // period bins: 12 per octave (ratio 1.059) from period 64 up, periods < 65536.  Narrow on purpose: a tandem repeat's classes sit at ratio 2 (one and two
+                                // unit lengths) and a connection needs ratio < 1.8, so a bin's list may reach only ~10 % beyond what its heads can connect to or it swallows the next class
+#define TH_CLS_MAXL 24          // lists per read
+#define TH_CLS_MIN_HEADS 16     // a bin gets a list when at least this many heads would use it ...
+#ifndef TH_CLS_MIN_WINDOW
+#define TH_CLS_MIN_WINDOW 512    // ... and its heads' windows hold about this many hits or more
+#endif
+#ifndef TH_CLS_MAX_SHARE
+#define TH_CLS_MAX_SHARE 8       // ... and it holds at most this many sixteenths of the read's hits
+#endif
+#define TH_CLS_DUP 3            // list entries per base slot of the read (capacity of its list area: 10 bytes each)
+// bin of a period: 12 (e - 6) + the number of thresholds T_i = round(1024 x 2^(i / 12)) at or below its 11-bit mantissa; -1 below 64
+__device__ __forceinline__ int th_pbin(int p)
+{
+    const int e = 31 - TH_CLZ_NZ(p | 1), x = (int)(((uint32_t)p << 10) >> e);
+    const int f = (int)(x >= 1085) + (int)(x >= 1149) + (int)(x >= 1218) + (int)(x >= 1290) + (int)(x >= 1367) + (int)(x >= 1448) + (int)(x >= 1534) + (int)(x >= 1625) + (int)(x >= 1722) + (int)(x >= 1825) + (int)(x >= 1933);
+    return p < 64 ? -1 : 12 * (e - 6) + f;
+}
+__device__ __forceinline__ int th_pbin_lo(int b)      // smallest period of bin b (b = TH_CLS_NB: one past the largest period)
+{
+    const int e = b / 12 + 6, f = b - 12 * (e - 6);
+    const int t = f == 0 ? 1024 : f == 1 ? 1085 : f == 2 ? 1149 : f == 3 ? 1218 : f == 4 ? 1290 : f == 5 ? 1367 : f == 6 ? 1448 : f == 7 ? 1534 : f == 8 ? 1625 : f == 9 ? 1722 : f == 10 ? 1825 : 1933;
+    return (int)((((uint32_t)t << e) + 1023u) >> 10);
+}
+
+template <bool PK, int RING, bool CLS = false>      // RING: entries of the LDS ring (0 = none, 512, 768, 1024); slot of hit x = x mod RING
 __global__ void __launch_bounds__(TH_CHAIN_BLOCK)
 th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
               const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ hit_n,
-              int *__restrict__ score, int *__restrict__ from, unsigned long long *__restrict__ eps)
+              int *__restrict__ score, int *__restrict__ from, unsigned long long *__restrict__ eps, unsigned long long *__restrict__ cls_rec = nullptr, uint16_t *__restrict__ cls_idx = nullptr)
 {
+    static_assert(!CLS || (PK && RING >= 2 * TH_WAVE && (RING & (RING - 1)) == 0), "the class lists hold 16-bit hit indices; a listed head reads its own chunk from the ring");
     // Measured alternatives (batch 16384, config 3; this version 43 ms): a per-wave LDS ring of the last 1024 hits
     // removes the window re-reads from HBM but its 48 KiB per workgroup cuts residency to 3 waves per SIMD (62 ms);
     // a 512-hit ring 46 ms; scoring 2 or 4 chunks ahead of the resolution 49 / 85 ms.  Each hit is re-read ~250 times by
@@ -73,6 +110,99 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
     // end / period of the 64 hits of cur's chunk, one per lane: the current hit's pair is a v_readlane away -- a load per hit
     // (two dependent round trips to L2 before the first trip could start) was a quarter of the kernel's time
     int c_e = lane < n ? E[lane] : 0, c_p = lane < n ? Pd[lane] : 1;
+    // ---- class lists of this read (see above): three passes over its hits, 64 at a time
+    __shared__ int s_cls[CLS ? TH_CHAIN_BLOCK / TH_WAVE : 1][CLS ? 128 : 1];       // per wave: [bin] heads of the bin, then the list of the bin (or -1)
+    unsigned long long *lst_rec = nullptr; uint16_t *lst_idx = nullptr;
+    int v_lbase = 0, v_run = 0, v_llo = 0, v_lhi = 0;      // lane j: list j's first entry in the read's list area / entries appended so far / its periods: llo < pp < lhi
+    int n_lists = 0;
+    if (CLS && n > 2 * TH_WAVE) {
+        int *s_b2l = s_cls[threadIdx.x >> 6];
+        lst_rec = cls_rec + (size_t)TH_CLS_DUP * off; lst_idx = cls_idx + (size_t)TH_CLS_DUP * off;
+        const int cap_entries = TH_UNI(TH_CLS_DUP * (int)(roff[r + 1] - off));
+        s_b2l[lane] = 0; s_b2l[lane + TH_WAVE] = 0;
+        TH_WAVE_FENCE();
+        // pass 0: run heads per period bin
+        {
+            int pe_ = 0, pp_ = 0;
+            for (int cb = 0; cb < n; cb += TH_WAVE) {
+                const bool okl = cb + lane < n;
+                const int e_ = okl ? E[cb + lane] : 0, p_ = okl ? Pd[cb + lane] : 1;
+                const int qe = th_shr1(e_, pe_), qp = th_shr1(p_, pp_), d_ = e_ - qe;
+                const bool fol = okl && (cb + lane) >= 1 && p_ == qp && d_ >= 1 && d_ < k && d_ <= p_;
+                const int b_ = th_pbin(p_);
+                if (okl && !fol && cb + lane >= 1 && b_ >= 0) atomicAdd(&s_b2l[b_], 1);
+                pe_ = TH_READLANE(e_, TH_WAVE - 1); pp_ = TH_READLANE(p_, TH_WAVE - 1);
+            }
+        }
+        TH_WAVE_FENCE();
+        // the bins that get a list (lane l looks after bins l and l + 64): enough heads, and LONG windows only -- a head's window holds about cp x (hits per base) hits, and below
+        // TH_CLS_MIN_WINDOW of them the scan of the hit array, its first trips served by the LDS ring, is cheaper than a list's upkeep (the main period's own class would be the
+        // largest list by far: two thirds of the hits)
+        const int win_thr = TH_UNI((int)(((long long)TH_CLS_MIN_WINDOW * (long long)(roff[r + 1] - off) + n - 1) / n));
+        const int b0 = lane, b1 = lane + TH_WAVE;
+        const bool sel0_ = s_b2l[b0] >= TH_CLS_MIN_HEADS && th_pbin_lo(b0) >= win_thr, sel1_ = b1 < TH_CLS_NB && s_b2l[b1] >= TH_CLS_MIN_HEADS && th_pbin_lo(min(b1, TH_CLS_NB - 1)) >= win_thr;
+        unsigned long long selm0 = TH_BALLOT(sel0_), selm1 = TH_BALLOT(sel1_);
+        while (__popcll(selm0) + __popcll(selm1) > TH_CLS_MAXL) { if (selm0) selm0 &= selm0 - 1; else selm1 &= selm1 - 1; }      // (more than 24: the shortest periods go without)
+        const int n0 = (int)__popcll(selm0);
+        const int j0 = (int)__popcll(selm0 & ((1ull << lane) - 1)), j1 = n0 + (int)__popcll(selm1 & ((1ull << lane) - 1));
+        const bool s0 = (selm0 >> lane) & 1, s1 = (selm1 >> lane) & 1;
+        n_lists = n0 + (int)__popcll(selm1);
+        TH_WAVE_FENCE();
+        s_b2l[b0] = s0 ? j0 : -1; s_b2l[b1] = s1 ? j1 : -1;
+        // a list's periods: everything a head of the bin can connect to -- 5 cp < 9 pp and 5 pp < 9 cp for cp in [lo, hi] <=> (5 lo) / 9 < pp < ceil(9 hi / 5) -- handed from the bin's lane to lane j through LDS
+        __shared__ int s_rng[CLS ? TH_CHAIN_BLOCK / TH_WAVE : 1][CLS ? 2 * TH_CLS_MAXL : 1];
+        int *s_r = s_rng[threadIdx.x >> 6];
+        if (s0) { s_r[2 * j0] = (5 * th_pbin_lo(b0)) / 9; s_r[2 * j0 + 1] = (9 * (th_pbin_lo(b0 + 1) - 1) + 4) / 5; }
+        if (s1) { s_r[2 * j1] = (5 * th_pbin_lo(b1)) / 9; s_r[2 * j1 + 1] = (9 * (th_pbin_lo(b1 + 1) - 1) + 4) / 5; }
+        TH_WAVE_FENCE();
+        if (lane < n_lists) { v_llo = s_r[2 * lane]; v_lhi = s_r[2 * lane + 1]; }
+        // pass 1: entries per list
+        int v_cnt = 0;                     // lane j: entries of list j
+        for (int cb = 0; cb < n; cb += TH_WAVE) {
+            const uint32_t p_ = cb + lane < n ? (uint32_t)Pd[cb + lane] : 0u;
+            for (int j = 0; j < n_lists; ++j) {
+                const uint32_t lo_ = (uint32_t)TH_READLANE(v_llo, j), hi_ = (uint32_t)TH_READLANE(v_lhi, j);
+                const int c_ = (int)__popcll(TH_BALLOT(p_ - lo_ - 1u < hi_ - lo_ - 1u));
+                if (lane == j) v_cnt += c_;
+            }
+        }
+        // a list pays only if it FILTERS: one that holds more than TH_CLS_MAX_SHARE / 16 of the read's hits (the main period's own class, when that is what has the long windows:
+        // config 4) costs its upkeep and the dearer trip and saves nothing -- dropped, the others close ranks (lane j -> its rank among the kept) and the bins follow
+        {
+            const unsigned long long keepm = TH_BALLOT(lane < n_lists && 16 * v_cnt <= TH_CLS_MAX_SHARE * n);
+            if (keepm != (n_lists >= 64 ? ~0ull : (1ull << n_lists) - 1)) {
+                const int nj = (int)__popcll(keepm & ((1ull << lane) - 1));
+                const bool kp = (keepm >> lane) & 1;
+                TH_WAVE_FENCE();
+                if (lane < n_lists) s_r[lane] = kp ? nj : -1;                     // old list -> new list
+                TH_WAVE_FENCE();
+                { const int o0 = s_b2l[b0], o1 = s_b2l[b1]; const int m0 = o0 >= 0 ? s_r[o0] : -1, m1 = o1 >= 0 ? s_r[o1] : -1; TH_WAVE_FENCE(); s_b2l[b0] = m0; s_b2l[b1] = m1; }
+                TH_WAVE_FENCE();
+                if (kp) { s_r[nj] = v_llo; s_r[TH_CLS_MAXL + nj] = v_lhi; }
+                TH_WAVE_FENCE();
+                const int nl_ = (int)__popcll(keepm);
+                // counts move with their lists
+                int moved = 0;
+                for (int j = 0; j < n_lists; ++j) { const int c_ = TH_READLANE(v_cnt, j); const int t_ = TH_READLANE(kp ? nj : -1, j); if (t_ >= 0 && lane == t_) moved = c_; }
+                v_cnt = moved;
+                if (lane < nl_) { v_llo = s_r[lane]; v_lhi = s_r[TH_CLS_MAXL + lane]; } else { v_llo = 0; v_lhi = 0; }
+                n_lists = TH_UNI(nl_);
+                TH_WAVE_FENCE();
+            }
+        }
+        // lists that do not fit the read's area are dropped from the top (their heads scan the hit array)
+        {
+            int tot = 0;
+            for (int j = 0; j < n_lists; ++j) { const int c_ = TH_READLANE(v_cnt, j); if (tot + c_ > cap_entries) { n_lists = j; break; } if (lane == j) v_lbase = tot; tot += c_; }
+        }
+        n_lists = TH_UNI(n_lists);
+#if defined(TH_CHAIN_PROF)
+        if (lane == 0) atomicAdd(&th_chain_prof[7], (unsigned long long)n_lists);
+#endif
+        TH_WAVE_FENCE();
+    }
+    int c_hj = -1;                         // this lane's hit: the list a head of its bin scans (or -1)
+    if (CLS && n_lists && lane < n) { const int b_ = th_pbin(c_p); const int j_ = b_ >= 0 ? s_cls[threadIdx.x >> 6][b_] : -1; c_hj = j_ < n_lists ? j_ : -1; }
     // FOLLOWERS.  A hit whose immediate predecessor has the same period and ends fewer than k bases before it -- the next k-mer of a
     // run of matching k-mers, ~80 % of the hits of a tandem repeat at 10 % error -- needs no scan: that predecessor is a connection
     // of type OVL (:151-166: same period, matched = 2 d < 2 k), an OVL connection ends the scan whether it improves or not
@@ -93,6 +223,7 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
                 TH_WAVE_FENCE();
             }
             if (cb + lane < n) { c_e = E[cb + lane]; c_p = Pd[cb + lane]; }
+            if (CLS && n_lists) { c_hj = -1; if (cb + lane < n) { const int b_ = th_pbin(c_p); const int j_ = b_ >= 0 ? s_cls[threadIdx.x >> 6][b_] : -1; c_hj = j_ < n_lists ? j_ : -1; } }
         }
         const int ring_lo = RING ? cb + TH_WAVE - RING : 0;      // oldest hit index the ring still holds
         const bool okl = cb + lane < n;
@@ -135,6 +266,83 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
         const uint32_t plo = (5u * (uint32_t)cp) / 9u, phi = (9u * (uint32_t)cp + 4u) / 5u;
         const int hslot = RP2 ? 0 : (cur_slot + h >= RING ? cur_slot + h - RING : cur_slot + h);        // cur mod RING
         int bslot = RP2 ? 0 : (hslot == 0 ? RING - 1 : hslot - 1);      // (cur - 1) mod RING
+        const int hj = (CLS && n_lists) ? TH_READLANE(c_hj, h) : -1;
+        if (CLS && hj >= 0) {
+            // ---- the head's bin has a list (see the top of the kernel).  One trip: 64 predecessors, lane l holding hit `idx`; `livem`: the lanes that hold one.  The rules of
+            // the scan below, with the max_h rule (:349) on hit indices: it counts the hits scanned since the last improvement, listed or not
+            int last_imp = cur;                         // hit index of the last improvement
+            auto cls_trip = [&](const unsigned long long rec, const int idx, const unsigned long long livem) -> unsigned long long {
+                const int pe = (int)((uint32_t)rec >> 16), pp = (int)((uint32_t)rec & 0xffffu), psc = (int)(rec >> 32);
+                const int ps = pe - pp;
+                const unsigned long long dstopm = livem & TH_BALLOT(pe < cs);                              // :331
+                const unsigned long long conm = livem & ~dstopm & TH_BALLOT(cs > ps) & TH_BALLOT((uint32_t)pp - plo - 1u < phi - plo - 1u);
+                const int dis1 = ce - pe, dis2 = cs - ps;
+                const int matched = min(dis1, k) + min(dis2, k);
+                const int dq = cp - pp;
+                const int dq2h = (int)((uint32_t)__mul24(dq, dq) >> 1);
+                const int clzh = TH_CLZ_NZ(dis1 + dis2) >> 1;
+                const int s = TH_LANE_OF_MASK(conm, lane) ? (psc + matched + clzh) - dq2h : -0x40000000;
+                unsigned long long impm = TH_BALLOT(s > best);
+                const unsigned long long samem = conm & TH_BALLOT(cp == pp);
+                unsigned long long stopm = dstopm | (samem & TH_BALLOT(matched < 2 * k));
+                // the max_h rule can fire in this trip only if its lowest index lies max_h hits or more below the last improvement (one inside the trip only moves that further down)
+                const bool mh = last_imp - TH_READLANE(idx, th_msb64nz(livem)) >= max_h;
+                if (impm) {
+                    if (impm & (impm - 1)) {
+                        const int rb = max(th_shr1_z(th_wave_incl_max(s)), best);
+                        impm = TH_BALLOT(s > rb);
+                    }
+                    if (mh) {
+                        // per lane the hit index of the last improvement before it in scan order; a hit MORE than max_h below that was never reached by the scan of the hit
+                        // array (it had stopped at an unlisted hit): whatever it scores, the scan ends in front of it
+                        const unsigned long long below = impm & ((1ull << lane) - 1);
+                        const int sh_ = __shfl(idx, th_msb64(below | 1ull));
+                        const int li = below ? sh_ : last_imp;
+                        const unsigned long long deadm = livem & TH_BALLOT(li - idx > max_h);
+                        impm &= ~deadm;
+                        stopm |= deadm | (livem & ~impm & TH_BALLOT(li - idx >= max_h));
+                    }
+                    stopm |= samem & impm;
+                    const unsigned long long taken = impm & (stopm ^ (stopm - 1));
+                    if (taken) { const int last = th_msb64nz(taken); best = TH_READLANE(s, last); bi = TH_READLANE(idx, last); last_imp = bi; }
+                } else if (mh) stopm |= livem & TH_BALLOT(last_imp - idx >= max_h);
+                return stopm;
+            };
+#if defined(TH_CHAIN_PROF)
+            int prof_trips = 0;
+#endif
+            unsigned long long ends = 0ull;
+            // (i) the hits of this chunk before the head, all of them: hit cur - 1 - lane for lane < h, from the LDS ring (where their scores were patched as they finished)
+            if (h > 0) {
+                const int idx = cur - 1 - lane;
+                const unsigned long long rec = ring[idx & (RING - 1)];
+                ends = cls_trip(rec, idx, (1ull << h) - 1);
+#if defined(TH_CHAIN_PROF)
+                ++prof_trips;
+#endif
+            }
+            ends = ((unsigned long long)(uint32_t)TH_UNI((int)(ends >> 32)) << 32) | (uint32_t)TH_UNI((int)ends);
+            // (ii) the list, from the entries appended before this chunk downwards: contiguous records and indices, the next trip's requested a trip ahead
+            int pos = TH_READLANE(v_run, hj) - 1;
+            if (!ends && pos >= 0) {
+                const int lb_ = TH_READLANE(v_lbase, hj);
+                const unsigned long long *recs = lst_rec + lb_; const uint16_t *idxs = lst_idx + lb_;
+                unsigned long long rec = recs[max(pos - lane, 0)]; int idx = (int)idxs[max(pos - lane, 0)];
+                for (;;) {
+#if defined(TH_CHAIN_PROF)
+                    ++prof_trips;
+#endif
+                    const unsigned long long rec_n = recs[max(pos - TH_WAVE - lane, 0)]; const int idx_n = (int)idxs[max(pos - TH_WAVE - lane, 0)];
+                    unsigned long long stop_ = cls_trip(rec, idx, pos >= TH_WAVE - 1 ? ~0ull : (2ull << pos) - 1);
+                    if (pos < TH_WAVE) stop_ |= 1ull;         // the list's last trip
+                    if (TH_UNI((int)(stop_ != 0ull))) break;
+                    pos -= TH_WAVE; rec = rec_n; idx = idx_n;
+                }
+            }
+#if defined(TH_CHAIN_PROF)
+            if (lane == 0) { atomicAdd(&th_chain_prof[0], 1ull); atomicAdd(&th_chain_prof[1], (unsigned long long)prof_trips); atomicAdd(&th_chain_prof[4], 1ull); atomicAdd(&th_chain_prof[5], (unsigned long long)prof_trips); }
+#endif
+        } else {
         // The packed records of a trip: 64 hits base, base-1, ... -- from the ring when the whole trip lies inside it, else from HBM (two
         // different loads under a wave-uniform branch: a select between the two POINTERS would become one flat load, which waits for the
         // wave's outstanding global stores -- the previous hit's results -- before every trip).  Lanes before the first hit read some
@@ -246,6 +454,7 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
         if (lane == 0) { atomicAdd(&th_chain_prof[0], 1ull); atomicAdd(&th_chain_prof[1], (unsigned long long)prof_trips); }
 #endif
         TH_LDS_ASYNC_WAIT(rec_next);           // a scan that stopped leaves its last request in flight: its registers stay reserved until it lands
+        }
         best -= 15;
         if (lane == 0 && best > init) {                                                                 // :352-354
             S[cur] = best; F[cur] = bi;
@@ -256,6 +465,25 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             } else best -= 15;
             seg_sc = max(best, init); seg_ps = TH_READLANE(ps, h); seg_lo = h + 1;
             if (lane == h) fin = seg_sc;
+        }
+        // the chunk's hits, finished, join the lists of their period class (records from registers: end, period, final score)
+        if (CLS && n_lists) {
+            const unsigned long long rec_ = (unsigned long long)(uint32_t)fin << 32 | (uint32_t)c_e << 16 | (uint32_t)c_p;
+            const uint32_t p_ = okl ? (uint32_t)c_p : 0u;
+            for (int j = 0; j < n_lists; ++j) {
+                const uint32_t lo_ = (uint32_t)TH_READLANE(v_llo, j), hi_ = (uint32_t)TH_READLANE(v_lhi, j);
+                const bool mem_ = p_ - lo_ - 1u < hi_ - lo_ - 1u;
+                const unsigned long long mm = TH_BALLOT(mem_);
+                if (mm) {
+                    const int at = TH_READLANE(v_lbase, j) + TH_READLANE(v_run, j) + th_mbcnt(mm);
+                    if (mem_) { lst_rec[at] = rec_; lst_idx[at] = (uint16_t)(cb + lane); }
+                    if (lane == j) v_run += (int)__popcll(mm);
+#if defined(TH_CHAIN_PROF)
+                    if (lane == 0) atomicAdd(&th_chain_prof[6], (unsigned long long)__popcll(mm));
+#endif
+                }
+            }
+            TH_WAVE_FENCE();
         }
         // the chunk's last hit is what the next chunk's first one looks back at
         const int last = min(TH_WAVE, n - cb) - 1;
