@@ -539,3 +539,25 @@ def test_emul_single_copy_reads_searched_on_the_device():
         n = U.assert_records_equal(seqs, got, para, "single copy %r" % (extra,))
         assert n >= 4, n
         th.close()
+
+
+def test_emul_chain_dp_period_class_lists_everywhere():
+    """round 6: th_k_chain_dp's period-class lists (th_k_chain.hip, CLS) -- a head of a listed period bin scans the hits of its own chunk, then its class's list of
+    finished hits instead of the hit array.  The product lists bins with 16 heads, long windows and lists that filter; this build (`libth_emul_cls.so`: two heads, any
+    window, any share) lists EVERYTHING, so the listed scan -- own-chunk trip, list trips, first / last trips of a list, the max_h rule (src/tandem_chain.c:349) on hit
+    indices in dense windows of error-free and low-error short periods, more bins than lists -- runs on every shape; scores and predecessors of every hit, chains and
+    par_pos against the oracle's stage dumps (src/tandem_chain.c:325-356)"""
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(U.ROOT, "tests", "cpu_emul"), "libth_emul_cls.so"], check=True, stdout=subprocess.DEVNULL)
+    lib = os.path.join(U.ROOT, "tests", "cpu_emul", "libth_emul_cls.so")
+    L = TH.load_library()
+    rng = np.random.default_rng(17)
+    seqs = [TH.synth_read(L, 31, i, p, c, e) for i, (p, c, e) in enumerate([(1000, 6, 0.10), (64, 60, 0.02), (64, 60, 0.0), (40, 90, 0.01), (200, 20, 0.10), (300, 12, 0.0),
+                                                                             (131, 30, 0.05), (2500, 3, 0.12), (97, 40, 0.15), (500, 9, 0.08)])]
+    # a read of several different repeats in a row: many period bins with heads (more than the 24 lists a read may keep)
+    seqs.append(b"".join(TH.synth_read(L, 32, i, p, 5, 0.06) for i, p in enumerate(range(70, 1400, 55))))
+    seqs.append(bytes(b"ACGT"[i] for i in rng.integers(0, 4, 4000)))
+    th = TH.TideHunter(lib_path=lib, only_unit=1)
+    th.process(seqs)
+    U.stage_compare(th, seqs, O.default_para(only_unit=1))
+    th.close()

@@ -305,3 +305,28 @@ def test_gpu_chain_dp_ring_variants_agree(monkeypatch):
         t.process(seqs)
         U.stage_compare(t, seqs, para)
         t.close()
+
+
+def test_gpu_chain_dp_period_class_lists_everywhere():
+    """round 6: the chain DP's period-class lists (th_k_chain.hip, CLS).  The product lists period bins with 16 heads, windows of 512 hits and lists that hold at most half
+    of the read's hits -- so on the device its listed scan only ever sees the long windows of multi-period heads.  `tests/cpu_emul/libth_clsall.so` (csrc/Makefile `clsall`,
+    built by build(); built here if the snapshot lacks it) is the same library with a list for EVERY bin that has two heads: the listed scan -- own-chunk trip from the
+    LDS ring, list trips, the max_h rule (src/tandem_chain.c:349) on hit indices in dense windows, lists dropped at capacity, more bins than lists -- runs on every shape.
+    Hits, DP scores and predecessors of every hit, chains and par_pos against the oracle's stage dumps (src/tandem_chain.c:325-356), and with the product library as well."""
+    import subprocess
+    ca = os.path.join(U.ROOT, "tests", "cpu_emul", "libth_clsall.so")
+    if not os.path.exists(ca):
+        subprocess.run(["make", "-s", "-C", os.path.join(U.ROOT, "tidehunter_amd", "csrc"), "clsall"], check=True, timeout=900)
+    L = TH.load_library()
+    rng = np.random.default_rng(23)
+    seqs = _synth(L, 96, 1000, 10, 0.10, 41) + _synth(L, 64, 200, 20, 0.10, 42) + _synth(L, 12, 5000, 4, 0.15, 43) + _synth(L, 24, 2000, 5, 0.12, 44)
+    seqs += [TH.synth_read(L, 45, i, p, c, e) for i, (p, c, e) in enumerate([(64, 60, 0.02), (64, 60, 0.0), (40, 90, 0.01), (300, 12, 0.0), (131, 30, 0.05), (97, 40, 0.15), (500, 9, 0.08), (31, 100, 0.03)] * 3)]
+    seqs += [b"".join(TH.synth_read(L, 46 + r, i, p, 5, 0.06) for i, p in enumerate(range(70, 1400, 55))) for r in range(4)]        # many period bins with heads in one read
+    seqs += [s for _, s in U.read_fastx(os.path.join(U.DATA, "test.fq"))]
+    seqs.append(bytes(b"ACGT"[i] for i in rng.integers(0, 4, 30000)))
+    para = O.default_para(only_unit=1)
+    for path in (ca, None):
+        t = TH.TideHunter(device=0, lib_path=path, only_unit=1)
+        t.process(seqs)
+        U.stage_compare(t, seqs, para)
+        t.close()

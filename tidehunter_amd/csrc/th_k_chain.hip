@@ -51,7 +51,9 @@ __device__ unsigned long long th_chain_prof[8];      // [4] heads that scanned a
 #define TH_CLS_NB 120           // period bins: 12 per octave (ratio 1.059) from period 64 up, periods < 65536.  Narrow on purpose: a tandem repeat's classes sit at ratio 2 (one and two
                                 // unit lengths) and a connection needs ratio < 1.8, so a bin's list may reach only ~10 % beyond what its heads can connect to or it swallows the next class
 #define TH_CLS_MAXL 24          // lists per read
+#ifndef TH_CLS_MIN_HEADS
 #define TH_CLS_MIN_HEADS 16     // a bin gets a list when at least this many heads would use it ...
+#endif
 #ifndef TH_CLS_MIN_WINDOW
 #define TH_CLS_MIN_WINDOW 512    // ... and its heads' windows hold about this many hits or more
 #endif
