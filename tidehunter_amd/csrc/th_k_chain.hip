@@ -52,7 +52,7 @@ __device__ unsigned long long th_chain_prof[8];      // [4] heads that scanned a
                                 // unit lengths) and a connection needs ratio < 1.8, so a bin's list may reach only ~10 % beyond what its heads can connect to or it swallows the next class
 #define TH_CLS_MAXL 24          // lists per read
 #ifndef TH_CLS_MIN_HEADS
-#define TH_CLS_MIN_HEADS 16     // a bin gets a list when at least this many heads would use it ...
+#define TH_CLS_MIN_HEADS 6      // a bin gets a list when at least this many heads would use it (measured at the headline shape: 32 -> 84.3 ms, 16 -> 78.6, 8 -> 75.6, 4 -> 74.8, 2 -> 76.1) ...
 #endif
 #ifndef TH_CLS_MIN_WINDOW
 #define TH_CLS_MIN_WINDOW 512    // ... and its heads' windows hold about this many hits or more
@@ -329,16 +329,26 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             if (!ends && pos >= 0) {
                 const int lb_ = TH_READLANE(v_lbase, hj);
                 const unsigned long long *recs = lst_rec + lb_; const uint16_t *idxs = lst_idx + lb_;
-                unsigned long long rec = recs[max(pos - lane, 0)]; int idx = (int)idxs[max(pos - lane, 0)];
-                for (;;) {
+                int li = pos - lane;                                   // this lane's entry of the trip at hand (negative: none)
+                unsigned long long rec = recs[max(li, 0)]; int idx = (int)idxs[max(li, 0)];
+                unsigned long long stop_ = 0ull;
+                // full trips (every lane holds an entry: the masks of the rules need no "lanes that hold one"), then the list's last, partial one
+                while (pos >= TH_WAVE - 1) {
 #if defined(TH_CHAIN_PROF)
                     ++prof_trips;
 #endif
-                    const unsigned long long rec_n = recs[max(pos - TH_WAVE - lane, 0)]; const int idx_n = (int)idxs[max(pos - TH_WAVE - lane, 0)];
-                    unsigned long long stop_ = cls_trip(rec, idx, pos >= TH_WAVE - 1 ? ~0ull : (2ull << pos) - 1);
-                    if (pos < TH_WAVE) stop_ |= 1ull;         // the list's last trip
-                    if (TH_UNI((int)(stop_ != 0ull))) break;
+                    li -= TH_WAVE;
+                    const unsigned long long rec_n = recs[max(li, 0)]; const int idx_n = (int)idxs[max(li, 0)];
+                    stop_ = cls_trip(rec, idx, ~0ull);
+                    stop_ = ((unsigned long long)(uint32_t)TH_UNI((int)(stop_ >> 32)) << 32) | (uint32_t)TH_UNI((int)stop_);
                     pos -= TH_WAVE; rec = rec_n; idx = idx_n;
+                    if (stop_) break;
+                }
+                if (!stop_ && pos >= 0) {
+#if defined(TH_CHAIN_PROF)
+                    ++prof_trips;
+#endif
+                    (void)cls_trip(rec, idx, (2ull << pos) - 1);
                 }
             }
 #if defined(TH_CHAIN_PROF)
