@@ -32,8 +32,17 @@ K = 8                                   # default k (src/tidehunter.h: DEF_KMER_
 _rng = np.random.default_rng(20261004)
 
 
-def rnd(n):
-    return bytes(b"ACGT"[i] for i in _rng.integers(0, 4, n))
+def rnd(n, rng=None):
+    return bytes(b"ACGT"[i] for i in (rng or _rng).integers(0, 4, n))
+
+
+def seeded(seed):
+    """a generator of a test's own: its draws do not depend on which tests ran before it in this process (pytest-xdist spreads the suite over workers)"""
+    return np.random.default_rng(seed)
+
+
+def is_rotation(a, b):
+    return len(a) == len(b) and a in b + b
 
 
 _comp = bytes.maketrans(b"ACGT", b"TGCA")
@@ -190,7 +199,7 @@ def test_filters_see_the_trimmed_consensus(backend, adapter_files):
     read = read_of(cons)
     assert [len(r) for r in records(backend, [read, read], adapters=adapter_files[0], min_len=100)] == [1, 1]
     assert records(backend, [read], adapters=adapter_files[0], min_len=101) == [[]]
-    plain = rnd(220)                                                   # no adapter anywhere: fullLen 0
+    plain = rnd(220, seeded(101))                                      # no adapter anywhere: fullLen 0
     got = records(backend, [read_of(plain), read], adapters=adapter_files[0], only_full_length=1)
     assert got[0] == [] and len(got[1]) == 1 and got[1][0]["full_length"] == 1
     got = records(backend, [read_of(plain)], adapters=adapter_files[0])
@@ -200,13 +209,16 @@ def test_filters_see_the_trimmed_consensus(backend, adapter_files):
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_only_longest_keeps_the_longer_span(backend):
     """-l (src/gen_cons.c:12-16): the second consensus replaces the first iff its span end - start is STRICTLY larger; else it is dropped"""
-    ua, ub = rnd(96), rnd(150)
+    g = seeded(102)
+    ua, ub = rnd(96, g), rnd(150, g)
     short_then_long = read_of(ua, 6) + read_of(ub, 10)                 # spans ~576 and ~1500 bases
     long_then_short = read_of(ua, 20) + read_of(ub, 6)                 # spans ~1920 and ~900 bases
     both = records(backend, [short_then_long])[0]
-    assert [r["seq"] for r in both] == [ua, ub]                        # chains by ascending end (src/tandem_chain.c:393-396)
+    # chains by ascending end (src/tandem_chain.c:393-396).  The first repeat starts the read, so its consensus is ua exactly; where the second one's first boundary falls
+    # depends on how many bases of the junction happen to continue its first k-mer backwards: its consensus is ub up to a rotation
+    assert len(both) == 2 and both[0]["seq"] == ua and is_rotation(both[1]["seq"], ub)
     got = records(backend, [short_then_long, long_then_short], only_longest=1)
-    assert [r["seq"] for r in got[0]] == [ub] and [r["seq"] for r in got[1]] == [ua]
+    assert len(got[0]) == 1 and is_rotation(got[0][0]["seq"], ub) and [r["seq"] for r in got[1]] == [ua]
     assert got[0][0]["end"] - got[0][0]["start"] > both[0]["end"] - both[0]["start"]
 
 
@@ -214,7 +226,7 @@ def test_only_longest_keeps_the_longer_span(backend):
 def test_two_units_consensus_is_the_first_unit(backend):
     """n_seqs <= 2 (src/abpoa_cons.c:57-83): no MSA; the consensus is unit 0 VERBATIM even when unit 1 differs; with a coverage bound the two
     units must be identical (_min_cov 2) or the run is dropped; FASTQ qualities are '!' (33)"""
-    P2 = rnd(256)
+    P2 = rnd(256, seeded(103))
     u = P2[-K:] + P2[:-K]
     same = u * 2 + u[:60]                                              # boundaries 7, 263, 519: two units
     differ = u + sub1(u, 100) + u[:60]
@@ -235,7 +247,7 @@ def test_two_units_consensus_is_the_first_unit(backend):
 
 
 def _unit256():
-    P2 = rnd(256)
+    P2 = rnd(256, seeded(104))
     return P2, P2[-K:] + P2[:-K]
 
 
