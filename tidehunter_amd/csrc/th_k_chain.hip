@@ -60,7 +60,7 @@ __device__ unsigned long long th_chain_prof[8];      // [4] heads that scanned a
 #ifndef TH_CLS_MAX_SHARE
 #define TH_CLS_MAX_SHARE 8       // ... and it holds at most this many sixteenths of the read's hits
 #endif
-#define TH_CLS_DUP 3            // list entries per base slot of the read (capacity of its list area: 10 bytes each)
+#define TH_CLS_DUP 3            // list entries per base slot of the read (capacity of its list area: 12 bytes each)
 // bin of a period: 12 (e - 6) + the number of thresholds T_i = round(1024 x 2^(i / 12)) at or below its 11-bit mantissa; -1 below 64
 __device__ __forceinline__ int th_pbin(int p)
 {
@@ -75,11 +75,12 @@ __device__ __forceinline__ int th_pbin_lo(int b)      // smallest period of bin 
     return (int)((((uint32_t)t << e) + 1023u) >> 10);
 }
 
+struct ThClsEnt { uint32_t ep; int sc; uint32_t ix; };      // a list entry: end << 16 | period, final score, hit index (one 12-byte load per lane and trip)
 template <bool PK, int RING, bool CLS = false>      // RING: entries of the LDS ring (0 = none, 512, 768, 1024); slot of hit x = x mod RING
 __global__ void __launch_bounds__(TH_CHAIN_BLOCK)
 th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
               const int *__restrict__ hit_end, const int *__restrict__ hit_per, const int *__restrict__ hit_n,
-              int *__restrict__ score, int *__restrict__ from, unsigned long long *__restrict__ eps, unsigned long long *__restrict__ cls_rec = nullptr, uint16_t *__restrict__ cls_idx = nullptr)
+              int *__restrict__ score, int *__restrict__ from, unsigned long long *__restrict__ eps, ThClsEnt *__restrict__ cls_ent = nullptr)
 {
     static_assert(!CLS || (PK && RING >= 2 * TH_WAVE && (RING & (RING - 1)) == 0), "the class lists hold 16-bit hit indices; a listed head reads its own chunk from the ring");
     // Measured alternatives (batch 16384, config 3; this version 43 ms): a per-wave LDS ring of the last 1024 hits
@@ -114,12 +115,12 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
     int c_e = lane < n ? E[lane] : 0, c_p = lane < n ? Pd[lane] : 1;
     // ---- class lists of this read (see above): three passes over its hits, 64 at a time
     __shared__ int s_cls[CLS ? TH_CHAIN_BLOCK / TH_WAVE : 1][CLS ? 128 : 1];       // per wave: [bin] heads of the bin, then the list of the bin (or -1)
-    unsigned long long *lst_rec = nullptr; uint16_t *lst_idx = nullptr;
+    ThClsEnt *lst_ent = nullptr;
     int v_lbase = 0, v_run = 0, v_llo = 0, v_lhi = 0;      // lane j: list j's first entry in the read's list area / entries appended so far / its periods: llo < pp < lhi
     int n_lists = 0;
     if (CLS && n > 2 * TH_WAVE) {
         int *s_b2l = s_cls[threadIdx.x >> 6];
-        lst_rec = cls_rec + (size_t)TH_CLS_DUP * off; lst_idx = cls_idx + (size_t)TH_CLS_DUP * off;
+        lst_ent = cls_ent + (size_t)TH_CLS_DUP * off;
         const int cap_entries = TH_UNI(TH_CLS_DUP * (int)(roff[r + 1] - off));
         s_b2l[lane] = 0; s_b2l[lane + TH_WAVE] = 0;
         TH_WAVE_FENCE();
@@ -273,8 +274,8 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             // ---- the head's bin has a list (see the top of the kernel).  One trip: 64 predecessors, lane l holding hit `idx`; `livem`: the lanes that hold one.  The rules of
             // the scan below, with the max_h rule (:349) on hit indices: it counts the hits scanned since the last improvement, listed or not
             int last_imp = cur;                         // hit index of the last improvement
-            auto cls_trip = [&](const unsigned long long rec, const int idx, const unsigned long long livem) -> unsigned long long {
-                const int pe = (int)((uint32_t)rec >> 16), pp = (int)((uint32_t)rec & 0xffffu), psc = (int)(rec >> 32);
+            auto cls_trip = [&](const uint32_t ep, const int psc, const int idx, const unsigned long long livem) -> unsigned long long {
+                const int pe = (int)(ep >> 16), pp = (int)(ep & 0xffffu);
                 const int ps = pe - pp;
                 const unsigned long long dstopm = livem & TH_BALLOT(pe < cs);                              // :331
                 const unsigned long long conm = livem & ~dstopm & TH_BALLOT(cs > ps) & TH_BALLOT((uint32_t)pp - plo - 1u < phi - plo - 1u);
@@ -318,7 +319,7 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             if (h > 0) {
                 const int idx = cur - 1 - lane;
                 const unsigned long long rec = ring[idx & (RING - 1)];
-                ends = cls_trip(rec, idx, (1ull << h) - 1);
+                ends = cls_trip((uint32_t)rec, (int)(rec >> 32), idx, (1ull << h) - 1);
 #if defined(TH_CHAIN_PROF)
                 ++prof_trips;
 #endif
@@ -327,28 +328,34 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
             // (ii) the list, from the entries appended before this chunk downwards: contiguous records and indices, the next trip's requested a trip ahead
             int pos = TH_READLANE(v_run, hj) - 1;
             if (!ends && pos >= 0) {
-                const int lb_ = TH_READLANE(v_lbase, hj);
-                const unsigned long long *recs = lst_rec + lb_; const uint16_t *idxs = lst_idx + lb_;
+                const ThClsEnt *ents = lst_ent + TH_READLANE(v_lbase, hj);
                 int li = pos - lane;                                   // this lane's entry of the trip at hand (negative: none)
-                unsigned long long rec = recs[max(li, 0)]; int idx = (int)idxs[max(li, 0)];
+                ThClsEnt ea = ents[max(li, 0)], eb;
                 unsigned long long stop_ = 0ull;
-                // full trips (every lane holds an entry: the masks of the rules need no "lanes that hold one"), then the list's last, partial one
+                // full trips (every lane holds an entry: the masks of the rules need no "lanes that hold one"), two per round of the loop -- the entries of a trip are requested
+                // during the trip before, into the OTHER register set: a copy of a loaded register at the loop's bottom would wait for the load right there -- then the
+                // list's last, partial trip
+#define TH_CLS_FULL_TRIP(CUR, NXT) { li -= TH_WAVE; NXT = ents[max(li, 0)]; stop_ = cls_trip(CUR.ep, CUR.sc, (int)CUR.ix, ~0ull); \
+                                     stop_ = ((unsigned long long)(uint32_t)TH_UNI((int)(stop_ >> 32)) << 32) | (uint32_t)TH_UNI((int)stop_); pos -= TH_WAVE; }
                 while (pos >= TH_WAVE - 1) {
 #if defined(TH_CHAIN_PROF)
                     ++prof_trips;
 #endif
-                    li -= TH_WAVE;
-                    const unsigned long long rec_n = recs[max(li, 0)]; const int idx_n = (int)idxs[max(li, 0)];
-                    stop_ = cls_trip(rec, idx, ~0ull);
-                    stop_ = ((unsigned long long)(uint32_t)TH_UNI((int)(stop_ >> 32)) << 32) | (uint32_t)TH_UNI((int)stop_);
-                    pos -= TH_WAVE; rec = rec_n; idx = idx_n;
+                    TH_CLS_FULL_TRIP(ea, eb);
+                    if (stop_) break;
+                    if (pos < TH_WAVE - 1) { ea = eb; break; }
+#if defined(TH_CHAIN_PROF)
+                    ++prof_trips;
+#endif
+                    TH_CLS_FULL_TRIP(eb, ea);
                     if (stop_) break;
                 }
+#undef TH_CLS_FULL_TRIP
                 if (!stop_ && pos >= 0) {
 #if defined(TH_CHAIN_PROF)
                     ++prof_trips;
 #endif
-                    (void)cls_trip(rec, idx, (2ull << pos) - 1);
+                    (void)cls_trip(ea.ep, ea.sc, (int)ea.ix, (2ull << pos) - 1);
                 }
             }
 #if defined(TH_CHAIN_PROF)
@@ -480,7 +487,6 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
         }
         // the chunk's hits, finished, join the lists of their period class (records from registers: end, period, final score)
         if (CLS && n_lists) {
-            const unsigned long long rec_ = (unsigned long long)(uint32_t)fin << 32 | (uint32_t)c_e << 16 | (uint32_t)c_p;
             const uint32_t p_ = okl ? (uint32_t)c_p : 0u;
             for (int j = 0; j < n_lists; ++j) {
                 const uint32_t lo_ = (uint32_t)TH_READLANE(v_llo, j), hi_ = (uint32_t)TH_READLANE(v_lhi, j);
@@ -488,7 +494,7 @@ th_k_chain_dp(const uint32_t *__restrict__ roff, int n_reads, ThDevPara P,
                 const unsigned long long mm = TH_BALLOT(mem_);
                 if (mm) {
                     const int at = TH_READLANE(v_lbase, j) + TH_READLANE(v_run, j) + th_mbcnt(mm);
-                    if (mem_) { lst_rec[at] = rec_; lst_idx[at] = (uint16_t)(cb + lane); }
+                    if (mem_) { ThClsEnt e_; e_.ep = (uint32_t)c_e << 16 | (uint32_t)c_p; e_.sc = fin; e_.ix = (uint32_t)(cb + lane); lst_ent[at] = e_; }
                     if (lane == j) v_run += (int)__popcll(mm);
 #if defined(TH_CHAIN_PROF)
                     if (lane == 0) atomicAdd(&th_chain_prof[6], (unsigned long long)__popcll(mm));

@@ -92,7 +92,7 @@ struct th_gpu {
     DBuf<uint16_t> d_xorder; DBuf<int> d_xstart, d_xend, d_xovf;
     DBuf<int> d_cov_c, d_cc_off;                           // compacted results
     DBuf<int> d_hit_end, d_hit_per, d_hit_n, d_score, d_from, d_cells, d_read_ch_base, d_read_ch_n;
-    DBuf<unsigned long long> d_gsort, d_eps, d_cls_rec; DBuf<uint16_t> d_cls;      // d_cls_rec / d_cls: the chain DP's period-class lists, TH_CLS_DUP entries (8-byte record + 16-bit hit index) per base slot
+    DBuf<unsigned long long> d_gsort, d_eps; DBuf<ThClsEnt> d_cls;      // d_cls: the chain DP's period-class lists, TH_CLS_DUP 12-byte entries per base slot
     DBuf<ThCnt> d_cnt; th_pvec<ThCnt> h_cnt;
     DBuf<ThChainRec> d_rec;
     DBuf<int> d_par, d_par_off, d_par_n, d_par_dst, d_parc, d_bnd, d_scratch, d_cov, d_cons_len, d_status, d_iden, d_ext, d_slb;
@@ -188,7 +188,7 @@ extern "C" void th_gpu_destroy(th_gpu_t *g)
     for (int s = 0; s < 2; ++s) { g->in[s].d_seq.release(); g->in[s].d_roff.release(); g->in[s].d_gsort_off.release(); if (g->in[s].ev_ok) th_rt_event_destroy(g->in[s].ev); }
     g->d_bseq.release(); g->d_tracked.release(); g->d_cons.release(); g->d_cons_c.release(); g->d_tmp.release(); g->d_pk2.release(); g->d_nmask.release(); g->d_xorder.release(); g->d_xstart.release(); g->d_xend.release(); g->d_xovf.release();
     g->d_cov_c.release(); g->d_cc_off.release(); g->d_hit_end.release(); g->d_hit_per.release(); g->d_hit_n.release(); g->d_score.release(); g->d_from.release(); g->d_cells.release();
-    g->d_read_ch_base.release(); g->d_read_ch_n.release(); g->d_gsort.release(); g->d_eps.release(); g->d_cls.release(); g->d_cls_rec.release(); g->d_cnt.release(); g->d_rec.release();
+    g->d_read_ch_base.release(); g->d_read_ch_n.release(); g->d_gsort.release(); g->d_eps.release(); g->d_cls.release(); g->d_cnt.release(); g->d_rec.release();
     g->d_par.release(); g->d_par_off.release(); g->d_par_n.release(); g->d_par_dst.release(); g->d_parc.release(); g->d_bnd.release(); g->d_scratch.release();
     g->d_cov.release(); g->d_cons_len.release(); g->d_status.release(); g->d_iden.release(); g->d_ext.release(); g->d_slb.release();
     g->d_rows.release(); g->d_list_n.release(); g->d_list_w.release(); g->d_list_l.release(); g->d_sublist.release();
@@ -218,7 +218,7 @@ static size_t th_arena_want(const th_gpu *g, int n, long long T)
 {
     const double avg = (double)T / n;
     const size_t poa = (size_t)std::min<double>((double)TH_POA_SCRATCH_BYTES / 2, 100.0 * avg * 4.0 * std::min(n, g->waves_poa) * 1.3);
-    return (size_t)(100.0 * (double)T) + (size_t)n * 1280 + poa + (256u << 20);             // (buffers carry 12.5 % slack; consensus jobs, items, par_pos: ~14 bytes per base)
+    return (size_t)(106.0 * (double)T) + (size_t)n * 1280 + poa + (256u << 20);             // (buffers carry 12.5 % slack; consensus jobs, items, par_pos: ~14 bytes per base)
 }
 // does a further pipeline of this batch size fit next to what the device already holds?  (a third of the free memory at most:
 // buffers that outgrow the arena still need room)
@@ -509,9 +509,9 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
         const int ring = env_int("TH_CHAIN_RING", 512);
         // (round 6: per-read period-class lists -- th_k_chain.hip, CLS -- with the default ring; TH_CHAIN_CLS=0: every head scans the hit array, as before)
         if (ring == 512 && env_int("TH_CHAIN_CLS", 1)) {
-            TRY(g->d_cls.ensure((size_t)TH_CLS_DUP * padT)); TRY(g->d_cls_rec.ensure((size_t)TH_CLS_DUP * padT));
+            TRY(g->d_cls.ensure((size_t)TH_CLS_DUP * padT));
             TH_LAUNCH((th_k_chain_dp<true, 512, true>), (n + 3) / 4, TH_CHAIN_BLOCK, g->stream, (const uint32_t *)in.d_roff.p, n, g->dp,
-                      (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p, g->d_eps.p, g->d_cls_rec.p, g->d_cls.p);
+                      (const int *)g->d_hit_end.p, (const int *)g->d_hit_per.p, (const int *)g->d_hit_n.p, g->d_score.p, g->d_from.p, g->d_eps.p, g->d_cls.p);
         } else
         if (ring >= 1024) CHAIN_LAUNCH(1024); else if (ring >= 768) CHAIN_LAUNCH(768); else if (ring >= 640) CHAIN_LAUNCH(640); else if (ring >= 512) CHAIN_LAUNCH(512); else CHAIN_LAUNCH(0);
 #undef CHAIN_LAUNCH
