@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""BUILD CONTAINER: profiles/r05_poa_phases.json from the GPU box's gpurun_out/poa_phases/poa_phases_raw.json (tools/poa_phases.sh) and the ISA of the
+"""BUILD CONTAINER: profiles/rNN_poa_phases.json from the GPU box's gpurun_out/poa_phases/poa_phases_raw.json (tools/poa_phases.sh) and the ISA of the
 `base` variant (tools/build_variant.sh base -> /tmp/th_variant_base/*.s).
 
 What it holds, per launch of thpoa_n::th_k_poa<3072, short, true> over 100 000 headline reads:
@@ -10,8 +10,8 @@ What it holds, per launch of thpoa_n::th_k_poa<3072, short, true> over 100 000 h
   row_tables    chunks and relaxation rounds of the row-table phase by loop kind
   traceback     tiles loaded, run trips / steps, single steps
   isa           static instruction counts of the packed row's trip bodies (basic blocks with the three interleaved 6-step DPP scans) in the product's ISA
-  before        the same phase split at the start of round 5 (commit 3a6a9c4 + instrumentation), for the record of where the round's cuts went
-usage: tools/poa_phases_report.py [raw.json] [isa.s] > profiles/r05_poa_phases.json"""
+  before        the same phase split at the end of the round before
+usage: tools/poa_phases_report.py [raw.json] [isa.s] > profiles/r06_poa_phases.json"""
 import glob, json, re, subprocess, sys, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 raw = json.load(open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(R, "gpurun_out/poa_phases/poa_phases_raw.json")))
@@ -59,12 +59,11 @@ if isa:
             trips.append({"block": m.group(1), "instructions": int(m.group(2)), "valu": int(m.group(3)), "lane_ops": int(m.group(4)), "packed": int(m.group(6)), "salu": int(m.group(7)), "s_nop": int(m.group(9))})
     out["isa"] = {"trip_bodies": trips, "note": "basic blocks of the product kernel that hold the three interleaved 6-step DPP scans = the trip bodies of th_poa_pk_row's instantiations, in address order: "
                   "(common row: first trip incl. the row's scalar set-up, further trip), (bubble row, one / two / three-four predecessors: first, further), (far row: first, further), general path's packed row"}
-out["before"] = {
-    "note": "start of round 5 (round 4's kernel + the instrumentation), same method except that the reference was the plain build (no dup9 variant yet), hence phases summing past the total",
-    "totals": {"valu_wave_instr": 209.25e9, "salu_wave_instr": 186.89e9, "ms": 420.7},
-    "phases": {"row_tables": {"valu_wave_instr": 24.9e9, "salu_wave_instr": 11.8e9, "ms_marginal": 43.3}, "dp": {"valu_wave_instr": 176.9e9, "salu_wave_instr": 147.9e9, "ms_marginal": 340.0},
-               "traceback": {"valu_wave_instr": 15.7e9, "salu_wave_instr": 25.3e9, "ms_marginal": 56.5}, "consensus": {"valu_wave_instr": 3.5e9, "salu_wave_instr": 0.07e9, "ms_marginal": 7.0}},
-    "dp_rows": {"common_packed": 603516790, "packed_one_pred": 150832198, "packed_two_preds": 182220215, "packed_three_four_preds": 26269012, "packed_far": 51821096,
-                "general_several_preds": 13187581, "general_one_far_pred": 7552573, "general_stores_full": 180914, "general_other": 2471233, "packed_further_trips": 188602573}}
+# the same split at the end of the round before, for the record of where this round's cuts went
+try:
+    prev = json.load(open(os.path.join(R, "profiles", "r05_poa_phases.json")))
+    out["before"] = {"note": "end of round 5 (profiles/r05_poa_phases.json), same method", "totals": prev["totals"]["product_build"], "phases": prev["phases"], "traceback": prev.get("traceback")}
+except (OSError, ValueError, KeyError):
+    pass
 json.dump(out, sys.stdout, indent=1)
 print()
