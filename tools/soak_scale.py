@@ -20,4 +20,14 @@ for name, n, period, copies, err, seed, opts in [("C3", 20000, 1000, 10, 0.10, 1
     cpu = subprocess.run([ORACLE, "-t", str(U.effective_cpus()), *opts, fn], capture_output=True, check=True).stdout; t2 = time.time()
     print("%-6s %6d reads (seed %d) %s: %s  records %d  md5 %s  gpu %.1f s  oracle %.1f s" % (
         name, n, seed, " ".join(opts) or "-", "IDENTICAL" if gpu == cpu else "DIFFERENT", gpu.count(b">"), hashlib.md5(gpu).hexdigest(), t1 - t0, t2 - t1), flush=True)
+    # round 6: the same reads through the product library and its two test twins -- built WITHOUT -structurizecfg-skip-uniform-regions, and with the chain DP's
+    # period-class lists for every bin -- via th_process_batch + th_format_output: the three must print the command line's bytes
+    reads = [s for _, s in U.read_fastx(fn)]
+    names = [b"soak_%s_%d" % (name.encode(), i) for i in range(n)]
+    for tag, path in (("product", None), ("flag-off twin", os.path.join(R, "tests", "cpu_emul", "libth_nostruct.so")), ("lists-everywhere twin", os.path.join(R, "tests", "cpu_emul", "libth_clsall.so"))):
+        if path is not None and not os.path.exists(path):
+            print("       %s: not built" % tag); continue
+        t = TH.TideHunter(device=0, lib_path=path, out_fmt=2 if "-f" in opts else 1)
+        t.process(reads); text = t.format_output(names); t.close()
+        print("       %-22s md5 %s %s" % (tag, hashlib.md5(text).hexdigest(), "= the command line" if text == gpu else "DIFFERS FROM THE COMMAND LINE"), flush=True)
     os.unlink(fn)
