@@ -1,3 +1,4 @@
+# GPU box: th_k_chain_dp with the period-class lists off and on (TH_CHAIN_CLS=0 / 1): VALU / SALU wave-instructions, wave-cycles, vector-memory and LDS instructions per launch
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/pmc3; mkdir -p $O; export TMPDIR=/tmp; cd /tmp
 for v in 0 1; do
   TH_CHAIN_CLS=$v timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_LDS --output-format csv -d $O/pmc_$v -o run -- python3 $R/bench.py --steps 1 --warmup 0 --quick > $O/pmc_$v.log 2>&1
