@@ -980,7 +980,7 @@ __device__ __forceinline__ uint32_t th_poa_dir(const ThPoaG &g, int row, int o)
 // ---- traceback: wave-uniform walk over tiles of 16 rows x 4 diagonals; the tile is DECODED by all lanes, WALKED on the scalar unit, its operations WRITTEN by all lanes ----
 // Round 6.  Round 5's walk (below, -DTH_POA_TB=5) took one scalar trip per event -- tile load, run of plain diagonal steps, single step -- and stored every step's
 // operation from lane 0 under an execution mask of its own: 45 scalar + 22 vector instructions per event, 500 M events per launch of 100 000 headline reads
-// (profiles/r05_poa_phases.json).  Here a tile is lane l = 4 k + c <-> cell (row ti - k, column tj - k + 2 - c): the walk enters at lane 2 and EVERY move goes to a
+// (profiles/r05_poa_phases.json).  Here a tile is lane l = 4 k + c <-> cell (row ti - k, column tj - k + TH_TB_C0 - c): the walk enters at lane TH_TB_C0 (column tj) and EVERY move goes to a
 // higher lane -- a diagonal step to the row d above to l + 3 d + 1, a vertical one (deletion) to l + 3 d, a horizontal one (insertion) to l + 1 -- so
 //   * what the walk needs of a cell is decoded ONCE per tile by the cell's own lane: lane masks of the plain diagonal steps, of the diagonal steps to any predecessor,
 //     of the four "the gap goes on" bits, and the successor LANE of a diagonal step in a register (one v_readlane per step to another predecessor);
@@ -989,6 +989,10 @@ __device__ __forceinline__ uint32_t th_poa_dir(const ThPoaG &g, int row, int o)
 // A gap state that leaves the tile is carried into the next one and tested against the entry cell's word there (round 5 fetched that one word from memory).
 #ifndef TH_POA_TB
 #define TH_POA_TB 6
+#endif
+#ifndef TH_TB_C0
+#define TH_TB_C0 3        // the tile diagonal (c) the walk enters on: c + 1 .. 3 are reached by insertions, c - 1 .. 0 by deletions and by diagonal steps that skip rows.  3: no room on the
+                          // insertion side -- a graph row in seven is a bubble's other branch that the path steps over, so the walk drifts towards c = 0 at ~0.2 per row: 91.3 -> 84.1 M tiles per launch, -1.5 ms (2: one diagonal either way)
 #endif
 #if TH_POA_TB >= 6
 __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
@@ -1003,7 +1007,7 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
         const int ti = ci, tj = cj;
         TH_PROF_CNT(4, 1);
         // ---- the tile: every lane fetches and decodes its cell
-        const int row = ti - lk, col = tj - lk + 2 - lc;
+        const int row = ti - lk, col = tj - lk + TH_TB_C0 - lc;
         // t_w: the cell's direction word as the DP stored it -- the raw 16-bit word (th_k_poa.hip), or bit 31 | the 32-bit word of a row with more than four predecessors;
         // 0 outside the row's band, as in round 5's walk.  The lanes decode the raw form (two instructions per mask); expanding it to the TH_D_* layout was 20 vector
         // instructions per tile for fields only the gap steps read -- those expand their one word on the scalar unit (TH_TB_D)
@@ -1013,7 +1017,7 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
             const int rb = g.r_beg[row], re = g.r_end[row], meta = g.r_meta[row], roff = g.r_off[row], rfoff = g.r_foff[row];
             const int4 pp = ((const int4 *)g.r_p)[row];
             t_p0 = pp.x; t_p1 = pp.y; t_p2 = pp.z; t_p3 = pp.w;
-            TH_KEEP_V(rb); TH_KEEP_V(re); TH_KEEP_V(meta); TH_KEEP_V(roff); TH_KEEP_V(rfoff);
+            TH_KEEP_V(rb); TH_KEEP_V(re); TH_KEEP_V(meta); TH_KEEP_V(roff); TH_KEEP_V(rfoff);      // (the four row words as ONE 16-byte table entry: measured, no difference -- 343.4 against 343.6 ms)
             if (col >= rb && col <= re) {
                 const int deg_ = (meta >> 8) & 0xff;
                 if (deg_ > TH_D16_WIDE_DEG) t_w = g.cell[rfoff + (col - rb)].w | (int)0x80000000;
@@ -1043,13 +1047,13 @@ __device__ int th_poa_traceback(ThPoaG &g, int bi, int qlen)
 #define TH_TB_D(p_) ({ const int w_ = TH_READLANE(t_w, (p_)); w_ < 0 ? (uint32_t)w_ & 0x7fffffffu : th_d16_expand((uint32_t)w_); })
 #define TH_TB_XM(st_) ((st_) == 1 ? x_e1 : (st_) == 2 ? x_e2 : (st_) == 3 ? x_f1 : x_f2)
 #define TH_TB_ROW(p_) (ti - ((p_) >> 2))
-#define TH_TB_COL(p_) (tj - ((p_) >> 2) + 2 - ((p_) & 3))
+#define TH_TB_COL(p_) (tj - ((p_) >> 2) + TH_TB_C0 - ((p_) & 3))
         // ---- the walk inside the tile: scalar unit only (plus one lane read per irregular step).  ONE exit at the bottom (a loop with several `break`s gets a
         // dispatch word that every trip sets and tests -- DESIGN.md, "Control flow the scalar unit does not pay for"): a move that leaves the tile puts the lane position
         // beyond it -- 64 .. 67 when the position itself still says where the walk is (a run of plain steps off the tile's last row), 128 when xr / xc do
-        int p = 2, xr = 0, xc = 0;
+        int p = TH_TB_C0, xr = 0, xc = 0;
         unsigned long long vis = 0, vis_d = 0, vis_i = 0;
-        if (st) { if (!((TH_TB_XM(st) >> 2) & 1)) st = 0; }       // a gap state carried in: does the entry cell extend it?
+        if (st) { if (!((TH_TB_XM(st) >> TH_TB_C0) & 1)) st = 0; }       // a gap state carried in: does the entry cell extend it?
         do {
             const unsigned long long bit = 1ull << p;
             vis |= bit;                                                             // (every trip leaves lane p by exactly one operation)
