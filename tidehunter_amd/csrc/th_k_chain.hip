@@ -40,13 +40,14 @@ __device__ unsigned long long th_chain_prof[8];      // [4] heads that scanned a
 // ---- PERIOD-CLASS LISTS (round 6; CLS).  A head evaluates 836 predecessors on average at the headline shape and 230 of them can connect at all: a connection needs
 // 5 cp < 9 pp and 5 pp < 9 cp (src/tandem_chain.c:154), and a third of a tandem repeat's hits carry two, three, ... unit lengths as period, so every 64-hit block of the
 // window holds hits of every class and nothing can be skipped block-wise (docs/HISTORY.md).  Instead each read keeps index-ordered LISTS of its finished hits by period class:
-// periods are binned at ratio 2^(1/3) (th_pbin); every bin that holds at least TH_CLS_MIN_HEADS run heads gets a list of ALL hits whose period bin a head of that bin could
-// connect to (a superset, bin-aligned; the scan's own period test stays).  A list entry is the hit's packed record {end << 16 | period, FINAL score} plus its 16-bit index;
+// periods are binned 12 per octave (th_pbin); a bin gets a list when it holds at least TH_CLS_MIN_HEADS run heads, its heads' windows are long and the list would filter
+// (below); the list holds ALL hits whose period lies in (5 lo / 9, ceil(9 hi / 5)) for the bin's periods [lo, hi] -- everything a head of the bin can connect to, ~6 % more at
+// either end; the scan's own period test stays.  A list entry (ThClsEnt, 12 bytes) is the hit's packed record {end << 16 | period, FINAL score} plus its index;
 // the hits of a 64-hit chunk are appended when the chunk is done (scores final, from registers), so the lists are contiguous, in index order, and a trip over a list is one
 // coalesced load like a trip over the hit array.  A head of a listed bin scans (i) the hits of its own chunk before it -- one unfiltered trip from the LDS ring, as every scan
 // starts -- and (ii) its list from the chunk's start downwards: the same trip, order and rules as the scan of the hit array; the hits it never sees are NO_CON ones, which
-// count in the max_h rule only, and that rule is evaluated on hit INDICES.  (A first version kept 16-bit indices only and gathered the records by them: 40 % fewer
-// instructions and 134 ms against 93 -- the gathers tripled the kernel's line traffic, and it was fabric-bound already.)  The list area holds TH_CLS_DUP entries per base
+// count in the max_h rule only, and that rule is evaluated on hit INDICES.  (A first version kept 16-bit indices only and gathered the records by them: 20 % fewer
+// instructions and 134 ms against 93 -- the gathers tripled the kernel's line traffic; with bins of ratio 1.26 every two-period list swallowed the one-period class: 99 ms.)  The list area holds TH_CLS_DUP entries per base
 // slot of the read; lists that do not fit are dropped and their heads scan the hit array as before: same results either way (TH_CHAIN_CLS=0: no lists at all).
 #define TH_CLS_NB 120           // period bins: 12 per octave (ratio 1.059) from period 64 up, periods < 65536.  Narrow on purpose: a tandem repeat's classes sit at ratio 2 (one and two
                                 // unit lengths) and a connection needs ratio < 1.8, so a bin's list may reach only ~10 % beyond what its heads can connect to or it swallows the next class
