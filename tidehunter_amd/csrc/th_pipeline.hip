@@ -211,7 +211,7 @@ static int th_select_device(const th_gpu *g)
     return 0;
 }
 
-// The handle's arena, sized for batches of up to n reads / T bases: ~56 bytes per base of per-position arrays and both input sets,
+// The handle's arena, sized for batches of up to n reads / T bases: ~106 bytes per base of per-position arrays (36 of them the chain DP's period-class lists, round 6) and both input sets,
 // the POA scratch of the full persistent grid at ~100 ints per base of the average read (3.7 MB per wave at the headline shape;
 // long-period batches need more and take their scratch from hipMalloc), and room for the per-job arrays.
 static size_t th_arena_want(const th_gpu *g, int n, long long T)
