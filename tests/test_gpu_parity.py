@@ -330,3 +330,20 @@ def test_gpu_chain_dp_period_class_lists_everywhere():
         t.process(seqs)
         U.stage_compare(t, seqs, para)
         t.close()
+
+
+def test_gpu_long_tandem_reads_take_the_long_read_paths():
+    """bench.py's `c_long` point (2000 reads of 100 kb, period 2000 x 50: outside the contract) has no oracle beside it at that size; here six such reads -- 70 ... 100 kb,
+    tandem repeats of 35 ... 50 units, so that the seeding's 64-bit sort words and HBM sort, the UNPACKED chain-DP records (reads of 65 536 bases and more: no period-class
+    lists either), the wave extraction's large instantiation and POA jobs of 50 units all see real repeat structure, not the random bases of
+    test_gpu_batch_with_a_long_read -- against the oracle: hits, DP cells, chains, par_pos and every record field."""
+    L = TH.load_library()
+    seqs = [TH.synth_read(L, 71, i, p, c, 0.10) for i, (p, c) in enumerate([(2000, 50), (2000, 35), (1500, 60), (2500, 30), (1000, 80), (3000, 25)])]
+    assert all(len(s) >= 65536 for s in seqs)
+    para = O.default_para()
+    t = TH.TideHunter(device=0)
+    got = t.process(seqs)
+    U.stage_compare(t, seqs, para)
+    assert U.assert_records_equal(seqs, got, para, "long tandem reads") >= 6
+    assert t.stats()["jobs_without_consensus"] == 0
+    t.close()
