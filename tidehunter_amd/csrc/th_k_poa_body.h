@@ -116,6 +116,9 @@ __device__ __forceinline__ int *th_poa_carve(ThPoaG &g, int *my, long long cap, 
 #if defined(TH_POA_PROF)
 __device__ unsigned long long th_poa_prof_rows[8];      // row-table phase: 0 fast chunks, 1 general chunks, 2 rounds of the fast loop (two per trip), 3 rounds of the general loop, 4 calls
 #define TH_PROF_ROWS(k, v) do { if (TH_LANE() == 0) atomicAdd(&th_poa_prof_rows[k], (unsigned long long)(v)); } while (0)
+// why a row of the DP took the one-column-per-lane path: 0 no predecessor (the source), 1 more than four, 2 one of them 64 rows or more back, 3 two or more outside the ring
+// (or too wide for it), 4 its own band too wide for the ring, 5 other, 6 a job of the 32-bit variants
+__device__ unsigned long long th_poa_prof_why[8];
 #else
 #define TH_PROF_ROWS(k, v) ((void)0)
 #endif
@@ -563,9 +566,17 @@ __device__ __forceinline__ void th_poa_pk_row(const uint8_t *s_qs, RT (*s_ring)[
 #else
 #define TH_POA_PK_PROF(cat)
 #endif
+// -DTH_POA_DUP_ROW=cat (tools/poa_row_paths.sh; absolute-score variants only): every row the row loop takes on path `cat` (the TH_POA_PROF categories) is computed
+// TWICE -- the loop's scalars restored in between, everything a row writes is written again with the same values -- so that the PMC totals of that build minus those of
+// the build with cat = -2 (same code, no row repeated), over the rows of the path, are the path's instructions per row, further trips and set-up included.
+#if defined(TH_POA_DUP_ROW) && !TH_POA_REL
+#define TH_ROW_CAT(c) (row_cat = (c));
+#else
+#define TH_ROW_CAT(c)
+#endif
 #define TH_POA_PK_ROW_DONE(cat, FOFF) do { \
         L_b = b; L_e = e; L_l = TH_UNI(left); L_r = TH_UNI(right); L_c = TH_LC_ON; TH_POA_SET_RMAX(rmax); \
-        TH_POA_PK_PROF(cat) \
+        TH_POA_PK_PROF(cat) TH_ROW_CAT(cat) \
         th_writelane6(m_beg, m_end, m_left, m_right, m_off, m_foff, b, e, L_l, L_r, my_off, (FOFF), sl); \
         if (i == flush_row) { \
             const int r_ = (i & ~63) + lane; \
@@ -646,6 +657,9 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
     // dispatch word that every row then sets, copies, tests and branches on (~20 scalar instructions per row of the common path's ~110, in the gfx950 assembly).  A failing row
     // instead records its code and moves the row counter to the end -- through a value the compiler cannot see through, or it would thread the jump back into an exit.
     int dp_fail = 0;
+#if defined(TH_POA_DUP_ROW) && !TH_POA_REL
+    int dup_cat = TH_POA_DUP_ROW; TH_OPAQUE_S(dup_cat);
+#endif
 #define TH_POA_DP_FAIL(code) { dp_fail = (code); int stop_ = n; TH_OPAQUE_S(stop_); i = stop_; continue; }
     for (int i = 0; i + 1 < n; ++i) {
         if ((i & 63) == 0) {
@@ -658,6 +672,12 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
             }
             TH_VM_WAIT0();      // here, once per 64 rows -- not at the first use below, where it would drain every row's stores
         }
+#if defined(TH_POA_DUP_ROW) && !TH_POA_REL
+        const uint32_t sv_ncell = ncell, sv_nfull = nfull; const int sv_lim = lim, sv_td = tail_dirty, sv_b = L_b, sv_e = L_e, sv_l = L_l, sv_r = L_r, sv_c = L_c;
+        int row_cat = -1, row_rep = 0;
+        row_again:
+        do {
+#endif
 #if defined(TH_POA_PROF)
         const unsigned long long row_t0 = TH_PROF_NOW();
 #endif
@@ -943,14 +963,35 @@ __device__ int th_poa_dp(ThPoaG &g, const uint8_t *__restrict__ q, const uint8_t
 #if defined(TH_POA_PROF)
         { const unsigned long long dt = TH_POA_PROF >= 2 ? TH_PROF_NOW() - row_t0 : (unsigned long long)(e - b + 1);
           const int cat = pk ? 1 : inn != 1 ? 2 : p0 != i - 1 ? 3 : needfull ? 4 : 5;     // (0: common packed row) / other packed / several predecessors / one far predecessor / stores full cells / other
-          TH_PROF_ROW(cat, dt); }
+          TH_PROF_ROW(cat, dt);
+          if (!pk) {
+              int why = 5;
+              if (WIDE || !LQ) why = 6; else if (inn == 0) why = 0; else if (inn > 4) why = 1;
+              else {
+                  int nfar = 0, old = 0;
+                  for (int o = 0; o < inn; ++o) {
+                      const int pi = o == 0 ? p0 : o == 1 ? p1 : o == 2 ? p2 : p3;
+                      if (fast) break;
+                      if (i - pi >= TH_WAVE) old = 1;
+                      else if (i - pi >= TH_POA_RING || TH_READLANE(m_end, pi & 63) - TH_READLANE(m_beg, pi & 63) >= TH_POA_RW) ++nfar;
+                  }
+                  why = old ? 2 : nfar >= 2 ? 3 : e - b >= TH_POA_RW ? 4 : 5;
+              }
+              if (TH_LANE() == 0) atomicAdd(&th_poa_prof_why[why], 1ull);
+          } }
 #endif
+        TH_ROW_CAT(pk ? 1 : inn != 1 ? 2 : p0 != i - 1 ? 3 : needfull ? 4 : 5)
         th_writelane6(m_beg, m_end, m_left, m_right, m_off, m_foff, b, e, L_l, L_r, my_off, my_foff, sl);
         if (i == flush_row) {          // chunk complete (or last row): its rows' metadata to the tables, coalesced
             const int r = (i & ~63) + lane;
             if (r <= i) { g.r_beg[r] = m_beg; g.r_end[r] = m_end; g.r_off[r] = m_off; g.r_foff[r] = m_foff; g.r_mpl[r] = m_left; g.r_mpr[r] = m_right; }
         }
         TH_WAVE_FENCE();
+#if defined(TH_POA_DUP_ROW) && !TH_POA_REL
+        } while (0);
+        { int again_ = (row_cat == dup_cat) & (row_rep == 0); TH_OPAQUE_S(again_);
+          if (again_) { ncell = sv_ncell; nfull = sv_nfull; lim = sv_lim; tail_dirty = sv_td; L_b = sv_b; L_e = sv_e; L_l = sv_l; L_r = sv_r; L_c = sv_c; row_rep = 1; goto row_again; } }
+#endif
     }
     if (dp_fail) return dp_fail;
     // global end: best predecessor row of the sink (row n-1) at column qlen, first in edge order

@@ -696,6 +696,10 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
                   pr[26], pr[0], pr[1], pr[2], pr[3], pr[24], pr[4], pr[5], pr[6], pr[7], pr[27]);
           for (int c = 0; c < 8; ++c) fprintf(stderr, "%s\"%s\": {\"rows\": %llu, \"cycles\": %llu}", c ? ", " : "", cat[c], pr[8 + c], pr[16 + c]);
           fprintf(stderr, ", \"packed_far\": {\"rows\": %llu, \"cycles\": %llu}}}\n", pr[28], pr[29]);
+          { unsigned long long wy[8]; hipMemcpyFromSymbol(wy, HIP_SYMBOL(thpoa_n::th_poa_prof_why), sizeof(wy));
+            fprintf(stderr, "[poa_prof_why] {\"rows_on_the_32_bit_path_by_reason\": {\"no_predecessor\": %llu, \"more_than_four\": %llu, \"one_64_rows_back\": %llu, \"two_outside_the_ring\": %llu, \"own_band_too_wide\": %llu, \"other\": %llu, \"job_of_a_32_bit_variant\": %llu}}\n",
+                    wy[0], wy[1], wy[2], wy[3], wy[4], wy[5], wy[6]);
+            unsigned long long zw[8] = { 0 }; hipMemcpyToSymbol(HIP_SYMBOL(thpoa_n::th_poa_prof_why), zw, sizeof(zw)); }
           unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(thpoa_n::th_poa_prof), z, sizeof(z));
           unsigned long long rw[8]; hipMemcpyFromSymbol(rw, HIP_SYMBOL(thpoa_n::th_poa_prof_rows), sizeof(rw));
           fprintf(stderr, "[poa_prof_rows] {\"fast_chunks\": %llu, \"general_chunks\": %llu, \"fast_rounds\": %llu, \"general_rounds\": %llu}\n", rw[0], rw[1], rw[2], rw[3]);
