@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box: byte identity of the command line against the oracle's on MORE reads than the tests take, drawn with other seeds
-(test_gpu_scale.py: 4096 / 4096 / 512 reads of seeds 1 / 2 / 3).   usage: python3 tools/soak_scale.py [scale]"""
+(test_gpu_scale.py: 4096 / 4096 / 512 reads of seeds 1 / 2 / 3).   usage: python3 tools/soak_scale.py [scale] [case,case...]"""
 import hashlib, os, subprocess, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
@@ -10,9 +10,13 @@ import oracle_lib as O
 O.load()
 EXE = os.path.join(R, "tidehunter_amd", "TideHunter-amd"); ORACLE = os.path.join(O.ODIR, "tho_oracle")
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+only = sys.argv[2].split(",") if len(sys.argv) > 2 else None       # optional: names of the cases to run
 lib = TH.load_library()
 for name, n, period, copies, err, seed, opts in [("C3", 20000, 1000, 10, 0.10, 11, []), ("C2", 20000, 200, 20, 0.10, 12, ["-f", "2"]),
-                                                 ("C4", 2000, 5000, 4, 0.15, 13, []), ("p2000", 4000, 2000, 5, 0.12, 14, ["-f", "2"])]:
+                                                 ("C4", 2000, 5000, 4, 0.15, 13, []), ("p2000", 4000, 2000, 5, 0.12, 14, ["-f", "2"]),
+                                                 ("long", 160, 2000, 50, 0.10, 15, [])]:       # (100 kb reads: the HBM sorts, the unpacked chain DP, thpoa_l with 50 units per job)
+    if only and name not in only:
+        continue
     n = max(64, int(n * scale))
     fn = "/dev/shm/soak_%s.fa" % name
     U.write_fasta(fn, [TH.synth_read(lib, seed, i, period, copies, err) for i in range(n)], prefix="soak_%s_" % name)
