@@ -347,3 +347,31 @@ def test_gpu_long_tandem_reads_take_the_long_read_paths():
     assert U.assert_records_equal(seqs, got, para, "long tandem reads") >= 6
     assert t.stats()["jobs_without_consensus"] == 0
     t.close()
+
+
+def test_gpu_poa_scratch_factor_follows_the_batch_before():
+    """Reads of 50 copies: the graph of 50 units outgrows the first attempt's scratch estimate (rows and band cells of a typical job x 1.5), the jobs are given back and rerun
+    with twice, then four times the factor (th_poa_retries, th_pipeline.hip).  When most jobs of a class needed that, the handle's NEXT batch starts the class there
+    (poa_fexp0): no job is given back again, and the records -- of both batches -- are the oracle's (the factor sizes arrays, nothing else).  TH_POA_ADAPT=0 keeps 1.5."""
+    L = TH.load_library()
+    seqs = [TH.synth_read(L, 72, i, 2000, 50, 0.10) for i in range(20)]
+    para = O.default_para()
+    t = TH.TideHunter(device=0)
+    first = t.process(seqs)
+    r1 = t.stats()["poa_jobs_rerun"]
+    second = t.process(seqs)
+    r2 = t.stats()["poa_jobs_rerun"]
+    assert r1 >= 10, "the first batch no longer needs reruns: pick a shape that does (%d)" % r1
+    assert r2 == r1, "the second batch gave %d jobs back" % (r2 - r1)
+    assert first == second
+    assert U.assert_records_equal(seqs, second, para, "50-copy reads, second batch") >= 20
+    assert t.stats()["jobs_without_consensus"] == 0
+    t.close()
+    os.environ["TH_POA_ADAPT"] = "0"
+    try:
+        t = TH.TideHunter(device=0)
+        assert t.process(seqs) == first and t.process(seqs) == first
+        assert t.stats()["poa_jobs_rerun"] == 2 * r1
+        t.close()
+    finally:
+        del os.environ["TH_POA_ADAPT"]

@@ -72,6 +72,7 @@ struct ThJobTables {
     int *par_dst, *parc;                             // compact copy: chain c's boundaries at parc[par_dst[c] ..]
     ThTask *tasks; ThUnit *units; th_job_t *jobs; int *list_n, *list_w, *list_l;
     int task_cap, unit_cap, parc_cap, cls_mask;
+    int fexp0[3];                                    // per POA class (0 wide, 1 narrow, 2 long): the first attempt's scratch factor is 1.5 * 2^fexp0 (th_pipeline.hip: poa_fexp0)
 };
 
 // the walk over one read's chains; EMIT = false counts into c[], EMIT = true writes at the offsets in c[] (advancing them)
@@ -115,7 +116,7 @@ __device__ __forceinline__ void th_jobs_walk(const ThJobTables &J, const ThDevPa
                     if (cls == 1) J.list_n[c[5]] = t; else if (cls == 2) J.list_l[c[6]] = t; else J.list_w[t - c[5] - c[6]] = t;
                     if (!only_unit) {
                         if (n_units <= 1) atomicOr(&C->err, TH_E_MSA_UNITS);
-                        atomicMax(cls == 1 ? &C->need_n : cls == 2 ? &C->need_l : &C->need_w, (unsigned long long)th_poa_need_ints(n_units, sum_len, max_len, 1.5, false, cls == 0));
+                        atomicMax(cls == 1 ? &C->need_n : cls == 2 ? &C->need_l : &C->need_w, (unsigned long long)th_poa_need_ints(n_units, sum_len, max_len, 1.5 * (double)(1 << J.fexp0[cls]), false, cls == 0));
                         atomicMax(&C->max_unit, max_len); atomicMax(&C->max_cons_cap, cons_cap);
                     }
                 }

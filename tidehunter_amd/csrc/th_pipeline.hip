@@ -104,6 +104,11 @@ struct th_gpu {
     bool sc_on = false; ThAdRead *h_adr = nullptr; DBuf<ThAdRead> d_adr; DBuf<int> d_single; bool adr_up = false;     // -s: whole-read adapter searches
     th_pvec<ThTask> h_tasks; th_pvec<int> h_cons_len, h_status, h_sublist;     // slow paths only
     int n_sync = 0;
+    // The POA's first attempt at a job sizes its scratch from an estimate of the graph's rows and band cells (th_poa_need_ints) times 1.5; a job that outgrows it is given back
+    // and rerun with twice the factor.  When MOST jobs of a class (0 wide, 1 narrow, 2 long) needed reruns in a batch -- 100 kb reads of 50 copies: the graph of 50 units has
+    // 5 x the rows of a unit and bands at the ring's limit, 1999 of 2011 jobs succeeded at the third attempt only, 2.4 of the step's 7.5 s were the two failed ones -- the next
+    // batch of this handle starts that class at the factor the majority needed (same results: the factor sizes arrays, nothing else).  TH_POA_ADAPT=0: always 1.5.
+    int poa_fexp0[3] = { 0, 0, 0 }, poa_adapt = 1;
     long long stat[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };      // cumulative, th_gpu_stats(): 0 jobs left without a consensus, 1 POA jobs given back for a rerun, 2 reruns of stages 2-3 / the job tables (arena or table too small), 3 batches, 4 consensus jobs
     int aln_wdiv = 10, aln_wadd = 24;     // first certified band of the unit alignments: half-width cons_len / wdiv + wadd
     int aln_xpct = 36;                    // flank extensions: band half-width requested from the anti-diagonal engine, percent of min(consensus, flank) (+ 8)
@@ -164,6 +169,7 @@ extern "C" th_gpu_t *th_gpu_create(const th_gpu_para_t *p, int device)
     g->sync_ev_ok = true;
     if (th_rt_stream_create(&g->stream) || th_rt_stream_create(&g->cstream)) { th_fail("hipStreamCreate failed"); delete g; return nullptr; }
     g->waves_part = env_int("TH_WAVES_PART", TH_PERSISTENT_WAVES(g->waves_part));
+    g->poa_adapt = env_int("TH_POA_ADAPT", 1);
     g->waves_poa = env_int("TH_WAVES_POA", TH_PERSISTENT_WAVES(g->waves_poa));
     g->waves_aln = env_int("TH_WAVES_ALN", TH_PERSISTENT_WAVES(g->waves_aln));
     g->waves_xw = env_int("TH_WAVES_XW", TH_PERSISTENT_WAVES(g->waves_xw));
@@ -426,6 +432,9 @@ static int th_poa_retries(th_gpu *g, KTimer &kt, const ThIn &in, int nt, int poa
         return 0;
     };
     double factor = 1.5;
+    int n_cls[3] = { 0, 0, 0 }, n_again[3][8] = { { 0 } };          // jobs per class as the batch started; jobs of the class rerun at attempt a
+    for (int t = 0; t < nt; ++t) ++n_cls[std::min(std::max(g->h_tasks[t].narrow, 0), 2)];
+    const double f0[3] = { (double)(1 << g->poa_fexp0[0]), (double)(1 << g->poa_fexp0[1]), (double)(1 << g->poa_fexp0[2]) };      // the factor the first attempt ran at, over 1.5
     for (int attempt = 0; attempt < 8; ++attempt, factor *= 2) {
         std::vector<int> narrow, wide, lng;
         for (int t = 0; t < nt; ++t) {
@@ -437,11 +446,18 @@ static int th_poa_retries(th_gpu *g, KTimer &kt, const ThIn &in, int nt, int poa
         if (narrow.empty() && wide.empty() && lng.empty()) break;
         bool ran_n = false, ran_w = false, ran_l = false;
         for (int t : wide) if (g->h_status[t] == 7) g->h_tasks[t].narrow = 0;             // from now on a 32-bit job
-        TRY(run_list(narrow, 1, false, factor, &ran_n));
-        TRY(run_list(lng, 2, false, factor, &ran_l));
-        TRY(run_list(wide, 0, false, factor, &ran_w));
+        if (attempt > 0) { n_again[1][attempt] = (int)narrow.size(); n_again[2][attempt] = (int)lng.size(); n_again[0][attempt] = (int)wide.size(); }
+        TRY(run_list(narrow, 1, false, factor * f0[1], &ran_n));
+        TRY(run_list(lng, 2, false, factor * f0[2], &ran_l));
+        TRY(run_list(wide, 0, false, factor * f0[0], &ran_w));
         if (!ran_n && !ran_w && !ran_l) break;
     }
+    if (g->poa_adapt && !poa_test_fail)
+        for (int c = 0; c < 3; ++c) {
+            int up = 0;
+            for (int a = 1; a < 8; ++a) if (n_cls[c] >= 16 && 2 * n_again[c][a] > n_cls[c]) up = a;          // most of the class's jobs got there
+            if (up) { g->poa_fexp0[c] = std::min(3, g->poa_fexp0[c] + up); if (getenv("TH_TRACE")) fprintf(stderr, "[th] poa class %d: the next batch starts at factor 1.5 x %d\n", c, 1 << g->poa_fexp0[c]); }
+        }
     {   // jobs whose adaptive band failed: one wave at a time if that is what the scratch allows
         factor = 1.0;
         for (int attempt = 0; attempt < 3; ++attempt, factor *= 2) {
@@ -583,7 +599,7 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
             TRY(g->d_units.ensure((size_t)g->unit_cap + 1)); TRY(g->d_parc.ensure((size_t)g->parc_cap + 1));
             ThJobTables J; J.roff = in.d_roff.p; J.read_ch_base = g->d_read_ch_base.p; J.read_ch_n = g->d_read_ch_n.p;
             J.par = g->d_par.p; J.par_off = g->d_par_off.p; J.par_n = g->d_par_n.p; J.par_dst = g->d_par_dst.p; J.parc = g->d_parc.p;
-            J.tasks = g->d_tasks.p; J.units = g->d_units.p; J.jobs = g->d_jobs.p; J.list_n = g->d_list_n.p; J.list_w = g->d_list_w.p; J.list_l = g->d_list_l.p; J.cls_mask = (env_int("TH_POA_LONG", 1) ? 3 : 1) | (env_int("TH_POA_FORCE_LONG", 0) ? 4 : 0);
+            J.tasks = g->d_tasks.p; J.units = g->d_units.p; J.jobs = g->d_jobs.p; J.list_n = g->d_list_n.p; J.list_w = g->d_list_w.p; J.list_l = g->d_list_l.p; J.cls_mask = (env_int("TH_POA_LONG", 1) ? 3 : 1) | (env_int("TH_POA_FORCE_LONG", 0) ? 4 : 0); for (int c_ = 0; c_ < 3; ++c_) J.fexp0[c_] = g->poa_fexp0[c_];
             J.task_cap = g->task_cap; J.unit_cap = g->unit_cap; J.parc_cap = g->parc_cap;
             ThScanCaps caps; caps.on = 1; for (int k = 0; k < 8; ++k) caps.v[k] = 0x7fffffff;
             caps.v[0] = g->parc_cap; caps.v[1] = g->task_cap; caps.v[2] = g->unit_cap;
@@ -656,9 +672,9 @@ extern "C" int th_gpu_run(th_gpu_t *g, int in_slot, int out_slot)
         // a handle reserved for larger batches takes the scratch of the full persistent grid at once (with slack for longer units)
         const long long wv_alloc = g->reserve_n > n ? th_poa_waves(g, std::max(g->reserve_n, n_task_n), need_n) : wv_n;
         TRY(g->d_scratch.ensure((size_t)std::max<long long>(std::max<long long>(std::max<long long>(need_n * std::max<long long>(wv_n, wv_alloc), need_w * wv_w), need_l * wv_l), 1024)));
-        TRY(th_poa_launch(g, kt, in, g->d_list_l.p, n_task_l, 2, cnt->max_unit, need_l, wv_l, &dc->q_poa_l, poa_small_cap | poa_test_fail << 8));       // (the long jobs first: the short ones fill the tail)
-        TRY(th_poa_launch(g, kt, in, g->d_list_n.p, n_task_n, 1, cnt->max_unit, need_n, wv_n, &dc->q_poa_n, poa_small_cap | poa_test_fail << 8));
-        TRY(th_poa_launch(g, kt, in, g->d_list_w.p, n_task_w, 0, cnt->max_unit, need_w, wv_w, &dc->q_poa_w, poa_small_cap | poa_test_fail << 8));
+        TRY(th_poa_launch(g, kt, in, g->d_list_l.p, n_task_l, 2, cnt->max_unit, need_l, wv_l, &dc->q_poa_l, poa_small_cap | g->poa_fexp0[2] << 1 | poa_test_fail << 8));       // (the long jobs first: the short ones fill the tail)
+        TRY(th_poa_launch(g, kt, in, g->d_list_n.p, n_task_n, 1, cnt->max_unit, need_n, wv_n, &dc->q_poa_n, poa_small_cap | g->poa_fexp0[1] << 1 | poa_test_fail << 8));
+        TRY(th_poa_launch(g, kt, in, g->d_list_w.p, n_task_w, 0, cnt->max_unit, need_w, wv_w, &dc->q_poa_w, poa_small_cap | g->poa_fexp0[0] << 1 | poa_test_fail << 8));
         if (trace) { th_rt_sync_event(g->stream, g->sync_ev); fprintf(stderr, "[th] %.3f s: poa done (%d + %d + %d jobs, %d / %d / %d waves, %lld MB scratch)\n", th_wall_s() - t_run0, n_task_n, n_task_l, n_task_w, wv_n, wv_l, wv_w, (long long)(std::max(std::max(need_n * wv_n, need_w * wv_w), need_l * wv_l) * 4 >> 20)); }
         for (int pass = 0;; ++pass) {
             // ---- item lists of the alignment kernels and the compacted consensus offsets, per job, on the device ----
