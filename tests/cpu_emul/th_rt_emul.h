@@ -11,6 +11,7 @@
 typedef int th_stream_t;
 #define TH_CHECK(x) (x)
 static inline int th_rt_malloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : -1; }
+static inline void th_rt_forget_error(void) { }
 static inline int th_rt_free(void *p) { free(p); return 0; }
 static inline int th_rt_h2d(void *d, const void *h, size_t n, th_stream_t) { memcpy(d, h, n); return 0; }
 static inline int th_rt_d2h(void *h, const void *d, size_t n, th_stream_t) { memcpy(h, d, n); return 0; }

@@ -420,7 +420,7 @@ static int th_poa_retries(th_gpu *g, KTimer &kt, const ThIn &in, int nt, int poa
         for (int t : grp) { const ThTask &k = g->h_tasks[t]; need = std::max(need, th_poa_need_ints(k.n_units, k.sum_len, k.max_len, factor, noband, wide)); max_unit = std::max(max_unit, k.max_len); }
         if (need * 4 > TH_POA_SCRATCH_BYTES) return 0;                       // even one wave cannot have it: the jobs keep their status
         const int wv = th_poa_waves(g, (long long)grp.size(), need);
-        if (g->d_scratch.ensure((size_t)(need * wv))) { g_th_err.clear(); return 0; }      // (no memory for it: likewise)
+        if (g->d_scratch.ensure((size_t)(need * wv))) { g_th_err.clear(); th_rt_forget_error(); return 0; }      // (no memory for it: likewise)
         th_room(g->h_sublist, grp.size()); g->h_sublist.assign(grp.begin(), grp.end());
         TRY(g->d_sublist.ensure(grp.size()));
         TRY(th_rt_h2d(g->d_sublist.p, g->h_sublist.data(), grp.size() * 4, g->stream));

@@ -12,6 +12,7 @@
 typedef hipStream_t th_stream_t;
 #define TH_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[tidehunter_amd] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
 static inline int th_rt_malloc(void **p, size_t n) { TH_CHECK(hipMalloc(p, n ? n : 1)); return 0; }
+static inline void th_rt_forget_error(void) { (void)hipGetLastError(); }      // after a failure that is handled (an allocation that was only tried): the next launch check must not see it
 static inline int th_rt_free(void *p) { if (p) TH_CHECK(hipFree(p)); return 0; }
 static inline int th_rt_h2d(void *d, const void *h, size_t n, th_stream_t s) { if (n) TH_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)); return 0; }
 static inline int th_rt_d2h(void *h, const void *d, size_t n, th_stream_t s) { if (n) TH_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s)); return 0; }
